@@ -1,0 +1,64 @@
+// Internal declarations shared by the translation units of libexprgrad_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "exprgrad_hip.h"
+
+namespace eg {
+
+// Thread-local error text behind eg_last_error().
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+void clear_error();
+
+#define EG_HIP_CHECK(expr)                                                             \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      ::eg::set_error("%s failed: %s (%d) at %s:%d", #expr, hipGetErrorString(_e),     \
+                      (int)_e, __FILE__, __LINE__);                                    \
+      return EG_ERR_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+#define EG_REQUIRE(cond, code, ...)   \
+  do {                                \
+    if (!(cond)) {                    \
+      ::eg::set_error(__VA_ARGS__);   \
+      return (code);                  \
+    }                                 \
+  } while (0)
+
+}  // namespace eg
+
+struct eg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  // Scratch for split-K partials and two-stage reductions; grown on demand, never shrunk.
+  void* workspace = nullptr;
+  size_t workspace_bytes = 0;
+  int compute_units = 256;
+  std::string arch;
+};
+
+struct eg_buf {
+  eg_ctx* ctx = nullptr;
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  bool owned = true;
+};
+
+namespace eg {
+// Ensure ctx->workspace holds at least `bytes`; synchronises the stream if it has to grow.
+int ensure_workspace(eg_ctx* ctx, size_t bytes);
+inline int set_device(eg_ctx* ctx) {
+  EG_HIP_CHECK(hipSetDevice(ctx->device));
+  return EG_OK;
+}
+}  // namespace eg

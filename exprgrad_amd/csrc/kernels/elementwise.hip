@@ -1,0 +1,339 @@
+// HBM-bound kernels of the compiled-tensor hot path: raw-indexed maps and their derived
+// gradients, broadcast bias add, axpy (gradientDescent), fill.
+//
+// Reference lowering being replaced: tests/cache/relu_basic.ir — one work-item per element in
+// work-groups of 16 (ir.nim:283), i.e. a quarter of a wavefront per group.  Here: 256-thread
+// blocks, 16-byte accesses per lane (1 KiB per wave instruction), grid-stride over at most
+// 8 blocks per CU.
+//
+// Arithmetic follows llvmgen.nim:212-301 operation by operation (fadd/fsub/fmul/fdiv, ordered
+// compares, select, libm-class exp/sin/cos); this file is built with -ffp-contract=off so no
+// multiply-add is fused that the reference's no-fast-math JIT (llvm.nim:486-491) keeps apart.
+#include "../eg_internal.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NT = 256;
+
+inline unsigned grid_for(const eg_ctx* ctx, long work_items) {
+  long blocks = (work_items + NT - 1) / NT;
+  long cap = 8L * ctx->compute_units;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---- forward maps -----------------------------------------------------------------------
+template <int OP>
+__device__ __forceinline__ float map_fwd(float x, float p) {
+  switch (OP) {
+    case EG_MAP_IDENTITY: return x;
+    case EG_MAP_RELU: return x >= 0.0f ? x : 0.0f;                 // dnn.nim:26-27 (0 <= x)
+    case EG_MAP_LEAKY_RELU: return (x >= 0.0f ? 1.0f : p) * x;     // dnn.nim:29-30
+    case EG_MAP_SIGMOID: return 1.0f / (1.0f + expf(-x));          // dnn.nim:32-33
+    case EG_MAP_TANH: {                                            // dnn.nim:35-40 (naive form)
+      const float a = expf(x), b = expf(-x);
+      return (a - b) / (a + b);
+    }
+    case EG_MAP_SCALE: return x * p;                               // base.nim:24
+    case EG_MAP_SIN: return sinf(x);                               // dnn.nim:42-43
+    case EG_MAP_XOR_LEAKY: return x <= 0.0f ? p * x : x;           // xor_from_scratch.nim:22
+    case EG_MAP_EXP: return expf(x);
+  }
+  return x;
+}
+
+// ---- derived gradients: exactly the instruction sequences passes.nim:392-505 emits ---------
+template <int OP>
+__device__ __forceinline__ float map_bwd(float x, float g, float p) {
+  switch (OP) {
+    case EG_MAP_IDENTITY: return g;
+    case EG_MAP_RELU: return x >= 0.0f ? g : 0.0f;  // select rule 471-476: select(c, g, 0) (+ nothing: 0.0 literal)
+    case EG_MAP_LEAKY_RELU: {
+      // out = s * x with s = select(c, 1, p): mul rule 399-403 -> grad_x = g * s (s has no tensor input).
+      const float s = x >= 0.0f ? 1.0f : p;
+      return g * s;
+    }
+    case EG_MAP_SIGMOID: {
+      // out = 1 / s, s = 1 + e, e = exp(n), n = -x.
+      // div rule 404-415: grad_s = (-1) * (g / (s*s)); add: grad_e = grad_s;
+      // exp rule 456-459: grad_n = grad_e * e; neg rule 416-419: grad_x = -grad_n.
+      const float e = expf(-x);
+      const float s = 1.0f + e;
+      const float gs = (-1.0f) * (g / (s * s));
+      return -(gs * e);
+    }
+    case EG_MAP_TANH: {
+      // out = d / t, d = a - b, t = a + b, a = exp(x), b = exp(n), n = -x.
+      const float a = expf(x), b = expf(-x);
+      const float d = a - b, t = a + b;
+      const float gd = g / t;                    // div: grad of numerator
+      const float gt = (-d) * (g / (t * t));     // div: grad of denominator
+      // visit order is reverse program order: t = a + b first, then d = a - b.
+      float ga = gt, gb = gt;                    // add rule
+      ga = ga + gd;                              // sub rule: (g, -g), accumulated with + (510-517)
+      gb = gb + (-gd);
+      const float gn = gb * b;                   // exp(n)
+      const float gx_from_n = -gn;               // neg
+      const float gx_from_a = ga * a;            // exp(x)
+      // exp(-x) is visited before exp(x) (later instruction first), so -gn is the first term.
+      return gx_from_n + gx_from_a;
+    }
+    case EG_MAP_SCALE: return g * p;
+    case EG_MAP_SIN: return cosf(x) * g;  // 460-464
+    case EG_MAP_XOR_LEAKY: {
+      // out = select(c, p*x, x): select rule gives select(c,g,0) for arg1 and select(c,0,g) for arg2;
+      // mul rule on p*x gives g1 * p.  Reverse visit: select first, then the mul.  x's gradient
+      // accumulates arg2's term first (it reaches x directly), then the mul's term.
+      const bool c = x <= 0.0f;
+      const float g1 = c ? g : 0.0f, g2 = c ? 0.0f : g;
+      return g2 + g1 * p;
+    }
+    case EG_MAP_EXP: return g * expf(x);
+  }
+  return g;
+}
+
+template <int OP, bool ACC>
+__global__ __launch_bounds__(NT) void map_kernel(const float* __restrict__ in, float* __restrict__ out, long n,
+                                                 float p, int vec) {
+  const long tid = (long)blockIdx.x * NT + threadIdx.x;
+  const long nthreads = (long)gridDim.x * NT;
+  if (vec) {
+    const long n4 = n >> 2;
+    for (long i = tid; i < n4; i += nthreads) {
+      f32x4 x = reinterpret_cast<const f32x4*>(in)[i];
+      f32x4 y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = map_fwd<OP>(x[j], p);
+      if (ACC) {
+        f32x4 o = reinterpret_cast<f32x4*>(out)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = o[j] + y[j];
+      }
+      reinterpret_cast<f32x4*>(out)[i] = y;
+    }
+    for (long i = (n4 << 2) + tid; i < n; i += nthreads) {
+      float y = map_fwd<OP>(in[i], p);
+      out[i] = ACC ? out[i] + y : y;
+    }
+  } else {
+    for (long i = tid; i < n; i += nthreads) {
+      float y = map_fwd<OP>(in[i], p);
+      out[i] = ACC ? out[i] + y : y;
+    }
+  }
+}
+
+template <int OP, bool ACC>
+__global__ __launch_bounds__(NT) void map_grad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
+                                                      float* __restrict__ gin, long n, float p, int vec) {
+  const long tid = (long)blockIdx.x * NT + threadIdx.x;
+  const long nthreads = (long)gridDim.x * NT;
+  if (vec) {
+    const long n4 = n >> 2;
+    for (long i = tid; i < n4; i += nthreads) {
+      f32x4 x = reinterpret_cast<const f32x4*>(in)[i];
+      f32x4 g = reinterpret_cast<const f32x4*>(gout)[i];
+      f32x4 y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = map_bwd<OP>(x[j], g[j], p);
+      if (ACC) {
+        f32x4 o = reinterpret_cast<f32x4*>(gin)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[j] = o[j] + y[j];
+      }
+      reinterpret_cast<f32x4*>(gin)[i] = y;
+    }
+    for (long i = (n4 << 2) + tid; i < n; i += nthreads) {
+      float y = map_bwd<OP>(in[i], gout[i], p);
+      gin[i] = ACC ? gin[i] + y : y;
+    }
+  } else {
+    for (long i = tid; i < n; i += nthreads) {
+      float y = map_bwd<OP>(in[i], gout[i], p);
+      gin[i] = ACC ? gin[i] + y : y;
+    }
+  }
+}
+
+// out[y,x] (+)= bias[x]
+template <bool ACC>
+__global__ __launch_bounds__(NT) void bias_add_kernel(const float* __restrict__ bias, float* __restrict__ out,
+                                                      long rows, long cols, int vec) {
+  const long tid = (long)blockIdx.x * NT + threadIdx.x;
+  const long nthreads = (long)gridDim.x * NT;
+  const long n = rows * cols;
+  if (vec) {  // cols % 4 == 0: a 16-byte chunk never straddles a row
+    const long n4 = n >> 2;
+    const long c4 = cols >> 2;
+    for (long i = tid; i < n4; i += nthreads) {
+      const long c = (i % c4) << 2;
+      f32x4 b = *reinterpret_cast<const f32x4*>(bias + c);
+      if (ACC) {
+        f32x4 o = reinterpret_cast<f32x4*>(out)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = o[j] + b[j];
+      }
+      reinterpret_cast<f32x4*>(out)[i] = b;
+    }
+  } else {
+    for (long i = tid; i < n; i += nthreads) {
+      const float b = bias[i % cols];
+      out[i] = ACC ? out[i] + b : b;
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void axpy_kernel(float alpha, const float* __restrict__ x, float* __restrict__ y,
+                                                  long n, int vec) {
+  const long tid = (long)blockIdx.x * NT + threadIdx.x;
+  const long nthreads = (long)gridDim.x * NT;
+  if (vec) {
+    const long n4 = n >> 2;
+    for (long i = tid; i < n4; i += nthreads) {
+      f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+      f32x4 yv = reinterpret_cast<f32x4*>(y)[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) yv[j] = yv[j] + alpha * xv[j];
+      reinterpret_cast<f32x4*>(y)[i] = yv;
+    }
+    for (long i = (n4 << 2) + tid; i < n; i += nthreads) y[i] = y[i] + alpha * x[i];
+  } else {
+    for (long i = tid; i < n; i += nthreads) y[i] = y[i] + alpha * x[i];
+  }
+}
+
+__global__ __launch_bounds__(NT) void fill_kernel(float value, float* __restrict__ out, long n, int vec) {
+  const long tid = (long)blockIdx.x * NT + threadIdx.x;
+  const long nthreads = (long)gridDim.x * NT;
+  if (vec) {
+    const long n4 = n >> 2;
+    const f32x4 v = {value, value, value, value};
+    for (long i = tid; i < n4; i += nthreads) reinterpret_cast<f32x4*>(out)[i] = v;
+    for (long i = (n4 << 2) + tid; i < n; i += nthreads) out[i] = value;
+  } else {
+    for (long i = tid; i < n; i += nthreads) out[i] = value;
+  }
+}
+
+#define EG_MAP_CASES(LAUNCH)                     \
+  switch (op) {                                  \
+    case EG_MAP_IDENTITY: LAUNCH(EG_MAP_IDENTITY); break;     \
+    case EG_MAP_RELU: LAUNCH(EG_MAP_RELU); break;             \
+    case EG_MAP_LEAKY_RELU: LAUNCH(EG_MAP_LEAKY_RELU); break; \
+    case EG_MAP_SIGMOID: LAUNCH(EG_MAP_SIGMOID); break;       \
+    case EG_MAP_TANH: LAUNCH(EG_MAP_TANH); break;             \
+    case EG_MAP_SCALE: LAUNCH(EG_MAP_SCALE); break;           \
+    case EG_MAP_SIN: LAUNCH(EG_MAP_SIN); break;               \
+    case EG_MAP_XOR_LEAKY: LAUNCH(EG_MAP_XOR_LEAKY); break;   \
+    case EG_MAP_EXP: LAUNCH(EG_MAP_EXP); break;               \
+    default:                                                  \
+      eg::set_error("unknown map op %d", op);                 \
+      return EG_ERR_INVALID;                                  \
+  }
+
+}  // namespace
+
+extern "C" {
+
+int eg_map(eg_ctx* ctx, int op, int64_t n, const float* in, float* out, float param, int accumulate) {
+  EG_REQUIRE(ctx, EG_ERR_INVALID, "eg_map: ctx is NULL");
+  EG_REQUIRE(n >= 0, EG_ERR_INVALID, "eg_map: negative length");
+  if (n == 0) return EG_OK;
+  EG_REQUIRE(in && out, EG_ERR_INVALID, "eg_map: NULL tensor");
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  const int vec = aligned16(in) && aligned16(out);
+  const unsigned grid = grid_for(ctx, vec ? (n + 3) / 4 : n);
+#define LAUNCH(OP)                                                                                          \
+  do {                                                                                                      \
+    if (accumulate)                                                                                         \
+      hipLaunchKernelGGL((map_kernel<OP, true>), dim3(grid), dim3(NT), 0, ctx->stream, in, out, (long)n, param, vec); \
+    else                                                                                                    \
+      hipLaunchKernelGGL((map_kernel<OP, false>), dim3(grid), dim3(NT), 0, ctx->stream, in, out, (long)n, param, vec); \
+  } while (0)
+  EG_MAP_CASES(LAUNCH)
+#undef LAUNCH
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
+int eg_map_grad(eg_ctx* ctx, int op, int64_t n, const float* in, const float* gout, float* gin, float param,
+                int accumulate) {
+  EG_REQUIRE(ctx, EG_ERR_INVALID, "eg_map_grad: ctx is NULL");
+  EG_REQUIRE(n >= 0, EG_ERR_INVALID, "eg_map_grad: negative length");
+  if (n == 0) return EG_OK;
+  EG_REQUIRE(in && gout && gin, EG_ERR_INVALID, "eg_map_grad: NULL tensor");
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  const int vec = aligned16(in) && aligned16(gout) && aligned16(gin);
+  const unsigned grid = grid_for(ctx, vec ? (n + 3) / 4 : n);
+#define LAUNCH(OP)                                                                                           \
+  do {                                                                                                       \
+    if (accumulate)                                                                                          \
+      hipLaunchKernelGGL((map_grad_kernel<OP, true>), dim3(grid), dim3(NT), 0, ctx->stream, in, gout, gin,   \
+                         (long)n, param, vec);                                                               \
+    else                                                                                                     \
+      hipLaunchKernelGGL((map_grad_kernel<OP, false>), dim3(grid), dim3(NT), 0, ctx->stream, in, gout, gin,  \
+                         (long)n, param, vec);                                                               \
+  } while (0)
+  EG_MAP_CASES(LAUNCH)
+#undef LAUNCH
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
+int eg_bias_add(eg_ctx* ctx, int64_t rows, int64_t cols, const float* bias, float* out, int accumulate) {
+  EG_REQUIRE(ctx, EG_ERR_INVALID, "eg_bias_add: ctx is NULL");
+  EG_REQUIRE(rows >= 0 && cols >= 0, EG_ERR_INVALID, "eg_bias_add: negative extent");
+  if (rows == 0 || cols == 0) return EG_OK;
+  EG_REQUIRE(bias && out, EG_ERR_INVALID, "eg_bias_add: NULL tensor");
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  const int vec = (cols % 4 == 0) && aligned16(bias) && aligned16(out);
+  const long n = rows * cols;
+  const unsigned grid = grid_for(ctx, vec ? n / 4 : n);
+  if (accumulate)
+    hipLaunchKernelGGL((bias_add_kernel<true>), dim3(grid), dim3(NT), 0, ctx->stream, bias, out, (long)rows,
+                       (long)cols, vec);
+  else
+    hipLaunchKernelGGL((bias_add_kernel<false>), dim3(grid), dim3(NT), 0, ctx->stream, bias, out, (long)rows,
+                       (long)cols, vec);
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
+int eg_axpy(eg_ctx* ctx, int64_t n, float alpha, const float* x, float* y) {
+  EG_REQUIRE(ctx, EG_ERR_INVALID, "eg_axpy: ctx is NULL");
+  EG_REQUIRE(n >= 0, EG_ERR_INVALID, "eg_axpy: negative length");
+  if (n == 0) return EG_OK;
+  EG_REQUIRE(x && y, EG_ERR_INVALID, "eg_axpy: NULL tensor");
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  const int vec = aligned16(x) && aligned16(y);
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(ctx, vec ? (n + 3) / 4 : n)), dim3(NT), 0, ctx->stream, alpha, x, y,
+                     (long)n, vec);
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
+int eg_fill_f32(eg_ctx* ctx, int64_t n, float value, float* out) {
+  EG_REQUIRE(ctx, EG_ERR_INVALID, "eg_fill_f32: ctx is NULL");
+  EG_REQUIRE(n >= 0, EG_ERR_INVALID, "eg_fill_f32: negative length");
+  if (n == 0) return EG_OK;
+  EG_REQUIRE(out, EG_ERR_INVALID, "eg_fill_f32: NULL tensor");
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  const int vec = aligned16(out);
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(ctx, vec ? (n + 3) / 4 : n)), dim3(NT), 0, ctx->stream, value, out,
+                     (long)n, vec);
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
+}  // extern "C"

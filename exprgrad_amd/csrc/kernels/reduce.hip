@@ -1,0 +1,205 @@
+// Reductions of the compiled-tensor hot path: column sums (bias gradients), row sums (softmax
+// denominators), full sums (scalar losses).
+//
+// The reference's GPU target has no usable lowering for these: a kernel whose write index
+// lacks an iterator keeps that loop serial inside every work-item (`gb[x] += g[y,x]` walks the
+// whole batch in one work-item) and a kernel with no independent loop at
+// all (`loss[0] += ...`) gets no InstrGpu (passes.nim:2411-2524).  Here every reduction is a
+// two-stage tree: wave-level shuffles -> LDS across the 4 waves of a block -> one partial per
+// block in the context workspace -> a single-block second pass in fixed order.  No float
+// atomics, so results are run-to-run deterministic.
+#include "../eg_internal.hpp"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// ---- column sum ---------------------------------------------------------------------------
+// in [rows, cols].  A wave covers RPW = 64 / colsP consecutive rows x colsP columns (colsP =
+// cols rounded up to a power of two, at most 64), so narrow matrices still issue nearly
+// contiguous loads.  blockIdx.y walks column tiles of 64 when cols > 64.
+// partial[blockIdx.x][cols] holds one row of sums per row-chunk.
+__global__ __launch_bounds__(NT) void colsum_partial_kernel(const float* __restrict__ in,
+                                                            float* __restrict__ partial, long rows, long cols,
+                                                            int colsP, long rows_per_block) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rpw = 64 / colsP;
+  const int r_in_wave = lane / colsP;
+  const long c = (long)blockIdx.y * 64 + (lane % colsP);
+  const long row_begin = (long)blockIdx.x * rows_per_block;
+  const long row_end = min(rows, row_begin + rows_per_block);
+  float acc = 0.f;
+  if (c < cols) {
+    for (long r = row_begin + wave * rpw + r_in_wave; r < row_end; r += 4 * rpw) acc += in[r * cols + c];
+  }
+  // fold the rpw row phases held in different lane groups
+  for (int off = 32; off >= colsP; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && lane < colsP && c < cols) {
+    const float s = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    partial[(long)blockIdx.x * cols + c] = s;
+  }
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(NT) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                          long cols, int nparts) {
+  const long c = (long)blockIdx.x * NT + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(long)p * cols + c];
+  out[c] = ACC ? out[c] + s : s;
+}
+
+// ---- row sum --------------------------------------------------------------------------------
+template <bool ACC>
+__global__ __launch_bounds__(NT) void rowsum_thread_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           long rows, long cols) {
+  for (long r = (long)blockIdx.x * NT + threadIdx.x; r < rows; r += (long)gridDim.x * NT) {
+    float s = 0.f;
+    for (long c = 0; c < cols; ++c) s += in[r * cols + c];
+    out[r] = ACC ? out[r] + s : s;
+  }
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(NT) void rowsum_wave_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         long rows, long cols) {
+  const int lane = threadIdx.x & 63;
+  const long wave = ((long)blockIdx.x * NT + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * NT) >> 6;
+  for (long r = wave; r < rows; r += nwaves) {
+    float s = 0.f;
+    for (long c = lane; c < cols; c += 64) s += in[r * cols + c];
+    s = wave_sum(s);
+    if (lane == 0) out[r] = ACC ? out[r] + s : s;
+  }
+}
+
+// ---- full sum -------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void sum_partial_kernel(const float* __restrict__ in, float* __restrict__ partial,
+                                                         long n) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) acc += in[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+template <bool ACC>
+__global__ __launch_bounds__(NT) void sum_final_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                       int nparts) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += NT) acc += partial[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float s = ((red[0] + red[1]) + red[2]) + red[3];
+    out[0] = ACC ? out[0] + s : s;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int eg_colsum(eg_ctx* ctx, int64_t rows, int64_t cols, const float* in, float* out, int accumulate) {
+  EG_REQUIRE(ctx, EG_ERR_INVALID, "eg_colsum: ctx is NULL");
+  EG_REQUIRE(rows >= 0 && cols >= 0, EG_ERR_INVALID, "eg_colsum: negative extent");
+  if (cols == 0) return EG_OK;
+  EG_REQUIRE(out && (rows == 0 || in), EG_ERR_INVALID, "eg_colsum: NULL tensor");
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  int colsP = 1;
+  while (colsP < cols && colsP < 64) colsP <<= 1;
+  const long col_tiles = (cols + 63) / 64;
+  // ~4 blocks per CU in total, at least 64 rows per block.
+  long nparts = (4L * ctx->compute_units + col_tiles - 1) / col_tiles;
+  const long max_parts = (rows + 63) / 64;
+  if (nparts > max_parts) nparts = max_parts;
+  if (nparts < 1) nparts = 1;
+  const long rows_per_block = (rows + nparts - 1) / nparts;
+  nparts = rows_per_block > 0 ? (rows + rows_per_block - 1) / rows_per_block : 1;
+  if (nparts < 1) nparts = 1;
+  rc = eg::ensure_workspace(ctx, (size_t)nparts * cols * sizeof(float));
+  if (rc) return rc;
+  float* partial = static_cast<float*>(ctx->workspace);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nparts, (unsigned)col_tiles), dim3(NT), 0, ctx->stream, in,
+                     partial, (long)rows, (long)cols, colsP, rows_per_block);
+  const unsigned fgrid = (unsigned)((cols + NT - 1) / NT);
+  if (accumulate)
+    hipLaunchKernelGGL((colsum_final_kernel<true>), dim3(fgrid), dim3(NT), 0, ctx->stream, partial, out, (long)cols,
+                       (int)nparts);
+  else
+    hipLaunchKernelGGL((colsum_final_kernel<false>), dim3(fgrid), dim3(NT), 0, ctx->stream, partial, out, (long)cols,
+                       (int)nparts);
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
+int eg_rowsum(eg_ctx* ctx, int64_t rows, int64_t cols, const float* in, float* out, int accumulate) {
+  EG_REQUIRE(ctx, EG_ERR_INVALID, "eg_rowsum: ctx is NULL");
+  EG_REQUIRE(rows >= 0 && cols >= 0, EG_ERR_INVALID, "eg_rowsum: negative extent");
+  if (rows == 0) return EG_OK;
+  EG_REQUIRE(out && (cols == 0 || in), EG_ERR_INVALID, "eg_rowsum: NULL tensor");
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  const long cap = 8L * ctx->compute_units;
+  if (cols <= 32) {
+    long blocks = (rows + NT - 1) / NT;
+    if (blocks > cap) blocks = cap;
+    if (accumulate)
+      hipLaunchKernelGGL((rowsum_thread_kernel<true>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, in, out,
+                         (long)rows, (long)cols);
+    else
+      hipLaunchKernelGGL((rowsum_thread_kernel<false>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, in, out,
+                         (long)rows, (long)cols);
+  } else {
+    long blocks = (rows + 3) / 4;
+    if (blocks > cap) blocks = cap;
+    if (accumulate)
+      hipLaunchKernelGGL((rowsum_wave_kernel<true>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, in, out,
+                         (long)rows, (long)cols);
+    else
+      hipLaunchKernelGGL((rowsum_wave_kernel<false>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, in, out,
+                         (long)rows, (long)cols);
+  }
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
+int eg_sum(eg_ctx* ctx, int64_t n, const float* in, float* out, int accumulate) {
+  EG_REQUIRE(ctx, EG_ERR_INVALID, "eg_sum: ctx is NULL");
+  EG_REQUIRE(n >= 0, EG_ERR_INVALID, "eg_sum: negative length");
+  EG_REQUIRE(out && (n == 0 || in), EG_ERR_INVALID, "eg_sum: NULL tensor");
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  long blocks = (n + NT * 4 - 1) / (NT * 4);
+  const long cap = 4L * ctx->compute_units;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  rc = eg::ensure_workspace(ctx, (size_t)blocks * sizeof(float));
+  if (rc) return rc;
+  float* partial = static_cast<float*>(ctx->workspace);
+  hipLaunchKernelGGL(sum_partial_kernel, dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, in, partial, (long)n);
+  if (accumulate)
+    hipLaunchKernelGGL((sum_final_kernel<true>), dim3(1), dim3(NT), 0, ctx->stream, partial, out, (int)blocks);
+  else
+    hipLaunchKernelGGL((sum_final_kernel<false>), dim3(1), dim3(NT), 0, ctx->stream, partial, out, (int)blocks);
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
+}  // extern "C"

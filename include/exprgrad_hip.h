@@ -1,0 +1,236 @@
+/*
+ * exprgrad_hip.h — C ABI of libexprgrad_hip.so, the MI355X (gfx950) kernel backend for
+ * exprgrad's compiled tensor hot path.
+ *
+ * This header is the drop-in boundary. Every entry point names the reference interface it
+ * replaces (paths relative to the exprgrad repository):
+ *
+ *   group 1  "runtime"  — 1:1 with the proc set every GPU runtime must provide,
+ *                         exprgrad/runtimes/gpu.nim:24-52 (implemented for OpenCL in
+ *                         exprgrad/runtimes/cl.nim:45-207).
+ *   group 2  "library"  — hand-written CDNA4 kernels for the kernel classes the reference
+ *                         lowers from `++=` statements (exprgrad/layers/base.nim:19-67,
+ *                         exprgrad/layers/dnn.nim:19-100) and that clgen.nim:217-257 would
+ *                         otherwise emit as OpenCL text.
+ *   group 3  "model"    — kernel-description programs: what model.nim:215-251 (newModel),
+ *                         model.nim:392-454 (call/apply/fit) and the three JIT builtins
+ *                         model.nim:148-172 do for a CompileGpu target.
+ *
+ * Conventions
+ *   - plain C: opaque handles, raw pointers, sizes; no C++ / torch types.
+ *   - every function returns an int status (EG_OK == 0); on failure a thread-local message is
+ *     available from eg_last_error().  The library never aborts or exits
+ *     (cl.nim:41-43 raises GpuError; a binding re-raises from the status).
+ *   - tensors are dense row-major float32, last dimension contiguous (tensors.nim:20-25);
+ *     all extents / indices are signed 64 bit (wrappers/llvm.nim:295-303, clgen.nim:59).
+ *   - one in-order HIP stream per context (cl.nim:92: one in-order command queue); copies are
+ *     blocking, fills and launches are asynchronous (cl.nim:111-131, 190-207).
+ *   - device pointers passed to group 2 may come from eg_buf_ptr() or from any other HIP
+ *     allocation on the context's device (e.g. a torch tensor's data_ptr()).
+ */
+#ifndef EXPRGRAD_HIP_H
+#define EXPRGRAD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EG_OK 0
+#define EG_ERR_INVALID 1     /* bad argument / handle / shape                          */
+#define EG_ERR_HIP 2         /* HIP runtime or driver error (message carries the code) */
+#define EG_ERR_COMPILE 3     /* hiprtc build failure (message carries the build log)   */
+#define EG_ERR_SIZE 4        /* host<->device size mismatch (cl.nim:112-113, 134-142)  */
+#define EG_ERR_UNSUPPORTED 5 /* kernel description the backend has no lowering for     */
+#define EG_ERR_RUNTIME 6     /* unknown target / input (model.nim:358-359, 395-396)    */
+#define EG_ERR_SHAPE 7       /* shape inference failure (passes.nim ShapeError)        */
+
+typedef struct eg_ctx eg_ctx;       /* GpuContext  (cl.nim:24-27)  */
+typedef struct eg_buf eg_buf;       /* GpuBuffer   (cl.nim:29-32)  */
+typedef struct eg_kernel eg_kernel; /* GpuKernel   (cl.nim:38-40)  */
+typedef struct eg_model eg_model;   /* Model[T] restricted to its GpuModel (model.nim:21-43) */
+
+/* Thread-local text of the last failure on this thread ("" if none). cl.nim:41-43. */
+const char* eg_last_error(void);
+/* ABI version of this header: major*1000 + minor. */
+int eg_version(void);
+
+/* ------------------------------------------------------------------ group 1: runtime -- */
+
+/* listDevices(): gpu.nim:34, cl.nim:64-66. */
+int eg_device_count(int* count);
+/* name/vendor/version/isGpu(device): gpu.nim:35-38, cl.nim:75-81. Any out pointer may be NULL. */
+int eg_device_info(int device, char* name, size_t name_cap, char* vendor, size_t vendor_cap,
+                   char* version, size_t version_cap, int* is_gpu);
+/* Static facts used for roofline reporting (not in the reference). */
+int eg_device_props(int device, int* compute_units, int* clock_khz, int64_t* hbm_bytes,
+                    char* arch, size_t arch_cap);
+
+/* newGpuContext(device): gpu.nim:39, cl.nim:83-93. Creates one non-blocking in-order stream. */
+int eg_ctx_create(int device, eg_ctx** out);
+/* Same, but launches go to a stream owned by the caller (hipStream_t as void*; NULL = the
+ * legacy default stream).  Lets a host that already owns streams (torch) stay in order. */
+int eg_ctx_create_on_stream(int device, void* hip_stream, eg_ctx** out);
+int eg_ctx_destroy(eg_ctx* ctx);
+/* Block until everything queued on the context's stream has finished. */
+int eg_ctx_sync(eg_ctx* ctx);
+/* hipStream_t of the context, as void*. */
+void* eg_ctx_stream(eg_ctx* ctx);
+int eg_ctx_device(eg_ctx* ctx);
+
+/* allocBuffer(ctx, size): gpu.nim:41, cl.nim:101-106. */
+int eg_buf_alloc(eg_ctx* ctx, size_t bytes, eg_buf** out);
+/* Wrap device memory owned by the caller (never freed by the library). */
+int eg_buf_wrap(eg_ctx* ctx, void* device_ptr, size_t bytes, eg_buf** out);
+/* dealloc(buffer): cl.nim:108-109 (the reference never calls it; here the caller must). */
+int eg_buf_free(eg_buf* buf);
+size_t eg_buf_size(const eg_buf* buf);
+void* eg_buf_ptr(const eg_buf* buf);
+/* write(buffer, data, size): gpu.nim:42, cl.nim:111-116. Blocking; bytes must equal the buffer size. */
+int eg_buf_write(eg_buf* buf, const void* host, size_t bytes);
+/* readInto(buffer, data): gpu.nim:45-46, cl.nim:128-139. Blocking; bytes must equal the buffer size. */
+int eg_buf_read(eg_buf* buf, void* host, size_t bytes);
+/* fill(buffer, value): gpu.nim:44, cl.nim:122-126. Asynchronous; pattern_bytes in {1,2,4,8}. */
+int eg_buf_fill(eg_buf* buf, const void* pattern, size_t pattern_bytes);
+
+/* compile(ctx, name, source): gpu.nim:48-49, cl.nim:149-179.  `source` is HIP C++ text holding
+ * an `extern "C" __global__` function called `name`; built with hiprtc for the context's
+ * device.  On failure the build log is in eg_last_error() (cl.nim:163-171). */
+int eg_kernel_compile(eg_ctx* ctx, const char* name, const char* source, eg_kernel** out);
+int eg_kernel_free(eg_kernel* kernel);
+/* arg(kernel, index, buffer): gpu.nim:51, cl.nim:186-188.  Arguments are sticky like
+ * clSetKernelArg: the JIT stub sets them, then launches (llvmgen.nim:461-500). */
+int eg_kernel_set_arg_buf(eg_kernel* kernel, int index, eg_buf* buf);
+/* arg[T](kernel, index, value): gpu.nim:50, cl.nim:181-184 (T = int / float32 / float64). */
+int eg_kernel_set_arg_i64(eg_kernel* kernel, int index, int64_t value);
+int eg_kernel_set_arg_f32(eg_kernel* kernel, int index, float value);
+int eg_kernel_set_arg_f64(eg_kernel* kernel, int index, double value);
+/* run(kernel, groupSize, localSize): gpu.nim:52, cl.nim:190-207.  dims in 1..3, dimension 0
+ * is the fastest varying (passes.nim:2439-2448). groups[d] work-groups of local[d] threads. */
+int eg_kernel_launch(eg_kernel* kernel, int dims, const int64_t* groups, const int64_t* local);
+
+/* ------------------------------------------------------------------ group 2: library -- */
+/* All functions enqueue on the context's stream and return immediately.  `accumulate` != 0
+ * means `out += value` (the `++=` of parser.nim:677-681 on an already written tensor),
+ * 0 means `out = value` (first writer, passes.nim:888-897). */
+
+/* Contraction  C[m,n] (+)= sum_k opA(m,k) * opB(k,n)  (+ bias[n]).
+ *   trans_a == 0: A is [M,K] row-major (lda >= K);  != 0: A is [K,M] (lda >= M)
+ *   trans_b == 0: B is [K,N] row-major (ldb >= N);  != 0: B is [N,K] (ldb >= K)
+ * Covers matmul (base.nim:27-28), dense forward with its bias kernel folded in
+ * (dnn.nim:19-24), and the two derived gradient contractions of passes.nim:519-549:
+ *   gradA[y,it] += g[y,x]*B[it,x]  -> trans_b = 1      gradB[it,x] += A[y,it]*g[y,x] -> trans_a = 1
+ * bias may be NULL. */
+int eg_sgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
+             const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc,
+             int accumulate, const float* bias);
+
+/* out[y,x] (+)= bias[x]   — dense's second kernel, dnn.nim:22-24. out is [rows, cols]. */
+int eg_bias_add(eg_ctx* ctx, int64_t rows, int64_t cols, const float* bias, float* out,
+                int accumulate);
+/* out[x] (+)= sum_y in[y,x]  — derived bias gradient (Appendix A.1 G5/G2 of SURVEY.md). */
+int eg_colsum(eg_ctx* ctx, int64_t rows, int64_t cols, const float* in, float* out,
+              int accumulate);
+/* out[y] (+)= sum_x in[y,x]  — softmax.sums without the exp (dnn.nim:90-92 shape). */
+int eg_rowsum(eg_ctx* ctx, int64_t rows, int64_t cols, const float* in, float* out,
+              int accumulate);
+/* out[0] (+)= sum_i in[i]    — scalar losses, base.nim:57-67 (no GPU lowering in the reference). */
+int eg_sum(eg_ctx* ctx, int64_t n, const float* in, float* out, int accumulate);
+/* y[i] += alpha * x[i]       — gradientDescent, base.nim:37-38 (alpha = -rate). */
+int eg_axpy(eg_ctx* ctx, int64_t n, float alpha, const float* x, float* y);
+/* out[i] = value             — result zeroing (model.nim:318, 383), gradLoss = 1 (passes.nim:575-606). */
+int eg_fill_f32(eg_ctx* ctx, int64_t n, float value, float* out);
+
+/* Fixed-function elementwise maps of the layer library (raw-indexed `{it}` kernels). */
+enum eg_map_op {
+  EG_MAP_IDENTITY = 0,
+  EG_MAP_RELU = 1,        /* select(x >= 0, x, 0)                      dnn.nim:26-27  */
+  EG_MAP_LEAKY_RELU = 2,  /* select(x >= 0, 1, p) * x                  dnn.nim:29-30  */
+  EG_MAP_SIGMOID = 3,     /* 1 / (1 + exp(-x))                         dnn.nim:32-33  */
+  EG_MAP_TANH = 4,        /* (e^x - e^-x) / (e^x + e^-x)               dnn.nim:35-40  */
+  EG_MAP_SCALE = 5,       /* x * p                                     base.nim:24    */
+  EG_MAP_SIN = 6,         /* sin(x)                                    dnn.nim:42-43  */
+  EG_MAP_XOR_LEAKY = 7,   /* select(x <= 0, p*x, x)   xor_from_scratch.nim:22          */
+  EG_MAP_EXP = 8
+};
+/* out[i] (+)= f(in[i]; param). */
+int eg_map(eg_ctx* ctx, int op, int64_t n, const float* in, float* out, float param,
+           int accumulate);
+/* gin[i] (+)= gout[i] * f'(in[i]; param) — the kernel passes.nim:519-549 derives from the map
+ * above (recomputing from the forward input, no saved activation). */
+int eg_map_grad(eg_ctx* ctx, int op, int64_t n, const float* in, const float* gout, float* gin,
+                float param, int accumulate);
+
+/* Direct (im2col-free) convolution, valid padding, stride 1 (dnn.nim:45-49):
+ *   out[n,y,x,f] (+)= sum_{dy,dx,c} img[n,y+dy,x+dx,c] * flt[f,dy,dx,c]
+ * img [N,H,W,C], flt [F,FH,FW,C], out [N,H-FH+1,W-FW+1,F], all dense row-major. */
+int eg_conv2_nhwc(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64_t C, int64_t F, int64_t FH,
+                  int64_t FW, const float* img, const float* flt, float* out, int accumulate);
+
+/* ------------------------------------------------------------------ group 3: model ---- */
+/* A program is the text form of exprgrad's `Program` (ir.nim:247-270) before `generate`:
+ * tensors, targets, and per target the ordered list of `++=` kernel descriptions
+ * (loops + reads + expr + write, ir.nim:211-230) plus the GenBackwards / GenGradient
+ * placeholders (ir.nim:196-209).  Grammar: DESIGN.md "Kernel-description text".
+ *
+ * eg_model_compile does what newModel does for a CompileGpu target (model.nim:232-251):
+ * autodiff + dead-kernel elimination, pattern-match every kernel to a library kernel or
+ * generate HIP source for it, hiprtc-build, allocate parameters. */
+int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out);
+int eg_model_free(eg_model* model);
+
+/* Introspection (model.emitIr, model.nim:262-264: the lowered plan as text). Returned pointer
+ * is owned by the model and valid until the next call of the same function. */
+const char* eg_model_plan_text(eg_model* model);
+/* Number of kernels in a target after autodiff + elimination, or -1. */
+int eg_model_kernel_count(eg_model* model, const char* target);
+
+/* Parameter / cache access (Model.params, model.nim:37-38).  Parameters live on the device;
+ * these copy (blocking).  `name` is the tensor name or "#<id>". */
+int eg_model_tensor_count(eg_model* model);
+int eg_model_param_info(eg_model* model, int tensor_id, int* kind, int* rank, int64_t* shape8,
+                        char* name, size_t name_cap);
+int eg_model_param_write(eg_model* model, int tensor_id, const float* host, int64_t count);
+int eg_model_param_read(eg_model* model, int tensor_id, float* host, int64_t count);
+/* Device pointer of a parameter or of its gradient in `target` (NULL if absent). For the
+ * data-parallel exchange step: gradients are laid out back to back in one flat bucket. */
+int eg_model_grad_bucket(eg_model* model, const char* target, float** device_ptr,
+                         int64_t* count);
+int eg_model_param_ptr(eg_model* model, int tensor_id, float** device_ptr, int64_t* count);
+
+/* Bind an input (writeInput, model.nim:357-368).  Host form copies H2D (blocking, as the
+ * reference does on every call); device form borrows the pointer. */
+int eg_model_set_input_host(eg_model* model, const char* name, const float* host, int rank,
+                            const int64_t* shape);
+int eg_model_set_input_device(eg_model* model, const char* name, const float* device_ptr,
+                              int rank, const int64_t* shape);
+
+/* call (model.nim:392-406): infer shapes from the bound inputs, (re)allocate and zero the
+ * target's result tensors, run its kernel list.  Asynchronous. */
+int eg_model_run(eg_model* model, const char* target);
+/* Split form used by the data-parallel step: everything up to (not including) the optimizer
+ * kernels, then the optimizer kernels.  run == run_backward + run_update. */
+int eg_model_run_backward(eg_model* model, const char* target);
+int eg_model_run_update(eg_model* model, const char* target);
+/* Scale applied to the seed gradient gradLoss (passes.nim:594-596) — B_local/B_global for
+ * batch-mean losses under data parallelism.  Default 1. */
+int eg_model_set_grad_scale(eg_model* model, float scale);
+
+/* readOutput (model.nim:370-376): shape of / blocking copy of the target's output tensor. */
+int eg_model_output_shape(eg_model* model, const char* target, int* rank, int64_t* shape8);
+int eg_model_read_output(eg_model* model, const char* target, float* host, int64_t count);
+/* Any tensor of the last run by id (debugging / parity tests). */
+int eg_model_tensor_shape(eg_model* model, int tensor_id, int* rank, int64_t* shape8);
+int eg_model_read_tensor(eg_model* model, int tensor_id, float* host, int64_t count);
+int eg_model_tensor_ptr(eg_model* model, int tensor_id, float** device_ptr, int64_t* count);
+
+/* Model.epoch (model.nim:39, bumped by fit at model.nim:436). */
+int eg_model_set_epoch(eg_model* model, int64_t epoch);
+int64_t eg_model_epoch(eg_model* model);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXPRGRAD_HIP_H */

@@ -1,0 +1,68 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads and exports exactly the
+symbols include/exprgrad_hip.h declares (no compute: there is no GPU in the build container)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "exprgrad_hip.h")
+
+
+def header_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(eg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_three_groups():
+    syms = header_symbols()
+    for must in ("eg_ctx_create", "eg_buf_write", "eg_kernel_compile", "eg_kernel_launch", "eg_sgemm",
+                 "eg_conv2_nhwc", "eg_model_compile", "eg_model_run"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from exprgrad_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = [s for s in header_symbols() if s not in exported]
+    assert not missing, f"declared in the header but not exported: {missing}"
+
+
+def test_binding_matches_header():
+    from exprgrad_amd import _lib
+    assert _lib.declared_symbols() == header_symbols()
+    handle = _lib.lib()  # sets argtypes for every symbol; raises if one is absent
+    assert handle.eg_version() >= 1000
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    """Without a GPU every entry point must fail loudly (GpuError), never compute on the CPU."""
+    import ctypes
+    import exprgrad_amd as eg
+    from exprgrad_amd import _lib
+    n = ctypes.c_int(-1)
+    _lib.call("eg_device_count", ctypes.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(eg.GpuError):
+        eg.newGpuContext()
+    h = ctypes.c_void_p()
+    rc = _lib.lib().eg_ctx_create(0, ctypes.byref(h))
+    assert rc != 0 and _lib.last_error()
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure; nothing under exprgrad_amd/ may reference it."""
+    pkg = os.path.join(ROOT, "exprgrad_amd")
+    offenders = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                if re.search(r"\boracle\b|refcpu|librefcpu", text):
+                    offenders.append(os.path.join(dirpath, f))
+    assert not offenders, offenders
