@@ -165,7 +165,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int VEC, bool EDGE, bool CONV>
-__global__ __launch_bounds__(NT) void gemm_f32_mfma_kernel(GemmArgs a) {
+__global__ __launch_bounds__(NT, 4) void gemm_f32_mfma_kernel(GemmArgs a) {
   constexpr int WAVES_N = BN / WN;
   constexpr int MI = WM / 32, NI = WN / 32;
   static_assert((BM / WM) * WAVES_N * 64 == NT, "4 waves per block");

@@ -22,7 +22,7 @@ def dev(ctx, arr):
 
 
 def gemm_case(ctx, refcpu, M, N, K, trans_a=False, trans_b=False, accumulate=False, bias=False, seed=0,
-              threads=8):
+              threads=8, return_inputs=False):
     rng = np.random.default_rng(seed)
     a = rng.random((K, M) if trans_a else (M, K), dtype=np.float32)
     b = (rng.random((N, K) if trans_b else (K, N), dtype=np.float32) * 2 - 1).astype(np.float32)
@@ -35,6 +35,8 @@ def gemm_case(ctx, refcpu, M, N, K, trans_a=False, trans_b=False, accumulate=Fal
     dbias = dev(ctx, bv) if bias else None
     ops.sgemm(ctx, M, N, K, da, a.shape[1], db, b.shape[1], dc, N, trans_a, trans_b, accumulate, dbias)
     got = dc.read()
+    if return_inputs:
+        return rel_err(got, want), got, want, a, b
     return rel_err(got, want), got, want
 
 
@@ -115,11 +117,8 @@ def test_matmul_vs_f64_shadow(gpu_ctx, refcpu):
     # within 1e-5 of the exact product at K = 1024
     M = N = 128
     K = 1024
-    rng = np.random.default_rng(11)
-    a = rng.random((M, K), dtype=np.float32)
-    b = rng.random((K, N), dtype=np.float32)
+    err, got, want, a, b = gemm_case(gpu_ctx, refcpu, M, N, K, seed=11, return_inputs=True)
     exact = refcpu.dgemm(a, b)
-    err, got, want = gemm_case(gpu_ctx, refcpu, M, N, K, seed=11)
     assert rel_err(want, exact) <= TOL
     assert rel_err(got, exact) <= TOL
     assert err <= TOL
