@@ -91,9 +91,11 @@ _SIGS = {
     "eg_model_set_grad_scale": (c_int, [c_void_p, c_f32]),
     "eg_model_output_shape": (c_int, [c_void_p, c_char_p, P(c_int), P(c_i64)]),
     "eg_model_read_output": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),
-    "eg_model_tensor_shape": (c_int, [c_void_p, c_int, P(c_int), P(c_i64)]),
-    "eg_model_read_tensor": (c_int, [c_void_p, c_int, c_void_p, c_i64]),
-    "eg_model_tensor_ptr": (c_int, [c_void_p, c_int, P(c_void_p), P(c_i64)]),
+    "eg_model_tensor_shape": (c_int, [c_void_p, c_char_p, c_int, P(c_int), P(c_i64)]),
+    "eg_model_read_tensor": (c_int, [c_void_p, c_char_p, c_int, c_void_p, c_i64]),
+    "eg_model_tensor_ptr": (c_int, [c_void_p, c_char_p, c_int, P(c_void_p), P(c_i64)]),
+    "eg_model_bind_grad_bucket": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),
+    "eg_model_clear_inputs": (c_int, [c_void_p]),
     "eg_model_set_epoch": (c_int, [c_void_p, c_i64]),
     "eg_model_epoch": (c_i64, [c_void_p]),
 }

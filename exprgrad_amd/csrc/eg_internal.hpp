@@ -47,6 +47,8 @@ struct eg_ctx {
   std::string arch;
 };
 
+struct eg_kernel;
+
 struct eg_buf {
   eg_ctx* ctx = nullptr;
   void* ptr = nullptr;
@@ -57,6 +59,12 @@ struct eg_buf {
 namespace eg {
 // Ensure ctx->workspace holds at least `bytes`; synchronises the stream if it has to grow.
 int ensure_workspace(eg_ctx* ctx, size_t bytes);
+// Launch a hiprtc-built kernel with an explicit argument array (bypasses the sticky arguments).
+int kernel_launch_raw(eg_kernel* kernel, unsigned gx, unsigned gy, unsigned gz, unsigned block, void** args);
+// Column sum with caller-provided scratch (colsum_scratch_floats(...) floats); see reduce.hip.
+long colsum_scratch_floats(const eg_ctx* ctx, long rows, long cols);
+int colsum_with_scratch(eg_ctx* ctx, long rows, long cols, const float* in, float* out, int accumulate,
+                        float* scratch);
 inline int set_device(eg_ctx* ctx) {
   EG_HIP_CHECK(hipSetDevice(ctx->device));
   return EG_OK;

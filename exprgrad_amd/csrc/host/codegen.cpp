@@ -1,0 +1,321 @@
+#include "codegen.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <set>
+
+#include "../eg_internal.hpp"
+
+namespace eg {
+namespace kd {
+
+namespace {
+
+struct Emitter {
+  const Kernel& k;
+  std::vector<Ty> ty;
+  std::vector<Slot> slots;
+  std::string body;
+
+  explicit Emitter(const Kernel& kernel) : k(kernel), ty(infer_types(kernel)) {}
+
+  int slot(Slot::Kind kind, int a = 0, int b = 0) {
+    for (size_t i = 0; i < slots.size(); ++i)
+      if (slots[i].kind == kind && slots[i].a == a && slots[i].b == b) return (int)i;
+    Slot s;
+    s.kind = kind;
+    s.a = a;
+    s.b = b;
+    slots.push_back(s);
+    return (int)slots.size() - 1;
+  }
+  std::string p(int i) const { return "p" + std::to_string(i); }
+  std::string reg(int r) const { return "r" + std::to_string(r); }
+
+  static std::string f32_literal(double v) {
+    const float f = (float)v;  // const_real(float type, double): llvmgen.nim:215-216
+    if (std::isinf(f)) return f > 0 ? "__builtin_inff()" : "(-__builtin_inff())";
+    if (std::isnan(f)) return "__builtin_nanf(\"\")";
+    char buf[64];
+    snprintf(buf, sizeof(buf), "%.9gf", (double)f);
+    std::string s = buf;
+    // "1f" is not a valid literal: make sure there is a '.' or an exponent
+    if (s.find('.') == std::string::npos && s.find('e') == std::string::npos && s.find("inf") == std::string::npos)
+      s.insert(s.size() - 1, ".0");
+    return s;
+  }
+
+  // element offset of a tensor op; op_index: reads 0..n-1, write = n
+  std::string flat_index(const Op& op, int op_index) {
+    std::string s;
+    for (size_t d = 0; d < op.dims.size(); ++d) {
+      const Lin& l = op.dims[d];
+      std::string term = std::to_string(l.constant) + "L";
+      for (auto& f : l.factors) term += " + " + std::to_string(f.second) + "L * " + reg(f.first);
+      if (!op.raw) term = p(slot(Slot::Stride, op_index, (int)d)) + " * (" + term + ")";
+      s += (d ? " + " : "") + term;
+    }
+    if (s.empty()) s = "0L";
+    return s;
+  }
+
+  int emit_instr(const Instr& ins, int index, std::string& out) {
+    const Ty t = ty[ins.res];
+    const char* ctype = t == Ty::Scalar ? "float" : (t == Ty::Index ? "long" : "bool");
+    auto a = [&](int i) { return reg(ins.args[i]); };
+    const bool scalar_args = !ins.args.empty() && ty[ins.args[0]] == Ty::Scalar;
+    std::string e;
+    switch (ins.kind) {
+      case IK::Scalar: e = f32_literal(ins.lit); break;
+      case IK::Index: e = std::to_string((long)ins.lit) + "L"; break;
+      case IK::Boolean: e = ins.lit != 0 ? "true" : "false"; break;
+      case IK::Add: e = a(0) + " + " + a(1); break;
+      case IK::Sub: e = a(0) + " - " + a(1); break;
+      case IK::Mul: e = a(0) + " * " + a(1); break;
+      case IK::Div: e = a(0) + " / " + a(1); break;
+      case IK::IndexDiv: e = a(0) + " / " + a(1); break;
+      case IK::Mod: e = a(0) + " % " + a(1); break;
+      case IK::Wrap: e = "((" + a(0) + " % " + a(1) + ") + " + a(1) + ") % " + a(1); break;  // llvmgen.nim:227-230
+      case IK::Negate: e = "-" + a(0); break;
+      case IK::Sin: e = "sinf(" + a(0) + ")"; break;
+      case IK::Cos: e = "cosf(" + a(0) + ")"; break;
+      case IK::Exp: e = "expf(" + a(0) + ")"; break;
+      case IK::Pow: e = "powf(" + a(0) + ", " + a(1) + ")"; break;
+      case IK::Sqrt: e = "sqrtf(" + a(0) + ")"; break;
+      case IK::Log: e = "logf(" + a(0) + ") / logf(" + a(1) + ")"; break;
+      case IK::Log10: e = "log10f(" + a(0) + ")"; break;
+      case IK::Log2: e = "log2f(" + a(0) + ")"; break;
+      case IK::Ln: e = "logf(" + a(0) + ")"; break;
+      case IK::Eq: e = a(0) + " == " + a(1); break;  // ordered compare: false on NaN (llvmgen.nim:253)
+      case IK::Lt: e = a(0) + " < " + a(1); break;
+      case IK::Le: e = a(0) + " <= " + a(1); break;
+      case IK::And: e = a(0) + " && " + a(1); break;
+      case IK::Or: e = a(0) + " || " + a(1); break;
+      case IK::Select: e = a(0) + " ? " + a(1) + " : " + a(2); break;
+      case IK::ToScalar: e = "(float)" + a(0); break;  // sitofp
+      case IK::ToIndex: e = "(long)" + a(0); break;    // fptosi
+      case IK::Shape: case IK::Len: case IK::ShapeLen: case IK::Epoch:
+        e = p(slot(Slot::InstrVal, index));
+        break;
+    }
+    (void)scalar_args;
+    out += std::string("      const ") + ctype + " " + reg(ins.res) + " = " + e + ";\n";
+    return EG_OK;
+  }
+
+  // loads + expression, at indentation of the innermost body
+  void emit_body(std::string& out) {
+    for (size_t i = 0; i < k.reads.size(); ++i) {
+      const Op& r = k.reads[i];
+      out += "      const float " + reg(r.reg) + " = t" + std::to_string(r.tensor) + "[" + flat_index(r, (int)i) + "];\n";
+    }
+    for (size_t i = 0; i < k.instrs.size(); ++i) emit_instr(k.instrs[i], (int)i, out);
+  }
+
+  std::string setup_decls() {
+    std::string s;
+    for (size_t i = 0; i < k.setup.size(); ++i)
+      s += "  const long " + reg(k.setup[i].res) + " = " + p(slot(Slot::SetupVal, (int)i)) + ";\n";
+    return s;
+  }
+};
+
+std::vector<int> distinct_tensors(const Kernel& k, bool include_write) {
+  std::vector<int> out;
+  auto add = [&](int t) {
+    for (int x : out)
+      if (x == t) return;
+    out.push_back(t);
+  };
+  if (include_write) add(k.write.tensor);
+  for (auto& r : k.reads) add(r.tensor);
+  return out;
+}
+
+std::string signature(const std::string& name, const std::vector<int>& tensors, int write_tensor, bool partial_first,
+                      size_t nslots) {
+  std::string s = "extern \"C\" __global__ void __launch_bounds__(256) " + name + "(";
+  bool first = true;
+  if (partial_first) {
+    s += "float* __restrict__ partial";
+    first = false;
+  }
+  for (int t : tensors) {
+    s += first ? "" : ", ";
+    first = false;
+    // the written tensor may also be read (optimizer kernels read their own parameter): no restrict
+    s += (t == write_tensor && !partial_first ? "float* t" : "const float* t") + std::to_string(t);
+  }
+  for (size_t i = 0; i < nslots; ++i) {
+    s += first ? "" : ", ";
+    first = false;
+    s += "long p" + std::to_string(i);
+  }
+  s += ")";
+  return s;
+}
+
+}  // namespace
+
+void split_loops(const Kernel& k, std::vector<int>& indep, std::vector<int>& red, bool& scatter) {
+  indep.clear();
+  red.clear();
+  std::set<int> ind_regs;
+  // identifyIndependent (passes.nim:1774-1782): iterators that appear bare in a write dimension,
+  // taken in write-dimension order so the last one is the fastest varying in memory.
+  for (auto& d : k.write.dims) {
+    const int r = d.only_register();
+    if (!r || ind_regs.count(r)) continue;
+    for (size_t l = 0; l < k.loops.size(); ++l)
+      if (k.loops[l].reg == r) {
+        ind_regs.insert(r);
+        indep.push_back((int)l);
+      }
+  }
+  for (size_t l = 0; l < k.loops.size(); ++l)
+    if (!ind_regs.count(k.loops[l].reg)) red.push_back((int)l);
+  scatter = false;
+  for (auto& d : k.write.dims)
+    for (auto& f : d.factors)
+      for (int l : red)
+        if (k.loops[l].reg == f.first) scatter = true;
+}
+
+bool split_reduction_capable(const Kernel& k) {
+  std::vector<int> indep, red;
+  bool scatter;
+  split_loops(k, indep, red, scatter);
+  if (scatter || red.empty()) return false;
+  // every write dim is a distinct bare iterator, or a constant (only when there is no independent loop)
+  std::set<int> seen;
+  for (auto& d : k.write.dims) {
+    const int r = d.only_register();
+    if (r) {
+      if (seen.count(r)) return false;
+      seen.insert(r);
+    } else if (!d.factors.empty() || d.constant != 0) {
+      return false;
+    }
+  }
+  if (seen.size() != indep.size()) return false;
+  if (indep.empty()) return true;  // single element 0
+  // constants mixed with iterators would need the other dims to have extent 1: not handled
+  for (auto& d : k.write.dims)
+    if (!d.only_register()) return false;
+  return true;
+}
+
+int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out) {
+  Emitter em(k);
+  out = GenericSource();
+  out.name = name;
+  split_loops(k, out.indep, out.red, out.scatter);
+  const int s_acc = em.slot(Slot::Accumulate);
+  const int s_total = em.slot(Slot::Total);
+  std::string code;
+  code += "  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;\n";
+  code += "  if (gid >= " + em.p(s_total) + ") return;\n";
+  code += em.setup_decls();
+  // decode: last independent loop varies fastest
+  for (size_t i = out.indep.size(); i-- > 0;) {
+    const int l = out.indep[i];
+    const std::string ext = em.p(em.slot(Slot::LoopExtent, l)), start = em.p(em.slot(Slot::LoopStart, l));
+    if (i == 0)
+      code += "  const long " + em.reg(k.loops[l].reg) + " = " + start + " + gid;\n";
+    else
+      code += "  const long " + em.reg(k.loops[l].reg) + " = " + start + " + gid % " + ext + "; gid /= " + ext + ";\n";
+  }
+  const int write_index = (int)k.reads.size();
+  std::string inner;
+  em.emit_body(inner);
+  if (out.scatter) {
+    // write index moves with the serial loops: read-modify-write per iteration (the tensor was zeroed)
+    for (int l : out.red) {
+      const std::string r = em.reg(k.loops[l].reg);
+      code += "  for (long " + r + " = " + em.p(em.slot(Slot::LoopStart, l)) + "; " + r + " < " +
+              em.p(em.slot(Slot::LoopStart, l)) + " + " + em.p(em.slot(Slot::LoopExtent, l)) + "; ++" + r + ") {\n";
+    }
+    code += inner;
+    code += "      { const long w = " + em.flat_index(k.write, write_index) + "; t" + std::to_string(k.write.tensor) +
+            "[w] = t" + std::to_string(k.write.tensor) + "[w] + " + em.reg(k.result) + "; }\n";
+    for (size_t i = 0; i < out.red.size(); ++i) code += "  }\n";
+  } else {
+    code += "  float acc = 0.0f;\n";
+    for (int l : out.red) {
+      const std::string r = em.reg(k.loops[l].reg);
+      code += "  for (long " + r + " = " + em.p(em.slot(Slot::LoopStart, l)) + "; " + r + " < " +
+              em.p(em.slot(Slot::LoopStart, l)) + " + " + em.p(em.slot(Slot::LoopExtent, l)) + "; ++" + r + ") {\n";
+    }
+    code += "    {\n" + inner;
+    code += out.red.empty() ? "      acc = " + em.reg(k.result) + ";\n" : "      acc = acc + " + em.reg(k.result) + ";\n";
+    code += "    }\n";
+    for (size_t i = 0; i < out.red.size(); ++i) code += "  }\n";
+    const std::string wt = "t" + std::to_string(k.write.tensor);
+    code += "  const long w = " + em.flat_index(k.write, write_index) + ";\n";
+    code += "  " + wt + "[w] = " + em.p(s_acc) + " ? " + wt + "[w] + acc : acc;\n";
+  }
+  out.tensor_args = distinct_tensors(k, true);
+  out.slots = em.slots;
+  out.source = signature(name, out.tensor_args, k.write.tensor, false, out.slots.size()) + " {\n" + code + "}\n";
+  return EG_OK;
+}
+
+int generate_mode_b(const Kernel& k, const std::string& name, int tx, GenericSource& out) {
+  Emitter em(k);
+  out = GenericSource();
+  out.name = name;
+  split_loops(k, out.indep, out.red, out.scatter);
+  if (!split_reduction_capable(k)) {
+    set_error("kernel is not eligible for the split reduction template");
+    return EG_ERR_UNSUPPORTED;
+  }
+  out.tx = tx;
+  out.ty = 256 / tx;
+  const int s_total = em.slot(Slot::Total);
+  const int s_rtotal = em.slot(Slot::RTotal);
+  const int s_chunk = em.slot(Slot::Chunk);
+  std::string code;
+  code += "  __shared__ float red[256];\n";
+  code += "  const int tx = threadIdx.x % " + std::to_string(tx) + ", ty = threadIdx.x / " + std::to_string(tx) + ";\n";
+  code += "  long ii = (long)blockIdx.y * " + std::to_string(tx) + " + tx;\n";
+  code += "  const bool active = ii < " + em.p(s_total) + ";\n";
+  code += "  const long flat_out = ii;\n";
+  code += em.setup_decls();
+  code += "  float acc = 0.0f;\n";
+  code += "  if (active) {\n";
+  for (size_t i = out.indep.size(); i-- > 0;) {
+    const int l = out.indep[i];
+    const std::string ext = em.p(em.slot(Slot::LoopExtent, l)), start = em.p(em.slot(Slot::LoopStart, l));
+    if (i == 0)
+      code += "  const long " + em.reg(k.loops[l].reg) + " = " + start + " + ii;\n";
+    else
+      code += "  const long " + em.reg(k.loops[l].reg) + " = " + start + " + ii % " + ext + "; ii /= " + ext + ";\n";
+  }
+  code += "  const long r_begin = (long)blockIdx.x * " + em.p(s_chunk) + ";\n";
+  code += "  long r_end = r_begin + " + em.p(s_chunk) + "; if (r_end > " + em.p(s_rtotal) + ") r_end = " + em.p(s_rtotal) + ";\n";
+  code += "  for (long rr = r_begin + ty; rr < r_end; rr += " + std::to_string(out.ty) + ") {\n";
+  code += "    long rem = rr;\n";
+  for (size_t i = out.red.size(); i-- > 0;) {  // innermost reduction loop varies fastest
+    const int l = out.red[i];
+    const std::string ext = em.p(em.slot(Slot::LoopExtent, l)), start = em.p(em.slot(Slot::LoopStart, l));
+    if (i == 0)
+      code += "    const long " + em.reg(k.loops[l].reg) + " = " + start + " + rem;\n";
+    else
+      code += "    const long " + em.reg(k.loops[l].reg) + " = " + start + " + rem % " + ext + "; rem /= " + ext + ";\n";
+  }
+  std::string inner;
+  em.emit_body(inner);
+  code += "    {\n" + inner + "      acc = acc + " + em.reg(k.result) + ";\n    }\n";
+  code += "  }\n  }\n";
+  code += "  red[threadIdx.x] = acc;\n  __syncthreads();\n";
+  code += "  if (ty == 0 && active) {\n    float s = 0.0f;\n";
+  code += "    for (int t = 0; t < " + std::to_string(out.ty) + "; ++t) s = s + red[t * " + std::to_string(tx) + " + tx];\n";
+  code += "    partial[(long)blockIdx.x * " + em.p(s_total) + " + flat_out] = s;\n  }\n";
+  out.tensor_args = distinct_tensors(k, false);
+  out.slots = em.slots;
+  out.source = signature(name, out.tensor_args, k.write.tensor, true, out.slots.size()) + " {\n" + code + "}\n";
+  return EG_OK;
+}
+
+}  // namespace kd
+}  // namespace eg

@@ -1,26 +1,1078 @@
-// TEMPORARY stubs for group 3 until the kernel-description compiler lands (replaced next commit).
+// Group 3 of the C ABI: compile a kernel-description program for the GPU and run its targets.
+//
+// What this replaces in the reference (for a CompileGpu target):
+//   newModel             model.nim:215-251   passes + parameter allocation + kernel build
+//   allocShapes (gpu)    model.nim:302-318   result tensors (re)allocated and zero-filled per call
+//   flushStateTensors    model.nim:326-345   parameters live on the device (and, unlike the
+//                                            reference, device-side updates are what readers see)
+//   writeInput/readOutput model.nim:357-376
+//   call / apply         model.nim:392-411   infer shapes, run the target's kernel list in order
+//   runGpuKernel & co.   model.nim:148-172   one launch per lowered kernel
+//
+// Every live kernel of a target is matched against the hand-written library
+// (contraction -> eg_sgemm with the following bias kernel folded into its epilogue,
+// convolution -> eg_conv2_nhwc, gradLoss seed -> eg_fill_f32); everything else gets generated
+// HIP source (codegen.hpp) built once with hiprtc.  A plan (shapes, launch arguments, result
+// arena) is cached per input-shape signature — the reference re-solves shapes on every call
+// (passes.nim:1386-1436).
+#include <cstring>
+#include <memory>
+#include <random>
+#include <set>
+#include <sstream>
+
 #include "../eg_internal.hpp"
-#define STUB(sig) extern "C" int sig { eg::set_error("group 3 (model) not built yet"); return EG_ERR_UNSUPPORTED; }
-STUB(eg_model_compile(eg_ctx*, const char*, eg_model**))
-STUB(eg_model_free(eg_model*))
-extern "C" const char* eg_model_plan_text(eg_model*) { return ""; }
-extern "C" int eg_model_kernel_count(eg_model*, const char*) { return -1; }
-extern "C" int eg_model_tensor_count(eg_model*) { return 0; }
-STUB(eg_model_param_info(eg_model*, int, int*, int*, int64_t*, char*, size_t))
-STUB(eg_model_param_write(eg_model*, int, const float*, int64_t))
-STUB(eg_model_param_read(eg_model*, int, float*, int64_t))
-STUB(eg_model_grad_bucket(eg_model*, const char*, float**, int64_t*))
-STUB(eg_model_param_ptr(eg_model*, int, float**, int64_t*))
-STUB(eg_model_set_input_host(eg_model*, const char*, const float*, int, const int64_t*))
-STUB(eg_model_set_input_device(eg_model*, const char*, const float*, int, const int64_t*))
-STUB(eg_model_run(eg_model*, const char*))
-STUB(eg_model_run_backward(eg_model*, const char*))
-STUB(eg_model_run_update(eg_model*, const char*))
-STUB(eg_model_set_grad_scale(eg_model*, float))
-STUB(eg_model_output_shape(eg_model*, const char*, int*, int64_t*))
-STUB(eg_model_read_output(eg_model*, const char*, float*, int64_t))
-STUB(eg_model_tensor_shape(eg_model*, int, int*, int64_t*))
-STUB(eg_model_read_tensor(eg_model*, int, float*, int64_t))
-STUB(eg_model_tensor_ptr(eg_model*, int, float**, int64_t*))
-STUB(eg_model_set_epoch(eg_model*, int64_t))
-extern "C" int64_t eg_model_epoch(eg_model*) { return 0; }
+#include "codegen.hpp"
+#include "kd.hpp"
+
+using namespace eg::kd;
+using eg::set_error;
+
+namespace {
+
+struct GemmMatch {
+  int a_read = 0, b_read = 0;  // indices into k.reads
+  bool trans_a = false, trans_b = false;
+  int li = 0, lj = 0, lk = 0;  // loop indices of m, n, k
+};
+
+bool bare2(const Op& op, int& r0, int& r1) {
+  if (op.raw || op.dims.size() != 2) return false;
+  r0 = op.dims[0].only_register();
+  r1 = op.dims[1].only_register();
+  return r0 && r1 && r0 != r1;
+}
+
+int loop_index(const Kernel& k, int reg) {
+  for (size_t l = 0; l < k.loops.size(); ++l)
+    if (k.loops[l].reg == reg) return (int)l;
+  return -1;
+}
+
+// c[i,j] += a(i,k) * b(k,j)      base.nim:27-28 and its two derived forms (passes.nim:519-549)
+bool match_gemm(const Kernel& k, GemmMatch& m) {
+  if (k.instrs.size() != 1 || k.instrs[0].kind != IK::Mul || k.result != k.instrs[0].res) return false;
+  if (k.reads.size() != 2 || k.loops.size() != 3 || !k.setup.empty()) return false;
+  for (auto& lp : k.loops)
+    if (lp.has_bounds) return false;
+  const std::vector<int>& args = k.instrs[0].args;
+  if (!((args[0] == k.reads[0].reg && args[1] == k.reads[1].reg) || (args[0] == k.reads[1].reg && args[1] == k.reads[0].reg)))
+    return false;
+  int wi, wj;
+  if (!bare2(k.write, wi, wj)) return false;
+  int kk = 0;
+  for (auto& lp : k.loops)
+    if (lp.reg != wi && lp.reg != wj) kk = lp.reg;
+  if (!kk || loop_index(k, wi) < 0 || loop_index(k, wj) < 0) return false;
+  int r[2][2];
+  if (!bare2(k.reads[0], r[0][0], r[0][1]) || !bare2(k.reads[1], r[1][0], r[1][1])) return false;
+  auto is = [](const int* p, int x, int y) { return (p[0] == x && p[1] == y) || (p[0] == y && p[1] == x); };
+  for (int a = 0; a < 2; ++a) {
+    const int b = 1 - a;
+    if (is(r[a], wi, kk) && is(r[b], kk, wj)) {
+      m.a_read = a;
+      m.b_read = b;
+      m.trans_a = r[a][0] == kk;
+      m.trans_b = r[b][0] == wj;
+      m.li = loop_index(k, wi);
+      m.lj = loop_index(k, wj);
+      m.lk = loop_index(k, kk);
+      return true;
+    }
+  }
+  return false;
+}
+
+// out[y,x] += bias[x] on the tensor the preceding contraction wrote   dnn.nim:22-24
+bool match_bias(const Kernel& k, int tensor) {
+  if (!k.instrs.empty() || k.reads.size() != 1 || k.result != k.reads[0].reg || k.write.tensor != tensor) return false;
+  if (k.loops.size() != 2 || !k.setup.empty()) return false;
+  for (auto& lp : k.loops)
+    if (lp.has_bounds) return false;
+  int wi, wj;
+  if (!bare2(k.write, wi, wj)) return false;
+  const Op& b = k.reads[0];
+  return !b.raw && b.dims.size() == 1 && b.dims[0].only_register() == wj;
+}
+
+struct ConvMatch {
+  int img_read = 0, flt_read = 0;
+  bool batched = true;
+};
+
+// out[n,y,x,f] += img[n,y+dy,x+dx,c] * flt[f,dy,dx,c]   dnn.nim:45-49 (4-D) / conv2.nim:128-132 (3-D)
+bool match_conv(const Kernel& k, ConvMatch& m) {
+  if (k.instrs.size() != 1 || k.instrs[0].kind != IK::Mul || k.result != k.instrs[0].res || k.reads.size() != 2) return false;
+  if (!k.setup.empty() || k.write.raw) return false;
+  for (auto& lp : k.loops)
+    if (lp.has_bounds) return false;
+  const size_t nd = k.write.dims.size();
+  if (nd != 4 && nd != 3) return false;
+  const bool batched = nd == 4;
+  if (k.loops.size() != (batched ? 7u : 6u)) return false;
+  std::vector<int> w;
+  for (auto& d : k.write.dims) {
+    int r = d.only_register();
+    if (!r) return false;
+    w.push_back(r);
+  }
+  const int off = batched ? 1 : 0;
+  const int n = batched ? w[0] : 0, y = w[off], x = w[off + 1], f = w[off + 2];
+  for (int a = 0; a < 2; ++a) {
+    const Op& img = k.reads[a];
+    const Op& flt = k.reads[1 - a];
+    if (img.raw || flt.raw || img.dims.size() != nd || flt.dims.size() != 4) continue;
+    int ff = flt.dims[0].only_register(), dy = flt.dims[1].only_register(), dx = flt.dims[2].only_register(),
+        c = flt.dims[3].only_register();
+    if (ff != f || !dy || !dx || !c) continue;
+    std::set<int> all = {y, x, f, dy, dx, c};
+    if (batched) all.insert(n);
+    if (all.size() != (batched ? 7u : 6u)) continue;
+    auto pair_sum = [](const Lin& l, int p, int q) {
+      return l.constant == 0 && l.factors.size() == 2 && l.factor_of(p) == 1 && l.factor_of(q) == 1;
+    };
+    if (batched && img.dims[0].only_register() != n) continue;
+    if (!pair_sum(img.dims[off], y, dy) || !pair_sum(img.dims[off + 1], x, dx) || img.dims[off + 2].only_register() != c)
+      continue;
+    m.img_read = a;
+    m.flt_read = 1 - a;
+    m.batched = batched;
+    return true;
+  }
+  return false;
+}
+
+enum class StepKind { Gemm, Conv, Seed, GenericA, GenericB };
+
+struct Generic {
+  GenericSource src;
+  eg_kernel* handle = nullptr;
+};
+
+// Static (shape independent) lowering decision for one live kernel.
+struct Lowered {
+  StepKind kind = StepKind::GenericA;
+  int all_index = 0;  // index into target.all
+  GemmMatch gemm;
+  int bias_tensor = 0;  // fused bias (0 = none)
+  bool absorbed = false;  // this kernel was folded into the previous step
+  ConvMatch conv;
+  Generic mode_a;
+  std::map<int, Generic> mode_b;  // by tx
+  bool b_capable = false;
+};
+
+// Concrete launch for one plan.
+struct Launch {
+  int lowered = 0;
+  StepKind kind = StepKind::GenericA;
+  bool accumulate = true;
+  // Gemm / Conv
+  long M = 0, N = 0, K = 0, lda = 0, ldb = 0, ldc = 0;
+  int a_tensor = 0, b_tensor = 0, c_tensor = 0, bias_tensor = 0;
+  bool trans_a = false, trans_b = false;
+  long cN = 0, cH = 0, cW = 0, cC = 0, cF = 0, cFH = 0, cFW = 0;
+  // Seed
+  long count = 0;
+  // Generic
+  Generic* generic = nullptr;
+  std::vector<long> params;
+  long blocks_x = 1, blocks_y = 1;
+  long partial_rows = 0, partial_cols = 0;  // mode B second stage
+  std::vector<int> epoch_slots;             // params refreshed from Model.epoch at every launch
+};
+
+struct DevTensor {
+  float* ptr = nullptr;
+  long count = 0;
+  std::vector<long> shape;
+};
+
+struct Plan {
+  std::string key;
+  Shapes shapes;
+  std::vector<Launch> launches;
+  int n_backward = 0;  // launches before the first parameter update
+  std::map<int, long> arena_offset;  // result tensor -> float offset in the arena
+  long arena_floats = 0;
+  long zero_floats = 0;  // leading part of the arena that is zeroed before every run
+  std::vector<int> bucket_zero;  // gradient-bucket tensors that need zeroing
+  float* arena = nullptr;
+};
+
+struct TargetState {
+  Target* target = nullptr;
+  std::vector<Lowered> lowered;  // parallel to target->live
+  std::map<std::string, std::unique_ptr<Plan>> plans;
+  Plan* last = nullptr;
+  // parameter gradients of this target, laid out back to back (data-parallel exchange bucket)
+  std::vector<int> grad_tensors;       // tensor ids (GenGradient destinations of parameters)
+  std::map<int, long> bucket_offset;   // tensor id -> float offset
+  long bucket_floats = 0;
+  float* bucket = nullptr;
+  bool bucket_owned = false;
+};
+
+struct BoundInput {
+  const float* device = nullptr;
+  std::vector<long> shape;
+  float* owned = nullptr;  // staging copy of a host input
+  long owned_count = 0;
+};
+
+}  // namespace
+
+struct eg_model {
+  eg_ctx* ctx = nullptr;
+  Program prog;
+  std::map<std::string, TargetState> targets;
+  std::map<int, DevTensor> params;  // device-resident parameters (model.params)
+  std::map<int, BoundInput> inputs;
+  float grad_scale = 1.0f;
+  long epoch = 0;
+  int kernel_serial = 0;
+  std::string plan_text;
+  std::vector<eg_kernel*> kernels;
+};
+
+namespace {
+
+long prod(const std::vector<long>& s) {
+  long p = 1;
+  for (long v : s) p *= v;
+  return p;
+}
+
+long align4(long n) { return (n + 3) & ~3L; }
+
+int build_generic(eg_model* m, Generic& g) {
+  int rc = eg_kernel_compile(m->ctx, g.src.name.c_str(), g.src.source.c_str(), &g.handle);
+  if (rc) {
+    std::string msg = eg_last_error();
+    set_error("%s\n--- generated source ---\n%s", msg.c_str(), g.src.source.c_str());
+    return rc;
+  }
+  m->kernels.push_back(g.handle);
+  return EG_OK;
+}
+
+int lower_target(eg_model* m, TargetState& ts) {
+  Target& t = *ts.target;
+  ts.lowered.clear();
+  ts.lowered.resize(t.live.size());
+  for (size_t p = 0; p < t.live.size(); ++p) {
+    Lowered& lo = ts.lowered[p];
+    lo.all_index = t.live[p];
+    const Kernel& k = t.all[lo.all_index];
+    if (lo.absorbed) continue;
+    if (k.is_seed) {
+      lo.kind = StepKind::Seed;
+      continue;
+    }
+    if (match_gemm(k, lo.gemm)) {
+      lo.kind = StepKind::Gemm;
+      // dense = contraction followed by the bias kernel on the same tensor (dnn.nim:21-24):
+      // fold it into the epilogue.  Not across the backward/update boundary.
+      if (p + 1 < t.live.size() && (int)(p + 1) != t.first_update) {
+        const Kernel& nk = t.all[t.live[p + 1]];
+        if (match_bias(nk, k.write.tensor) && nk.write.dims[1].only_register() &&
+            k.write.dims.size() == 2) {
+          lo.bias_tensor = nk.reads[0].tensor;
+          ts.lowered[p + 1].absorbed = true;
+          ts.lowered[p + 1].all_index = t.live[p + 1];
+        }
+      }
+      continue;
+    }
+    if (match_conv(k, lo.conv)) {
+      lo.kind = StepKind::Conv;
+      continue;
+    }
+    lo.kind = StepKind::GenericA;
+    lo.b_capable = split_reduction_capable(k);
+    char name[64];
+    snprintf(name, sizeof(name), "eg_k%d_a", m->kernel_serial++);
+    int rc = generate_mode_a(k, name, lo.mode_a.src);
+    if (rc) return rc;
+    rc = build_generic(m, lo.mode_a);
+    if (rc) return rc;
+  }
+  return EG_OK;
+}
+
+float* tensor_ptr(eg_model* m, TargetState& ts, Plan& plan, int tid) {
+  const TensorDef& d = m->prog.tensors[tid];
+  if (d.kind == TK::Param) return m->params[tid].ptr;
+  if (d.kind == TK::Input) {
+    auto it = m->inputs.find(tid);
+    return it == m->inputs.end() ? nullptr : const_cast<float*>(it->second.device);
+  }
+  auto b = ts.bucket_offset.find(tid);
+  if (b != ts.bucket_offset.end()) return ts.bucket + b->second;
+  auto a = plan.arena_offset.find(tid);
+  if (a != plan.arena_offset.end()) return plan.arena + a->second;
+  return nullptr;
+}
+
+// write covers the whole tensor with plain stores?
+bool full_cover(const Kernel& k, const KernelInfo& info, const std::vector<long>& shape) {
+  std::set<int> seen;
+  if (k.write.raw) {
+    if (k.write.dims.size() != 1) return false;
+    const int r = k.write.dims[0].only_register();
+    const int l = r ? loop_index(k, r) : -1;
+    return l >= 0 && info.bounds[l].first == 0 && info.bounds[l].second == prod(shape);
+  }
+  if (k.write.dims.size() != shape.size()) return false;
+  for (size_t d = 0; d < shape.size(); ++d) {
+    const Lin& lin = k.write.dims[d];
+    const int r = lin.only_register();
+    if (r) {
+      const int l = loop_index(k, r);
+      if (l < 0 || seen.count(r) || info.bounds[l].first != 0 || info.bounds[l].second != shape[d]) return false;
+      seen.insert(r);
+    } else if (!(lin.factors.empty() && lin.constant == 0 && shape[d] == 1)) {
+      return false;
+    }
+  }
+  return true;
+}
+
+int fill_params(eg_model* m, const Kernel& k, const KernelInfo& info, const Shapes& shapes, const GenericSource& src,
+                bool accumulate, long total, long rtotal, long chunk, std::vector<long>& out) {
+  out.clear();
+  for (const Slot& s : src.slots) {
+    long v = 0;
+    switch (s.kind) {
+      case Slot::Accumulate: v = accumulate ? 1 : 0; break;
+      case Slot::Total: v = total; break;
+      case Slot::RTotal: v = rtotal; break;
+      case Slot::Chunk: v = chunk; break;
+      case Slot::LoopStart: v = info.bounds[s.a].first; break;
+      case Slot::LoopExtent: v = info.bounds[s.a].second - info.bounds[s.a].first; break;
+      case Slot::Stride: {
+        const Op& op = s.a < (int)k.reads.size() ? k.reads[s.a] : k.write;
+        const std::vector<long>& shp = shapes.at(op.tensor);
+        long stride = 1;
+        for (int d = (int)shp.size() - 1; d > s.b; --d) stride *= shp[d];
+        v = stride;
+        break;
+      }
+      case Slot::SetupVal: v = info.vals.at(k.setup[s.a].res); break;
+      case Slot::InstrVal: {
+        const Instr& ins = k.instrs[s.a];
+        if (ins.kind == IK::Epoch) {
+          v = m->epoch;
+        } else {
+          const std::vector<long>& shp = shapes.at(ins.tensor);
+          if (ins.kind == IK::Len) v = prod(shp);
+          else if (ins.kind == IK::ShapeLen) v = (long)shp.size();
+          else {
+            int d = ins.dim < 0 ? ins.dim + (int)shp.size() : ins.dim;
+            if (d < 0 || d >= (int)shp.size()) {
+              set_error("shape()[%d] out of range for a rank-%zu tensor", ins.dim, shp.size());
+              return EG_ERR_SHAPE;
+            }
+            v = shp[d];
+          }
+        }
+        break;
+      }
+      default: break;
+    }
+    out.push_back(v);
+  }
+  return EG_OK;
+}
+
+std::string shape_key(eg_model* m) {
+  std::ostringstream os;
+  for (auto& in : m->inputs) {
+    os << in.first << ":";
+    for (long s : in.second.shape) os << s << ",";
+    os << ";";
+  }
+  os << "e" << 0;
+  return os.str();
+}
+
+int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
+  Target& t = *ts.target;
+  Shapes& shapes = plan.shapes;
+  for (auto& in : m->inputs) {
+    const TensorDef& d = m->prog.tensors[in.first];
+    if (d.has_shape && !d.shape.empty()) {  // staticShapeMismatch (tests/test_errors.nim:56-59)
+      bool ok = d.shape.size() == in.second.shape.size();
+      for (size_t i = 0; ok && i < d.shape.size(); ++i)
+        if (d.shape[i] >= 0 && d.shape[i] != in.second.shape[i]) ok = false;
+      if (!ok) {
+        set_error("input \"%s\" does not match its static shape", d.name.c_str());
+        return EG_ERR_SHAPE;
+      }
+    }
+    shapes[in.first] = in.second.shape;
+  }
+  for (auto& p : m->params) shapes[p.first] = p.second.shape;
+
+  // shape inference over EVERY kernel (eliminated ones included: the reference collects shape
+  // constraints before dead kernels are dropped, model.nim:46-77)
+  std::vector<KernelInfo> infos(t.all.size());
+  std::set<int> live_set(t.live.begin(), t.live.end());
+  for (size_t i = 0; i < t.all.size(); ++i) {
+    const Kernel& k = t.all[i];
+    bool ready = true;
+    int missing = 0;
+    for (auto& r : k.reads)
+      if (!shapes.count(r.tensor)) {
+        ready = false;
+        missing = r.tensor;
+      }
+    if (ready)
+      for (auto& s : k.setup)
+        if (s.tensor && !shapes.count(s.tensor)) {
+          ready = false;
+          missing = s.tensor;
+        }
+    if (!ready) {
+      if (live_set.count((int)i)) {
+        const TensorDef& d = m->prog.tensors[missing];
+        if (d.kind == TK::Input) {
+          set_error("input \"%s\" of target \"%s\" was not provided", d.name.c_str(), t.name.c_str());
+          return EG_ERR_RUNTIME;
+        }
+        set_error("the shape of tensor %d is under-constrained", missing);
+        return EG_ERR_SHAPE;
+      }
+      continue;
+    }
+    int rc = infer_kernel(m->prog, k, shapes, m->epoch, infos[i]);
+    if (rc) {
+      if (live_set.count((int)i)) return rc;
+      eg::clear_error();
+    }
+  }
+
+  // which result tensors does the live list write; who writes first
+  std::map<int, int> first_writer;  // tensor -> position in live
+  std::vector<int> result_tensors;
+  for (size_t p = 0; p < t.live.size(); ++p) {
+    const Kernel& k = t.all[t.live[p]];
+    const int wt = k.write.tensor;
+    if (m->prog.tensors[wt].kind == TK::Result && !first_writer.count(wt)) {
+      first_writer[wt] = (int)p;
+      result_tensors.push_back(wt);
+    }
+  }
+  if (t.output && m->prog.tensors[t.output].kind == TK::Result && !first_writer.count(t.output)) {
+    if (!shapes.count(t.output)) {
+      set_error("the shape of the output of target \"%s\" is under-constrained", t.name.c_str());
+      return EG_ERR_SHAPE;
+    }
+    result_tensors.push_back(t.output);  // never written: stays zero
+  }
+
+  // decide overwrite vs accumulate per launch; collect tensors that must be zeroed
+  std::set<int> needs_zero;
+  plan.launches.clear();
+  plan.n_backward = -1;
+  for (size_t p = 0; p < t.live.size(); ++p) {
+    if ((int)p == t.first_update) plan.n_backward = (int)plan.launches.size();
+    Lowered& lo = ts.lowered[p];
+    if (lo.absorbed) continue;
+    const Kernel& k = t.all[lo.all_index];
+    const KernelInfo& info = infos[lo.all_index];
+    const int wt = k.write.tensor;
+    const bool is_result = m->prog.tensors[wt].kind == TK::Result;
+    const bool first = is_result && first_writer[wt] == (int)p;
+    const std::vector<long>& wshape = shapes.at(wt);
+    Launch L;
+    L.lowered = (int)p;
+    L.kind = lo.kind;
+    if (lo.kind == StepKind::Seed) {
+      L.count = prod(wshape);
+      L.c_tensor = wt;
+      L.accumulate = false;
+      plan.launches.push_back(L);
+      continue;
+    }
+    bool overwrite = first && full_cover(k, info, wshape);
+    if (lo.kind == StepKind::Gemm) {
+      const GemmMatch& g = lo.gemm;
+      const Op& A = k.reads[g.a_read];
+      const Op& B = k.reads[g.b_read];
+      L.M = info.bounds[g.li].second;
+      L.N = info.bounds[g.lj].second;
+      L.K = info.bounds[g.lk].second;
+      const std::vector<long>& as = shapes.at(A.tensor);
+      const std::vector<long>& bs = shapes.at(B.tensor);
+      // loop bounds come from the first tensor that names the iterator; the other operands must agree
+      const long a_m = g.trans_a ? as[1] : as[0], a_k = g.trans_a ? as[0] : as[1];
+      const long b_k = g.trans_b ? bs[1] : bs[0], b_n = g.trans_b ? bs[0] : bs[1];
+      if (a_m < L.M || a_k < L.K || b_k < L.K || b_n < L.N || wshape[0] < L.M || wshape[1] < L.N) {
+        set_error("contraction operands have inconsistent shapes ([%ld,%ld] x [%ld,%ld])", a_m, a_k, b_k, b_n);
+        return EG_ERR_SHAPE;
+      }
+      L.lda = as[1];
+      L.ldb = bs[1];
+      L.ldc = wshape[1];
+      L.a_tensor = A.tensor;
+      L.b_tensor = B.tensor;
+      L.c_tensor = wt;
+      L.trans_a = g.trans_a;
+      L.trans_b = g.trans_b;
+      L.bias_tensor = lo.bias_tensor;
+    } else if (lo.kind == StepKind::Conv) {
+      const Op& img = k.reads[lo.conv.img_read];
+      const Op& flt = k.reads[lo.conv.flt_read];
+      const std::vector<long>& is = shapes.at(img.tensor);
+      const std::vector<long>& fs = shapes.at(flt.tensor);
+      const int off = lo.conv.batched ? 1 : 0;
+      L.cN = lo.conv.batched ? is[0] : 1;
+      L.cH = is[off];
+      L.cW = is[off + 1];
+      L.cC = is[off + 2];
+      L.cF = fs[0];
+      L.cFH = fs[1];
+      L.cFW = fs[2];
+      if (fs[3] != L.cC) {
+        set_error("conv2: image has %ld channels, filters have %ld", L.cC, fs[3]);
+        return EG_ERR_SHAPE;
+      }
+      L.a_tensor = img.tensor;
+      L.b_tensor = flt.tensor;
+      L.c_tensor = wt;
+    } else {
+      // generic: choose the template
+      std::vector<int> indep, red;
+      bool scatter;
+      split_loops(k, indep, red, scatter);
+      long total = 1, rtotal = 1;
+      for (int l : indep) total *= info.bounds[l].second - info.bounds[l].first;
+      for (int l : red) rtotal *= info.bounds[l].second - info.bounds[l].first;
+      if (total < 0) total = 0;
+      if (rtotal < 0) rtotal = 0;
+      const bool use_b = lo.b_capable && !scatter && rtotal >= 2048 && total <= 8192 && total * 64 <= rtotal &&
+                         full_cover(k, info, wshape);
+      if (scatter) overwrite = false;
+      if (use_b) {
+        int tx = 1;
+        while (tx < total && tx < 64) tx <<= 1;
+        Generic& g = lo.mode_b[tx];
+        if (!g.handle) {
+          char name[64];
+          snprintf(name, sizeof(name), "eg_k%d_b%d", m->kernel_serial++, tx);
+          int rc = generate_mode_b(k, name, tx, g.src);
+          if (rc) return rc;
+          rc = build_generic(m, g);
+          if (rc) return rc;
+        }
+        const int ty = 256 / tx;
+        const long col_tiles = (total + tx - 1) / tx;
+        long nchunks = (4L * m->ctx->compute_units + col_tiles - 1) / col_tiles;
+        const long max_chunks = (rtotal + ty * 8 - 1) / (ty * 8);
+        if (nchunks > max_chunks) nchunks = max_chunks;
+        if (nchunks < 1) nchunks = 1;
+        const long chunk = (rtotal + nchunks - 1) / nchunks;
+        nchunks = (rtotal + chunk - 1) / chunk;
+        L.kind = StepKind::GenericB;
+        L.generic = &g;
+        L.blocks_x = nchunks;
+        L.blocks_y = col_tiles;
+        L.partial_rows = nchunks;
+        L.partial_cols = total;
+        int rc = fill_params(m, k, info, shapes, g.src, !overwrite, total, rtotal, chunk, L.params);
+        if (rc) return rc;
+      } else {
+        L.kind = StepKind::GenericA;
+        L.generic = &lo.mode_a;
+        L.blocks_x = (total + 255) / 256;
+        int rc = fill_params(m, k, info, shapes, lo.mode_a.src, !overwrite, total, rtotal, 0, L.params);
+        if (rc) return rc;
+      }
+      for (size_t si = 0; si < L.generic->src.slots.size(); ++si) {
+        const Slot& sl = L.generic->src.slots[si];
+        if (sl.kind == Slot::InstrVal && k.instrs[sl.a].kind == IK::Epoch) L.epoch_slots.push_back((int)si);
+      }
+      L.c_tensor = wt;
+    }
+    L.accumulate = !overwrite;
+    if (is_result && first && !overwrite) needs_zero.insert(wt);
+    plan.launches.push_back(L);
+  }
+  if (plan.n_backward < 0) plan.n_backward = (int)plan.launches.size();
+  if (t.output && m->prog.tensors[t.output].kind == TK::Result && !first_writer.count(t.output)) needs_zero.insert(t.output);
+
+  // arena layout: tensors that need zeroing first (one memset), then the rest
+  plan.arena_offset.clear();
+  plan.bucket_zero.clear();
+  long off = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int tid : result_tensors) {
+      if (ts.bucket_offset.count(tid)) {
+        if (pass == 0 && needs_zero.count(tid)) plan.bucket_zero.push_back(tid);
+        continue;
+      }
+      const bool z = needs_zero.count(tid) != 0;
+      if ((pass == 0) != z) continue;
+      plan.arena_offset[tid] = off;
+      off += align4(prod(shapes.at(tid)));
+    }
+    if (pass == 0) plan.zero_floats = off;
+  }
+  plan.arena_floats = off;
+  if (off > 0) {
+    EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+    EG_HIP_CHECK(hipMalloc((void**)&plan.arena, (size_t)off * sizeof(float)));
+  }
+  return EG_OK;
+}
+
+int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
+  eg_ctx* ctx = m->ctx;
+  switch (L.kind) {
+    case StepKind::Seed:
+      return eg_fill_f32(ctx, L.count, m->grad_scale, tensor_ptr(m, ts, plan, L.c_tensor));
+    case StepKind::Gemm:
+      return eg_sgemm(ctx, L.trans_a, L.trans_b, L.M, L.N, L.K, tensor_ptr(m, ts, plan, L.a_tensor), L.lda,
+                      tensor_ptr(m, ts, plan, L.b_tensor), L.ldb, tensor_ptr(m, ts, plan, L.c_tensor), L.ldc,
+                      L.accumulate, L.bias_tensor ? tensor_ptr(m, ts, plan, L.bias_tensor) : nullptr);
+    case StepKind::Conv:
+      return eg_conv2_nhwc(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, tensor_ptr(m, ts, plan, L.a_tensor),
+                           tensor_ptr(m, ts, plan, L.b_tensor), tensor_ptr(m, ts, plan, L.c_tensor), L.accumulate);
+    case StepKind::GenericA:
+    case StepKind::GenericB: {
+      if (L.blocks_x <= 0 || L.blocks_y <= 0) return EG_OK;
+      const GenericSource& src = L.generic->src;
+      std::vector<void*> args;
+      std::vector<float*> ptrs;
+      ptrs.reserve(src.tensor_args.size() + 1);
+      float* partial = nullptr;
+      float* scratch = nullptr;
+      if (L.kind == StepKind::GenericB) {
+        const long pfloats = (L.partial_rows * L.partial_cols + 3) & ~3L;
+        const long sfloats = eg::colsum_scratch_floats(ctx, L.partial_rows, L.partial_cols);
+        int rc = eg::ensure_workspace(ctx, (size_t)(pfloats + sfloats) * sizeof(float));
+        if (rc) return rc;
+        partial = static_cast<float*>(ctx->workspace);
+        scratch = partial + pfloats;
+        ptrs.push_back(partial);
+      }
+      for (int tid : src.tensor_args) {
+        float* p = tensor_ptr(m, ts, plan, tid);
+        if (!p && prod(plan.shapes.at(tid)) > 0) {
+          set_error("tensor %d has no device storage", tid);
+          return EG_ERR_INVALID;
+        }
+        ptrs.push_back(p);
+      }
+      for (auto& p : ptrs) args.push_back(&p);
+      for (auto& v : L.params) args.push_back(&v);
+      for (int slot : L.epoch_slots) L.params[slot] = m->epoch;
+      int rc = eg::kernel_launch_raw(L.generic->handle, (unsigned)L.blocks_x, (unsigned)L.blocks_y, 1, 256, args.data());
+      if (rc) return rc;
+      if (L.kind == StepKind::GenericB)
+        return eg::colsum_with_scratch(ctx, L.partial_rows, L.partial_cols, partial,
+                                       tensor_ptr(m, ts, plan, L.c_tensor), L.accumulate, scratch);
+      return EG_OK;
+    }
+  }
+  return EG_OK;
+}
+
+int get_plan(eg_model* m, const char* target, TargetState** ts_out, Plan** plan_out) {
+  EG_REQUIRE(m && target, EG_ERR_INVALID, "NULL model or target");
+  auto it = m->targets.find(target);
+  // model.nim:395-396
+  EG_REQUIRE(it != m->targets.end(), EG_ERR_RUNTIME, "%s is not a target of the model", target);
+  TargetState& ts = it->second;
+  const std::string key = shape_key(m);
+  auto p = ts.plans.find(key);
+  if (p == ts.plans.end()) {
+    std::unique_ptr<Plan> plan(new Plan());
+    plan->key = key;
+    int rc = make_plan(m, ts, *plan);
+    if (rc) {
+      if (plan->arena) hipFree(plan->arena);
+      return rc;
+    }
+    p = ts.plans.emplace(key, std::move(plan)).first;
+  }
+  ts.last = p->second.get();
+  *ts_out = &ts;
+  *plan_out = p->second.get();
+  return EG_OK;
+}
+
+int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero) {
+  int rc = eg::set_device(m->ctx);
+  if (rc) return rc;
+  if (zero) {
+    // allocShapes / zeroResultTensor (model.nim:318, 383): results start from zero on every call
+    if (plan.zero_floats > 0)
+      EG_HIP_CHECK(hipMemsetAsync(plan.arena, 0, (size_t)plan.zero_floats * sizeof(float), m->ctx->stream));
+    for (int tid : plan.bucket_zero)
+      EG_HIP_CHECK(hipMemsetAsync(ts.bucket + ts.bucket_offset[tid], 0, (size_t)prod(plan.shapes.at(tid)) * sizeof(float),
+                                  m->ctx->stream));
+  }
+  for (int i = begin; i < end; ++i) {
+    rc = run_launch(m, ts, plan, plan.launches[i]);
+    if (rc) return rc;
+  }
+  return EG_OK;
+}
+
+void describe(eg_model* m) {
+  std::ostringstream os;
+  for (auto& kv : m->targets) {
+    TargetState& ts = kv.second;
+    os << "target " << kv.first << " (" << ts.target->live.size() << " kernels)\n";
+    for (size_t p = 0; p < ts.lowered.size(); ++p) {
+      const Lowered& lo = ts.lowered[p];
+      const Kernel& k = ts.target->all[lo.all_index];
+      const char* kind = lo.absorbed ? "fused-into-previous"
+                         : lo.kind == StepKind::Gemm ? (lo.bias_tensor ? "gemm+bias" : "gemm")
+                         : lo.kind == StepKind::Conv ? "conv2"
+                         : lo.kind == StepKind::Seed ? "seed-fill"
+                         : (lo.b_capable ? "generic(map|split-reduce)" : "generic(map)");
+      os << "  [" << p << "] " << kind;
+      if (lo.kind == StepKind::Gemm) os << (lo.gemm.trans_a ? " T" : " N") << (lo.gemm.trans_b ? "T" : "N");
+      os << " : " << to_text(k) << "\n";
+    }
+  }
+  m->plan_text = os.str();
+}
+
+}  // namespace
+
+// ---- helpers implemented next to the group-1 / group-2 code ------------------------------------
+extern "C" {
+
+int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out) {
+  EG_REQUIRE(ctx && program_text && out, EG_ERR_INVALID, "eg_model_compile: NULL argument");
+  std::unique_ptr<eg_model> m(new eg_model());
+  m->ctx = ctx;
+  int rc = parse(program_text, m->prog);
+  if (rc) return rc;
+  rc = compile_program(m->prog);
+  if (rc) return rc;
+  rc = eg::set_device(ctx);
+  if (rc) return rc;
+  // parameters: uniform in initRange (model.nim:241-247); deterministic here, tests overwrite them
+  std::mt19937 rng(10);
+  for (size_t tid = 1; tid < m->prog.tensors.size(); ++tid) {
+    const TensorDef& d = m->prog.tensors[tid];
+    if (d.kind != TK::Param) continue;
+    DevTensor dt;
+    dt.shape = d.shape;
+    dt.count = prod(d.shape);
+    if (dt.count > 0) {
+      EG_HIP_CHECK(hipMalloc((void**)&dt.ptr, (size_t)dt.count * sizeof(float)));
+      std::vector<float> host(dt.count);
+      std::uniform_real_distribution<float> dist((float)d.lo, (float)d.hi);
+      for (auto& v : host) v = d.hi > d.lo ? dist(rng) : (float)d.lo;
+      EG_HIP_CHECK(hipMemcpy(dt.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    m->params[(int)tid] = dt;
+  }
+  for (auto& t : m->prog.targets) {
+    TargetState& ts = m->targets[t.name];
+    ts.target = &t;
+    // gradient bucket: GenGradient destinations of parameters, in kernel-list order
+    long off = 0;
+    for (auto& k : t.source)
+      if (k.gen == Gen::Gradient && m->prog.tensors[k.gen_tensor].kind == TK::Param &&
+          !ts.bucket_offset.count(k.gen_dest)) {
+        ts.grad_tensors.push_back(k.gen_dest);
+        ts.bucket_offset[k.gen_dest] = off;
+        off += align4(prod(m->prog.tensors[k.gen_tensor].shape));
+      }
+    ts.bucket_floats = off;
+    if (off > 0) {
+      EG_HIP_CHECK(hipMalloc((void**)&ts.bucket, (size_t)off * sizeof(float)));
+      EG_HIP_CHECK(hipMemset(ts.bucket, 0, (size_t)off * sizeof(float)));
+      ts.bucket_owned = true;
+    }
+    rc = lower_target(m.get(), ts);
+    if (rc) return rc;
+  }
+  describe(m.get());
+  *out = m.release();
+  return EG_OK;
+}
+
+int eg_model_free(eg_model* m) {
+  if (!m) return EG_OK;
+  hipSetDevice(m->ctx->device);
+  hipStreamSynchronize(m->ctx->stream);
+  for (auto& kv : m->targets) {
+    for (auto& p : kv.second.plans)
+      if (p.second->arena) hipFree(p.second->arena);
+    if (kv.second.bucket_owned && kv.second.bucket) hipFree(kv.second.bucket);
+  }
+  for (auto& p : m->params)
+    if (p.second.ptr) hipFree(p.second.ptr);
+  for (auto& in : m->inputs)
+    if (in.second.owned) hipFree(in.second.owned);
+  for (eg_kernel* k : m->kernels) eg_kernel_free(k);
+  delete m;
+  return EG_OK;
+}
+
+const char* eg_model_plan_text(eg_model* m) { return m ? m->plan_text.c_str() : ""; }
+
+int eg_model_kernel_count(eg_model* m, const char* target) {
+  if (!m || !target) return -1;
+  auto it = m->targets.find(target);
+  return it == m->targets.end() ? -1 : (int)it->second.target->live.size();
+}
+
+int eg_model_tensor_count(eg_model* m) { return m ? (int)m->prog.tensors.size() - 1 : 0; }
+
+int eg_model_param_info(eg_model* m, int tensor_id, int* kind, int* rank, int64_t* shape8, char* name,
+                        size_t name_cap) {
+  EG_REQUIRE(m && tensor_id >= 1 && tensor_id < (int)m->prog.tensors.size(), EG_ERR_INVALID, "bad tensor id %d", tensor_id);
+  const TensorDef& d = m->prog.tensors[tensor_id];
+  if (kind) *kind = (int)d.kind;
+  if (rank) *rank = d.has_shape ? (int)d.shape.size() : -1;
+  if (shape8)
+    for (size_t i = 0; i < d.shape.size() && i < 8; ++i) shape8[i] = d.shape[i];
+  if (name && name_cap) {
+    snprintf(name, name_cap, "%s", d.name.c_str());
+  }
+  return EG_OK;
+}
+
+int eg_model_param_write(eg_model* m, int tensor_id, const float* host, int64_t count) {
+  EG_REQUIRE(m && host, EG_ERR_INVALID, "eg_model_param_write: NULL argument");
+  auto it = m->params.find(tensor_id);
+  EG_REQUIRE(it != m->params.end(), EG_ERR_INVALID, "tensor %d is not a parameter", tensor_id);
+  EG_REQUIRE(count == it->second.count, EG_ERR_SIZE, "parameter %d has %ld elements, got %ld", tensor_id,
+             it->second.count, (long)count);
+  if (count == 0) return EG_OK;
+  EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+  EG_HIP_CHECK(hipMemcpyAsync(it->second.ptr, host, (size_t)count * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+  EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  return EG_OK;
+}
+
+int eg_model_param_read(eg_model* m, int tensor_id, float* host, int64_t count) {
+  EG_REQUIRE(m && host, EG_ERR_INVALID, "eg_model_param_read: NULL argument");
+  auto it = m->params.find(tensor_id);
+  EG_REQUIRE(it != m->params.end(), EG_ERR_INVALID, "tensor %d is not a parameter", tensor_id);
+  EG_REQUIRE(count == it->second.count, EG_ERR_SIZE, "parameter %d has %ld elements, got %ld", tensor_id,
+             it->second.count, (long)count);
+  if (count == 0) return EG_OK;
+  EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+  EG_HIP_CHECK(hipMemcpyAsync(host, it->second.ptr, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
+  EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  return EG_OK;
+}
+
+int eg_model_param_ptr(eg_model* m, int tensor_id, float** device_ptr, int64_t* count) {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  auto it = m->params.find(tensor_id);
+  EG_REQUIRE(it != m->params.end(), EG_ERR_INVALID, "tensor %d is not a parameter", tensor_id);
+  if (device_ptr) *device_ptr = it->second.ptr;
+  if (count) *count = it->second.count;
+  return EG_OK;
+}
+
+int eg_model_grad_bucket(eg_model* m, const char* target, float** device_ptr, int64_t* count) {
+  EG_REQUIRE(m && target, EG_ERR_INVALID, "NULL argument");
+  auto it = m->targets.find(target);
+  EG_REQUIRE(it != m->targets.end(), EG_ERR_RUNTIME, "%s is not a target of the model", target);
+  if (device_ptr) *device_ptr = it->second.bucket;
+  if (count) *count = it->second.bucket_floats;
+  return EG_OK;
+}
+
+int eg_model_bind_grad_bucket(eg_model* m, const char* target, float* device_ptr, int64_t count) {
+  EG_REQUIRE(m && target && device_ptr, EG_ERR_INVALID, "NULL argument");
+  auto it = m->targets.find(target);
+  EG_REQUIRE(it != m->targets.end(), EG_ERR_RUNTIME, "%s is not a target of the model", target);
+  TargetState& ts = it->second;
+  EG_REQUIRE(count >= ts.bucket_floats, EG_ERR_SIZE, "gradient bucket needs %ld floats, got %ld", ts.bucket_floats,
+             (long)count);
+  EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+  EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  if (ts.bucket_owned && ts.bucket) hipFree(ts.bucket);
+  ts.bucket = device_ptr;
+  ts.bucket_owned = false;
+  return EG_OK;
+}
+
+static int bind_input(eg_model* m, const char* name, const float* device, const float* host, int rank,
+                      const int64_t* shape) {
+  EG_REQUIRE(m && name, EG_ERR_INVALID, "NULL argument");
+  auto it = m->prog.inputs.find(name);
+  // model.nim:358-359
+  EG_REQUIRE(it != m->prog.inputs.end(), EG_ERR_RUNTIME, "%s is not an input to the model", name);
+  EG_REQUIRE(rank >= 0 && rank <= 8 && (rank == 0 || shape), EG_ERR_INVALID, "bad input rank");
+  BoundInput& b = m->inputs[it->second];
+  b.shape.assign(shape, shape + rank);
+  const long count = prod(b.shape);
+  if (host) {
+    EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+    if (b.owned_count < count) {
+      EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+      if (b.owned) EG_HIP_CHECK(hipFree(b.owned));
+      b.owned = nullptr;
+      b.owned_count = 0;
+      EG_HIP_CHECK(hipMalloc((void**)&b.owned, (size_t)(count > 0 ? count : 1) * sizeof(float)));
+      b.owned_count = count;
+    }
+    if (count > 0) {
+      // blocking H2D on every call, as the reference does (model.nim:364-368 -> cl.nim:111-116)
+      EG_HIP_CHECK(hipMemcpyAsync(b.owned, host, (size_t)count * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+      EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    }
+    b.device = b.owned;
+  } else {
+    EG_REQUIRE(device || count == 0, EG_ERR_INVALID, "NULL device pointer for input %s", name);
+    b.device = device;
+  }
+  return EG_OK;
+}
+
+int eg_model_set_input_host(eg_model* m, const char* name, const float* host, int rank, const int64_t* shape) {
+  EG_REQUIRE(host || rank == 0, EG_ERR_INVALID, "NULL host pointer");
+  static const float dummy = 0;
+  return bind_input(m, name, nullptr, host ? host : &dummy, rank, shape);
+}
+
+int eg_model_set_input_device(eg_model* m, const char* name, const float* device_ptr, int rank, const int64_t* shape) {
+  return bind_input(m, name, device_ptr, nullptr, rank, shape);
+}
+
+int eg_model_clear_inputs(eg_model* m) {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  hipSetDevice(m->ctx->device);
+  hipStreamSynchronize(m->ctx->stream);
+  for (auto& in : m->inputs)
+    if (in.second.owned) hipFree(in.second.owned);
+  m->inputs.clear();
+  return EG_OK;
+}
+
+int eg_model_run(eg_model* m, const char* target) {
+  TargetState* ts;
+  Plan* plan;
+  int rc = get_plan(m, target, &ts, &plan);
+  if (rc) return rc;
+  return run_range(m, *ts, *plan, 0, (int)plan->launches.size(), true);
+}
+
+int eg_model_run_backward(eg_model* m, const char* target) {
+  TargetState* ts;
+  Plan* plan;
+  int rc = get_plan(m, target, &ts, &plan);
+  if (rc) return rc;
+  return run_range(m, *ts, *plan, 0, plan->n_backward, true);
+}
+
+int eg_model_run_update(eg_model* m, const char* target) {
+  TargetState* ts;
+  Plan* plan;
+  int rc = get_plan(m, target, &ts, &plan);
+  if (rc) return rc;
+  return run_range(m, *ts, *plan, plan->n_backward, (int)plan->launches.size(), false);
+}
+
+int eg_model_set_grad_scale(eg_model* m, float scale) {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  m->grad_scale = scale;
+  return EG_OK;
+}
+
+static int find_tensor(eg_model* m, const char* target, int* tid, TargetState** ts) {
+  auto it = m->targets.find(target);
+  EG_REQUIRE(it != m->targets.end(), EG_ERR_RUNTIME, "%s is not a target of the model", target);
+  *ts = &it->second;
+  *tid = it->second.target->output;
+  EG_REQUIRE(*tid != 0, EG_ERR_INVALID, "target %s has no output tensor", target);
+  EG_REQUIRE(it->second.last, EG_ERR_INVALID, "target %s has not been run", target);
+  return EG_OK;
+}
+
+static int tensor_shape(eg_model* m, TargetState& ts, int tid, int* rank, int64_t* shape8) {
+  EG_REQUIRE(ts.last, EG_ERR_INVALID, "the target has not been run");
+  auto s = ts.last->shapes.find(tid);
+  EG_REQUIRE(s != ts.last->shapes.end(), EG_ERR_INVALID, "tensor %d has no shape in the last run", tid);
+  if (rank) *rank = (int)s->second.size();
+  if (shape8)
+    for (size_t i = 0; i < s->second.size() && i < 8; ++i) shape8[i] = s->second[i];
+  return EG_OK;
+}
+
+static int read_tensor(eg_model* m, TargetState& ts, int tid, float* host, int64_t count) {
+  EG_REQUIRE(ts.last && host, EG_ERR_INVALID, "nothing to read");
+  auto s = ts.last->shapes.find(tid);
+  EG_REQUIRE(s != ts.last->shapes.end(), EG_ERR_INVALID, "tensor %d has no shape in the last run", tid);
+  const long n = prod(s->second);
+  EG_REQUIRE(count == n, EG_ERR_SIZE, "Buffer size is not equal to target size (%ld vs %ld)", n, (long)count);
+  if (n == 0) return EG_OK;
+  float* p = tensor_ptr(m, ts, *ts.last, tid);
+  EG_REQUIRE(p, EG_ERR_INVALID, "tensor %d was not materialised by the last run", tid);
+  EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+  EG_HIP_CHECK(hipMemcpyAsync(host, p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
+  EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  return EG_OK;
+}
+
+int eg_model_output_shape(eg_model* m, const char* target, int* rank, int64_t* shape8) {
+  EG_REQUIRE(m && target, EG_ERR_INVALID, "NULL argument");
+  int tid;
+  TargetState* ts;
+  int rc = find_tensor(m, target, &tid, &ts);
+  if (rc) return rc;
+  return tensor_shape(m, *ts, tid, rank, shape8);
+}
+
+int eg_model_read_output(eg_model* m, const char* target, float* host, int64_t count) {
+  EG_REQUIRE(m && target, EG_ERR_INVALID, "NULL argument");
+  int tid;
+  TargetState* ts;
+  int rc = find_tensor(m, target, &tid, &ts);
+  if (rc) return rc;
+  return read_tensor(m, *ts, tid, host, count);
+}
+
+static TargetState* last_target(eg_model* m, const char* target) {
+  auto it = m->targets.find(target ? target : "");
+  return it == m->targets.end() ? nullptr : &it->second;
+}
+
+int eg_model_tensor_shape(eg_model* m, const char* target, int tensor_id, int* rank, int64_t* shape8) {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  TargetState* ts = last_target(m, target);
+  EG_REQUIRE(ts, EG_ERR_RUNTIME, "%s is not a target of the model", target ? target : "(null)");
+  return tensor_shape(m, *ts, tensor_id, rank, shape8);
+}
+
+int eg_model_read_tensor(eg_model* m, const char* target, int tensor_id, float* host, int64_t count) {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  TargetState* ts = last_target(m, target);
+  EG_REQUIRE(ts, EG_ERR_RUNTIME, "%s is not a target of the model", target ? target : "(null)");
+  return read_tensor(m, *ts, tensor_id, host, count);
+}
+
+int eg_model_tensor_ptr(eg_model* m, const char* target, int tensor_id, float** device_ptr, int64_t* count) {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  TargetState* ts = last_target(m, target);
+  EG_REQUIRE(ts && ts->last, EG_ERR_RUNTIME, "target has not been run");
+  auto s = ts->last->shapes.find(tensor_id);
+  EG_REQUIRE(s != ts->last->shapes.end(), EG_ERR_INVALID, "tensor %d has no shape in the last run", tensor_id);
+  if (device_ptr) *device_ptr = tensor_ptr(m, *ts, *ts->last, tensor_id);
+  if (count) *count = prod(s->second);
+  return EG_OK;
+}
+
+int eg_model_set_epoch(eg_model* m, int64_t epoch) {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  m->epoch = epoch;
+  return EG_OK;
+}
+
+int64_t eg_model_epoch(eg_model* m) { return m ? m->epoch : 0; }
+
+}  // extern "C"

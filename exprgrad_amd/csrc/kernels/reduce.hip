@@ -113,6 +113,51 @@ __global__ __launch_bounds__(NT) void sum_final_kernel(const float* __restrict__
 
 }  // namespace
 
+namespace eg {
+
+static void colsum_geometry(const eg_ctx* ctx, long rows, long cols, long& nparts, long& rows_per_block,
+                            long& col_tiles) {
+  col_tiles = (cols + 63) / 64;
+  // ~4 blocks per CU in total, at least 64 rows per block.
+  nparts = (4L * ctx->compute_units + col_tiles - 1) / col_tiles;
+  const long max_parts = (rows + 63) / 64;
+  if (nparts > max_parts) nparts = max_parts;
+  if (nparts < 1) nparts = 1;
+  rows_per_block = (rows + nparts - 1) / nparts;
+  nparts = rows_per_block > 0 ? (rows + rows_per_block - 1) / rows_per_block : 1;
+  if (nparts < 1) nparts = 1;
+}
+
+long colsum_scratch_floats(const eg_ctx* ctx, long rows, long cols) {
+  long nparts, rpb, tiles;
+  colsum_geometry(ctx, rows, cols, nparts, rpb, tiles);
+  return nparts * cols;
+}
+
+int colsum_with_scratch(eg_ctx* ctx, long rows, long cols, const float* in, float* out, int accumulate,
+                        float* scratch) {
+  if (cols == 0) return EG_OK;
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  int colsP = 1;
+  while (colsP < cols && colsP < 64) colsP <<= 1;
+  long nparts, rows_per_block, col_tiles;
+  colsum_geometry(ctx, rows, cols, nparts, rows_per_block, col_tiles);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nparts, (unsigned)col_tiles), dim3(NT), 0, ctx->stream, in,
+                     scratch, rows, cols, colsP, rows_per_block);
+  const unsigned fgrid = (unsigned)((cols + NT - 1) / NT);
+  if (accumulate)
+    hipLaunchKernelGGL((colsum_final_kernel<true>), dim3(fgrid), dim3(NT), 0, ctx->stream, scratch, out, cols,
+                       (int)nparts);
+  else
+    hipLaunchKernelGGL((colsum_final_kernel<false>), dim3(fgrid), dim3(NT), 0, ctx->stream, scratch, out, cols,
+                       (int)nparts);
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
+}  // namespace eg
+
 extern "C" {
 
 int eg_colsum(eg_ctx* ctx, int64_t rows, int64_t cols, const float* in, float* out, int accumulate) {
@@ -120,33 +165,9 @@ int eg_colsum(eg_ctx* ctx, int64_t rows, int64_t cols, const float* in, float* o
   EG_REQUIRE(rows >= 0 && cols >= 0, EG_ERR_INVALID, "eg_colsum: negative extent");
   if (cols == 0) return EG_OK;
   EG_REQUIRE(out && (rows == 0 || in), EG_ERR_INVALID, "eg_colsum: NULL tensor");
-  int rc = eg::set_device(ctx);
+  int rc = eg::ensure_workspace(ctx, (size_t)eg::colsum_scratch_floats(ctx, rows, cols) * sizeof(float));
   if (rc) return rc;
-  int colsP = 1;
-  while (colsP < cols && colsP < 64) colsP <<= 1;
-  const long col_tiles = (cols + 63) / 64;
-  // ~4 blocks per CU in total, at least 64 rows per block.
-  long nparts = (4L * ctx->compute_units + col_tiles - 1) / col_tiles;
-  const long max_parts = (rows + 63) / 64;
-  if (nparts > max_parts) nparts = max_parts;
-  if (nparts < 1) nparts = 1;
-  const long rows_per_block = (rows + nparts - 1) / nparts;
-  nparts = rows_per_block > 0 ? (rows + rows_per_block - 1) / rows_per_block : 1;
-  if (nparts < 1) nparts = 1;
-  rc = eg::ensure_workspace(ctx, (size_t)nparts * cols * sizeof(float));
-  if (rc) return rc;
-  float* partial = static_cast<float*>(ctx->workspace);
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)nparts, (unsigned)col_tiles), dim3(NT), 0, ctx->stream, in,
-                     partial, (long)rows, (long)cols, colsP, rows_per_block);
-  const unsigned fgrid = (unsigned)((cols + NT - 1) / NT);
-  if (accumulate)
-    hipLaunchKernelGGL((colsum_final_kernel<true>), dim3(fgrid), dim3(NT), 0, ctx->stream, partial, out, (long)cols,
-                       (int)nparts);
-  else
-    hipLaunchKernelGGL((colsum_final_kernel<false>), dim3(fgrid), dim3(NT), 0, ctx->stream, partial, out, (long)cols,
-                       (int)nparts);
-  EG_HIP_CHECK(hipGetLastError());
-  return EG_OK;
+  return eg::colsum_with_scratch(ctx, rows, cols, in, out, accumulate, static_cast<float*>(ctx->workspace));
 }
 
 int eg_rowsum(eg_ctx* ctx, int64_t rows, int64_t cols, const float* in, float* out, int accumulate) {

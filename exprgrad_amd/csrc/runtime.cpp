@@ -65,6 +65,16 @@ struct eg_kernel {
   std::vector<Arg> args;
 };
 
+namespace eg {
+int kernel_launch_raw(eg_kernel* kernel, unsigned gx, unsigned gy, unsigned gz, unsigned block, void** args) {
+  EG_REQUIRE(kernel, EG_ERR_INVALID, "kernel_launch_raw: kernel is NULL");
+  if (gx == 0 || gy == 0 || gz == 0) return EG_OK;
+  EG_HIP_CHECK(hipSetDevice(kernel->ctx->device));
+  EG_HIP_CHECK(hipModuleLaunchKernel(kernel->fn, gx, gy, gz, block, 1, 1, 0, kernel->ctx->stream, args, nullptr));
+  return EG_OK;
+}
+}  // namespace eg
+
 extern "C" {
 
 const char* eg_last_error(void) { return eg::g_error.c_str(); }

@@ -1,0 +1,714 @@
+"""Python mirror of exprgrad's graph-building front-end, for the tests and the benchmark.
+
+The reference builds programs with a Nim macro DSL (`out[y, x] ++= a[y, it] * b[it, x]`,
+exprgrad/parser.nim:677-681, exprgrad/dsl.nim).  That front-end is not part of the hot path and
+stays the reference's; what crosses the drop-in boundary is the *kernel description* it
+produces (ir.nim:211-230).  This module produces exactly that description — as the text
+`eg_model_compile` consumes — from Python statements that read like the reference's:
+
+    y, x, it = iters("y x it")
+    c = Fun()
+    c[y, x] += input("a")[y, it] * input("b")[it, x]          # c*[y,x] ++= a[y,it] * b[it,x]
+    hr = Fun()
+    hr.raw[it] += select(h.raw[it] <= 0.0, 0.1 * h.raw[it], h.raw[it])   # hr*{it} ++= ...
+    model = compile(c.target("c"), gpu=ctx)
+
+Semantics mirrored (with the reference location):
+  * expression builders, typed Scalar / Index / Boolean                    dsl.nim:21-146
+  * register numbering = post-order build of the value expression, one register per builder
+    node per block (shared sub-expressions such as sq(x) = x * x reuse it)  parser.nim:159-217
+  * loops are created in order of first use of an iterator: value first, then write index
+                                                                            parser.nim:183-196, 231-242
+  * Fun graph node kinds and flattening order (children first, effects, generators)
+                                                                            parser.nim:72-97, 317-384
+  * backwards / grad / optimize / backprop / target                         parser.nim:738-815
+"""
+import itertools
+
+SCALAR, INDEX, BOOLEAN = "scalar", "index", "boolean"
+
+# instruction kinds, spelled as in ir.nim:51-76 without the Instr prefix, lower case
+_ARITH = {"add", "sub", "mul", "div", "indexdiv", "mod", "wrap", "negate", "sin", "cos", "exp", "pow", "sqrt",
+          "log", "log10", "log2", "ln"}
+
+
+class ParserError(Exception):
+    """parser.nim ParserError."""
+
+
+class Expr:
+    """ExprBuilder (parser.nim:27-47): kind in {instr, iter, read}."""
+
+    __slots__ = ("kind", "instr", "children", "typ", "lit", "tensor", "is_raw", "dim", "iter", "bounds", "_res")
+
+    def __init__(self, kind, typ, instr=None, children=(), lit=None, tensor=None, is_raw=False, dim=0, iter=None,
+                 bounds=None):
+        self.kind, self.typ, self.instr = kind, typ, instr
+        self.children = list(children)
+        self.lit, self.tensor, self.is_raw, self.dim, self.iter, self.bounds = lit, tensor, is_raw, dim, iter, bounds
+        self._res = {}
+
+    # ---- arithmetic (dsl.nim:41-72) -------------------------------------------------------
+    def _coerce(self, other):
+        if isinstance(other, Expr):
+            return other
+        if isinstance(other, bool):
+            return literal(other)
+        if self.typ == INDEX and isinstance(other, int):
+            return literal(int(other))
+        if self.typ == SCALAR and isinstance(other, (int, float)):
+            return literal(float(other))
+        raise TypeError(f"cannot combine {self.typ} expression with {other!r}")
+
+    def _bin(self, other, instr, typ=None, swap=False):
+        other = self._coerce(other)
+        if other.typ != self.typ:
+            raise TypeError(f"{instr}: operand types differ ({self.typ} vs {other.typ})")
+        a, b = (other, self) if swap else (self, other)
+        return Expr("instr", typ or self.typ, instr=instr, children=[a, b])
+
+    def __add__(self, o): return self._bin(o, "add")
+    def __radd__(self, o): return self._bin(o, "add", swap=True)
+    def __sub__(self, o): return self._bin(o, "sub")
+    def __rsub__(self, o): return self._bin(o, "sub", swap=True)
+    def __mul__(self, o): return self._bin(o, "mul")
+    def __rmul__(self, o): return self._bin(o, "mul", swap=True)
+
+    def __truediv__(self, o):
+        if self.typ != SCALAR:
+            raise TypeError("`/` is defined for Scalar only (dsl.nim:55); use // for Index")
+        return self._bin(o, "div")
+
+    def __rtruediv__(self, o): return self._bin(o, "div", swap=True)
+    def __floordiv__(self, o): return self._bin(o, "indexdiv")
+    def __mod__(self, o): return self._bin(o, "mod")
+    def __neg__(self): return Expr("instr", self.typ, instr="negate", children=[self])
+
+    # comparisons: only ==, <, <= exist (dsl.nim:35, 45-46); a > b is b < a, a >= b is b <= a
+    def __lt__(self, o): return self._bin(o, "lt", BOOLEAN)
+    def __le__(self, o): return self._bin(o, "le", BOOLEAN)
+    def __gt__(self, o): return self._bin(o, "lt", BOOLEAN, swap=True)
+    def __ge__(self, o): return self._bin(o, "le", BOOLEAN, swap=True)
+    def eq(self, o): return self._bin(o, "eq", BOOLEAN)
+    __hash__ = object.__hash__
+
+    def __and__(self, o): return self._bin(o, "and", BOOLEAN)
+    def __or__(self, o): return self._bin(o, "or", BOOLEAN)
+
+    def __iadd__(self, value):
+        """`tensor[dims] += value` is the `++=` statement: returns a marker Fun.__setitem__ consumes."""
+        if self.kind != "read":
+            raise ParserError("`+=` on an expression is only valid as `tensor[index] += value`")
+        if not isinstance(value, Expr):
+            value = literal(float(value))
+        return _Accumulate(self, value)
+
+    def __bool__(self):
+        raise TypeError("expression builders have no truth value; use select(cond, a, b)")
+
+
+class _Accumulate:
+    def __init__(self, target, value):
+        self.target, self.value = target, value
+
+
+def literal(value):
+    """parser.nim:104-121."""
+    if isinstance(value, Expr):
+        return value
+    if isinstance(value, bool):
+        return Expr("instr", BOOLEAN, instr="boolean", lit=bool(value))
+    if isinstance(value, int):
+        return Expr("instr", INDEX, instr="index", lit=int(value))
+    return Expr("instr", SCALAR, instr="scalar", lit=float(value))
+
+
+def _scalar(x):
+    return x if isinstance(x, Expr) else literal(float(x))
+
+
+def _unop(name):
+    def f(a):
+        a = _scalar(a)
+        return Expr("instr", SCALAR, instr=name, children=[a])
+    f.__name__ = name
+    return f
+
+
+sin, cos, exp, sqrt, ln, log10, log2 = (_unop(n) for n in ("sin", "cos", "exp", "sqrt", "ln", "log10", "log2"))
+
+
+def pow(a, b):  # noqa: A001 - mirrors dsl.nim:59
+    return Expr("instr", SCALAR, instr="pow", children=[_scalar(a), _scalar(b)])
+
+
+def log(x, base):
+    return Expr("instr", SCALAR, instr="log", children=[_scalar(x), _scalar(base)])
+
+
+def to_scalar(i):
+    return Expr("instr", SCALAR, instr="toscalar", children=[literal(i)])
+
+
+def to_index(s):
+    return Expr("instr", INDEX, instr="toindex", children=[_scalar(s)])
+
+
+toScalar, toIndex = to_scalar, to_index
+
+
+def epoch():
+    return Expr("instr", INDEX, instr="epoch")
+
+
+def select(cond, a, b):
+    """dsl.nim:79-83."""
+    if not isinstance(a, Expr) and not isinstance(b, Expr):
+        a, b = literal(float(a)), literal(float(b))
+    elif not isinstance(a, Expr):
+        a = b._coerce(a)
+    elif not isinstance(b, Expr):
+        b = a._coerce(b)
+    return Expr("instr", a.typ, instr="select", children=[cond, a, b])
+
+
+def sq(x):
+    return x * x  # dsl.nim:135-136: the SAME builder twice -> one register used twice
+
+
+def max(x, y):  # noqa: A001 - dsl.nim:138-139
+    x, y = _scalar(x), _scalar(y)
+    return select(x > y, x, y)
+
+
+def min(x, y):  # noqa: A001 - dsl.nim:141-142
+    x, y = _scalar(x), _scalar(y)
+    return select(x < y, x, y)
+
+
+def iters(names):
+    """Iterator literals (parser.nim:123-129).  `iters("y x it")` -> three Index builders."""
+    out = [Expr("iter", INDEX, iter=n) for n in names.replace(",", " ").split()]
+    return out[0] if len(out) == 1 else out
+
+
+def iter_in(name, start, stop):
+    """`x in start..<stop` (parser.nim:609-627): an iterator with explicit bounds."""
+    return Expr("iter", INDEX, iter=name, bounds=(literal(start), literal(stop)))
+
+
+class _Shape:
+    def __init__(self, fun):
+        self.fun = fun
+
+    def __getitem__(self, dim):
+        return Expr("instr", INDEX, instr="shape", tensor=self.fun, dim=int(dim))
+
+    def __len__(self):
+        raise TypeError("use shape_len(fun)")
+
+
+class _Raw:
+    def __init__(self, fun):
+        self.fun = fun
+
+    def __getitem__(self, index):
+        return Expr("read", SCALAR, tensor=self.fun, is_raw=True, children=[literal(index)])
+
+    def __setitem__(self, index, acc):
+        self.fun._add_statement(acc, [literal(index)], True)
+
+
+_fun_ids = itertools.count(1)
+
+
+class Fun:
+    """Graph node (parser.nim:72-97)."""
+
+    def __init__(self, kind="result", name="", **kw):
+        self.kind, self.name = kind, name
+        self.children = []
+        self.kernels = []       # KernelBuilder list (result / effect)
+        self.tensor = 0
+        self.targets = set()
+        self.locked = False
+        self.shape_constr = None
+        self.uid = next(_fun_ids)
+        self.__dict__.update(kw)
+
+    # a[y, x] / a.raw[i]  (dsl.nim:95-107)
+    def __getitem__(self, idx):
+        idx = idx if isinstance(idx, tuple) else (idx,)
+        return Expr("read", SCALAR, tensor=self, is_raw=False, children=[literal(i) for i in idx])
+
+    def __setitem__(self, idx, acc):
+        idx = idx if isinstance(idx, tuple) else (idx,)
+        self._add_statement(acc, [literal(i) for i in idx], False)
+
+    @property
+    def raw(self):
+        return _Raw(self)
+
+    @property
+    def shape(self):
+        return _Shape(self)
+
+    def len(self):
+        return Expr("instr", INDEX, instr="len", tensor=self)
+
+    def _add_statement(self, acc, dims, is_raw):
+        if not isinstance(acc, _Accumulate):
+            raise ParserError("kernels accumulate: write `t[idx] += value` (the reference's `++=`)")
+        tgt = acc.target
+        if tgt.tensor is not self or tgt.is_raw != is_raw or len(tgt.children) != len(dims):
+            raise ParserError("`+=` target mismatch")
+        if self.kind not in ("result", "effect"):
+            raise ParserError("Unable to add a kernel to a " + self.kind)  # parser.nim:437-438
+        if self.locked:
+            raise ParserError("tensor is locked")
+        self.kernels.append(_KernelBuilder(self, dims, is_raw, acc.value))
+        _collect_children(acc.value, self)  # parser.nim:430-441
+
+    # ---- shape constraints (parser.nim:683-697) --------------------------------------------
+    def copy_shape(self, src):
+        if self.kind != "result":
+            raise ParserError("Cannot set shape of " + self.kind)
+        self.shape_constr = ("copy", src)
+        if src not in self.children:
+            self.children.append(src)
+
+    copyShape = copy_shape
+
+    def with_shape(self, *dims):
+        if self.kind != "result":
+            raise ParserError("Cannot set shape of " + self.kind)
+        dims = [literal(d) for d in dims]
+        self.shape_constr = ("dims", dims)
+        for d in dims:
+            _collect_children(d, self)
+
+    withShape = with_shape
+
+    def lock(self):
+        self.locked = True
+
+    # ---- graph API (parser.nim:738-815) ----------------------------------------------------
+    def target(self, name, compile_target="gpu"):
+        return Fun("target", name, children=[self], compile_target=compile_target)
+
+    def backwards(self):
+        return backwards(self)
+
+    def params(self, stop=()):
+        return params(self, set(stop))
+
+    def optimize(self, *args):
+        return optimize(self, *args)
+
+    def backprop(self, optim):
+        return backprop(self, optim)
+
+    def grad(self, fun):
+        return grad(self, fun)
+
+
+def _collect_children(expr, fun):
+    for c in expr.children:
+        _collect_children(c, fun)
+    if expr.bounds:
+        for b in expr.bounds:
+            _collect_children(b, fun)
+    if expr.tensor is not None and expr.tensor is not fun and expr.tensor not in fun.children:
+        fun.children.append(expr.tensor)
+
+
+def input(name, shape=()):  # noqa: A001 - parser.nim:724-731
+    return Fun("input", name, input_shape=[int(s) for s in shape])
+
+
+def param(shape, init_range=(-0.1, 0.1), name=""):
+    """parser.nim:713-722."""
+    return Fun("param", name, param_shape=[int(s) for s in shape], init_range=(float(init_range[0]), float(init_range[1])))
+
+
+def backwards(fun):
+    return Fun("backwards", children=[fun])
+
+
+def params(fun, stop=frozenset()):
+    """parser.nim:742-756.  (The reference returns a HashSet; here: discovery order, deterministic.)"""
+    out = []
+    if not (fun.kind == "target" and fun.name in stop):
+        for c in fun.children:
+            for p in params(c, stop):
+                if p not in out:
+                    out.append(p)
+        if fun.kind == "param" and fun not in out:
+            out.append(fun)
+    return out
+
+
+def optimize(gradients, a, b=None):
+    """optimize(gradients, params, optim) / optimize(gradients, optim)   parser.nim:758-778."""
+    if b is None:
+        plist, optim = params(gradients), a
+    else:
+        plist, optim = a, b
+    result = Fun("multiple")
+    for p in plist:
+        effect = Fun("effect", effect=p)
+        g = Fun("gradient", children=[gradients, p])
+        optim(effect, g)
+        result.children.append(effect)
+    return result
+
+
+def backprop(loss, optim):
+    return optimize(backwards(loss), optim)  # parser.nim:780-781
+
+
+def grad(gradients, fun):
+    return Fun("gradient", children=[gradients, fun])  # parser.nim:783-784
+
+
+# ------------------------------------------------------------------------------------------------
+# Kernel building (parser.nim:159-254) and program flattening (parser.nim:261-417)
+
+class _KernelBuilder:
+    def __init__(self, target, dims, is_raw, value):
+        self.target, self.dims, self.is_raw, self.value = target, dims, is_raw, value
+
+
+class LinearIndex:
+    """ir.nim:120-123 after foldLinearIndices: constant + sum(factor * register); `setup`
+    instructions only for shape()/len() terms of explicit loop bounds."""
+
+    def __init__(self, constant=0, factors=None, setup=None):
+        self.constant, self.factors, self.setup = constant, dict(factors or {}), list(setup or [])
+
+    def tokens(self):
+        out = ["L", str(self.constant), str(len(self.factors))]
+        for r, f in self.factors.items():
+            out += [str(r), str(f)]
+        return out
+
+
+class Kernel:
+    def __init__(self):
+        self.nregs = 0
+        self.loops = []    # (iter_reg, name, bounds or None)
+        self.setup = []    # instrs evaluated on the host: shape/len terms of explicit bounds
+        self.reads = []    # (tensor_id, reg, is_raw, [LinearIndex])
+        self.instrs = []   # (kind, res, [args], extra)
+        self.result = 0
+        self.write = None  # (tensor_id, reg, is_raw, [LinearIndex])
+        self.generator = None  # ("backwards", tid) | ("gradient", of_tid, dest_tid)
+
+    def alloc(self):
+        self.nregs += 1
+        return self.nregs
+
+
+class _Ctx:
+    def __init__(self):
+        self.kernel = Kernel()
+        self.iters = {}
+        self.blocks = 0
+
+    def block(self):
+        self.blocks += 1
+        return self.blocks - 1
+
+
+def _build(expr, instrs, block, ctx):
+    """parser.nim:159-217."""
+    if block in expr._res:
+        return expr._res[block]
+    k = ctx.kernel
+    if expr.kind == "read":
+        dims = [_build_linear(d, ctx) for d in expr.children]
+        res = k.alloc()
+        k.reads.append((expr.tensor.tensor, res, expr.is_raw, dims))
+    elif expr.kind == "iter":
+        if expr.iter not in ctx.iters:
+            reg = k.alloc()
+            ctx.iters[expr.iter] = reg
+            bounds = None
+            if expr.bounds:
+                bounds = (_build_linear(expr.bounds[0], ctx), _build_linear(expr.bounds[1], ctx))
+            k.loops.append((reg, expr.iter, bounds))
+        res = ctx.iters[expr.iter]
+    else:
+        args = [_build(c, instrs, block, ctx) for c in expr.children]
+        extra = None
+        if expr.instr in ("index", "scalar", "boolean"):
+            extra = expr.lit
+        elif expr.instr == "shape":
+            extra = (expr.tensor.tensor, expr.dim)
+        elif expr.instr in ("len", "shapelen"):
+            extra = (expr.tensor.tensor,)
+        res = k.alloc()
+        instrs.append((expr.instr, res, args, extra))
+    expr._res[block] = res
+    return res
+
+
+def _fold(expr, ctx):
+    """foldLinearIndices for the affine index expressions the hot path uses: iter, literal,
+    +, -, * literal, shape()/len().  Returns LinearIndex or None if not affine."""
+    if expr.kind == "iter":
+        reg = _build(expr, [], -1, ctx)
+        return LinearIndex(0, {reg: 1})
+    if expr.kind != "instr":
+        return None
+    if expr.instr == "index":
+        return LinearIndex(int(expr.lit))
+    if expr.instr in ("shape", "len"):
+        setup = []
+        reg = _build(expr, setup, ctx.block(), ctx)
+        ctx.kernel.setup.extend(setup)
+        return LinearIndex(0, {reg: 1})
+    if expr.instr in ("add", "sub"):
+        a, b = _fold(expr.children[0], ctx), _fold(expr.children[1], ctx)
+        if a is None or b is None:
+            return None
+        sign = 1 if expr.instr == "add" else -1
+        out = LinearIndex(a.constant + sign * b.constant, a.factors)
+        for r, f in b.factors.items():
+            out.factors[r] = out.factors.get(r, 0) + sign * f
+        out.factors = {r: f for r, f in out.factors.items() if f != 0}
+        return out
+    if expr.instr == "negate":
+        a = _fold(expr.children[0], ctx)
+        if a is None:
+            return None
+        return LinearIndex(-a.constant, {r: -f for r, f in a.factors.items()})
+    if expr.instr == "mul":
+        a, b = _fold(expr.children[0], ctx), _fold(expr.children[1], ctx)
+        if a is None or b is None:
+            return None
+        if not a.factors:
+            a, b = b, a
+        if b.factors:
+            return None
+        return LinearIndex(a.constant * b.constant, {r: f * b.constant for r, f in a.factors.items() if f * b.constant})
+    return None
+
+
+def _build_linear(expr, ctx):
+    lin = _fold(expr, ctx)
+    if lin is None:
+        raise ParserError("tensor indices must be affine in the iterators for the GPU hot path "
+                          "(`div`/`mod` indices, used by maxpool2/upsample2, are out of scope)")
+    return lin
+
+
+def _clear(expr):
+    for c in expr.children:
+        _clear(c)
+    if expr.bounds:
+        for b in expr.bounds:
+            _clear(b)
+    expr._res = {}
+
+
+def _dedup_reads(k):
+    """deduplicateReads (passes.nim:352-369)."""
+    unique, subs, reads = {}, {}, []
+    for (tid, reg, raw, dims) in k.reads:
+        key = (tid, raw, tuple((d.constant, tuple(sorted(d.factors.items()))) for d in dims))
+        if key in unique:
+            subs[reg] = unique[key]
+        else:
+            unique[key] = reg
+            reads.append((tid, reg, raw, dims))
+    k.reads = reads
+    if subs:
+        k.instrs = [(kind, res, [subs.get(a, a) for a in args], extra) for (kind, res, args, extra) in k.instrs]
+        k.result = subs.get(k.result, k.result)
+
+
+def _build_kernel(kb):
+    """parser.nim:231-259."""
+    _clear(kb.value)
+    for d in kb.dims:
+        _clear(d)
+    ctx = _Ctx()
+    k = ctx.kernel
+    k.result = _build(kb.value, k.instrs, ctx.block(), ctx)
+    wdims = [_build_linear(d, ctx) for d in kb.dims]
+    k.write = (kb.target.tensor, k.result, kb.is_raw, wdims)
+    _dedup_reads(k)
+    return k
+
+
+class Target:
+    def __init__(self, name, output):
+        self.name, self.output = name, output
+        self.kernels = []
+
+
+class Program:
+    def __init__(self):
+        self.tensors = []   # dicts: kind, name, shape, range
+        self.inputs = {}
+        self.targets = {}
+        self.shape_constraints = []  # ("copy", dest, src) | ("dims", dest, [LinearIndex])
+
+    def alloc_tensor(self, **kw):
+        self.tensors.append(kw)
+        return len(self.tensors)
+
+    # ---- kernel-description text (grammar: DESIGN.md) --------------------------------------
+    def to_text(self):
+        out = ["kd 1 f32"]
+        for i, t in enumerate(self.tensors, 1):
+            name = t.get("name") or "-"
+            line = ["tensor", str(i), t["kind"], name.replace(" ", "_")]
+            shape = t.get("shape")
+            if shape is None or (t["kind"] == "input" and not shape):
+                line.append("-1")
+            else:
+                line += [str(len(shape))] + [str(s) for s in shape]
+            if t["kind"] == "param":
+                line += [repr(t["range"][0]), repr(t["range"][1])]
+            out.append(" ".join(line))
+        for c in self.shape_constraints:
+            if c[0] == "copy":
+                out.append(f"shapecopy {c[1]} {c[2]}")
+            else:
+                toks = ["shapedims", str(c[1]), str(len(c[2]))]
+                for d in c[2]:
+                    toks += d.tokens()
+                out.append(" ".join(toks))
+        for name, tgt in self.targets.items():
+            out.append(f"target {name} {tgt.output}")
+            for k in tgt.kernels:
+                if k.generator:
+                    out.append(" ".join(str(x) for x in k.generator))
+                    continue
+                out.append(f"kernel {k.nregs}")
+                for ins in k.setup:
+                    out.append("setup " + _ins_text(ins))
+                for (reg, nm, bounds) in k.loops:
+                    if bounds:
+                        out.append(" ".join(["loop", str(reg), nm, "1"] + bounds[0].tokens() + bounds[1].tokens()))
+                    else:
+                        out.append(f"loop {reg} {nm} 0")
+                for (tid, reg, raw, dims) in k.reads:
+                    toks = ["read", str(tid), str(reg), "1" if raw else "0", str(len(dims))]
+                    for d in dims:
+                        toks += d.tokens()
+                    out.append(" ".join(toks))
+                for ins in k.instrs:
+                    out.append("ins " + _ins_text(ins))
+                out.append(f"result {k.result}")
+                tid, reg, raw, dims = k.write
+                toks = ["write", str(tid), str(reg), "1" if raw else "0", str(len(dims))]
+                for d in dims:
+                    toks += d.tokens()
+                out.append(" ".join(toks))
+                out.append("endkernel")
+            out.append("endtarget")
+        return "\n".join(out) + "\n"
+
+
+def _ins_text(ins):
+    kind, res, args, extra = ins
+    toks = [kind, str(res), str(len(args))] + [str(a) for a in args]
+    if kind == "scalar":
+        toks.append(repr(float(extra)))
+    elif kind == "index":
+        toks.append(str(int(extra)))
+    elif kind == "boolean":
+        toks.append("1" if extra else "0")
+    elif kind == "shape":
+        toks += [str(extra[0]), str(extra[1])]
+    elif kind in ("len", "shapelen"):
+        toks.append(str(extra[0]))
+    return " ".join(toks)
+
+
+def _alloc_tensors(fun, program):
+    """parser.nim:261-315."""
+    if fun.tensor == 0:
+        k = fun.kind
+        if k == "input":
+            if fun.name not in program.inputs:
+                program.inputs[fun.name] = program.alloc_tensor(kind="input", name=fun.name, shape=list(fun.input_shape))
+            fun.tensor = program.inputs[fun.name]
+            if program.tensors[fun.tensor - 1]["shape"] != list(fun.input_shape):
+                raise ParserError(f'Expected shapes for input "{fun.name}" do not match.')
+        elif k == "param":
+            fun.tensor = program.alloc_tensor(kind="param", name=fun.name, shape=list(fun.param_shape), range=fun.init_range)
+        elif k in ("result", "gradient"):
+            fun.tensor = program.alloc_tensor(kind="result", name=fun.name)
+        elif k == "effect":
+            _alloc_tensors(fun.effect, program)
+            fun.tensor = fun.effect.tensor
+        for c in fun.children:
+            _alloc_tensors(c, program)
+        if k == "target":
+            fun.tensor = fun.children[0].tensor
+
+
+def _flatten(fun, target, program):
+    """parser.nim:317-384."""
+    if target.name in fun.targets:
+        return
+    for c in fun.children:
+        _flatten(c, target, program)
+    if fun.kind == "effect":
+        _flatten(fun.effect, target, program)
+    fun.targets.add(target.name)
+    if fun.kind in ("result", "effect"):
+        for kb in fun.kernels:
+            target.kernels.append(_build_kernel(kb))
+        if fun.shape_constr:
+            if fun.shape_constr[0] == "copy":
+                c = ("copy", fun.tensor, fun.shape_constr[1].tensor)
+            else:
+                ctx = _Ctx()
+                c = ("dims", fun.tensor, [_build_linear(d, ctx) for d in fun.shape_constr[1]])
+            if c not in program.shape_constraints:
+                program.shape_constraints.append(c)
+    elif fun.kind == "backwards":
+        k = Kernel()
+        k.generator = ("backwards", fun.children[0].tensor)
+        target.kernels.append(k)
+    elif fun.kind == "gradient":
+        k = Kernel()
+        k.generator = ("gradient", fun.children[1].tensor, fun.tensor)
+        target.kernels.append(k)
+
+
+def _collect_targets(fun, targets):
+    """parser.nim:386-402."""
+    if fun.kind == "target":
+        if fun.name in targets:
+            if targets[fun.name] is not fun:
+                raise ParserError(f'There are multiple targets named "{fun.name}". Target names must be unique '
+                                  "within a model. Choose a different name every target.")
+            return
+        targets[fun.name] = fun
+    for c in fun.children:
+        _collect_targets(c, targets)
+    if fun.kind == "effect":
+        _collect_targets(fun.effect, targets)
+
+
+def to_program(*graphs):
+    """toProgram (parser.nim:404-417)."""
+    program = Program()
+    targets = {}
+    for fun in graphs:
+        _alloc_tensors(fun, program)
+        _collect_targets(fun, targets)
+    for name, fun in targets.items():
+        t = Target(name, fun.tensor)
+        _flatten(fun, t, program)
+        program.targets[name] = t
+    return program
+
+
+toProgram = to_program

@@ -1,0 +1,184 @@
+"""The reference's layer library restated in the Python DSL — statement for statement.
+
+Sources: exprgrad/layers/base.nim:19-67 and exprgrad/layers/dnn.nim:19-100.  Iterator
+declaration order after `|` does not affect the lowered kernel (loops are created on first
+use, parser.nim:183-196), so it is not reproduced.  Layers outside the hot path (maxpool2 /
+avgpool2 / upsample2 / dropout: non-affine indices or random tensors) are not provided.
+"""
+from . import dsl
+from .dsl import Fun, iters, param, select, sq, to_scalar
+
+
+def _layer(name):
+    f = Fun()
+    f.name = name
+    return f
+
+
+# ---- base.nim ------------------------------------------------------------------------------
+def add(a, b):
+    it = iters("it")
+    r = _layer("+")
+    r.raw[it] += a.raw[it] + b.raw[it]                 # base.nim:19
+    return r
+
+
+def sub(a, b):
+    it = iters("it")
+    r = _layer("-")
+    r.raw[it] += a.raw[it] - b.raw[it]                 # base.nim:20
+    return r
+
+
+def minimum(a, b):
+    it = iters("it")
+    r = _layer("min")
+    r.raw[it] += dsl.min(a.raw[it], b.raw[it])         # base.nim:21
+    return r
+
+
+def maximum(a, b):
+    it = iters("it")
+    r = _layer("max")
+    r.raw[it] += dsl.max(a.raw[it], b.raw[it])         # base.nim:22
+    return r
+
+
+def scale(a, factor):
+    it = iters("it")
+    r = _layer("*")
+    r.raw[it] += a.raw[it] * float(factor)             # base.nim:24
+    return r
+
+
+def divide(a, factor):
+    it = iters("it")
+    r = _layer("/")
+    r.raw[it] += a.raw[it] / float(factor)             # base.nim:25
+    return r
+
+
+def matmul(a, b):
+    y, x, it = iters("y x it")
+    r = _layer("matmul")
+    r[y, x] += a[y, it] * b[it, x]                     # base.nim:27-28
+    return r
+
+
+def transpose(mat):
+    y, x = iters("y x")
+    r = _layer("transpose")
+    r[y, x] += mat[x, y]                               # base.nim:32-33
+    return r
+
+
+def gradient_descent(rate=0.01):
+    """makeOpt(gradientDescent, rate=...)  base.nim:37-38."""
+    def optim(p, g):
+        it = iters("it")
+        p.raw[it] += -g.raw[it] * float(rate)
+    return optim
+
+
+gradientDescent = gradient_descent
+
+
+def adam(eta=0.01, beta1=0.9, beta2=0.999, eps=1e-8):
+    raise NotImplementedError("adam needs cache tensors and epoch(): SURVEY.md §8(f) row f2 (next)")
+
+
+def mse(a, b):
+    it = iters("it")
+    r = _layer("mse")
+    r[0] += sq(a.raw[it] - b.raw[it]) / to_scalar(a.shape[0])                 # base.nim:57-58
+    return r
+
+
+def binary_cross_entropy(pred, labels):
+    it = iters("it")
+    r = _layer("binaryCrossEntropy")
+    r[0] += -(labels.raw[it] * dsl.ln(pred.raw[it]) +
+              (1.0 - labels.raw[it]) * dsl.ln(1.0 - pred.raw[it])) / to_scalar(pred.shape[0])   # base.nim:60-64
+    return r
+
+
+def cross_entropy(pred, labels):
+    it = iters("it")
+    r = _layer("crossEntropy")
+    r[0] += -(labels.raw[it] * dsl.ln(pred.raw[it])) / to_scalar(pred.shape[0])   # base.nim:66-67
+    return r
+
+
+binaryCrossEntropy, crossEntropy = binary_cross_entropy, cross_entropy
+
+
+# ---- dnn.nim -------------------------------------------------------------------------------
+def dense(values, inp, outp, has_bias=True):
+    y, x, it = iters("y x it")
+    weights = param([inp, outp], name="weights")
+    r = _layer("dense")
+    r[y, x] += values[y, it] * weights[it, x]          # dnn.nim:21
+    if has_bias:
+        bias = param([outp], name="bias")
+        r[y, x] += bias[x]                             # dnn.nim:22-24
+    return r
+
+
+def relu(inp):
+    it = iters("it")
+    r = _layer("relu")
+    r.raw[it] += select(inp.raw[it] >= 0.0, inp.raw[it], 0.0)           # dnn.nim:26-27
+    return r
+
+
+def leaky_relu(inp, leak=0.01):
+    it = iters("it")
+    r = _layer("leakyRelu")
+    r.raw[it] += select(inp.raw[it] >= 0.0, 1.0, float(leak)) * inp.raw[it]   # dnn.nim:29-30
+    return r
+
+
+leakyRelu = leaky_relu
+
+
+def sigmoid(inp):
+    it = iters("it")
+    r = _layer("sigmoid")
+    r.raw[it] += 1.0 / (1.0 + dsl.exp(-inp.raw[it]))                    # dnn.nim:32-33
+    return r
+
+
+def tanh(inp):
+    it = iters("it")
+    r = _layer("tanh")
+    a = dsl.exp(inp.raw[it])
+    b = dsl.exp(-inp.raw[it])
+    r.raw[it] += (a - b) / (a + b)                                      # dnn.nim:35-40
+    return r
+
+
+def sin(inp):
+    it = iters("it")
+    r = _layer("sin")
+    r.raw[it] += dsl.sin(inp.raw[it])                                   # dnn.nim:42-43
+    return r
+
+
+def conv2(images, filters, w=None, h=None, nfilters=None):
+    """conv2(images, filters: Fun) or conv2(images, chans, w, h, filters: int)   dnn.nim:45-53."""
+    if not isinstance(filters, Fun):
+        chans = filters
+        filters = param([nfilters, h, w, chans], name="filters")
+    image, y, x, flt, dx, dy, chan = iters("image y x filter dx dy chan")
+    r = _layer("conv2")
+    r[image, y, x, flt] += images[image, y + dy, x + dx, chan] * filters[flt, dy, dx, chan]
+    return r
+
+
+def softmax(inp):
+    y, x = iters("y x")
+    sums = _layer("softmax.sums")
+    sums[y] += dsl.exp(inp[y, x])                                       # dnn.nim:90-92
+    r = _layer("softmax")
+    r[y, x] += dsl.exp(inp[y, x]) / sums[y]                             # dnn.nim:94
+    return r

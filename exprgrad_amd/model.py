@@ -1,0 +1,193 @@
+"""Host-side mirror of exprgrad/model.nim for GPU targets, over group 3 of the C ABI.
+
+    model = compile(net, gpu=ctx)                 # compile[float32](net, gpu=ctx)   model.nim:270-273
+    out = model.call("predict", {"x": x})         # model.nim:392-406
+    model.apply("train", {"x": x, "y": y})        # model.nim:408-411
+    model.fit("train", {"x": x, "y": y}, batch_size=32)                             # model.nim:413-454
+    model.params[tensor_id]                       # Model.params                     model.nim:37
+
+Inputs may be numpy arrays (copied host->device on every call, as the reference's writeInput
+does, model.nim:364-368) or device tensors (anything with .data_ptr() and .shape, e.g. a torch
+tensor: borrowed, no copy).  Outputs are fresh numpy arrays (readOutput, model.nim:375-376).
+"""
+import ctypes
+
+import numpy as np
+
+from . import dsl
+from ._lib import call, GpuError, RuntimeErrorEG  # noqa: F401
+from .runtime import GpuContext
+
+
+class _Params:
+    """dict-like view of the device-resident parameters: get copies D2H, set copies H2D."""
+
+    def __init__(self, model):
+        self._m = model
+
+    def ids(self):
+        return list(self._m._param_shapes)
+
+    def __iter__(self):
+        return iter(self._m._param_shapes)
+
+    def __len__(self):
+        return len(self._m._param_shapes)
+
+    def __getitem__(self, tid):
+        shape = self._m._param_shapes[tid]
+        out = np.empty(shape, dtype=np.float32)
+        call("eg_model_param_read", self._m.handle, int(tid), out.ctypes.data_as(ctypes.c_void_p), out.size)
+        return out
+
+    def __setitem__(self, tid, value):
+        shape = self._m._param_shapes[tid]
+        arr = np.ascontiguousarray(value, dtype=np.float32)
+        if list(arr.shape) != list(shape):
+            raise GpuError(f"parameter {tid} has shape {list(shape)}, got {list(arr.shape)}")
+        call("eg_model_param_write", self._m.handle, int(tid), arr.ctypes.data_as(ctypes.c_void_p), arr.size)
+
+    def items(self):
+        return [(t, self[t]) for t in self.ids()]
+
+
+class Model:
+    def __init__(self, program, ctx):
+        if not isinstance(ctx, GpuContext):
+            raise GpuError("compile(..., gpu=ctx) needs a GpuContext: this backend has no CPU path")
+        self.ctx = ctx
+        self.program = program
+        self.source_text = program.to_text()
+        h = ctypes.c_void_p()
+        call("eg_model_compile", ctx.handle, self.source_text.encode(), ctypes.byref(h))
+        self.handle = h
+        self._param_shapes = {}
+        for tid, t in enumerate(program.tensors, 1):
+            if t["kind"] == "param":
+                self._param_shapes[tid] = list(t["shape"])
+        self.params = _Params(self)
+        self._keep = {}
+
+    # ---- introspection -----------------------------------------------------------------------
+    def emit_ir(self):
+        """emitIr (model.nim:262-264): the lowered plan, one line per kernel."""
+        from . import _lib
+        return (_lib.lib().eg_model_plan_text(self.handle) or b"").decode()
+
+    emitIr = emit_ir
+
+    def kernel_count(self, target):
+        return call("eg_model_kernel_count", self.handle, target.encode())
+
+    @property
+    def epoch(self):
+        from . import _lib
+        return _lib.lib().eg_model_epoch(self.handle)
+
+    @epoch.setter
+    def epoch(self, v):
+        call("eg_model_set_epoch", self.handle, int(v))
+
+    # ---- inputs ------------------------------------------------------------------------------
+    def _bind(self, name, tensor):
+        if hasattr(tensor, "data_ptr"):  # device tensor: borrow
+            shape = [int(s) for s in tensor.shape]
+            arr = (ctypes.c_int64 * max(len(shape), 1))(*shape)
+            self._keep[name] = tensor
+            call("eg_model_set_input_device", self.handle, name.encode(), ctypes.c_void_p(tensor.data_ptr()), len(shape), arr)
+        else:
+            a = np.ascontiguousarray(tensor, dtype=np.float32)
+            arr = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+            call("eg_model_set_input_host", self.handle, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.ndim, arr)
+
+    def _bind_all(self, args):
+        call("eg_model_clear_inputs", self.handle)
+        self._keep = {}
+        items = args.items() if isinstance(args, dict) else args
+        for name, tensor in items:
+            self._bind(name, tensor)
+
+    # ---- call / apply / fit ------------------------------------------------------------------
+    def call(self, target, args=()):
+        """call (model.nim:392-406)."""
+        self._bind_all(args)
+        call("eg_model_run", self.handle, target.encode())
+        return self._read_output(target)
+
+    def apply(self, target, args=()):
+        """apply = discard call (model.nim:408-411), without the device->host copy."""
+        self._bind_all(args)
+        call("eg_model_run", self.handle, target.encode())
+
+    def _read_output(self, target):
+        tgt = self.program.targets[target]
+        if tgt.output == 0:
+            return None
+        rank = ctypes.c_int(0)
+        shape = (ctypes.c_int64 * 8)()
+        call("eg_model_output_shape", self.handle, target.encode(), ctypes.byref(rank), shape)
+        out = np.empty([shape[i] for i in range(rank.value)], dtype=np.float32)
+        call("eg_model_read_output", self.handle, target.encode(), out.ctypes.data_as(ctypes.c_void_p), out.size)
+        return out
+
+    def read_tensor(self, target, tensor_id):
+        rank = ctypes.c_int(0)
+        shape = (ctypes.c_int64 * 8)()
+        call("eg_model_tensor_shape", self.handle, target.encode(), int(tensor_id), ctypes.byref(rank), shape)
+        out = np.empty([shape[i] for i in range(rank.value)], dtype=np.float32)
+        call("eg_model_read_tensor", self.handle, target.encode(), int(tensor_id), out.ctypes.data_as(ctypes.c_void_p),
+             out.size)
+        return out
+
+    def fit(self, target, args, batch_size=32, log_status=False):
+        """fit (model.nim:413-454): one epoch of mini-batches; the tail that does not fill a batch is
+        dropped (batchCount = shape[0] div batchSize), Model.epoch is bumped once."""
+        items = list(args.items() if isinstance(args, dict) else args)
+        if not items:
+            raise RuntimeErrorEG("Model.fit requires at least one input tensor. Use Model.apply instead if the "
+                                 "target has zero inputs.")
+        if target not in self.program.targets:
+            raise RuntimeErrorEG(target + " is not a target of the model")
+        batch_count = int(items[0][1].shape[0]) // batch_size
+        self.epoch = self.epoch + 1
+        for b in range(batch_count):
+            lo = b * batch_size
+            # viewFirst (tensors.nim:290-297): a zero-copy slice of the leading dimension
+            self.apply(target, [(n, a[lo:lo + batch_size]) for n, a in items])
+
+    # ---- data-parallel hooks ---------------------------------------------------
+    def grad_bucket(self, target):
+        """(device pointer, float count) of the flat parameter-gradient bucket of `target`."""
+        p = ctypes.c_void_p()
+        n = ctypes.c_int64(0)
+        call("eg_model_grad_bucket", self.handle, target.encode(), ctypes.byref(p), ctypes.byref(n))
+        return p.value or 0, n.value
+
+    def bind_grad_bucket(self, target, tensor):
+        """Let the gradients of `target` live in caller-owned device memory (a torch tensor)."""
+        self._bucket_keep = tensor
+        call("eg_model_bind_grad_bucket", self.handle, target.encode(), ctypes.c_void_p(tensor.data_ptr()),
+             int(tensor.numel()))
+
+    def run_backward(self, target, args=None):
+        if args is not None:
+            self._bind_all(args)
+        call("eg_model_run_backward", self.handle, target.encode())
+
+    def run_update(self, target):
+        call("eg_model_run_update", self.handle, target.encode())
+
+    def set_grad_scale(self, scale):
+        call("eg_model_set_grad_scale", self.handle, float(scale))
+
+    def close(self):
+        if self.handle:
+            call("eg_model_free", self.handle)
+            self.handle = None
+
+
+def compile(*graphs, gpu=None):  # noqa: A001 - mirrors compile[T](graphs, gpu) model.nim:270-273
+    if len(graphs) == 1 and isinstance(graphs[0], (list, tuple)):
+        graphs = tuple(graphs[0])
+    program = dsl.to_program(*graphs)
+    return Model(program, gpu)

@@ -198,6 +198,10 @@ int eg_model_param_read(eg_model* model, int tensor_id, float* host, int64_t cou
  * data-parallel exchange step: gradients are laid out back to back in one flat bucket. */
 int eg_model_grad_bucket(eg_model* model, const char* target, float** device_ptr,
                          int64_t* count);
+/* Use caller-owned device memory (>= the bucket's count floats) for the gradients of `target`,
+ * e.g. a torch tensor that torch.distributed can all-reduce in place. */
+int eg_model_bind_grad_bucket(eg_model* model, const char* target, float* device_ptr,
+                              int64_t count);
 int eg_model_param_ptr(eg_model* model, int tensor_id, float** device_ptr, int64_t* count);
 
 /* Bind an input (writeInput, model.nim:357-368).  Host form copies H2D (blocking, as the
@@ -206,6 +210,10 @@ int eg_model_set_input_host(eg_model* model, const char* name, const float* host
                             const int64_t* shape);
 int eg_model_set_input_device(eg_model* model, const char* name, const float* device_ptr,
                               int rank, const int64_t* shape);
+
+/* Forget every bound input (a later run of a target that needs one then fails with
+ * EG_ERR_RUNTIME, like a call without that argument). */
+int eg_model_clear_inputs(eg_model* model);
 
 /* call (model.nim:392-406): infer shapes from the bound inputs, (re)allocate and zero the
  * target's result tensors, run its kernel list.  Asynchronous. */
@@ -221,10 +229,13 @@ int eg_model_set_grad_scale(eg_model* model, float scale);
 /* readOutput (model.nim:370-376): shape of / blocking copy of the target's output tensor. */
 int eg_model_output_shape(eg_model* model, const char* target, int* rank, int64_t* shape8);
 int eg_model_read_output(eg_model* model, const char* target, float* host, int64_t count);
-/* Any tensor of the last run by id (debugging / parity tests). */
-int eg_model_tensor_shape(eg_model* model, int tensor_id, int* rank, int64_t* shape8);
-int eg_model_read_tensor(eg_model* model, int tensor_id, float* host, int64_t count);
-int eg_model_tensor_ptr(eg_model* model, int tensor_id, float** device_ptr, int64_t* count);
+/* Any tensor of the last run of `target`, by id (debugging / parity tests). */
+int eg_model_tensor_shape(eg_model* model, const char* target, int tensor_id, int* rank,
+                          int64_t* shape8);
+int eg_model_read_tensor(eg_model* model, const char* target, int tensor_id, float* host,
+                         int64_t count);
+int eg_model_tensor_ptr(eg_model* model, const char* target, int tensor_id, float** device_ptr,
+                        int64_t* count);
 
 /* Model.epoch (model.nim:39, bumped by fit at model.nim:436). */
 int eg_model_set_epoch(eg_model* model, int64_t epoch);

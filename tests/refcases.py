@@ -1,0 +1,296 @@
+"""Programs of the reference's own tests, restated in the Python DSL mirror.
+
+Each builder returns the graph(s) to compile; the inputs and expected outputs live in
+tests/golden/known_answers.json (data transcribed from the reference's tests, with citations).
+Used by the CPU tests of the oracle and by the GPU tests of the product, so both are pinned to
+the same vectors.
+"""
+import json
+import os
+
+import numpy as np
+
+from exprgrad_amd import dsl, layers
+from exprgrad_amd.dsl import Fun, iters, param, select, sq
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "known_answers.json")
+
+
+def load_golden():
+    with open(GOLDEN) as f:
+        return json.load(f)
+
+
+def arr(spec):
+    return np.array(spec["data"], dtype=np.float32).reshape(spec["shape"])
+
+
+# ---- tests/test_model.nim ---------------------------------------------------------------------
+def identity():
+    it = iters("it")
+    r = Fun()
+    r.raw[it] += dsl.input("x").raw[it]
+    return [r.target("y")]
+
+
+def double():
+    it = iters("it")
+    r = Fun()
+    r.raw[it] += dsl.input("x").raw[it] * 2.0
+    return [r.target("y")]
+
+
+def matmul():
+    y, x, it = iters("y x it")
+    c = Fun()
+    c[y, x] += dsl.input("a")[y, it] * dsl.input("b")[it, x]
+    return [c.target("c")]
+
+
+def relu():
+    it = iters("it")
+    inp = dsl.input("inp")
+    outp = Fun()
+    outp.raw[it] += select(0.0 < inp.raw[it], inp.raw[it], 0.0)
+    return [outp.target("outp")]
+
+
+def mean_squared_error():
+    it = iters("it")
+    loss = Fun()
+    loss[0] += sq(dsl.input("pred").raw[it] - dsl.input("labels").raw[it])
+    return [loss.target("loss")]
+
+
+def transpose():
+    x, y = iters("x y")
+    b = Fun()
+    b[y, x] += dsl.input("a")[x, y]
+    return [b.target("b")]
+
+
+def maximum():
+    it = iters("it")
+    x = dsl.input("x")
+    res = Fun()
+    res.raw[it] += dsl.max(x.raw[it], dsl.input("y").raw[it])
+    res.copy_shape(x)
+    return [res.target("z")]
+
+
+def conv1():
+    x, dx = iters("x dx")
+    res = Fun()
+    res[x] += dsl.input("image")[x + dx] * dsl.input("filter")[dx]
+    return [res.target("res")]
+
+
+def single_write():
+    res = Fun()
+    res[0] += dsl.literal(10.0)
+    return [res.target("y")]
+
+
+def shape_case():
+    it = iters("it")
+    res = Fun()
+    res.raw[it] += dsl.literal(1.0)
+    res.with_shape(3, 2, 1)
+    return [res.target("y")]
+
+
+def dimensions():
+    inp = dsl.input("x")
+    res = Fun()
+    res[0] += dsl.to_scalar(inp.shape[0])
+    res[1] += dsl.to_scalar(inp.shape[-2])
+    res[2] += dsl.to_scalar(inp.shape[-1])
+    res[3] += dsl.to_scalar(dsl.Expr("instr", dsl.INDEX, instr="shapelen", tensor=inp))
+    res[4] += dsl.to_scalar(inp.len())
+    res.with_shape(5)
+    return [res.target("y")]
+
+
+def loop_bounds():
+    res = Fun()
+    res[dsl.iter_in("x", 2, 4)] += dsl.literal(1.0)
+    res[dsl.iter_in("x", 0, 1)] += dsl.literal(-1.0)
+    res[dsl.iter_in("x", 1, 1)] += dsl.literal(-2.0)
+    res.with_shape(5)
+    return [res.target("res")]
+
+
+def xor_from_scratch(rate=0.1):
+    """tests/test_model.nim:169-194 == examples/xor_from_scratch/xor_from_scratch.nim:19-31."""
+    y, x, it = iters("y x it")
+    hidden = Fun()
+    hidden[y, x] += dsl.input("x")[y, it] * param([2, 4])[it, x]
+    hidden[y, x] += param([4])[x]
+    hidden_relu = Fun()
+    hidden_relu.raw[it] += select(hidden.raw[it] <= 0.0, 0.1 * hidden.raw[it], hidden.raw[it])
+    output = Fun()
+    output[y, x] += hidden_relu[y, it] * param([4, 1])[it, x]
+    output[y, x] += param([1])[x]
+    output_sigmoid = Fun()
+    output_sigmoid.raw[it] += 1.0 / (1.0 + dsl.exp(-output.raw[it]))
+    pred = output_sigmoid.target("predict")
+    loss = Fun()
+    loss[0] += sq(pred.raw[it] - dsl.input("y").raw[it])
+
+    def optim(p, g):
+        p.raw[it] += -rate * g.raw[it]
+
+    return [loss.target("loss").backprop(optim).target("train")]
+
+
+def derive_polynomial():
+    it = iters("it")
+    x = dsl.input("x")
+    y = Fun()
+    y.raw[it] += sq(x.raw[it]) + 2.0 * x.raw[it] + 1.0
+    return [y.backwards().grad(x).target("x^2+2x+1")]
+
+
+def derive_multiply():
+    it = iters("it")
+    x = dsl.input("x")
+    a, b, c, d = Fun(), Fun(), Fun(), Fun()
+    a.raw[it] += x.raw[it] * x.raw[it] * x.raw[it]
+    b.raw[it] += x.raw[it] / 2.0
+    c.raw[it] += 1.0 / x.raw[it]
+    d.raw[it] += x.raw[it] / x.raw[it]
+    return [a.backwards().grad(x).target("x^3"), b.backwards().grad(x).target("x/2"),
+            c.backwards().grad(x).target("1/x"), d.backwards().grad(x).target("x/x")]
+
+
+def derive_trigonometry():
+    it = iters("it")
+    x = dsl.input("x")
+    a, b = Fun(), Fun()
+    a.raw[it] += dsl.sin(x.raw[it])
+    b.raw[it] += dsl.cos(x.raw[it])
+    return [a.backwards().grad(x).target("sin"), b.backwards().grad(x).target("cos")]
+
+
+def derive_exp():
+    it = iters("it")
+    x = dsl.input("x")
+    a, b, c, d, e = Fun(), Fun(), Fun(), Fun(), Fun()
+    a.raw[it] += dsl.exp(x.raw[it])
+    b.raw[it] += dsl.exp(2.0 * x.raw[it])
+    c.raw[it] += dsl.pow(x.raw[it], 3.0)
+    d.raw[it] += dsl.pow(2.0, x.raw[it])
+    e.raw[it] += dsl.pow(x.raw[it], x.raw[it])
+    return [a.backwards().grad(x).target("exp(x)"), b.backwards().grad(x).target("exp(2x)"),
+            c.backwards().grad(x).target("x^3"), d.backwards().grad(x).target("2^x"),
+            e.backwards().grad(x).target("x^x")]
+
+
+def derive_log():
+    it = iters("it")
+    x = dsl.input("x")
+    a, b, c, d, e = Fun(), Fun(), Fun(), Fun(), Fun()
+    a.raw[it] += dsl.ln(x.raw[it])
+    b.raw[it] += dsl.log10(x.raw[it])
+    c.raw[it] += dsl.log2(x.raw[it])
+    d.raw[it] += dsl.log(x.raw[it], 5.0)
+    e.raw[it] += dsl.log(2.0, x.raw[it])
+    return [a.backwards().grad(x).target("ln(x)"), b.backwards().grad(x).target("log10(x)"),
+            c.backwards().grad(x).target("log2(x)"), d.backwards().grad(x).target("log(x,5)"),
+            e.backwards().grad(x).target("log(2,x)")]
+
+
+# ---- tests/test_talks.nim ---------------------------------------------------------------------
+def increment():
+    it = iters("it")
+    r = Fun()
+    r.raw[it] += dsl.input("input").raw[it] + 1.0
+    return [r.target("increment")]
+
+
+def sum_positive():
+    it = iters("it")
+    inp = dsl.input("input")
+    r = Fun()
+    r[0] += select(inp.raw[it] > 0.0, inp.raw[it], 0.0)
+    return [r.target("sumPositive")]
+
+
+def linear():
+    x, y, it = iters("x y it")
+    inp, weights, biases = dsl.input("input"), dsl.input("weights"), dsl.input("biases")
+    r = Fun()
+    r[y, x] += inp[y, it] * weights[it, x]
+    r[y, x] += biases[x]
+    return [r.target("predict")]
+
+
+def multiply_and_square():
+    x, y, it = iters("x y it")
+    a, b = dsl.input("a"), dsl.input("b")
+    c = Fun()
+    c[y, x] += a[y, it] * b[it, x]
+    d = Fun()
+    d.raw[it] += c.raw[it] * c.raw[it]
+    return [c.target("multiply"), d.target("multiplyAndSquare")]
+
+
+# ---- tests/test_gpu.nim -----------------------------------------------------------------------
+def leaky_relu_gpu():
+    it = iters("it")
+    x = dsl.input("x")
+    y = Fun()
+    y.raw[it] += select(x.raw[it] > 0.0, x.raw[it], 0.01 * x.raw[it])
+    return [y.target("y")]
+
+
+# ---- tests/test_dnn.nim -----------------------------------------------------------------------
+def xor_layers(rate=0.2):
+    """tests/test_dnn.nim:23-34."""
+    net = layers.dense(dsl.input("x"), 2, 4)
+    net = layers.leaky_relu(net)
+    net = layers.dense(net, 4, 1)
+    net = layers.sigmoid(net).target("predict")
+    net = layers.mse(net, dsl.input("y")).target("loss")
+    return [net.backprop(layers.gradient_descent(rate)).target("train")]
+
+
+# ---- BASELINE.json configs (definitions: SURVEY.md §8d) ----------------------------------------
+def dense_softmax_net(n_in=784, n_hidden=512, n_out=10, rate=0.01):
+    """configs[4]: dense(784,512) -> relu -> dense(512,10) -> softmax -> crossEntropy -> GD(0.01)."""
+    net = layers.dense(dsl.input("x"), n_in, n_hidden)
+    net = layers.relu(net)
+    net = layers.dense(net, n_hidden, n_out)
+    net = layers.softmax(net).target("predict")
+    net = layers.cross_entropy(net, dsl.input("y")).target("loss")
+    return [net.backprop(layers.gradient_descent(rate)).target("train")]
+
+
+def conv2_bench():
+    """configs[3] / dnn.nim:45-49 with the filter bank as an input."""
+    return [layers.conv2(dsl.input("images"), dsl.input("filters")).target("conv2")]
+
+
+def conv2_3d():
+    """benchmarks/conv2/conv2.nim:128-132 (no batch dimension)."""
+    y, x, f, c, dy, dx = iters("y x filter chan dy dx")
+    image, filters = dsl.input("image"), dsl.input("filters")
+    r = Fun()
+    r[y, x, f] += image[y + dy, x + dx, c] * filters[f, dy, dx, c]
+    return [r.target("conv2")]
+
+
+BUILDERS = {
+    "identity": identity, "double": double, "matmul": matmul, "relu": relu,
+    "meanSquaredError": mean_squared_error, "transpose": transpose, "max": maximum, "conv1": conv1,
+    "singleWrite": single_write, "shape": shape_case, "dimensions": dimensions, "loopBounds": loop_bounds,
+    "derive/polynomial": derive_polynomial, "derive/multiply": derive_multiply,
+    "derive/trigonometry": derive_trigonometry, "derive/exp": derive_exp, "derive/log": derive_log,
+    "increment": increment, "sumPositive": sum_positive, "multiple": linear,
+    "multiplyAndSquare": multiply_and_square, "leakyReluGpu": leaky_relu_gpu, "matmulTalks": matmul,
+    "matmulExample": matmul,
+}
+
+
+def program_text(graphs):
+    return dsl.to_program(*graphs).to_text()

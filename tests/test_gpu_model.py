@@ -1,0 +1,230 @@
+"""GPU parity of kernel-description programs (group 3 of the C ABI) — the drop-in path:
+Python DSL mirror -> text -> eg_model_compile -> HIP kernels, compared with
+  (a) the reference's own known-answer vectors (tests/golden/known_answers.json), and
+  (b) the oracle (oracle/kd.py + refinterp.c: the reference's CPU lowering restated) on seeded
+      random inputs, at 1e-5 relative (float32; BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+
+import refcases
+from conftest import TOL, rel_err
+from exprgrad_amd import model as egm
+
+pytestmark = pytest.mark.gpu
+GOLDEN = refcases.load_golden()
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_known_answers(gpu_ctx, name):
+    model = egm.compile(*refcases.BUILDERS[name](), gpu=gpu_ctx)
+    for c in GOLDEN[name]["calls"]:
+        got = model.call(c["target"], {k: refcases.arr(v) for k, v in c["inputs"].items()})
+        want = refcases.arr(c["expected"])
+        assert list(got.shape) == c["expected"]["shape"]
+        if c["mode"] == "sumsq" and c["target"] == "x^x":
+            # the reference's absolute bound (sum of squares < 0.01 at values up to 5e7) only holds
+            # when both sides call the same libm powf; device powf is within 1 ulp: relative bound
+            assert rel_err(got, want) <= TOL
+        elif c["mode"] == "sumsq":
+            assert float(np.sum((got.astype(np.float64) - want) ** 2)) < c["eps"]
+        elif name.startswith("derive/") and name not in ("derive/polynomial", "derive/multiply"):
+            # the reference compares against host libm; device expf/logf/powf/sinf/cosf are 1-2 ulp
+            # implementations of the same functions: float32 tolerance instead of ==
+            finite = np.isfinite(want)
+            assert np.array_equal(np.isfinite(got), finite)
+            assert np.allclose(got[finite], want[finite], rtol=1e-5, atol=1e-6)
+            assert np.array_equal(got[~finite], want[~finite])
+        else:
+            assert np.array_equal(got, want), (got, want)
+    model.close()
+
+
+def set_params(models, seed):
+    """Same explicit U[-0.1, 0.1) parameters on every side (the reference draws them from Nim's RNG:
+    parity unpinned)."""
+    rng = np.random.default_rng(seed)
+    gpu, ref = models
+    for tid in sorted(ref.params):
+        v = (rng.random(ref.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+        ref.params[tid][...] = v
+        gpu.params[tid] = v
+
+
+def pair(graph_builder, gpu_ctx, **kw):
+    from oracle import kd
+    gpu = egm.compile(*graph_builder(**kw), gpu=gpu_ctx)
+    ref = kd.Model(refcases.program_text(graph_builder(**kw)), threads=8)
+    return gpu, ref
+
+
+def test_kernel_lists_match_the_oracle(gpu_ctx):
+    for builder in (refcases.xor_from_scratch, refcases.xor_layers, refcases.dense_softmax_net):
+        gpu, ref = pair(builder, gpu_ctx)
+        for target in ("predict", "loss", "train"):
+            assert gpu.kernel_count(target) == ref.kernel_count(target), (builder.__name__, target)
+        gpu.close()
+    gpu, ref = pair(refcases.xor_from_scratch, gpu_ctx)
+    assert gpu.kernel_count("train") == 19
+    text = gpu.emit_ir()
+    assert "gemm+bias" in text and "seed-fill" in text
+    gpu.close()
+
+
+@pytest.mark.parametrize("batch", [4, 37, 1024])
+def test_xor_from_scratch_step_parity(gpu_ctx, batch):
+    # configs[2] of BASELINE.json (reduced batch: the oracle is a sequential interpreter)
+    gpu, ref = pair(refcases.xor_from_scratch, gpu_ctx)
+    set_params((gpu, ref), seed=3)
+    rng = np.random.default_rng(batch)
+    x = rng.integers(0, 2, size=(batch, 2)).astype(np.float32)
+    y = (x[:, :1] != x[:, 1:]).astype(np.float32)
+    assert rel_err(gpu.call("predict", {"x": x}), ref.call("predict", {"x": x})) <= TOL
+    assert rel_err(gpu.call("loss", {"x": x, "y": y}), ref.call("loss", {"x": x, "y": y})) <= TOL
+    for step in range(3):
+        gpu.apply("train", {"x": x, "y": y})
+        ref.apply("train", {"x": x, "y": y})
+        for tid in sorted(ref.params):
+            assert rel_err(gpu.params[tid], ref.params[tid]) <= TOL, (step, tid)
+    gpu.close()
+
+
+def test_xor_from_scratch_converges_on_gpu(gpu_ctx):
+    # tests/test_model.nim:169-194 (sum of squared errors < 0.1), own seed
+    gpu = egm.compile(*refcases.xor_from_scratch(), gpu=gpu_ctx)
+    rng = np.random.default_rng(1)
+    for tid in gpu.params.ids():
+        shape = gpu.params[tid].shape
+        gpu.params[tid] = (rng.random(shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+    x = np.array([[0, 0], [0, 1], [1, 0], [1, 1]], dtype=np.float32)
+    y = np.array([[0], [1], [1], [0]], dtype=np.float32)
+    for _ in range(4000):
+        gpu.apply("train", {"x": x, "y": y})
+    pred = gpu.call("predict", {"x": x})
+    assert float(np.sum((pred - y) ** 2)) < 0.1
+    gpu.close()
+
+
+def test_xor_layers_and_fit(gpu_ctx):
+    # tests/test_dnn.nim:23-47 and 51-78: apply and fit(batchSize=4) must do the same thing
+    a, ref = pair(refcases.xor_layers, gpu_ctx)
+    b = egm.compile(*refcases.xor_layers(), gpu=gpu_ctx)
+    set_params((a, ref), seed=1)
+    for tid in b.params.ids():
+        b.params[tid] = a.params[tid]
+    x = np.array([[0, 0], [0, 1], [1, 0], [1, 1]], dtype=np.float32)
+    y = np.array([[0], [1], [1], [0]], dtype=np.float32)
+    for _ in range(20):
+        a.apply("train", {"x": x, "y": y})
+        b.fit("train", {"x": x, "y": y}, batch_size=4)
+        ref.apply("train", {"x": x, "y": y})
+    assert b.epoch == 20
+    for tid in a.params.ids():
+        assert np.array_equal(a.params[tid], b.params[tid])
+        assert rel_err(a.params[tid], ref.params[tid]) <= TOL
+    for _ in range(4000):
+        a.apply("train", {"x": x, "y": y})
+    internal = float(a.call("loss", {"x": x, "y": y}).sum())
+    loss = float(np.sum((a.call("predict", {"x": x}) - y) ** 2))
+    assert internal < 0.1 and loss < 0.1
+    assert abs(loss / y.size - internal) < 1e-4
+    a.close()
+    b.close()
+
+
+@pytest.mark.parametrize("dims", [(20, 16, 10, 64), (784, 512, 10, 96)])
+def test_dense_softmax_step_parity(gpu_ctx, dims):
+    # configs[4] of BASELINE.json at a reduced batch: dense -> relu -> dense -> softmax -> crossEntropy -> GD
+    n_in, n_hidden, n_out, batch = dims
+    gpu, ref = pair(refcases.dense_softmax_net, gpu_ctx, n_in=n_in, n_hidden=n_hidden, n_out=n_out)
+    set_params((gpu, ref), seed=5)
+    rng = np.random.default_rng(7)
+    x = rng.random((batch, n_in), dtype=np.float32)
+    labels = rng.integers(0, n_out, size=batch)
+    y = np.eye(n_out, dtype=np.float32)[labels]                       # oneHot, tensors.nim:273-276
+    assert rel_err(gpu.call("predict", {"x": x}), ref.call("predict", {"x": x})) <= TOL
+    assert rel_err(gpu.call("loss", {"x": x, "y": y}), ref.call("loss", {"x": x, "y": y})) <= TOL
+    before = {t: ref.params[t].copy() for t in ref.params}
+    gpu.apply("train", {"x": x, "y": y})
+    ref.apply("train", {"x": x, "y": y})
+    for tid in sorted(ref.params):
+        # compare the UPDATE (rate * gradient): comparing parameters would hide gradient errors
+        # behind the much larger parameter values
+        du_gpu = gpu.params[tid] - before[tid]
+        du_ref = ref.params[tid] - before[tid]
+        assert rel_err(du_gpu, du_ref) <= 2e-5 + 1e-7 / max(np.abs(du_ref).max(), 1e-30), tid
+        assert rel_err(gpu.params[tid], ref.params[tid]) <= TOL
+    gpu.close()
+
+
+def test_conv2_targets(gpu_ctx, refcpu):
+    rng = np.random.default_rng(4)
+    img = rng.random((2, 19, 17, 16), dtype=np.float32)
+    flt = ((rng.random((24, 3, 3, 16), dtype=np.float32) - 0.5) * 4).astype(np.float32)
+    m4 = egm.compile(*refcases.conv2_bench(), gpu=gpu_ctx)
+    assert "conv2" in m4.emit_ir()
+    want = refcpu.conv2_nhwc(img, flt)
+    assert rel_err(m4.call("conv2", {"images": img, "filters": flt}), want) <= TOL
+    m3 = egm.compile(*refcases.conv2_3d(), gpu=gpu_ctx)
+    assert rel_err(m3.call("conv2", {"image": img[0], "filters": flt}), want[0]) <= TOL
+    m4.close()
+    m3.close()
+
+
+def test_shape_changes_between_calls(gpu_ctx):
+    # the reference re-infers shapes on every call (model.nim:392-406): different batch sizes must work
+    model = egm.compile(*refcases.matmul(), gpu=gpu_ctx)
+    rng = np.random.default_rng(0)
+    for (m, k, n) in [(3, 4, 5), (64, 32, 16), (3, 4, 5), (1, 1, 1)]:
+        a = rng.random((m, k), dtype=np.float32)
+        b = rng.random((k, n), dtype=np.float32)
+        assert rel_err(model.call("c", {"a": a, "b": b}), a.astype(np.float64) @ b.astype(np.float64)) <= TOL
+    model.close()
+
+
+def test_device_inputs_are_borrowed(gpu_ctx):
+    model = egm.compile(*refcases.matmul(), gpu=gpu_ctx)
+    a = np.arange(6, dtype=np.float32).reshape(2, 3)
+    b = np.arange(12, dtype=np.float32).reshape(3, 4)
+
+    class Dev:  # anything with data_ptr() and shape (a torch tensor in bench.py)
+        def __init__(self, arr):
+            self.t = gpu_ctx.allocTensor(arr.shape)
+            self.t.write(arr)
+            self.shape = arr.shape
+
+        def data_ptr(self):
+            return self.t.ptr
+
+    out = model.call("c", {"a": Dev(a), "b": Dev(b)})
+    assert np.array_equal(out, a @ b)
+    model.close()
+
+
+def test_errors(gpu_ctx):
+    # tests/test_errors.nim:20-59
+    import exprgrad_amd as eg
+    from exprgrad_amd import dsl
+    model = egm.compile(*refcases.matmul(), gpu=gpu_ctx)
+    with pytest.raises(eg.RuntimeErrorEG):       # invalidTarget
+        model.call("myTarget")
+    with pytest.raises(eg.RuntimeErrorEG):       # invalidInput
+        model.call("c", {"a": np.zeros((2, 3)), "b": np.zeros((3, 2)), "abc": np.zeros((2, 3))})
+    with pytest.raises(eg.RuntimeErrorEG):       # missingInput (a TODO in the reference; defined here)
+        model.call("c", {"a": np.zeros((2, 3))})
+    with pytest.raises(eg.ShapeError):           # rank mismatch (readDimension)
+        model.call("c", {"a": np.zeros((2, 3, 1)), "b": np.zeros((3, 2))})
+    model.close()
+    y, x, it = dsl.iters("y x it")
+    c = dsl.Fun()
+    c[y, x] += dsl.input("a", [2, 3])[y, it] * dsl.input("b")[it, x]
+    model = egm.compile(c.target("c"), gpu=gpu_ctx)
+    with pytest.raises(eg.ShapeError):           # staticShapeMismatch
+        model.call("c", {"a": np.zeros((10, 10)), "b": np.zeros((10, 2))})
+    model.close()
+    ones = dsl.Fun()
+    ones.raw[it] += dsl.literal(1.0)
+    model = egm.compile(ones.target("ones"), gpu=gpu_ctx)
+    with pytest.raises(eg.ShapeError):           # underconstrainedShape ("ones" without withShape)
+        model.call("ones")
+    model.close()
