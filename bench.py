@@ -1,13 +1,19 @@
 #!/usr/bin/env python
-"""Benchmark of the compiled-tensor hot path on MI355X (contract: see DESIGN.md "Measurement").
+"""Benchmark of exprgrad's compiled-tensor hot path on MI355X (contract: DESIGN.md "Measurement").
 
-  python bench.py --gpus 1 --steps K --warmup W      # matmul M=N=K=4096 float32 (BASELINE configs[1])
+  python bench.py --gpus 1 --steps K --warmup W
+      matmul M=N=K=4096 float32 (BASELINE.json configs[1], the config the metric is quoted on):
+      value = GFLOP/s; the same JSON line also carries the single-GPU numbers of the other
+      configs ("extra": dense-net train step, XOR train step, conv2) measured in the same run.
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+      data-parallel dense-net train step (configs[4]): batch 65536 per GPU ("weak" scaling,
+      N = 8 is the 524288 global batch of the config), RCCL all-reduce of the parameter gradients
+      before the gradientDescent update; value = samples/s over all ranks.
 
-One "step" is one pass of the hot path over one batch of synthetic input that is already
-resident in HBM when the timed region starts.  Prints ONE JSON line on rank 0.
+One "step" is one pass of the hot path over one batch of synthetic input already resident in HBM
+when the timed region starts.  Rank 0 prints ONE JSON line.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -16,24 +22,69 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA = 64 FLOP/clk/SIMD x 4 x 256 CUs x 2.4 GHz
-HBM_PEAK_GBS = 8000.0         # HBM3E spec
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
+HBM_PEAK_GBS = 8000.0         # HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s)
+
+DENSE = dict(n_in=784, n_hidden=512, n_out=10, rate=0.01, batch=65536)
+# algorithmic GEMM FLOPs per sample of the dense-net train step (SURVEY.md §8d cfg 5):
+# forward 2 GEMMs, backward 3 (input gradient of the first layer is eliminated)
+DENSE_FLOPS_PER_SAMPLE = 2 * (2 * 784 * 512) + 3 * (2 * 512 * 10)
+XOR_BYTES_PER_SAMPLE = 72 * 4  # kernel-list traffic of the XOR train target
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="auto", choices=["auto", "matmul"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "matmul", "train", "xor", "conv2"])
     ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch of the train/xor workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
     return ap.parse_args()
 
 
+class Timer:
+    """K steps bracketed by barrier + synchronize on both sides; max over ranks; per-step HIP
+    events on the stream the kernels are launched on (torch's current stream == the context's)."""
+
+    def __init__(self, torch, dist, world, stream):
+        self.torch, self.dist, self.world, self.stream = torch, dist, world, stream
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, step, steps, warmup):
+        torch = self.torch
+        for _ in range(warmup):
+            step()
+        self.sync()
+        starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for i in range(steps):
+            starts[i].record(self.stream)
+            step()
+            ends[i].record(self.stream)
+        self.sync()
+        elapsed = time.perf_counter() - t0
+        if self.world > 1:
+            t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        ev = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
+        return elapsed, sum(ev) / len(ev), ev[0]
+
+
+# ------------------------------------------------------------------------------ CPU baselines
+
 def cpu_baseline_matmul(n, budget_s=12.0):
-    """The oracle's matmul loop nest (reference order y, it, x; threaded over y across all host
-    cores exactly as builtinRunThreads splits it) on a bounded row-slice of the same problem."""
+    """The oracle's matmul loop nest (reference order y, it, x; the y loop split over all host
+    cores exactly as builtinRunThreads splits it, model.nim:110-132) on a bounded row slice."""
     import numpy as np
     from oracle import refcpu
     refcpu.build()
@@ -46,7 +97,6 @@ def cpu_baseline_matmul(n, budget_s=12.0):
     t0 = time.perf_counter()
     refcpu.sgemm(a, b, threads=threads)
     dt = time.perf_counter() - t0
-    # scale the slice so the timed run is about budget_s of CPU wall time (bounded by the full problem)
     rows2 = int(min(n, max(rows, rows * budget_s / max(dt, 1e-6))))
     rows2 = max(cores, rows2 // cores * cores)
     a = rng.random((rows2, n), dtype=np.float32)
@@ -54,10 +104,152 @@ def cpu_baseline_matmul(n, budget_s=12.0):
     t0 = time.perf_counter()
     refcpu.sgemm(a, b, threads=threads)
     dt = time.perf_counter() - t0
-    gflops = 2.0 * rows2 * n * n / dt / 1e9
-    return {"value": round(gflops, 2), "unit": "GFLOP/s", "cores": threads, "kind": "port",
-            "sample": f"rows 0..{rows2} of the {n}x{n}x{n} product ({rows2}x{n}x{n}), oracle/refcpu.c ref_sgemm, "
-                      f"{dt:.2f} s wall"}
+    return {"value": round(2.0 * rows2 * n * n / dt / 1e9, 2), "unit": "GFLOP/s", "cores": threads, "kind": "port",
+            "sample": f"rows 0..{rows2} of the {n}^3 product, oracle/refcpu.c ref_sgemm (reference loop order, "
+                      f"y split over {threads} threads), {dt:.2f} s wall"}
+
+
+def cpu_baseline_train(text, batch_cpu=2048):
+    """The oracle's train step (reference kernel list; contractions threaded over their independent
+    outer loop like the Threads target) at a reduced batch, scaled per sample."""
+    import numpy as np
+    from oracle import kd
+    cores = os.cpu_count() or 1
+    m = kd.Model(text, threads=cores)
+    rng = np.random.default_rng(5)
+    for tid in m.params:
+        m.params[tid][...] = (rng.random(m.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+    x = rng.random((batch_cpu, DENSE["n_in"]), dtype=np.float32)
+    y = np.eye(DENSE["n_out"], dtype=np.float32)[rng.integers(0, DENSE["n_out"], size=batch_cpu)]
+    m.apply("train", {"x": x, "y": y})
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 8.0 or reps < 1:
+        m.apply("train", {"x": x, "y": y})
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(batch_cpu / dt, 1), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} train steps at batch {batch_cpu} (oracle/kd.py + refcpu.c; contractions on {cores} "
+                      f"threads, elementwise kernels single-threaded as in the reference), {dt * 1e3:.1f} ms/step"}
+
+
+# ------------------------------------------------------------------------------ workloads
+
+def run_matmul(args, env):
+    torch, ops, ctx, timer = env["torch"], env["ops"], env["ctx"], env["timer"]
+    n = args.size
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(2 + env["rank"])
+    a = torch.rand((n, n), device="cuda", dtype=torch.float32, generator=gen)  # U[0,1): matmul_gpu.nim:69-70
+    b = torch.rand((n, n), device="cuda", dtype=torch.float32, generator=gen)
+    c = torch.empty((n, n), device="cuda", dtype=torch.float32)
+    elapsed, ev_avg, ev_min = timer.run(lambda: ops.sgemm(ctx, n, n, n, a, n, b, n, c, n), args.steps, args.warmup)
+    flops = 2.0 * n * n * n
+    achieved = flops / (ev_avg * 1e-3) / 1e12
+    return {
+        "metric": "GFLOP/s matmul 4096^3 f32 (1 GPU)" if n == 4096 else f"GFLOP/s matmul {n}^3 f32",
+        "value": round(flops * args.steps * env["world"] / elapsed / 1e9, 1), "unit": "GFLOP/s",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "config": {"workload": f"matmul M=N=K={n} float32 (BASELINE configs[1]): C = A*B through eg_sgemm "
+                               "(MFMA + LDS tiled HIP kernel), A, B ~ U[0,1) resident in HBM",
+                   "parallelism": "single" if env["world"] == 1 else f"{env['world']} independent replicas"},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "kernel": "gemm_f32_mfma_kernel<128,128,64,64,NN>", "flops_per_launch": flops,
+                     "kernel_ms_avg": round(ev_avg, 4), "kernel_ms_min": round(ev_min, 4)},
+    }
+
+
+def build_dense(env, batch):
+    from exprgrad_amd import examples as refcases
+    from exprgrad_amd import model as egm
+    from exprgrad_amd.parallel import DataParallel, GpuEngine
+    torch = env["torch"]
+    model = egm.compile(*refcases.dense_softmax_net(DENSE["n_in"], DENSE["n_hidden"], DENSE["n_out"], DENSE["rate"]),
+                        gpu=env["ctx"])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)  # identical parameters on every rank
+    for tid in model.params.ids():
+        shape = model._param_shapes[tid]
+        model.params[tid] = (torch.rand(shape, device="cuda", generator=gen) * 0.2 - 0.1).cpu().numpy()
+    gen.manual_seed(100 + env["rank"])  # a different shard of synthetic data per rank
+    x = torch.rand((batch, DENSE["n_in"]), device="cuda", dtype=torch.float32, generator=gen)
+    labels = torch.randint(0, DENSE["n_out"], (batch,), device="cuda", generator=gen)
+    y = torch.nn.functional.one_hot(labels, DENSE["n_out"]).to(torch.float32).contiguous()
+    dp = DataParallel(GpuEngine(model, "train"), reduction="mean")
+    return model, dp, x, y
+
+
+def run_train(args, env):
+    batch = args.batch or DENSE["batch"]
+    model, dp, x, y = build_dense(env, batch)
+    world = env["world"]
+    inputs = [("x", x), ("y", y)]
+    elapsed, ev_avg, ev_min = env["timer"].run(lambda: dp.step(inputs), args.steps, args.warmup)
+    samples = batch * world * args.steps
+    step_flops = DENSE_FLOPS_PER_SAMPLE * batch
+    achieved = step_flops / (ev_avg * 1e-3) / 1e12
+    out = {
+        "metric": "train samples/s dense net 784-512-10 (data parallel)",
+        "value": round(samples / elapsed, 1), "unit": "samples/s",
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "steps_per_s": round(args.steps / elapsed, 2),
+        "config": {"workload": "dense(784,512)-relu-dense(512,10)-softmax-crossEntropy-gradientDescent(0.01) train "
+                               "step (BASELINE configs[4]), synthetic x ~ U[0,1), one-hot labels, forward + "
+                               "backward + parameter-gradient all-reduce + update",
+                   "global_batch": batch * world, "per_gpu_batch": batch,
+                   "parallelism": f"dp{world}" if world > 1 else "single",
+                   "grad_bucket_floats": model.grad_bucket("train")[1]},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "kernel": "whole train step on one GPU (5 contractions dominate: gemm_f32_mfma_kernel)",
+                     "flops_per_launch": step_flops, "kernel_ms_avg": round(ev_avg, 4),
+                     "kernel_ms_min": round(ev_min, 4)},
+    }
+    return out, model
+
+
+def run_xor(args, env):
+    from exprgrad_amd import examples as refcases
+    from exprgrad_amd import model as egm
+    torch = env["torch"]
+    batch = args.batch or 65536
+    model = egm.compile(*refcases.xor_from_scratch(), gpu=env["ctx"])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    x = torch.randint(0, 2, (batch, 2), device="cuda", generator=gen).to(torch.float32)
+    y = (x[:, :1] != x[:, 1:]).to(torch.float32).contiguous()
+    inputs = [("x", x), ("y", y)]
+    steps = max(args.steps, 50)
+    elapsed, ev_avg, ev_min = env["timer"].run(lambda: model.apply("train", inputs), steps, args.warmup)
+    gbs = XOR_BYTES_PER_SAMPLE * batch / (ev_avg * 1e-3) / 1e9
+    return {"metric": "train steps/s XOR net (examples/xor_from_scratch) batch 65536", "value": round(steps / elapsed, 1),
+            "unit": "steps/s", "samples_per_s": round(batch * steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "whole step (19 kernels; launch-latency bound)",
+                         "bytes_per_launch": XOR_BYTES_PER_SAMPLE * batch, "kernel_ms_avg": round(ev_avg, 4)}}
+
+
+def run_conv2(args, env):
+    torch, ops, ctx = env["torch"], env["ops"], env["ctx"]
+    N, H, W, C, F, FH, FW = 1, 256, 256, 64, 64, 3, 3  # BASELINE configs[3]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4)
+    img = torch.rand((N, H, W, C), device="cuda", generator=gen)                 # conv2.nim:337
+    flt = torch.rand((F, FH, FW, C), device="cuda", generator=gen) * 4 - 2       # conv2.nim:338
+    out = torch.empty((N, H - FH + 1, W - FW + 1, F), device="cuda")
+    steps = max(args.steps, 50)
+    elapsed, ev_avg, ev_min = env["timer"].run(
+        lambda: ops.conv2_nhwc(ctx, N, H, W, C, F, FH, FW, img, flt, out), steps, args.warmup)
+    flops = 2.0 * N * (H - FH + 1) * (W - FW + 1) * F * FH * FW * C
+    achieved = flops / (ev_avg * 1e-3) / 1e12
+    return {"metric": "GFLOP/s conv2 3x3 256x256x64->64 f32", "value": round(flops * steps / elapsed / 1e9, 1),
+            "unit": "GFLOP/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "gemm_f32_mfma_kernel<128,64,64,32,NT,conv>", "flops_per_launch": flops,
+                         "kernel_ms_avg": round(ev_avg, 4)}}
 
 
 def main():
@@ -77,61 +269,44 @@ def main():
 
     stream = torch.cuda.current_stream()
     ctx = eg.newGpuContext(local_rank, stream=stream.cuda_stream)
+    env = {"torch": torch, "ops": ops, "ctx": ctx, "world": world, "rank": rank,
+           "timer": Timer(torch, dist, world, stream)}
 
-    n = args.size
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(2 + rank)
-    a = torch.rand((n, n), device="cuda", dtype=torch.float32, generator=gen)  # U[0,1): matmul_gpu.nim:69-70
-    b = torch.rand((n, n), device="cuda", dtype=torch.float32, generator=gen)
-    c = torch.empty((n, n), device="cuda", dtype=torch.float32)
+    workload = args.workload
+    if workload == "auto":
+        workload = "matmul" if world == 1 else "train"
 
-    def step():
-        ops.sgemm(ctx, n, n, n, a, n, b, n, c, n)
+    model = None
+    if workload == "matmul":
+        line = run_matmul(args, env)
+    elif workload == "train":
+        line, model = run_train(args, env)
+    elif workload == "xor":
+        line = run_xor(args, env)
+    else:
+        line = run_conv2(args, env)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        starts[i].record(stream)
-        step()
-        ends[i].record(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
-    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+    line = {**{k: line[k] for k in ("metric", "value", "unit")}, **base,
+            **{k: v for k, v in line.items() if k not in ("metric", "value", "unit")}}
 
-    flops = 2.0 * n * n * n
+    if rank == 0 and world == 1:
+        if not args.no_extra and args.workload == "auto":
+            # single-GPU numbers of the other BASELINE configs, same run (reference point for the
+            # 1 -> N scaling of the data-parallel step: compare extra.train.value with the --gpus N value)
+            extra = {}
+            small = argparse.Namespace(**{**vars(args), "steps": min(args.steps, 20), "warmup": 3, "batch": 0})
+            extra["train"], model = run_train(small, env)
+            extra["xor"] = run_xor(small, env)
+            extra["conv2"] = run_conv2(small, env)
+            line["extra"] = extra
+        if not args.no_cpu_baseline:
+            if workload == "matmul":
+                line["cpu_baseline"] = cpu_baseline_matmul(args.size)
+            elif workload == "train":
+                line["cpu_baseline"] = cpu_baseline_train(model.source_text)
     if rank == 0:
-        value = flops * args.steps * world / elapsed / 1e9
-        achieved = flops / (avg_kernel_ms * 1e-3) / 1e12
-        line = {
-            "metric": "GFLOP/s matmul 4096^3 f32 (1 GPU)" if n == 4096 else f"GFLOP/s matmul {n}^3 f32",
-            "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"matmul M=N=K={n} float32, C = A*B via eg_sgemm (MFMA+LDS tiled HIP kernel), "
-                                   "inputs resident in HBM", "parallelism": "replicas" if world > 1 else "single"},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "gemm_f32_mfma_kernel<128,128,64,64,NN>",
-                         "kernel_ms_avg": round(avg_kernel_ms, 4), "kernel_ms_min": round(kernel_ms[0], 4)},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_matmul(n)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

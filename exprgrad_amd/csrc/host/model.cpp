@@ -218,6 +218,7 @@ struct BoundInput {
   std::vector<long> shape;
   float* owned = nullptr;  // staging copy of a host input
   long owned_count = 0;
+  bool bound = false;
 };
 
 }  // namespace
@@ -305,7 +306,7 @@ float* tensor_ptr(eg_model* m, TargetState& ts, Plan& plan, int tid) {
   if (d.kind == TK::Param) return m->params[tid].ptr;
   if (d.kind == TK::Input) {
     auto it = m->inputs.find(tid);
-    return it == m->inputs.end() ? nullptr : const_cast<float*>(it->second.device);
+    return (it == m->inputs.end() || !it->second.bound) ? nullptr : const_cast<float*>(it->second.device);
   }
   auto b = ts.bucket_offset.find(tid);
   if (b != ts.bucket_offset.end()) return ts.bucket + b->second;
@@ -388,6 +389,7 @@ int fill_params(eg_model* m, const Kernel& k, const KernelInfo& info, const Shap
 std::string shape_key(eg_model* m) {
   std::ostringstream os;
   for (auto& in : m->inputs) {
+    if (!in.second.bound) continue;
     os << in.first << ":";
     for (long s : in.second.shape) os << s << ",";
     os << ";";
@@ -400,6 +402,7 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   Target& t = *ts.target;
   Shapes& shapes = plan.shapes;
   for (auto& in : m->inputs) {
+    if (!in.second.bound) continue;
     const TensorDef& d = m->prog.tensors[in.first];
     if (d.has_shape && !d.shape.empty()) {  // staticShapeMismatch (tests/test_errors.nim:56-59)
       bool ok = d.shape.size() == in.second.shape.size();
@@ -909,6 +912,7 @@ static int bind_input(eg_model* m, const char* name, const float* device, const 
   EG_REQUIRE(it != m->prog.inputs.end(), EG_ERR_RUNTIME, "%s is not an input to the model", name);
   EG_REQUIRE(rank >= 0 && rank <= 8 && (rank == 0 || shape), EG_ERR_INVALID, "bad input rank");
   BoundInput& b = m->inputs[it->second];
+  b.bound = true;
   b.shape.assign(shape, shape + rank);
   const long count = prod(b.shape);
   if (host) {
@@ -946,11 +950,18 @@ int eg_model_set_input_device(eg_model* m, const char* name, const float* device
 
 int eg_model_clear_inputs(eg_model* m) {
   EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
-  hipSetDevice(m->ctx->device);
-  hipStreamSynchronize(m->ctx->stream);
-  for (auto& in : m->inputs)
-    if (in.second.owned) hipFree(in.second.owned);
-  m->inputs.clear();
+  // Host-staged inputs keep their staging buffer (reused by the next host bind); only the
+  // bindings are forgotten.  No synchronisation: nothing is freed.
+  for (auto it = m->inputs.begin(); it != m->inputs.end();) {
+    if (it->second.owned) {
+      it->second.device = nullptr;
+      it->second.shape.clear();
+      it->second.bound = false;
+      ++it;
+    } else {
+      it = m->inputs.erase(it);
+    }
+  }
   return EG_OK;
 }
 

@@ -1,0 +1,66 @@
+"""Programs of the reference's examples and of BASELINE.json's configs, in the Python DSL mirror.
+
+Shared by the tests and bench.py (definitions only, no data).
+"""
+from . import dsl, layers
+from .dsl import Fun, iters, param, select, sq
+
+
+def xor_from_scratch(rate=0.1):
+    """tests/test_model.nim:169-194 == examples/xor_from_scratch/xor_from_scratch.nim:19-31."""
+    y, x, it = iters("y x it")
+    hidden = Fun()
+    hidden[y, x] += dsl.input("x")[y, it] * param([2, 4])[it, x]
+    hidden[y, x] += param([4])[x]
+    hidden_relu = Fun()
+    hidden_relu.raw[it] += select(hidden.raw[it] <= 0.0, 0.1 * hidden.raw[it], hidden.raw[it])
+    output = Fun()
+    output[y, x] += hidden_relu[y, it] * param([4, 1])[it, x]
+    output[y, x] += param([1])[x]
+    output_sigmoid = Fun()
+    output_sigmoid.raw[it] += 1.0 / (1.0 + dsl.exp(-output.raw[it]))
+    pred = output_sigmoid.target("predict")
+    loss = Fun()
+    loss[0] += sq(pred.raw[it] - dsl.input("y").raw[it])
+
+    def optim(p, g):
+        p.raw[it] += -rate * g.raw[it]
+
+    return [loss.target("loss").backprop(optim).target("train")]
+
+
+def xor_layers(rate=0.2):
+    """tests/test_dnn.nim:23-34."""
+    net = layers.dense(dsl.input("x"), 2, 4)
+    net = layers.leaky_relu(net)
+    net = layers.dense(net, 4, 1)
+    net = layers.sigmoid(net).target("predict")
+    net = layers.mse(net, dsl.input("y")).target("loss")
+    return [net.backprop(layers.gradient_descent(rate)).target("train")]
+
+
+# ---- BASELINE.json configs (definitions: SURVEY.md §8d) ----------------------------------------
+def dense_softmax_net(n_in=784, n_hidden=512, n_out=10, rate=0.01):
+    """configs[4]: dense(784,512) -> relu -> dense(512,10) -> softmax -> crossEntropy -> GD(0.01)."""
+    net = layers.dense(dsl.input("x"), n_in, n_hidden)
+    net = layers.relu(net)
+    net = layers.dense(net, n_hidden, n_out)
+    net = layers.softmax(net).target("predict")
+    net = layers.cross_entropy(net, dsl.input("y")).target("loss")
+    return [net.backprop(layers.gradient_descent(rate)).target("train")]
+
+
+def conv2_bench():
+    """configs[3] / dnn.nim:45-49 with the filter bank as an input."""
+    return [layers.conv2(dsl.input("images"), dsl.input("filters")).target("conv2")]
+
+
+def conv2_3d():
+    """benchmarks/conv2/conv2.nim:128-132 (no batch dimension)."""
+    y, x, f, c, dy, dx = iters("y x filter chan dy dx")
+    image, filters = dsl.input("image"), dsl.input("filters")
+    r = Fun()
+    r[y, x, f] += image[y + dy, x + dx, c] * filters[f, dy, dx, c]
+    return [r.target("conv2")]
+
+

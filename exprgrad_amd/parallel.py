@@ -1,0 +1,75 @@
+"""Data-parallel training step: batch sharded over ranks, one all-reduce of the flat
+parameter-gradient bucket before the optimizer kernels.
+
+The reference has no multi-device code at all; this step is defined by
+BASELINE.json's north_star and pinned by equivalence with the single-device full-batch step
+(SURVEY.md §8e):
+
+  * every forward/backward kernel is independent per sample, except the parameter-gradient
+    reductions over the batch — so rank r runs the target's kernel list on rows
+    [r*B/W, (r+1)*B/W) of every input (the slicing of viewFirst, tensors.nim:290-297) up to,
+    not including, the optimizer kernels (gradientDescent, base.nim:37-38);
+  * one SUM all-reduce of the gradient bucket (RCCL over xGMI on GPUs: torch.distributed's
+    "nccl" backend; gloo in the CPU tests);
+  * losses that divide by the batch (`mse`, `crossEntropy`: toScalar(shape[0]) evaluated at run
+    time, base.nim:57-67) see B/W instead of B, so the seed gradient gradLoss (passes.nim:594-596)
+    is scaled by B_local/B_global ("mean"); sum-type losses (the XOR example) use 1 ("sum");
+  * every rank then applies the identical optimizer update to its replica of the parameters.
+
+One process per GPU; the engine's HIP stream is torch's current stream, so the collective is
+ordered after the backward kernels and before the update kernels without host synchronisation.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard(args, rank, world):
+    """Rows [rank*B/world, (rank+1)*B/world) of every input (B must divide evenly)."""
+    items = args.items() if isinstance(args, dict) else args
+    out = []
+    for name, a in items:
+        b = a.shape[0]
+        if b % world != 0:
+            raise ValueError(f"batch {b} of input {name} does not divide over {world} ranks")
+        per = b // world
+        out.append((name, a[rank * per:(rank + 1) * per]))
+    return out
+
+
+class GpuEngine:
+    """Adapter: exprgrad_amd.model.Model -> the engine protocol DataParallel drives."""
+
+    def __init__(self, model, target):
+        self.model, self.target = model, target
+        _, count = model.grad_bucket(target)
+        # gradients live in a torch tensor so torch.distributed can reduce them in place
+        self.bucket = torch.zeros(max(count, 1), dtype=torch.float32, device="cuda")
+        if count > 0:
+            model.bind_grad_bucket(target, self.bucket)
+
+    def set_grad_scale(self, s):
+        self.model.set_grad_scale(s)
+
+    def run_backward(self, args):
+        self.model.run_backward(self.target, args)
+
+    def run_update(self):
+        self.model.run_update(self.target)
+
+
+class DataParallel:
+    def __init__(self, engine, reduction="mean", group=None):
+        if reduction not in ("mean", "sum"):
+            raise ValueError("reduction must be 'mean' (loss divides by the batch) or 'sum'")
+        self.engine, self.reduction, self.group = engine, reduction, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def step(self, local_args):
+        """One training step on this rank's shard.  Asynchronous on GPUs."""
+        e = self.engine
+        e.set_grad_scale(1.0 / self.world if self.reduction == "mean" else 1.0)
+        e.run_backward(local_args)
+        if self.world > 1:
+            dist.all_reduce(e.bucket, op=dist.ReduceOp.SUM, group=self.group)
+        e.run_update()

@@ -68,6 +68,7 @@ class Kernel:
         self.result = 0
         self.write = None
         self.generator = None
+        self.is_seed = False
 
     def alloc(self):
         self.nregs += 1
@@ -81,6 +82,7 @@ class Kernel:
         k.reads = list(self.reads)
         k.instrs = list(self.instrs)
         k.result, k.write, k.generator = self.result, self.write, self.generator
+        k.is_seed = self.is_seed
         return k
 
 
@@ -369,6 +371,7 @@ def generate(prog, kernels):
             seed.instrs = [Instr("scalar", r_val, [], 1.0)]
             seed.result = r_val
             seed.write = Op(grad_loss, r_val, True, [Lin(0, {r_it: 1})])
+            seed.is_seed = True
             grad_kernels.append(seed)
             grad_tensors[loss] = grad_loss
             for k2 in kernels[i + 1:]:                      # 608-612
@@ -450,6 +453,10 @@ def reorder_loops(k):
 
 def compile_target(prog, name):
     output, kernels = prog.targets[name]
+    grads = [(k.generator[1], k.generator[2]) for k in kernels
+             if k.generator and k.generator[0] == "gradient" and prog.tensors[k.generator[1]]["kind"] == "param"]
+    prog.param_grads = getattr(prog, "param_grads", {})
+    prog.param_grads[name] = grads
     all_kernels = generate(prog, kernels)
     # Shape constraints are collected from every kernel BEFORE dead kernels are dropped
     # (model.nim:46-77: inferShapeConstraints precedes generate/deadKernelElim), so the
@@ -733,6 +740,42 @@ class Model:
         return len(self.compiled[target][1])
 
     def call(self, target, inputs):
+        self._forward_backward(target, inputs, 1.0, stop_at_update=False)
+        output = self.compiled[target][0]
+        return self.last[output] if output else None
+
+    def apply(self, target, inputs):
+        self.call(target, inputs)
+
+    # ---- split step for the data-parallel tests: [forward + backward] | all-reduce | [update] ----
+    def param_grads(self, target):
+        """[(param tensor id, gradient tensor id)] of the target's optimizer (GenGradient markers)."""
+        return list(self.prog.param_grads[target])
+
+    def run_backward(self, target, inputs, grad_scale=1.0):
+        self._forward_backward(target, inputs, grad_scale, stop_at_update=True)
+
+    def run_update(self, target):
+        for k in self._pending:
+            self._run_one(k, *self._pending_state)
+        self._pending = []
+
+    def _run_one(self, k, infos, shapes, tensors, grad_scale):
+        bounds, vals = infos[id(k)]
+        wt = k.write.tensor
+        if wt not in tensors:
+            tensors[wt] = np.zeros(shapes[wt], dtype=np.float32)
+        pat = contraction_pattern(k) if self.fast else None
+        if k.is_seed:
+            # gradLoss{i} = 1 (passes.nim:594-596), times B_local/B_global under data parallelism
+            tensors[wt] += np.float32(grad_scale)
+        elif pat is not None:
+            a_op, b_op, ta, tb = pat
+            refcpu.sgemm(tensors[a_op.tensor], tensors[b_op.tensor], ta, tb, out=tensors[wt], threads=self.threads)
+        else:
+            run_kernel(k, bounds, vals, shapes, tensors, self.epoch)
+
+    def _forward_backward(self, target, inputs, grad_scale, stop_at_update):
         if target not in self.compiled:
             raise KeyError(target + " is not a target of the model")      # model.nim:395-396
         output, kernels, all_kernels = self.compiled[target]
@@ -762,21 +805,19 @@ class Model:
             except (ShapeError, KeyError):
                 if id(k) in live:
                     raise
-        for k in kernels:
-            bounds, vals = infos[id(k)]
-            wt = k.write.tensor
-            if wt not in tensors:
-                tensors[wt] = np.zeros(shapes[wt], dtype=np.float32)
-            pat = contraction_pattern(k) if self.fast else None
-            if pat is not None:
-                a_op, b_op, ta, tb = pat
-                refcpu.sgemm(tensors[a_op.tensor], tensors[b_op.tensor], ta, tb, out=tensors[wt],
-                             threads=self.threads)
-            else:
-                run_kernel(k, bounds, vals, shapes, tensors, self.epoch)
+        first_update = len(kernels)
+        for i, k in enumerate(kernels):
+            if self.prog.tensors[k.write.tensor]["kind"] == "param":
+                first_update = i
+                break
+        stop = first_update if stop_at_update else len(kernels)
+        for k in kernels[:stop]:
+            self._run_one(k, infos, shapes, tensors, grad_scale)
+        # gradient tensors of parameters must exist even if nothing wrote them
+        for _, gt in self.prog.param_grads.get(target, []):
+            if gt not in tensors and gt in shapes:
+                tensors[gt] = np.zeros(shapes[gt], dtype=np.float32)
+        self._pending = list(kernels[stop:])
+        self._pending_state = (infos, shapes, tensors, grad_scale)
         self.last = tensors
         self.last_shapes = shapes
-        return tensors[output] if output else None
-
-    def apply(self, target, inputs):
-        self.call(target, inputs)
