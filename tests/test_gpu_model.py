@@ -228,3 +228,33 @@ def test_errors(gpu_ctx):
     with pytest.raises(eg.ShapeError):           # underconstrainedShape ("ones" without withShape)
         model.call("ones")
     model.close()
+
+
+def test_data_parallel_engine_world1(gpu_ctx):
+    """GpuEngine + DataParallel on one rank == plain apply (the bucket lives in a torch tensor the
+    all-reduce would work on in place); gradients land in the bound bucket."""
+    torch = pytest.importorskip("torch")
+    from exprgrad_amd.parallel import DataParallel, GpuEngine
+    import exprgrad_amd as eg
+    stream = torch.cuda.current_stream()
+    ctx = eg.newGpuContext(0, stream=stream.cuda_stream)
+    a = egm.compile(*refcases.dense_softmax_net(n_in=20, n_hidden=16, n_out=10), gpu=ctx)
+    b = egm.compile(*refcases.dense_softmax_net(n_in=20, n_hidden=16, n_out=10), gpu=ctx)
+    rng = np.random.default_rng(2)
+    for tid in a.params.ids():
+        v = (rng.random(a.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+        a.params[tid] = v
+        b.params[tid] = v
+    x = torch.rand((64, 20), device="cuda")
+    y = torch.nn.functional.one_hot(torch.randint(0, 10, (64,), device="cuda"), 10).to(torch.float32).contiguous()
+    engine = GpuEngine(b, "train")
+    dp = DataParallel(engine, reduction="mean")
+    for _ in range(3):
+        a.apply("train", [("x", x), ("y", y)])
+        dp.step([("x", x), ("y", y)])
+    torch.cuda.synchronize()
+    for tid in a.params.ids():
+        assert np.array_equal(a.params[tid], b.params[tid])
+    assert float(engine.bucket.abs().sum()) > 0
+    a.close()
+    b.close()
