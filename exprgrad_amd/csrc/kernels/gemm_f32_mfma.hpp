@@ -1,0 +1,354 @@
+// f32 contraction kernel template for CDNA4 (gfx950) matrix cores — see gemm_f32_mfma.hip for the
+// role of this kernel in the backend.  Kept in a header so the tuning harness
+// (tools/gemm_tune.hip) instantiates exactly the code the library ships.
+//
+// Design (gfx950):
+//   * v_mfma_f32_32x32x2_f32: exact f32 products and accumulation (an fmaf chain), 64 cycles per
+//     instruction per SIMD = the 157 TFLOP/s f32 matrix peak.  No reduced-precision path exists
+//     or is wanted (parity is 1e-5 relative against the reference's f32 CPU path).
+//   * block tile BM x BN x BK, (BM/WM)*(BN/WN) waves; every wave owns a WM x WN sub-tile made of
+//     32x32 MFMA blocks, accumulators stay in registers for the whole K loop (the reference
+//     re-reads and re-writes C once per k: tests/cache/matmul_basic.ir).
+//   * both operand tiles are staged in LDS as [k][m|n] so that an MFMA operand fetch is a
+//     ds_read of 32 consecutive dwords per half-wave (bank-conflict free).  An operand whose
+//     global layout is k-contiguous (A of NN/NT, B of NT) is transposed on the way in: coalesced
+//     16-byte global loads along k, four ds_write_b32; the row stride is chosen so those writes
+//     spread over all 32 banks.
+//   * double-buffered LDS + register prefetch of the next k-tile: one barrier per k-tile; operand
+//     fragments of k-step kk+1 are fetched before the MFMAs of k-step kk issue.
+//   * XCD-aware tile order: consecutive block ids land on different XCDs (id % 8), so ids are
+//     remapped to give each XCD's private L2 a contiguous, squarish patch of output tiles.
+//   * split-K (grid.z) with a deterministic second pass for contractions whose output is small
+//     and whose K is the batch (the weight gradients): no float atomics, fixed summation order.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace eg {
+namespace gemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  float* partial;  // split-K slabs [splits][M][N] or nullptr
+  long M, N, K;
+  long lda, ldb, ldc;
+  long k_per_split;  // multiple of BK
+  int tiles_m, tiles_n;
+  int accumulate;
+  // Implicit-GEMM convolution (A gathered from an NHWC image): m = (n, y, x), k = (dy, dx, c).
+  long cH, cW, cC, cFW, cHo, cWo;
+};
+
+// Row stride (in floats) of an LDS operand tile [BK][stride].
+//  - m|n-contiguous operand: 16-byte ds_write_b128 rows, no padding needed.
+//  - k-contiguous operand (transposed while staging): BK/4 lanes share a row and write
+//    k = 4c+j, so a half-wave covers R = 128/BK rows; stride % 8 == R/4 puts its 32 lanes on 32
+//    distinct banks (BK 16 -> +2, BK 32 -> +1, BK 8 -> +4).
+template <int BMN, int BK, bool KC>
+struct LdsStride {
+  static constexpr int value = KC ? BMN + 32 / BK : BMN;
+};
+
+// One operand tile: BMN rows/cols along m|n, BK along k.
+//   KC == true : global element (mn, k) at  base[mn * ld + k]   (k contiguous)
+//   KC == false: global element (mn, k) at  base[k * ld + mn]   (m|n contiguous)
+//   CONV (KC only): element (m, k) of the virtual im2col matrix, read straight from the image:
+//       base[((n*H + y + dy)*W + x + dx)*C + c],  m = (n*Ho + y)*Wo + x,  k = (dy*FW + dx)*C + c
+//     (dnn.nim:45-49: images[image, y + dy, x + dx, chan], valid padding, stride 1).
+template <int BMN, int BK, int NT, bool KC, int VEC, bool EDGE, bool CONV>
+struct TileLoader {
+  static_assert(!CONV || KC, "the gathered operand is k(channel)-contiguous");
+  static constexpr int STRIDE = LdsStride<BMN, BK, KC>::value;
+  static constexpr int ELEMS = BMN * BK;
+  static constexpr int CHUNKS = ELEMS / VEC;
+  static constexpr int NVEC = (CHUNKS + NT - 1) / NT;  // load instructions per thread
+  static constexpr int PER_THREAD = NVEC * VEC;         // floats per thread
+  static constexpr bool PARTIAL = CHUNKS % NT != 0;     // small tile: trailing threads idle
+  static constexpr int CPR = (KC ? BK : BMN) / VEC;     // chunks per tile row
+
+  float regs[PER_THREAD];
+  long row_off[NVEC];  // CONV: element offset of the output pixel's top-left input pixel
+
+  __device__ __forceinline__ static void coords(int idx, int& mn, int& k) {
+    if (KC) {
+      mn = idx / CPR;
+      k = (idx % CPR) * VEC;
+    } else {
+      k = idx / CPR;
+      mn = (idx % CPR) * VEC;
+    }
+  }
+
+  __device__ __forceinline__ void init(const GemmArgs& a, long mn0, int tid) {
+    if (CONV) {
+#pragma unroll
+      for (int i = 0; i < NVEC; ++i) {
+        int mn, k;
+        coords(tid + i * NT, mn, k);
+        const long m = mn0 + mn;
+        const long img = m / (a.cHo * a.cWo), rem = m % (a.cHo * a.cWo);
+        const long y = rem / a.cWo, x = rem % a.cWo;
+        row_off[i] = ((img * a.cH + y) * a.cW + x) * a.cC;
+      }
+    }
+  }
+
+  // mn0/k0: tile origin; mn_lim/k_lim: exclusive global limits (only read when EDGE).
+  __device__ __forceinline__ void load(const GemmArgs& a, const float* __restrict__ base, long ld, long mn0, long k0,
+                                       long mn_lim, long k_lim, int tid) {
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+      const int idx = tid + i * NT;
+      int mn, k;
+      coords(idx, mn, k);
+      const long gmn = mn0 + mn, gk = k0 + k;
+      const float* p;
+      if (CONV) {
+        const long tap = gk / a.cC, c = gk % a.cC;
+        const long dy = tap / a.cFW, dx = tap % a.cFW;
+        p = base + row_off[i] + (dy * a.cW + dx) * a.cC + c;
+      } else {
+        p = KC ? base + gmn * ld + gk : base + gk * ld + gmn;
+      }
+      bool ok = !PARTIAL || idx < CHUNKS;
+      if (EDGE) ok = ok && (gmn < mn_lim) && (gk < k_lim);
+      if (VEC == 4) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) v = *reinterpret_cast<const f32x4*>(p);
+        regs[i * 4 + 0] = v[0];
+        regs[i * 4 + 1] = v[1];
+        regs[i * 4 + 2] = v[2];
+        regs[i * 4 + 3] = v[3];
+      } else {
+        regs[i] = ok ? *p : 0.f;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < NVEC; ++i) {
+      const int idx = tid + i * NT;
+      if (PARTIAL && idx >= CHUNKS) continue;
+      int mn, k;
+      coords(idx, mn, k);
+      if (KC) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) lds[(k + j) * STRIDE + mn] = regs[i * VEC + j];
+      } else {
+        if (VEC == 4) {
+          f32x4 v = {regs[i * 4 + 0], regs[i * 4 + 1], regs[i * 4 + 2], regs[i * 4 + 3]};
+          *reinterpret_cast<f32x4*>(&lds[k * STRIDE + mn]) = v;
+        } else {
+          lds[k * STRIDE + mn] = regs[i];
+        }
+      }
+    }
+  }
+};
+
+// Bijective XCD remap (block id b runs on XCD b % 8): give every XCD a contiguous id range.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  constexpr int NXCD = 8;
+  const int q = nwg / NXCD, r = nwg % NXCD;
+  const int xcd = bid % NXCD, local = bid / NXCD;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + local;
+}
+
+template <int BM, int BN, int WM, int WN>
+struct Geometry {
+  static constexpr int WAVES = (BM / WM) * (BN / WN);
+  static constexpr int NT = WAVES * 64;
+};
+
+// K loop of one block.  E = predicate every global load against the problem edges.
+// ABL (tuning harness only; the library always instantiates 0): bit 0 = no LDS fragment reads in
+// the k loop, bit 1 = no global loads / LDS stores after the first tile, bit 2 = no barriers.
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int VEC, bool E, bool CONV, int ABL>
+__device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32], long m_blk,
+                                              long n_blk, long k_begin, long k_end, int nk, int tid, int wm0, int wn0) {
+  constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  using LoadA = TileLoader<BM, BK, NT, A_KC, VEC, E, CONV>;
+  using LoadB = TileLoader<BN, BK, NT, B_KC, VEC, E, false>;
+  constexpr int SA = LoadA::STRIDE, SB = LoadB::STRIDE;
+  constexpr int BUF = BK * (SA + SB);  // one stage: A tile then B tile
+  const int lane = tid & 63;
+
+  LoadA la;
+  LoadB lb;
+  la.init(a, m_blk, tid);
+  lb.init(a, n_blk, tid);
+  if (nk > 0) {
+    la.load(a, a.A, a.lda, m_blk, k_begin, a.M, k_end, tid);
+    lb.load(a, a.B, a.ldb, n_blk, k_begin, a.N, k_end, tid);
+    la.store(lds, tid);
+    lb.store(lds + BK * SA, tid);
+  }
+  __syncthreads();
+
+  const int a_off = (lane >> 5) * SA + wm0 + (lane & 31);
+  const int b_off = (lane >> 5) * SB + wn0 + (lane & 31);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const bool more = (ABL & 2) ? false : kt + 1 < nk;
+    if (more) {
+      const long k0 = k_begin + (long)(kt + 1) * BK;
+      la.load(a, a.A, a.lda, m_blk, k0, a.M, k_end, tid);
+      lb.load(a, a.B, a.ldb, n_blk, k0, a.N, k_end, tid);
+    }
+    const float* as = lds + cur * BUF + a_off;
+    const float* bs = lds + cur * BUF + BK * SA + b_off;
+    // software pipeline over the k-steps of this tile: fragments of step kk+1 are in flight
+    // while the MFMAs of step kk issue
+    float av[2][MI], bv[2][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) av[0][i] = as[i * 32];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bv[0][j] = bs[j * 32];
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int c = kk & 1, n = c ^ 1;
+      if ((ABL & 1) && kk + 1 < BK / 2) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) av[n][i] = av[c][i];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bv[n][j] = bv[c][j];
+      } else if (kk + 1 < BK / 2) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) av[n][i] = as[(kk + 1) * 2 * SA + i * 32];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bv[n][j] = bs[(kk + 1) * 2 * SB + j * 32];
+      }
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i], bv[c][j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      la.store(lds + (cur ^ 1) * BUF, tid);
+      lb.store(lds + (cur ^ 1) * BUF + BK * SA, tid);
+    }
+    if (!(ABL & 4)) __syncthreads();
+  }
+}
+
+// MINB: blocks per CU the register allocator must leave room for (waves/SIMD = MINB * WAVES / 4).
+// EDGE kernels still run their interior tiles on the unpredicated loop.
+template <int BM, int BN, int BK, int WM, int WN, int MINB, bool A_KC, bool B_KC, int VEC, bool EDGE, bool CONV,
+          int ABL = 0>
+__global__ __launch_bounds__((Geometry<BM, BN, WM, WN>::NT), (MINB * Geometry<BM, BN, WM, WN>::WAVES + 3) / 4) void
+gemm_f32_mfma_kernel(GemmArgs a) {
+  constexpr int WAVES_N = BN / WN;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int SA = LdsStride<BM, BK, A_KC>::value, SB = LdsStride<BN, BK, B_KC>::value;
+
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (SA + SB)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WM;
+  const int wn0 = (wave % WAVES_N) * WN;
+
+  // ---- tile coordinates: XCD-contiguous ids, then 8-row groups so co-resident tiles share
+  //      A row-panels and B column-panels inside one L2.
+  const int nwg = a.tiles_m * a.tiles_n;
+  const int wgid = xcd_remap(blockIdx.x, nwg);
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * a.tiles_n;
+  const int group = wgid / per_group;
+  const int first_m = group * GROUP;
+  const int gsize = min(a.tiles_m - first_m, GROUP);
+  const int in_group = wgid % per_group;
+  const long m_blk = (long)(first_m + in_group % gsize) * BM;
+  const long n_blk = (long)(in_group / gsize) * BN;
+
+  const long k_begin = (long)blockIdx.z * a.k_per_split;
+  const long k_end = min(a.K, k_begin + a.k_per_split);
+  const int nk = (int)((k_end - k_begin + BK - 1) / BK);
+
+  f32x16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (EDGE) {
+    const bool interior = m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0;
+    if (interior)
+      gemm_mainloop<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, false, CONV, ABL>(a, lds, acc, m_blk, n_blk, k_begin, k_end, nk,
+                                                                          tid, wm0, wn0);
+    else
+      gemm_mainloop<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, true, CONV, ABL>(a, lds, acc, m_blk, n_blk, k_begin, k_end, nk,
+                                                                         tid, wm0, wn0);
+  } else {
+    gemm_mainloop<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, false, CONV, ABL>(a, lds, acc, m_blk, n_blk, k_begin, k_end, nk,
+                                                                        tid, wm0, wn0);
+  }
+
+  // ---- epilogue.  32x32 accumulator block: register r of lane l holds
+  //      row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31.
+  const bool to_partial = a.partial != nullptr;
+  float* out = to_partial ? a.partial + (long)blockIdx.z * a.M * a.N : a.C;
+  const long ldo = to_partial ? a.N : a.ldc;
+  const bool accumulate = !to_partial && a.accumulate;
+  const bool has_bias = !to_partial && a.bias != nullptr;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const long n = n_blk + wn0 + j * 32 + (lane & 31);
+      const bool n_ok = !EDGE || n < a.N;
+      float bias = 0.f;
+      if (has_bias && n_ok) bias = a.bias[n];
+      const long m_base = m_blk + wm0 + i * 32 + 4 * (lane >> 5);
+      float* col = out + n;
+      if (accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long m = m_base + (r & 3) + 8 * (r >> 2);
+          if (EDGE && (m >= a.M || !n_ok)) continue;
+          col[m * ldo] = (col[m * ldo] + acc[i][j][r]) + bias;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const long m = m_base + (r & 3) + 8 * (r >> 2);
+          if (EDGE && (m >= a.M || !n_ok)) continue;
+          col[m * ldo] = acc[i][j][r] + bias;
+        }
+      }
+    }
+  }
+}
+
+// Second pass of split-K: C[m,n] = (accumulate ? C : 0) + sum_z partial[z][m][n] + bias[n],
+// slabs added in increasing z (fixed order => run-to-run deterministic).
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial, float* C,
+                                                                 const float* __restrict__ bias, long M, long N,
+                                                                 long ldc, int splits, int accumulate) {
+  const long total = M * N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / N, n = i % N;
+    float s = 0.f;
+    for (int z = 0; z < splits; ++z) s += partial[(long)z * total + i];
+    float* p = C + m * ldc + n;
+    if (accumulate) s = *p + s;
+    if (bias) s += bias[n];
+    *p = s;
+  }
+}
+
+}  // namespace gemm
+}  // namespace eg
