@@ -267,7 +267,10 @@ def main():
     import exprgrad_amd as eg
     from exprgrad_amd import ops
 
-    stream = torch.cuda.current_stream()
+    # a side stream (not the legacy NULL stream) so the backend can capture its launch sequences
+    # into HIP graphs; torch allocations, events and the RCCL collective all follow it
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     ctx = eg.newGpuContext(local_rank, stream=stream.cuda_stream)
     env = {"torch": torch, "ops": ops, "ctx": ctx, "world": world, "rank": rank,
            "timer": Timer(torch, dist, world, stream)}

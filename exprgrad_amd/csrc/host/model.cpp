@@ -15,6 +15,7 @@
 // HIP source (codegen.hpp) built once with hiprtc.  A plan (shapes, launch arguments, result
 // arena) is cached per input-shape signature — the reference re-solves shapes on every call
 // (passes.nim:1386-1436).
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <random>
@@ -198,6 +199,15 @@ struct Plan {
   long zero_floats = 0;  // leading part of the arena that is zeroed before every run
   std::vector<int> bucket_zero;  // gradient-bucket tensors that need zeroing
   float* arena = nullptr;
+  // The launch sequence of a range (whole call / backward part / update part) is captured into a
+  // HIP graph on its second execution and replayed afterwards: the small-batch targets are
+  // launch-latency bound (19 kernels for the XOR step), a replay costs one submission.
+  struct Captured {
+    hipGraphExec_t exec = nullptr;
+    std::string key;  // everything baked into the captured kernel arguments
+    int runs = 0;
+  };
+  Captured graphs[3];
 };
 
 struct TargetState {
@@ -706,9 +716,7 @@ int get_plan(eg_model* m, const char* target, TargetState** ts_out, Plan** plan_
   return EG_OK;
 }
 
-int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero) {
-  int rc = eg::set_device(m->ctx);
-  if (rc) return rc;
+int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero) {
   if (zero) {
     // allocShapes / zeroResultTensor (model.nim:318, 383): results start from zero on every call
     if (plan.zero_floats > 0)
@@ -718,9 +726,80 @@ int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool
                                   m->ctx->stream));
   }
   for (int i = begin; i < end; ++i) {
-    rc = run_launch(m, ts, plan, plan.launches[i]);
+    int rc = run_launch(m, ts, plan, plan.launches[i]);
     if (rc) return rc;
   }
+  return EG_OK;
+}
+
+bool graphs_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("EG_NO_GRAPH");
+    return !(e && e[0] && e[0] != '0');
+  }();
+  return on;
+}
+
+// slot: 0 = whole call, 1 = backward part, 2 = update part
+int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero, int slot) {
+  int rc = eg::set_device(m->ctx);
+  if (rc) return rc;
+  Plan::Captured& cap = plan.graphs[slot];
+  if (!graphs_enabled() || end - begin < 2) return run_range_eager(m, ts, plan, begin, end, zero);
+  // every pointer / scalar that ends up in a kernel argument
+  std::ostringstream key;
+  for (auto& in : m->inputs)
+    if (in.second.bound) key << in.first << "=" << (const void*)in.second.device << ";";
+  key << "w" << m->ctx->workspace << "b" << (void*)ts.bucket << "g" << m->grad_scale << "e" << m->epoch;
+  const std::string k = key.str();
+  if (cap.exec && cap.key == k) {
+    EG_HIP_CHECK(hipGraphLaunch(cap.exec, m->ctx->stream));
+    return EG_OK;
+  }
+  if (cap.exec) {
+    hipGraphExecDestroy(cap.exec);
+    cap.exec = nullptr;
+  }
+  // first execution with these arguments runs eagerly (lazy kernel builds, workspace growth);
+  // the second one is captured
+  if (cap.key != k || cap.runs < 1) {
+    if (cap.key != k) cap.runs = 0;
+    cap.key = k;
+    cap.runs++;
+    return run_range_eager(m, ts, plan, begin, end, zero);
+  }
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamBeginCapture(m->ctx->stream, hipStreamCaptureModeThreadLocal);
+  static const bool debug = getenv("EG_DEBUG_GRAPH") != nullptr;
+  if (e != hipSuccess) {  // capture unavailable on this stream: stay eager
+    if (debug) fprintf(stderr, "[eg] begin capture failed: %s\n", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return run_range_eager(m, ts, plan, begin, end, zero);
+  }
+  rc = run_range_eager(m, ts, plan, begin, end, zero);
+  e = hipStreamEndCapture(m->ctx->stream, &graph);
+  if (rc) {
+    if (graph) hipGraphDestroy(graph);
+    return rc;
+  }
+  if (e != hipSuccess || !graph) {
+    if (debug) fprintf(stderr, "[eg] end capture failed: %s\n", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return run_range_eager(m, ts, plan, begin, end, zero);
+  }
+  if (debug) {
+    size_t n = 0;
+    hipGraphGetNodes(graph, nullptr, &n);
+    fprintf(stderr, "[eg] captured %zu nodes for slot %d of target %s\n", n, slot, ts.target->name.c_str());
+  }
+  e = hipGraphInstantiate(&cap.exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    cap.exec = nullptr;
+    return run_range_eager(m, ts, plan, begin, end, zero);
+  }
+  EG_HIP_CHECK(hipGraphLaunch(cap.exec, m->ctx->stream));
   return EG_OK;
 }
 
@@ -808,8 +887,11 @@ int eg_model_free(eg_model* m) {
   hipSetDevice(m->ctx->device);
   hipStreamSynchronize(m->ctx->stream);
   for (auto& kv : m->targets) {
-    for (auto& p : kv.second.plans)
+    for (auto& p : kv.second.plans) {
+      for (auto& g : p.second->graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
       if (p.second->arena) hipFree(p.second->arena);
+    }
     if (kv.second.bucket_owned && kv.second.bucket) hipFree(kv.second.bucket);
   }
   for (auto& p : m->params)
@@ -970,7 +1052,7 @@ int eg_model_run(eg_model* m, const char* target) {
   Plan* plan;
   int rc = get_plan(m, target, &ts, &plan);
   if (rc) return rc;
-  return run_range(m, *ts, *plan, 0, (int)plan->launches.size(), true);
+  return run_range(m, *ts, *plan, 0, (int)plan->launches.size(), true, 0);
 }
 
 int eg_model_run_backward(eg_model* m, const char* target) {
@@ -978,7 +1060,7 @@ int eg_model_run_backward(eg_model* m, const char* target) {
   Plan* plan;
   int rc = get_plan(m, target, &ts, &plan);
   if (rc) return rc;
-  return run_range(m, *ts, *plan, 0, plan->n_backward, true);
+  return run_range(m, *ts, *plan, 0, plan->n_backward, true, 1);
 }
 
 int eg_model_run_update(eg_model* m, const char* target) {
@@ -986,7 +1068,7 @@ int eg_model_run_update(eg_model* m, const char* target) {
   Plan* plan;
   int rc = get_plan(m, target, &ts, &plan);
   if (rc) return rc;
-  return run_range(m, *ts, *plan, plan->n_backward, (int)plan->launches.size(), false);
+  return run_range(m, *ts, *plan, plan->n_backward, (int)plan->launches.size(), false, 2);
 }
 
 int eg_model_set_grad_scale(eg_model* m, float scale) {

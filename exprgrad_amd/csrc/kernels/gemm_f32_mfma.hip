@@ -9,6 +9,9 @@
 // tile shape, split-K, vector/edge variant, launch, deterministic second pass.
 #include "gemm_f32_mfma.hpp"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "../eg_internal.hpp"
 
 namespace {
@@ -59,6 +62,41 @@ int launch_config(eg_ctx* ctx, bool a_kc, bool b_kc, const GemmArgs& args, int s
   return EG_OK;
 }
 
+// Convolution variants: deeper k-tiles (BK = 32) — with F = 64 filters a block has little matrix
+// work per barrier, so the prefetch distance of one k-tile must cover the L2 latency.
+template <int BM, int BN, int CBK, int WM, int WN, int MINB>
+int launch_conv(eg_ctx* ctx, const GemmArgs& args, bool vec) {
+  constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
+  dim3 grid((unsigned)(args.tiles_m * args.tiles_n), 1, 1);
+  if (vec)
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, CBK, WM, WN, MINB, true, true, 4, true, true>), grid, dim3(NT), 0,
+                       ctx->stream, args);
+  else
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, CBK, WM, WN, MINB, true, true, 1, true, true>), grid, dim3(NT), 0,
+                       ctx->stream, args);
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
+int run_conv(eg_ctx* ctx, GemmArgs args, bool vec) {
+  int v = 0;
+  if (const char* f = getenv("EG_CONV_VARIANT")) v = atoi(f);  // tuning aid
+  args.partial = nullptr;
+  auto tiles = [&](int bm, int bn, int bk) {
+    args.tiles_m = (int)((args.M + bm - 1) / bm);
+    args.tiles_n = (int)((args.N + bn - 1) / bn);
+    args.k_per_split = ((args.K + bk - 1) / bk) * bk;
+  };
+  if (args.N > 64 || v == 9) return -1;  // wide filter banks: the generic tile choice
+  switch (v) {
+    // measured on cfg 4 (256x256x64 -> 64, 3x3): 64x64x32 66 TF, 128x64x32 64, 256x64x32 63, 128x64x16 62
+    case 1: tiles(128, 64, 32); return launch_conv<128, 64, 32, 64, 32, 2>(ctx, args, vec);
+    case 2: tiles(256, 64, 32); return launch_conv<256, 64, 32, 64, 32, 1>(ctx, args, vec);
+    case 4: tiles(128, 64, 16); return launch_conv<128, 64, 16, 64, 32, 4>(ctx, args, vec);
+    default: tiles(64, 64, 32); return launch_conv<64, 64, 32, 32, 32, 4>(ctx, args, vec);
+  }
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Relative cost of running the problem with a given tile: (block rounds on the chip) x (work of
@@ -98,13 +136,19 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, bool conv, bool v
   // Candidates: 256x256 (16 waves, 1 block/CU) for large outputs, 128x128 (4 waves, 4 blocks/CU),
   // and narrow tiles for bias-sized N (the N = 1/4/10 layers of the XOR and dense nets, F = 64
   // filter banks) so the padding wasted in the matrix core stays small.
-  static const TileCfg cfgs[] = {{256, 256, 1}, {128, 128, 4}, {128, 64, 4}, {128, 32, 4}};
+  static const TileCfg cfgs[] = {{256, 256, 1}, {128, 128, 4}, {128, 64, 4}, {128, 32, 4}, {256, 64, 2}, {64, 64, 4}};
+  constexpr int NCFG = 6;
+  int forced_bm = 0, forced_bn = 0;
+  if (const char* f = getenv("EG_GEMM_FORCE_TILE")) sscanf(f, "%d,%d", &forced_bm, &forced_bn);  // tuning aid
   int best = 1, best_splits = 1;
   double best_cost = 0;
-  for (int c = 0; c < 4; ++c) {
-    if (cfgs[c].bn == 64 && N > 64) continue;
-    if (cfgs[c].bn == 32 && N > 32) continue;
-    if (cfgs[c].bn >= 128 && N <= 64) continue;
+  for (int c = 0; c < NCFG; ++c) {
+    if (forced_bm && (cfgs[c].bm != forced_bm || cfgs[c].bn != forced_bn)) continue;
+    if (!forced_bm) {
+      if (cfgs[c].bn == 64 && N > 64) continue;
+      if (cfgs[c].bn == 32 && N > 32) continue;
+      if (cfgs[c].bn >= 128 && N <= 64) continue;
+    }
     int sp;
     const double cost = tile_cost(cfgs[c], M, N, k_tiles, ctx->compute_units, sp);
     if (best_cost == 0 || cost < best_cost) {
@@ -142,6 +186,10 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, bool conv, bool v
   int rc;
   if (BN == 32)
     rc = launch_config<128, 32, 32, 32, 4>(ctx, a_kc, b_kc, args, splits, vec, edge, conv);
+  else if (BN == 64 && BM == 256)
+    rc = launch_config<256, 64, 64, 32, 2>(ctx, a_kc, b_kc, args, splits, vec, edge, conv);
+  else if (BN == 64 && BM == 64)
+    rc = launch_config<64, 64, 32, 32, 4>(ctx, a_kc, b_kc, args, splits, vec, edge, conv);
   else if (BN == 64)
     rc = launch_config<128, 64, 64, 32, 4>(ctx, a_kc, b_kc, args, splits, vec, edge, conv);
   else if (BN == 128)
@@ -233,5 +281,7 @@ extern "C" int eg_conv2_nhwc(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64
   args.cHo = Ho;
   args.cWo = Wo;
   const bool vec = (C % 4 == 0) && aligned16(img) && aligned16(flt);
+  rc = run_conv(ctx, args, vec);
+  if (rc >= 0) return rc;
   return run_gemm(ctx, true, true, args, /*conv=*/true, vec);
 }

@@ -91,8 +91,9 @@ struct TileLoader {
         int mn, k;
         coords(tid + i * NT, mn, k);
         const long m = mn0 + mn;
-        const long img = m / (a.cHo * a.cWo), rem = m % (a.cHo * a.cWo);
-        const long y = rem / a.cWo, x = rem % a.cWo;
+        const long img = m / (a.cHo * a.cWo);
+        const unsigned rem = (unsigned)(m - img * (a.cHo * a.cWo));
+        const unsigned y = rem / (unsigned)a.cWo, x = rem % (unsigned)a.cWo;
         row_off[i] = ((img * a.cH + y) * a.cW + x) * a.cC;
       }
     }
@@ -109,9 +110,20 @@ struct TileLoader {
       const long gmn = mn0 + mn, gk = k0 + k;
       const float* p;
       if (CONV) {
-        const long tap = gk / a.cC, c = gk % a.cC;
-        const long dy = tap / a.cFW, dx = tap % a.cFW;
-        p = base + row_off[i] + (dy * a.cW + dx) * a.cC + c;
+        // k -> (dy, dx, c).  The k-tile origin k0 is block-uniform: when C is a multiple of BK the
+        // whole tile lies inside one filter tap and the split is scalar work; otherwise a
+        // 32-bit division per chunk (64-bit division is a ~100 instruction software routine).
+        const unsigned C = (unsigned)a.cC, FW = (unsigned)a.cFW;
+        unsigned tap, c;
+        if (C % BK == 0) {
+          tap = (unsigned)k0 / C;
+          c = (unsigned)k0 % C + (unsigned)k;
+        } else {
+          tap = (unsigned)gk / C;
+          c = (unsigned)gk % C;
+        }
+        const unsigned dy = tap / FW, dx = tap % FW;
+        p = base + row_off[i] + ((long)(dy * (unsigned)a.cW + dx) * C + c);
       } else {
         p = KC ? base + gmn * ld + gk : base + gk * ld + gmn;
       }
