@@ -181,7 +181,8 @@ struct Geometry {
 
 // K loop of one block.  E = predicate every global load against the problem edges.
 // ABL (tuning harness only; the library always instantiates 0): bit 0 = no LDS fragment reads in
-// the k loop, bit 1 = no global loads / LDS stores after the first tile, bit 2 = no barriers.
+// the k loop, bit 1 = no global loads / LDS stores after the first tile, bit 2 = no barriers,
+// bit 3 = no LDS stores only, bit 4 = no global loads only.
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int VEC, bool E, bool CONV, int ABL>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32], long m_blk,
                                               long n_blk, long k_begin, long k_end, int nk, int tid, int wm0, int wn0) {
@@ -211,7 +212,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const bool more = (ABL & 2) ? false : kt + 1 < nk;
-    if (more) {
+    if (more && !(ABL & 16)) {
       const long k0 = k_begin + (long)(kt + 1) * BK;
       la.load(a, a.A, a.lda, m_blk, k0, a.M, k_end, tid);
       lb.load(a, a.B, a.ldb, n_blk, k0, a.N, k_end, tid);
@@ -245,7 +246,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
         for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i], bv[c][j], acc[i][j], 0, 0, 0);
     }
-    if (more) {
+    if (more && !(ABL & 8)) {
       la.store(lds + (cur ^ 1) * BUF, tid);
       lb.store(lds + (cur ^ 1) * BUF + BK * SA, tid);
     }

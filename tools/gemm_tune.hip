@@ -61,6 +61,11 @@ std::vector<Variant> variants() {
       VA(256, 256, 16, 64, 64, 1, AKC, BKC, 1),
       VA(256, 256, 16, 64, 64, 1, AKC, BKC, 2),
       VA(256, 256, 16, 64, 64, 1, AKC, BKC, 7),
+      VA(256, 256, 16, 64, 64, 1, AKC, BKC, 8),
+      VA(256, 256, 16, 64, 64, 1, AKC, BKC, 16),
+      VA(256, 256, 16, 64, 64, 1, AKC, BKC, 4),
+      VA(128, 128, 16, 64, 64, 4, AKC, BKC, 8),
+      VA(128, 128, 16, 64, 64, 4, AKC, BKC, 16),
   };
 }
 
