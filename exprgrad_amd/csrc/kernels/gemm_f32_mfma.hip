@@ -31,8 +31,10 @@ int launch_config(eg_ctx* ctx, bool a_kc, bool b_kc, const GemmArgs& args, int s
   dim3 grid((unsigned)(args.tiles_m * args.tiles_n), 1, (unsigned)splits);
   dim3 block(NT);
   hipStream_t s = ctx->stream;
-#define EG_GEMM_LAUNCH(AKC, BKC, V, E, CV) \
-  hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, MINB, AKC, BKC, V, E, CV>), grid, block, 0, s, args)
+  // 16-byte aligned operands: interior tiles run the LDS-DMA loop (gemm_f32_mfma.hpp)
+#define EG_GEMM_LAUNCH(AKC, BKC, V, E, CV)                                                                        \
+  hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, MINB, AKC, BKC, V, E, CV, 0, (V == 4 && !CV)>), grid, \
+                     block, 0, s, args)
 #define EG_GEMM_LAYOUT(AKC, BKC)                  \
   do {                                            \
     if (!edge)                                    \
@@ -195,7 +197,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, bool conv, bool v
   else if (BN == 128)
     rc = launch_config<128, 128, 64, 64, 4>(ctx, a_kc, b_kc, args, splits, vec, edge, conv);
   else
-    rc = launch_config<256, 256, 64, 64, 1>(ctx, a_kc, b_kc, args, splits, vec, edge, conv);
+    rc = launch_config<256, 256, 128, 64, 1>(ctx, a_kc, b_kc, args, splits, vec, edge, conv);
   if (rc) return rc;
 
   if (splits > 1) {

@@ -254,10 +254,133 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-DMA variant of the K loop (interior tiles, 16-byte aligned operands, BK = 16).
+//
+// Ablation of the register-staged loop (tools/gemm_tune.hip, 4096^3) shows the VGPR -> LDS stores
+// are its largest single cost (128x128: 144.6 TF without them vs 133.4 with; 256x256: 143.6 vs
+// 137.5): ds_write moves at most ~80 B/clk/CU and blocks the operand reads of the other waves
+// meanwhile.  `global_load_lds_dwordx4` writes the tile into LDS from the memory pipeline instead:
+// no staging registers, no ds_write.  Its LDS image is lane-linear (wave-uniform base + lane*16 B),
+// so the layouts are chosen to be lane-linear:
+//   * m|n-contiguous operand: [k][m|n] rows, one 1 KiB instruction covers 256 consecutive floats;
+//     fragments are ds_read_b32 of 32 consecutive dwords (conflict free).
+//   * k-contiguous operand: [m|n][16] rows of four 16-byte chunks; chunk c of row r is stored in
+//     slot c ^ ((r >> 2) & 3) — the permutation is applied to the per-lane GLOBAL address, the LDS
+//     side stays linear — and fragments are ds_read_b128: one read feeds four MFMA k-steps, and the
+//     16 lanes of every ds_read_b128 service group fall on 16 distinct 16-byte slots.
+// MFMA k assignment inside a 16-deep tile: step (pp, j), pp in {0,1}, j in 0..3, multiplies
+// k = 8*pp + j (lanes 0-31) and k = 8*pp + 4 + j (lanes 32-63); any assignment is valid as long as
+// both operands use the same one.
+template <int BMN, int NT, bool KC>
+struct DmaLoader {
+  static constexpr int BK = 16;
+  static constexpr int INSTRS = BK * BMN / 256;  // 1 KiB wave instructions per tile
+  static constexpr int WAVES = NT / 64;
+
+  // issue this wave's share of the tile whose origin is (mn0, k0) into `tile` (LDS, lane-linear)
+  __device__ __forceinline__ static void issue(const float* __restrict__ base, long ld, long mn0, long k0, float* tile,
+                                               int wave, int lane) {
+#pragma unroll
+    for (int t = 0; t < (INSTRS + WAVES - 1) / WAVES; ++t) {
+      const int instr = wave + t * WAVES;
+      if (INSTRS % WAVES != 0 && instr >= INSTRS) break;
+      const int q = instr * 64 + lane;  // 16-byte chunk index inside the tile
+      const float* src;
+      if (KC) {
+        const int r = q >> 2, slot = q & 3;
+        const int c = slot ^ ((r >> 2) & 3);
+        src = base + (mn0 + r) * ld + k0 + c * 4;
+      } else {
+        constexpr int CPR = BMN / 4;
+        const int k = q / CPR, col = (q % CPR) * 4;
+        src = base + (k0 + k) * ld + mn0 + col;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(tile + instr * 256), 16, 0, 0);
+    }
+  }
+};
+
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+__device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32],
+                                                  long m_blk, long n_blk, long k_begin, int nk, int tid, int wm0,
+                                                  int wn0) {
+  constexpr int BK = 16;
+  constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int BUF = BK * (BM + BN);
+  using DmaA = DmaLoader<BM, NT, A_KC>;
+  using DmaB = DmaLoader<BN, NT, B_KC>;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, hi = lane >> 5;
+
+  if (nk > 0) {
+    DmaA::issue(a.A, a.lda, m_blk, k_begin, lds, wave, lane);
+    DmaB::issue(a.B, a.ldb, n_blk, k_begin, lds + BK * BM, wave, lane);
+  }
+  __syncthreads();  // hipcc drains vmcnt before the barrier while an LDS-DMA is in flight
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      const long k0 = k_begin + (long)(kt + 1) * BK;
+      float* nxt = lds + (cur ^ 1) * BUF;
+      DmaA::issue(a.A, a.lda, m_blk, k0, nxt, wave, lane);
+      DmaB::issue(a.B, a.ldb, n_blk, k0, nxt + BK * BM, wave, lane);
+    }
+    const float* As = lds + cur * BUF;
+    const float* Bs = As + BK * BM;
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+      float av[MI][4], bv[NI][4];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm0 + mi * 32 + i;
+        if (A_KC) {
+          const int slot = (2 * pp + hi) ^ ((row >> 2) & 3);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(As + row * 16 + slot * 4);
+          av[mi][0] = v[0];
+          av[mi][1] = v[1];
+          av[mi][2] = v[2];
+          av[mi][3] = v[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) av[mi][j] = As[(8 * pp + j + 4 * hi) * BM + row];
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int col = wn0 + ni * 32 + i;
+        if (B_KC) {
+          const int slot = (2 * pp + hi) ^ ((col >> 2) & 3);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + col * 16 + slot * 4);
+          bv[ni][0] = v[0];
+          bv[ni][1] = v[1];
+          bv[ni][2] = v[2];
+          bv[ni][3] = v[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[ni][j] = Bs[(8 * pp + j + 4 * hi) * BN + col];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+}
+
 // MINB: blocks per CU the register allocator must leave room for (waves/SIMD = MINB * WAVES / 4).
 // EDGE kernels still run their interior tiles on the unpredicated loop.
+// DMA: interior tiles use the LDS-DMA loop (requires VEC == 4, BK == 16, no CONV).
 template <int BM, int BN, int BK, int WM, int WN, int MINB, bool A_KC, bool B_KC, int VEC, bool EDGE, bool CONV,
-          int ABL = 0>
+          int ABL = 0, bool DMA = false>
 __global__ __launch_bounds__((Geometry<BM, BN, WM, WN>::NT), (MINB * Geometry<BM, BN, WM, WN>::WAVES + 3) / 4) void
 gemm_f32_mfma_kernel(GemmArgs a) {
   constexpr int WAVES_N = BN / WN;
@@ -297,7 +420,10 @@ gemm_f32_mfma_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (EDGE) {
+  static_assert(!DMA || (VEC == 4 && BK == 16 && !CONV), "LDS-DMA loop: aligned operands, BK = 16, no gather");
+  if (DMA && (!EDGE || (m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0))) {
+    gemm_mainloop_dma<BM, BN, WM, WN, A_KC, B_KC>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
+  } else if (EDGE) {
     const bool interior = m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0;
     if (interior)
       gemm_mainloop<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, false, CONV, ABL>(a, lds, acc, m_blk, n_blk, k_begin, k_end, nk,

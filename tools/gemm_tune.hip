@@ -36,6 +36,15 @@ void launch_variant(const GemmArgs& a, dim3 grid, hipStream_t s) {
 #define VA(BM, BN, BK, WM, WN, MINB, AKC, BKC, ABL) \
   { #BM "x" #BN "x" #BK " w" #WM "x" #WN " b" #MINB " abl" #ABL, BM, BN, BK, launch_variant<BM, BN, BK, WM, WN, MINB, AKC, BKC, ABL>, 0 }
 
+template <int BM, int BN, int WM, int WN, int MINB, bool AKC, bool BKC>
+void launch_dma(const GemmArgs& a, dim3 grid, hipStream_t s) {
+  constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
+  hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, 16, WM, WN, MINB, AKC, BKC, 4, false, false, 0, true>), grid, dim3(NT),
+                     0, s, a);
+}
+#define VD(BM, BN, WM, WN, MINB, AKC, BKC) \
+  { #BM "x" #BN "x16 w" #WM "x" #WN " b" #MINB " DMA", BM, BN, 16, launch_dma<BM, BN, WM, WN, MINB, AKC, BKC>, 0 }
+
 #define V(BM, BN, BK, WM, WN, MINB, AKC, BKC) \
   { #BM "x" #BN "x" #BK " w" #WM "x" #WN " b" #MINB, BM, BN, BK, launch_variant<BM, BN, BK, WM, WN, MINB, AKC, BKC>, 0 }
 
@@ -54,6 +63,11 @@ std::vector<Variant> variants() {
       V(256, 256, 16, 128, 64, 1, AKC, BKC),
       V(256, 256, 16, 128, 128, 1, AKC, BKC),
       V(256, 128, 8, 64, 64, 2, AKC, BKC),
+      VD(128, 128, 64, 64, 4, AKC, BKC),
+      VD(256, 256, 64, 64, 1, AKC, BKC),
+      VD(256, 128, 64, 64, 2, AKC, BKC),
+      VD(128, 256, 64, 64, 2, AKC, BKC),
+      VD(256, 256, 128, 64, 1, AKC, BKC),
       VA(128, 128, 16, 64, 64, 4, AKC, BKC, 1),
       VA(128, 128, 16, 64, 64, 4, AKC, BKC, 2),
       VA(128, 128, 16, 64, 64, 4, AKC, BKC, 4),
