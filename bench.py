@@ -155,7 +155,7 @@ def run_matmul(args, env):
                    "parallelism": "single" if env["world"] == 1 else f"{env['world']} independent replicas"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                     "kernel": "gemm_f32_mfma_kernel<128,128,64,64,NN>", "flops_per_launch": flops,
+                     "kernel": "eg::gemm::gemm_f32_mfma_kernel<256,256,16,128,64,NN,DMA>", "flops_per_launch": flops,
                      "kernel_ms_avg": round(ev_avg, 4), "kernel_ms_min": round(ev_min, 4)},
     }
 

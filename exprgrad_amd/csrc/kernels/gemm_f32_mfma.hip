@@ -70,7 +70,11 @@ template <int BM, int BN, int CBK, int WM, int WN, int MINB>
 int launch_conv(eg_ctx* ctx, const GemmArgs& args, bool vec) {
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
   dim3 grid((unsigned)(args.tiles_m * args.tiles_n), 1, 1);
-  if (vec)
+  // channels a multiple of the k-tile: interior tiles gather with LDS-DMA (a k-tile lies inside one tap)
+  if (vec && args.cC % CBK == 0 && getenv("EG_CONV_NO_DMA") == nullptr)
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, CBK, WM, WN, MINB, true, true, 4, true, true, 0, true>), grid,
+                       dim3(NT), 0, ctx->stream, args);
+  else if (vec)
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, CBK, WM, WN, MINB, true, true, 4, true, true>), grid, dim3(NT), 0,
                        ctx->stream, args);
   else

@@ -255,7 +255,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
 }
 
 // ---------------------------------------------------------------------------------------------
-// LDS-DMA variant of the K loop (interior tiles, 16-byte aligned operands, BK = 16).
+// LDS-DMA variant of the K loop (interior tiles, 16-byte aligned operands, BK = 16 or 32).
 //
 // Ablation of the register-staged loop (tools/gemm_tune.hip, 4096^3) shows the VGPR -> LDS stores
 // are its largest single cost (128x128: 144.6 TF without them vs 133.4 with; 256x256: 143.6 vs
@@ -272,25 +272,57 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
 // MFMA k assignment inside a 16-deep tile: step (pp, j), pp in {0,1}, j in 0..3, multiplies
 // k = 8*pp + j (lanes 0-31) and k = 8*pp + 4 + j (lanes 32-63); any assignment is valid as long as
 // both operands use the same one.
-template <int BMN, int NT, bool KC>
+// BK = 32 (used by the convolution: more matrix work per barrier) has eight chunks per row and
+// the slot permutation c ^ ((r >> 1) & 7), with the same conflict-free property.
+// CONV: the k-contiguous A operand is the virtual im2col matrix, its rows gathered from the NHWC
+// image (requires C % BK == 0 so that a k-tile lies inside one filter tap).
+template <int BMN, int BK, int NT, bool KC, bool CONV>
 struct DmaLoader {
-  static constexpr int BK = 16;
   static constexpr int INSTRS = BK * BMN / 256;  // 1 KiB wave instructions per tile
   static constexpr int WAVES = NT / 64;
+  static constexpr int PER_WAVE = (INSTRS + WAVES - 1) / WAVES;
+  static constexpr int CHUNKS = BK / 4;  // 16-byte chunks per k-contiguous row
+
+  long row_off[PER_WAVE];  // CONV: element offset of this lane's output pixel's top-left input pixel
+
+  __device__ __forceinline__ static int swizzle(int r) { return BK == 16 ? (r >> 2) & 3 : (r >> 1) & 7; }
+
+  __device__ __forceinline__ void init(const GemmArgs& a, long mn0, int wave, int lane) {
+    if (CONV) {
+#pragma unroll
+      for (int t = 0; t < PER_WAVE; ++t) {
+        const int q = (wave + t * WAVES) * 64 + lane;
+        const long m = mn0 + q / CHUNKS;
+        const long img = m / (a.cHo * a.cWo);
+        const unsigned rem = (unsigned)(m - img * (a.cHo * a.cWo));
+        const unsigned y = rem / (unsigned)a.cWo, x = rem % (unsigned)a.cWo;
+        row_off[t] = ((img * a.cH + y) * a.cW + x) * a.cC;
+      }
+    }
+  }
 
   // issue this wave's share of the tile whose origin is (mn0, k0) into `tile` (LDS, lane-linear)
-  __device__ __forceinline__ static void issue(const float* __restrict__ base, long ld, long mn0, long k0, float* tile,
-                                               int wave, int lane) {
+  __device__ __forceinline__ void issue(const GemmArgs& a, const float* __restrict__ base, long ld, long mn0, long k0,
+                                        float* tile, int wave, int lane) const {
+    long tap_off = 0;
+    if (CONV) {  // block-uniform: scalar work
+      const unsigned C = (unsigned)a.cC, FW = (unsigned)a.cFW;
+      const unsigned tap = (unsigned)k0 / C, c0 = (unsigned)k0 % C;
+      tap_off = (long)((tap / FW) * (unsigned)a.cW + tap % FW) * C + c0;
+    }
 #pragma unroll
-    for (int t = 0; t < (INSTRS + WAVES - 1) / WAVES; ++t) {
+    for (int t = 0; t < PER_WAVE; ++t) {
       const int instr = wave + t * WAVES;
       if (INSTRS % WAVES != 0 && instr >= INSTRS) break;
       const int q = instr * 64 + lane;  // 16-byte chunk index inside the tile
       const float* src;
       if (KC) {
-        const int r = q >> 2, slot = q & 3;
-        const int c = slot ^ ((r >> 2) & 3);
-        src = base + (mn0 + r) * ld + k0 + c * 4;
+        const int r = q / CHUNKS, slot = q % CHUNKS;
+        const int c = slot ^ swizzle(r);
+        if (CONV)
+          src = base + row_off[t] + tap_off + c * 4;
+        else
+          src = base + (mn0 + r) * ld + k0 + c * 4;
       } else {
         constexpr int CPR = BMN / 4;
         const int k = q / CPR, col = (q % CPR) * 4;
@@ -302,22 +334,26 @@ struct DmaLoader {
   }
 };
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool CONV>
 __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32],
                                                   long m_blk, long n_blk, long k_begin, int nk, int tid, int wm0,
                                                   int wn0) {
-  constexpr int BK = 16;
+  static_assert(BK == 16 || BK == 32, "LDS-DMA loop: BK is 16 or 32");
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int BUF = BK * (BM + BN);
-  using DmaA = DmaLoader<BM, NT, A_KC>;
-  using DmaB = DmaLoader<BN, NT, B_KC>;
+  using DmaA = DmaLoader<BM, BK, NT, A_KC, CONV>;
+  using DmaB = DmaLoader<BN, BK, NT, B_KC, false>;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, hi = lane >> 5;
 
+  DmaA da;
+  DmaB db;
+  da.init(a, m_blk, wave, lane);
+  db.init(a, n_blk, wave, lane);
   if (nk > 0) {
-    DmaA::issue(a.A, a.lda, m_blk, k_begin, lds, wave, lane);
-    DmaB::issue(a.B, a.ldb, n_blk, k_begin, lds + BK * BM, wave, lane);
+    da.issue(a, a.A, a.lda, m_blk, k_begin, lds, wave, lane);
+    db.issue(a, a.B, a.ldb, n_blk, k_begin, lds + BK * BM, wave, lane);
   }
   __syncthreads();  // hipcc drains vmcnt before the barrier while an LDS-DMA is in flight
 
@@ -326,20 +362,20 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
     if (kt + 1 < nk) {
       const long k0 = k_begin + (long)(kt + 1) * BK;
       float* nxt = lds + (cur ^ 1) * BUF;
-      DmaA::issue(a.A, a.lda, m_blk, k0, nxt, wave, lane);
-      DmaB::issue(a.B, a.ldb, n_blk, k0, nxt + BK * BM, wave, lane);
+      da.issue(a, a.A, a.lda, m_blk, k0, nxt, wave, lane);
+      db.issue(a, a.B, a.ldb, n_blk, k0, nxt + BK * BM, wave, lane);
     }
     const float* As = lds + cur * BUF;
     const float* Bs = As + BK * BM;
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
+    for (int pp = 0; pp < BK / 8; ++pp) {
       float av[MI][4], bv[NI][4];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int row = wm0 + mi * 32 + i;
         if (A_KC) {
-          const int slot = (2 * pp + hi) ^ ((row >> 2) & 3);
-          const f32x4 v = *reinterpret_cast<const f32x4*>(As + row * 16 + slot * 4);
+          const int slot = (2 * pp + hi) ^ DmaA::swizzle(row);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(As + row * BK + slot * 4);
           av[mi][0] = v[0];
           av[mi][1] = v[1];
           av[mi][2] = v[2];
@@ -353,8 +389,8 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
       for (int ni = 0; ni < NI; ++ni) {
         const int col = wn0 + ni * 32 + i;
         if (B_KC) {
-          const int slot = (2 * pp + hi) ^ ((col >> 2) & 3);
-          const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + col * 16 + slot * 4);
+          const int slot = (2 * pp + hi) ^ DmaB::swizzle(col);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + col * BK + slot * 4);
           bv[ni][0] = v[0];
           bv[ni][1] = v[1];
           bv[ni][2] = v[2];
@@ -378,7 +414,8 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
 
 // MINB: blocks per CU the register allocator must leave room for (waves/SIMD = MINB * WAVES / 4).
 // EDGE kernels still run their interior tiles on the unpredicated loop.
-// DMA: interior tiles use the LDS-DMA loop (requires VEC == 4, BK == 16, no CONV).
+// DMA: interior tiles use the LDS-DMA loop (requires VEC == 4, BK in {16, 32}; with CONV the host
+// checks C % BK == 0).
 template <int BM, int BN, int BK, int WM, int WN, int MINB, bool A_KC, bool B_KC, int VEC, bool EDGE, bool CONV,
           int ABL = 0, bool DMA = false>
 __global__ __launch_bounds__((Geometry<BM, BN, WM, WN>::NT), (MINB * Geometry<BM, BN, WM, WN>::WAVES + 3) / 4) void
@@ -420,9 +457,9 @@ gemm_f32_mfma_kernel(GemmArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  static_assert(!DMA || (VEC == 4 && BK == 16 && !CONV), "LDS-DMA loop: aligned operands, BK = 16, no gather");
+  static_assert(!DMA || VEC == 4, "LDS-DMA loop: 16-byte aligned operands");
   if (DMA && (!EDGE || (m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0))) {
-    gemm_mainloop_dma<BM, BN, WM, WN, A_KC, B_KC>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
+    gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
   } else if (EDGE) {
     const bool interior = m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0;
     if (interior)
