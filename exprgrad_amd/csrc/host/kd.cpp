@@ -215,6 +215,7 @@ int parse(const char* text, Program& prog) {
         if (!d.has_shape) P_FAIL("kd line %d: a parameter needs a static shape", lineno);
         if (!tk.next_double(d.lo) || !tk.next_double(d.hi)) P_FAIL("kd line %d: bad init range", lineno);
       }
+      if (d.kind == TK::Cache && !d.has_shape) P_FAIL("kd line %d: a cache tensor needs a static shape", lineno);
       if (d.kind == TK::Input) prog.inputs[d.name] = (int)id;
       prog.tensors.push_back(d);
     } else if (kw == "shapecopy") {
@@ -631,7 +632,9 @@ void dead_kernel_elim(const Program& prog, Target& t) {
   t.live.swap(live);
   t.first_update = -1;
   for (size_t p = 0; p < t.live.size(); ++p)
-    if (prog.tensors[t.all[t.live[p]].write.tensor].kind == TK::Param) {
+    // persistent state: parameters and optimizer caches (adam.m / adam.v, base.nim:45)
+    if (prog.tensors[t.all[t.live[p]].write.tensor].kind == TK::Param ||
+        prog.tensors[t.all[t.live[p]].write.tensor].kind == TK::Cache) {
       t.first_update = (int)p;
       break;
     }

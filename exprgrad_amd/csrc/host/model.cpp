@@ -313,7 +313,7 @@ int lower_target(eg_model* m, TargetState& ts) {
 
 float* tensor_ptr(eg_model* m, TargetState& ts, Plan& plan, int tid) {
   const TensorDef& d = m->prog.tensors[tid];
-  if (d.kind == TK::Param) return m->params[tid].ptr;
+  if (d.kind == TK::Param || d.kind == TK::Cache) return m->params[tid].ptr;
   if (d.kind == TK::Input) {
     auto it = m->inputs.find(tid);
     return (it == m->inputs.end() || !it->second.bound) ? nullptr : const_cast<float*>(it->second.device);
@@ -843,7 +843,8 @@ int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out) {
   std::mt19937 rng(10);
   for (size_t tid = 1; tid < m->prog.tensors.size(); ++tid) {
     const TensorDef& d = m->prog.tensors[tid];
-    if (d.kind != TK::Param) continue;
+    // caches (model.nim:248-249: zero tensors) live next to the parameters: same lifetime, same access
+    if (d.kind != TK::Param && d.kind != TK::Cache) continue;
     DevTensor dt;
     dt.shape = d.shape;
     dt.count = prod(d.shape);
@@ -851,7 +852,7 @@ int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out) {
       EG_HIP_CHECK(hipMalloc((void**)&dt.ptr, (size_t)dt.count * sizeof(float)));
       std::vector<float> host(dt.count);
       std::uniform_real_distribution<float> dist((float)d.lo, (float)d.hi);
-      for (auto& v : host) v = d.hi > d.lo ? dist(rng) : (float)d.lo;
+      for (auto& v : host) v = d.kind == TK::Cache ? 0.0f : (d.hi > d.lo ? dist(rng) : (float)d.lo);
       EG_HIP_CHECK(hipMemcpy(dt.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
     }
     m->params[(int)tid] = dt;

@@ -331,6 +331,12 @@ def param(shape, init_range=(-0.1, 0.1), name=""):
     return Fun("param", name, param_shape=[int(s) for s in shape], init_range=(float(init_range[0]), float(init_range[1])))
 
 
+def cache(fun, name=""):
+    """cache(param, name) (parser.nim:795-798): persistent zero-initialised state shaped like `fun`
+    (adam's moment estimates), wrapped in an effect so kernels can accumulate into it."""
+    return Fun("effect", effect=Fun("cache", name, cache=fun))
+
+
 def backwards(fun):
     return Fun("backwards", children=[fun])
 
@@ -646,6 +652,13 @@ def _alloc_tensors(fun, program):
         elif k == "effect":
             _alloc_tensors(fun.effect, program)
             fun.tensor = fun.effect.tensor
+        elif k == "cache":
+            # TensorCache (parser.nim:296-303): shaped like the tensor it shadows (a parameter)
+            _alloc_tensors(fun.cache, program)
+            src = program.tensors[fun.cache.tensor - 1]
+            if src.get("shape") is None:
+                raise ParserError("cache() needs a tensor with a static shape (a parameter)")
+            fun.tensor = program.alloc_tensor(kind="cache", name=fun.name, shape=list(src["shape"]))
         for c in fun.children:
             _alloc_tensors(c, program)
         if k == "target":

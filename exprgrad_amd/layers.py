@@ -84,7 +84,18 @@ gradientDescent = gradient_descent
 
 
 def adam(eta=0.01, beta1=0.9, beta2=0.999, eps=1e-8):
-    raise NotImplementedError("adam needs cache tensors and epoch(): SURVEY.md §8(f) row f2 (next)")
+    """makeOpt(adam, ...)  base.nim:40-53 (Kingma & Ba 2014).  Uses epoch(): drive it with Model.fit,
+    which bumps Model.epoch (model.nim:436); at epoch 0 the bias correction divides by zero, as in
+    the reference."""
+    def optim(p, g):
+        it = iters("it")
+        m, v = dsl.cache(p, "adam.m"), dsl.cache(p, "adam.v")
+        m.raw[it] += m.raw[it] * (beta1 - 1.0) + (1.0 - beta1) * g.raw[it]           # base.nim:47
+        v.raw[it] += v.raw[it] * (beta2 - 1.0) + (1.0 - beta2) * sq(g.raw[it])       # base.nim:48
+        m_hat = m.raw[it] / (1.0 - dsl.pow(beta1, to_scalar(dsl.epoch())))
+        v_hat = v.raw[it] / (1.0 - dsl.pow(beta2, to_scalar(dsl.epoch())))
+        p.raw[it] += -eta * m_hat / (dsl.sqrt(v_hat) + eps)                          # base.nim:49-53
+    return optim
 
 
 def mse(a, b):

@@ -22,26 +22,27 @@ from .runtime import GpuContext
 class _Params:
     """dict-like view of the device-resident parameters: get copies D2H, set copies H2D."""
 
-    def __init__(self, model):
+    def __init__(self, model, shapes=None):
         self._m = model
+        self._shapes = model._param_shapes if shapes is None else shapes
 
     def ids(self):
-        return list(self._m._param_shapes)
+        return list(self._shapes)
 
     def __iter__(self):
-        return iter(self._m._param_shapes)
+        return iter(self._shapes)
 
     def __len__(self):
-        return len(self._m._param_shapes)
+        return len(self._shapes)
 
     def __getitem__(self, tid):
-        shape = self._m._param_shapes[tid]
+        shape = self._shapes[tid]
         out = np.empty(shape, dtype=np.float32)
         call("eg_model_param_read", self._m.handle, int(tid), out.ctypes.data_as(ctypes.c_void_p), out.size)
         return out
 
     def __setitem__(self, tid, value):
-        shape = self._m._param_shapes[tid]
+        shape = self._shapes[tid]
         arr = np.ascontiguousarray(value, dtype=np.float32)
         if list(arr.shape) != list(shape):
             raise GpuError(f"parameter {tid} has shape {list(shape)}, got {list(arr.shape)}")
@@ -62,10 +63,14 @@ class Model:
         call("eg_model_compile", ctx.handle, self.source_text.encode(), ctypes.byref(h))
         self.handle = h
         self._param_shapes = {}
+        self._cache_shapes = {}
         for tid, t in enumerate(program.tensors, 1):
             if t["kind"] == "param":
                 self._param_shapes[tid] = list(t["shape"])
-        self.params = _Params(self)
+            elif t["kind"] == "cache":
+                self._cache_shapes[tid] = list(t["shape"])
+        self.params = _Params(self)                          # Model.params (model.nim:37)
+        self.caches = _Params(self, self._cache_shapes)      # Model.caches (model.nim:38): adam.m / adam.v
         self._keep = {}
 
     # ---- introspection -----------------------------------------------------------------------
@@ -180,10 +185,64 @@ class Model:
     def set_grad_scale(self, scale):
         call("eg_model_set_grad_scale", self.handle, float(scale))
 
+    # ---- save / load (io/serialize.nim:344-379) ------------------------------------------------
+    def save(self, path):
+        """model.save(path): program + params + caches (serialize.nim:366-369) — here the
+        kernel-description text and the device-resident state flushed to the host first (the
+        reference never copies GPU-side updates back, model.nim:326-345).  Also stores Model.epoch,
+        which the reference forgets.  Own container (numpy .npz), not the reference's byte format."""
+        state = {"program": np.frombuffer(self.source_text.encode(), dtype=np.uint8), "epoch": np.int64(self.epoch)}
+        for tid in self.params.ids():
+            state[f"param_{tid}"] = self.params[tid]
+        for tid in self.caches.ids():
+            state[f"cache_{tid}"] = self.caches[tid]
+        with open(path, "wb") as f:
+            np.savez(f, **state)
+
     def close(self):
         if self.handle:
             call("eg_model_free", self.handle)
             self.handle = None
+
+
+class _LoadedProgram:
+    """What Model needs from a Program when it is rebuilt from saved text."""
+
+    def __init__(self, text):
+        self._text = text
+        self.tensors = []
+        self.targets = {}
+        for line in text.splitlines():
+            tok = line.split()
+            if not tok:
+                continue
+            if tok[0] == "tensor":
+                rank = int(tok[4])
+                self.tensors.append({"kind": tok[2], "name": "" if tok[3] == "-" else tok[3],
+                                     "shape": [int(v) for v in tok[5:5 + rank]] if rank >= 0 else None})
+            elif tok[0] == "target":
+                self.targets[tok[1]] = type("T", (), {"output": int(tok[2])})()
+
+    def to_text(self):
+        return self._text
+
+
+def load_model(path, gpu=None):
+    """loadModel(path, gpu) (serialize.nim:351-364): rebuild the kernels from the stored program and
+    restore parameters, caches and epoch."""
+    with np.load(path) as data:
+        text = bytes(data["program"]).decode()
+        model = Model(_LoadedProgram(text), gpu)
+        for key in data.files:
+            if key.startswith("param_"):
+                model.params[int(key[6:])] = data[key]
+            elif key.startswith("cache_"):
+                model.caches[int(key[6:])] = data[key]
+        model.epoch = int(data["epoch"])
+    return model
+
+
+loadModel = load_model
 
 
 def compile(*graphs, gpu=None):  # noqa: A001 - mirrors compile[T](graphs, gpu) model.nim:270-273

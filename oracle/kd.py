@@ -732,9 +732,12 @@ class Model:
         self.fast = fast_contractions
         self.threads = threads
         self.last = {}
+        self.caches = {}
         for tid, t in self.prog.tensors.items():
             if t["kind"] == "param":
                 self.params[tid] = np.zeros(t["shape"], dtype=np.float32)
+            elif t["kind"] == "cache":      # model.nim:248-249: zero tensors that persist across calls
+                self.caches[tid] = np.zeros(t["shape"], dtype=np.float32)
 
     def kernel_count(self, target):
         return len(self.compiled[target][1])
@@ -790,7 +793,7 @@ class Model:
                 if len(static) != arr.ndim or any(s >= 0 and s != a for s, a in zip(static, arr.shape)):
                     raise ShapeError(f"input {name}: expected shape {static}, got {list(arr.shape)}")
             shapes[tid], tensors[tid] = list(arr.shape), arr
-        for tid, p in self.params.items():
+        for tid, p in list(self.params.items()) + list(self.caches.items()):
             shapes[tid], tensors[tid] = list(p.shape), p
         live = {id(k) for k in kernels}
         infos = {}
@@ -807,7 +810,7 @@ class Model:
                     raise
         first_update = len(kernels)
         for i, k in enumerate(kernels):
-            if self.prog.tensors[k.write.tensor]["kind"] == "param":
+            if self.prog.tensors[k.write.tensor]["kind"] in ("param", "cache"):
                 first_update = i
                 break
         stop = first_update if stop_at_update else len(kernels)
