@@ -65,6 +65,16 @@ int kernel_launch_raw(eg_kernel* kernel, unsigned gx, unsigned gy, unsigned gz, 
 long colsum_scratch_floats(const eg_ctx* ctx, long rows, long cols);
 int colsum_with_scratch(eg_ctx* ctx, long rows, long cols, const float* in, float* out, int accumulate,
                         float* scratch);
+// Second stage of a row-fused kernel's batch reductions (host/rowfuse.hpp): partial is
+// [nblocks][E]; column e belongs to segment s with offset[s] <= e < offset[s+1] and is summed over
+// the blocks (fixed tree order) into dst[s][e - offset[s]].
+struct RowFinalizeArgs {
+  float* dst[16];
+  int offset[17];
+  int accumulate[16];
+  int nseg;
+};
+int row_finalize(eg_ctx* ctx, const float* partial, int nblocks, int E, const RowFinalizeArgs& args);
 inline int set_device(eg_ctx* ctx) {
   EG_HIP_CHECK(hipSetDevice(ctx->device));
   return EG_OK;

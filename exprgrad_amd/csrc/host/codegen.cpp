@@ -62,10 +62,50 @@ struct Emitter {
   int emit_instr(const Instr& ins, int index, std::string& out) {
     const Ty t = ty[ins.res];
     const char* ctype = t == Ty::Scalar ? "float" : (t == Ty::Index ? "long" : "bool");
-    auto a = [&](int i) { return reg(ins.args[i]); };
-    const bool scalar_args = !ins.args.empty() && ty[ins.args[0]] == Ty::Scalar;
-    std::string e;
-    switch (ins.kind) {
+    std::string special;
+    if (ins.kind == IK::Shape || ins.kind == IK::Len || ins.kind == IK::ShapeLen || ins.kind == IK::Epoch)
+      special = p(slot(Slot::InstrVal, index));
+    out += std::string("      const ") + ctype + " " + reg(ins.res) + " = " + instr_expression(ins, special, "r") + ";\n";
+    return EG_OK;
+  }
+
+  // loads + expression, at indentation of the innermost body
+  void emit_body(std::string& out) {
+    for (size_t i = 0; i < k.reads.size(); ++i) {
+      const Op& r = k.reads[i];
+      out += "      const float " + reg(r.reg) + " = t" + std::to_string(r.tensor) + "[" + flat_index(r, (int)i) + "];\n";
+    }
+    for (size_t i = 0; i < k.instrs.size(); ++i) emit_instr(k.instrs[i], (int)i, out);
+  }
+
+  std::string setup_decls() {
+    std::string s;
+    for (size_t i = 0; i < k.setup.size(); ++i)
+      s += "  const long " + reg(k.setup[i].res) + " = " + p(slot(Slot::SetupVal, (int)i)) + ";\n";
+    return s;
+  }
+};
+
+}  // namespace
+
+std::string f32_literal(double v) {
+  const float f = (float)v;  // const_real(float type, double): llvmgen.nim:215-216
+  if (std::isinf(f)) return f > 0 ? "__builtin_inff()" : "(-__builtin_inff())";
+  if (std::isnan(f)) return "__builtin_nanf(\"\")";
+  char buf[64];
+  snprintf(buf, sizeof(buf), "%.9gf", (double)f);
+  std::string s = buf;
+  // "1f" is not a valid literal: make sure there is a '.' or an exponent
+  if (s.find('.') == std::string::npos && s.find('e') == std::string::npos && s.find("inf") == std::string::npos)
+    s.insert(s.size() - 1, ".0");
+  return s;
+}
+
+// One scalar instruction as a C expression over variables `<prefix><register>`; llvmgen.nim:212-276.
+std::string instr_expression(const Instr& ins, const std::string& special, const std::string& prefix) {
+  auto a = [&](int i) { return prefix + std::to_string(ins.args[i]); };
+  std::string e;
+  switch (ins.kind) {
       case IK::Scalar: e = f32_literal(ins.lit); break;
       case IK::Index: e = std::to_string((long)ins.lit) + "L"; break;
       case IK::Boolean: e = ins.lit != 0 ? "true" : "false"; break;
@@ -95,30 +135,13 @@ struct Emitter {
       case IK::ToScalar: e = "(float)" + a(0); break;  // sitofp
       case IK::ToIndex: e = "(long)" + a(0); break;    // fptosi
       case IK::Shape: case IK::Len: case IK::ShapeLen: case IK::Epoch:
-        e = p(slot(Slot::InstrVal, index));
+        e = special;  // host-evaluated builtins (model.nim:83-104): a kernel argument or a constant
         break;
-    }
-    (void)scalar_args;
-    out += std::string("      const ") + ctype + " " + reg(ins.res) + " = " + e + ";\n";
-    return EG_OK;
   }
+  return e;
+}
 
-  // loads + expression, at indentation of the innermost body
-  void emit_body(std::string& out) {
-    for (size_t i = 0; i < k.reads.size(); ++i) {
-      const Op& r = k.reads[i];
-      out += "      const float " + reg(r.reg) + " = t" + std::to_string(r.tensor) + "[" + flat_index(r, (int)i) + "];\n";
-    }
-    for (size_t i = 0; i < k.instrs.size(); ++i) emit_instr(k.instrs[i], (int)i, out);
-  }
-
-  std::string setup_decls() {
-    std::string s;
-    for (size_t i = 0; i < k.setup.size(); ++i)
-      s += "  const long " + reg(k.setup[i].res) + " = " + p(slot(Slot::SetupVal, (int)i)) + ";\n";
-    return s;
-  }
-};
+namespace {
 
 std::vector<int> distinct_tensors(const Kernel& k, bool include_write) {
   std::vector<int> out;

@@ -47,6 +47,12 @@ void split_loops(const Kernel& k, std::vector<int>& indep, std::vector<int>& red
 // shape (all write dims bare distinct iterators, or a single constant element).
 bool split_reduction_capable(const Kernel& k);
 
+// C float literal that parses back to exactly (float)v.
+std::string f32_literal(double v);
+// One scalar instruction as a C expression over variables `<prefix><register id>`; `special`
+// is the text used for the host-evaluated builtins (shape / len / shapelen / epoch).
+std::string instr_expression(const Instr& ins, const std::string& special, const std::string& prefix);
+
 int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out);
 int generate_mode_b(const Kernel& k, const std::string& name, int tx, GenericSource& out);
 

@@ -25,6 +25,7 @@
 #include "../eg_internal.hpp"
 #include "codegen.hpp"
 #include "kd.hpp"
+#include "rowfuse.hpp"
 
 using namespace eg::kd;
 using eg::set_error;
@@ -143,7 +144,7 @@ bool match_conv(const Kernel& k, ConvMatch& m) {
   return false;
 }
 
-enum class StepKind { Gemm, Conv, Seed, GenericA, GenericB };
+enum class StepKind { Gemm, Conv, Seed, GenericA, GenericB, RowFused };
 
 struct Generic {
   GenericSource src;
@@ -181,6 +182,16 @@ struct Launch {
   long blocks_x = 1, blocks_y = 1;
   long partial_rows = 0, partial_cols = 0;  // mode B second stage
   std::vector<int> epoch_slots;             // params refreshed from Model.epoch at every launch
+  int row_group = -1;                       // RowFused: index into Plan::row_groups
+};
+
+// A run of per-sample kernels fused into one generated kernel (rowfuse.hpp), built per plan.
+struct PlanRowGroup {
+  RowGroup g;
+  eg_kernel* handle = nullptr;
+  float* partial = nullptr;  // [nblocks][g.red_total]
+  int nblocks = 0;
+  std::vector<int> red_tensors;  // reduction destinations, in segment order
 };
 
 struct DevTensor {
@@ -202,6 +213,7 @@ struct Plan {
   // The launch sequence of a range (whole call / backward part / update part) is captured into a
   // HIP graph on its second execution and replayed afterwards: the small-batch targets are
   // launch-latency bound (19 kernels for the XOR step), a replay costs one submission.
+  std::vector<std::unique_ptr<PlanRowGroup>> row_groups;
   struct Captured {
     hipGraphExec_t exec = nullptr;
     std::string key;  // everything baked into the captured kernel arguments
@@ -408,6 +420,231 @@ std::string shape_key(eg_model* m) {
   return os.str();
 }
 
+bool row_fusion_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("EG_NO_ROWFUSE");
+    return !(e && e[0] && e[0] != '0');
+  }();
+  return on;
+}
+
+// Partition the live kernel list into row groups (rowfuse.hpp) and build their kernels.
+// group_of[p] = index into plan.row_groups, or -1 for kernels that keep their own launch.
+int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos,
+                    const std::map<int, int>& first_writer, std::vector<int>& group_of) {
+  Target& t = *ts.target;
+  const Shapes& shapes = plan.shapes;
+  if (!row_fusion_enabled()) return EG_OK;
+  long B = 0;
+  for (auto& in : m->inputs)
+    if (in.second.bound && !in.second.shape.empty()) {
+      B = in.second.shape[0];
+      break;
+    }
+  if (B <= 0) return EG_OK;
+  const int n = (int)t.live.size();
+  std::vector<RowKernelInfo> rki(n);
+  for (int p = 0; p < n; ++p) rki[p] = analyse_row_kernel(m->prog, t.all[t.live[p]], infos[t.live[p]], shapes, B);
+  // a bias folded into a library contraction is not available on its own
+  for (int p = 1; p < n; ++p)
+    if (ts.lowered[p].absorbed && !rki[p - 1].ok) rki[p].ok = false;
+
+  constexpr long LOCAL_BUDGET = 192;  // floats of per-thread state
+  constexpr long RED_MAX = 512;
+  int p = 0;
+  while (p < n) {
+    if (!rki[p].ok) {
+      ++p;
+      continue;
+    }
+    // grow a group from p
+    std::unique_ptr<PlanRowGroup> pg(new PlanRowGroup());
+    RowGroup& g = pg->g;
+    g.B = B;
+    int q = p;
+    int row_kernels = 0;
+    while (q < n && rki[q].ok && !(q != p && q == t.first_update) && !(p < t.first_update && q >= t.first_update && t.first_update >= 0)) {
+      const Kernel& k = t.all[t.live[q]];
+      const RowKernelInfo& ri = rki[q];
+      // tentative roles with this kernel added
+      std::map<int, RowGroupTensor> roles = g.tensors;
+      bool ok = true;
+      const int yreg = ri.row_loop >= 0 ? k.loops[ri.row_loop].reg : 0;
+      auto op_is_row = [&](const Op& op) {
+        if (ri.row_loop < 0) return false;
+        for (auto& d : op.dims)
+          if (d.factor_of(yreg)) return true;
+        return false;
+      };
+      auto touch = [&](const Op& op, bool write) {
+        const std::vector<long>& shp = shapes.at(op.tensor);
+        auto it = roles.find(op.tensor);
+        RowGroupTensor gt;
+        if (it != roles.end()) gt = it->second;
+        gt.tensor = op.tensor;
+        if (op_is_row(op)) {
+          const long inner = prod(shp) / B;
+          if (it != roles.end() && gt.role != RowGroupTensor::RowLocal && gt.role != RowGroupTensor::RowExternal) ok = false;
+          gt.inner = inner;
+          if (write) gt.role = RowGroupTensor::RowLocal;
+          else if (it == roles.end()) gt.role = RowGroupTensor::RowExternal;
+        } else {
+          const long count = prod(shp);
+          if (it != roles.end() && (gt.role == RowGroupTensor::RowLocal || gt.role == RowGroupTensor::RowExternal)) ok = false;
+          gt.inner = count;
+          if (write) {
+            const RowGroupTensor::Role want = ri.small_only ? RowGroupTensor::SmallLocal : RowGroupTensor::Reduction;
+            if (it != roles.end() && gt.role != want && gt.role != RowGroupTensor::SmallExternal) ok = false;
+            if (it != roles.end() && gt.role == RowGroupTensor::SmallExternal) ok = false;  // read earlier in the group
+            gt.role = want;
+          } else {
+            if (it != roles.end() && gt.role == RowGroupTensor::Reduction) ok = false;  // needs the grid-wide total
+            if (it == roles.end()) gt.role = RowGroupTensor::SmallExternal;
+          }
+        }
+        roles[op.tensor] = gt;
+      };
+      for (auto& rd : k.reads) touch(rd, false);
+      touch(k.write, true);
+      if (ok && ri.small_only) {
+        // thread-local recomputation only: the tensor must not exist outside the group
+        const int wt = k.write.tensor;
+        auto fw = first_writer.find(wt);
+        if (fw == first_writer.end() || fw->second != q || wt == t.output) ok = false;
+      }
+      long locals = 0, reds = 0;
+      int segs = 0;
+      for (auto& kv : roles) {
+        if (kv.second.role == RowGroupTensor::RowLocal || kv.second.role == RowGroupTensor::SmallLocal) locals += kv.second.inner;
+        if (kv.second.role == RowGroupTensor::Reduction) {
+          locals += kv.second.inner;
+          reds += kv.second.inner;
+          ++segs;
+        }
+      }
+      if (locals > LOCAL_BUDGET || reds > RED_MAX || segs > 16) ok = false;
+      // a contraction keeps its folded bias in the same group
+      if (ok && q + 1 < n && ts.lowered[q + 1].absorbed && !rki[q + 1].ok) ok = false;
+      if (!ok) break;
+      g.tensors = roles;
+      g.kernel_index.push_back(t.live[q]);
+      g.infos.push_back(ri);
+      if (!ri.small_only) ++row_kernels;
+      ++q;
+    }
+    // an absorbed bias must not be split from its contraction by the end of the group
+    while (q > p && q < n && ts.lowered[q].absorbed) {
+      --q;
+      g.kernel_index.pop_back();
+      g.infos.pop_back();
+    }
+    row_kernels = 0;
+    for (auto& ri : g.infos)
+      if (!ri.small_only) ++row_kernels;
+    if (q - p < 2 || row_kernels < 2) {
+      p = std::max(q, p + 1);
+      continue;
+    }
+    // roles may contain tensors of kernels popped above or of the kernel that failed: rebuild exactly
+    g.tensors.clear();
+    {
+      std::vector<int> keep = g.kernel_index;
+      std::vector<RowKernelInfo> keep_infos = g.infos;
+      g.kernel_index.clear();
+      g.infos.clear();
+      for (size_t i = 0; i < keep.size(); ++i) {
+        const Kernel& k = t.all[keep[i]];
+        const RowKernelInfo& ri = keep_infos[i];
+        const int yreg = ri.row_loop >= 0 ? k.loops[ri.row_loop].reg : 0;
+        auto touch = [&](const Op& op, bool write) {
+          bool row = false;
+          if (ri.row_loop >= 0)
+            for (auto& d : op.dims)
+              if (d.factor_of(yreg)) row = true;
+          RowGroupTensor& gt = g.tensors[op.tensor];
+          gt.tensor = op.tensor;
+          const long count = prod(shapes.at(op.tensor));
+          if (row) {
+            gt.inner = count / B;
+            if (write) gt.role = RowGroupTensor::RowLocal;
+            else if (gt.role != RowGroupTensor::RowLocal) gt.role = RowGroupTensor::RowExternal;
+          } else {
+            gt.inner = count;
+            if (write) gt.role = ri.small_only ? RowGroupTensor::SmallLocal : RowGroupTensor::Reduction;
+            else if (gt.role != RowGroupTensor::SmallLocal && gt.role != RowGroupTensor::Reduction)
+              gt.role = RowGroupTensor::SmallExternal;
+          }
+        };
+        for (auto& rd : k.reads) touch(rd, false);
+        touch(k.write, true);
+        g.kernel_index.push_back(keep[i]);
+        g.infos.push_back(ri);
+      }
+    }
+    // liveness: what must come from / go to memory
+    auto written_outside_before = [&](int tensor) {
+      for (int s = 0; s < p; ++s)
+        if (t.all[t.live[s]].write.tensor == tensor) return true;
+      return false;
+    };
+    auto used_after = [&](int tensor) {
+      if (tensor == t.output) return true;
+      for (int s = q; s < n; ++s) {
+        const Kernel& k = t.all[t.live[s]];
+        if (k.write.tensor == tensor) return true;
+        for (auto& rd : k.reads)
+          if (rd.tensor == tensor) return true;
+      }
+      return false;
+    };
+    bool leaks = false;  // a thread-local small tensor somebody outside the group wants
+    for (auto& kv : g.tensors)
+      if (kv.second.role == RowGroupTensor::SmallLocal && (used_after(kv.first) || written_outside_before(kv.first)))
+        leaks = true;
+    if (leaks) {
+      p = std::max(q, p + 1);
+      continue;
+    }
+    long red_off = 0;
+    for (auto& kv : g.tensors) {
+      RowGroupTensor& gt = kv.second;
+      if (gt.role == RowGroupTensor::RowLocal) {
+        gt.load_first = written_outside_before(kv.first);
+        gt.store = used_after(kv.first);
+      } else if (gt.role == RowGroupTensor::Reduction) {
+        const TK kind = m->prog.tensors[kv.first].kind;
+        gt.accumulate = kind != TK::Result || written_outside_before(kv.first);
+        gt.red_offset = red_off;
+        red_off += gt.inner;
+        pg->red_tensors.push_back(kv.first);
+      }
+    }
+    g.red_total = red_off;
+    char name[64];
+    snprintf(name, sizeof(name), "eg_rows%d", m->kernel_serial++);
+    g.name = name;
+    int rc = generate_row_group(m->prog, t.all, infos, shapes, g);
+    if (rc) return rc;
+    rc = eg_kernel_compile(m->ctx, g.name.c_str(), g.source.c_str(), &pg->handle);
+    if (rc) {
+      std::string msg = eg_last_error();
+      set_error("%s\n--- generated source ---\n%s", msg.c_str(), g.source.c_str());
+      return rc;
+    }
+    m->kernels.push_back(pg->handle);
+    pg->nblocks = (int)((B + 255) / 256);
+    if (g.red_total > 0) {
+      EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+      EG_HIP_CHECK(hipMalloc((void**)&pg->partial, (size_t)pg->nblocks * g.red_total * sizeof(float)));
+    }
+    const int gi = (int)plan.row_groups.size();
+    for (int s = p; s < q; ++s) group_of[s] = gi;
+    plan.row_groups.push_back(std::move(pg));
+    p = q;
+  }
+  return EG_OK;
+}
+
 int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   Target& t = *ts.target;
   Shapes& shapes = plan.shapes;
@@ -484,12 +721,29 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
     result_tensors.push_back(t.output);  // never written: stays zero
   }
 
+  // ---- row fusion (rowfuse.hpp): runs of per-sample kernels become one generated kernel each
+  std::vector<int> group_of(t.live.size(), -1);
+  plan.row_groups.clear();
+  int rc_groups = form_row_groups(m, ts, plan, infos, first_writer, group_of);
+  if (rc_groups) return rc_groups;
+
   // decide overwrite vs accumulate per launch; collect tensors that must be zeroed
   std::set<int> needs_zero;
   plan.launches.clear();
   plan.n_backward = -1;
   for (size_t p = 0; p < t.live.size(); ++p) {
     if ((int)p == t.first_update) plan.n_backward = (int)plan.launches.size();
+    if (group_of[p] >= 0) {
+      if (p == 0 || group_of[p - 1] != group_of[p]) {  // first kernel of the group: one launch for all
+        Launch L;
+        L.lowered = (int)p;
+        L.kind = StepKind::RowFused;
+        L.row_group = group_of[p];
+        L.accumulate = false;
+        plan.launches.push_back(L);
+      }
+      continue;
+    }
     Lowered& lo = ts.lowered[p];
     if (lo.absorbed) continue;
     const Kernel& k = t.all[lo.all_index];
@@ -652,6 +906,34 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
     case StepKind::Conv:
       return eg_conv2_nhwc(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, tensor_ptr(m, ts, plan, L.a_tensor),
                            tensor_ptr(m, ts, plan, L.b_tensor), tensor_ptr(m, ts, plan, L.c_tensor), L.accumulate);
+    case StepKind::RowFused: {
+      PlanRowGroup& pg = *plan.row_groups[L.row_group];
+      std::vector<float*> ptrs;
+      ptrs.push_back(pg.partial);
+      for (int tid : pg.g.ptr_args) ptrs.push_back(tensor_ptr(m, ts, plan, tid));
+      std::vector<void*> args;
+      for (auto& p : ptrs) args.push_back(&p);
+      long B = pg.g.B, EP = m->epoch;
+      float GS = m->grad_scale;
+      args.push_back(&B);
+      args.push_back(&GS);
+      args.push_back(&EP);
+      int rc = eg::kernel_launch_raw(pg.handle, (unsigned)pg.nblocks, 1, 1, 256, args.data());
+      if (rc) return rc;
+      if (pg.g.red_total > 0) {
+        eg::RowFinalizeArgs fa = {};
+        fa.nseg = (int)pg.red_tensors.size();
+        for (int s = 0; s < fa.nseg; ++s) {
+          const RowGroupTensor& gt = pg.g.tensors.at(pg.red_tensors[s]);
+          fa.dst[s] = tensor_ptr(m, ts, plan, pg.red_tensors[s]);
+          fa.offset[s] = (int)gt.red_offset;
+          fa.accumulate[s] = gt.accumulate ? 1 : 0;
+        }
+        fa.offset[fa.nseg] = (int)pg.g.red_total;
+        return eg::row_finalize(ctx, pg.partial, pg.nblocks, (int)pg.g.red_total, fa);
+      }
+      return EG_OK;
+    }
     case StepKind::GenericA:
     case StepKind::GenericB: {
       if (L.blocks_x <= 0 || L.blocks_y <= 0) return EG_OK;
@@ -891,6 +1173,8 @@ int eg_model_free(eg_model* m) {
     for (auto& p : kv.second.plans) {
       for (auto& g : p.second->graphs)
         if (g.exec) hipGraphExecDestroy(g.exec);
+      for (auto& rg : p.second->row_groups)
+        if (rg->partial) hipFree(rg->partial);
       if (p.second->arena) hipFree(p.second->arena);
     }
     if (kv.second.bucket_owned && kv.second.bucket) hipFree(kv.second.bucket);

@@ -1,0 +1,314 @@
+#include "rowfuse.hpp"
+
+#include <algorithm>
+#include <cstdio>
+
+#include "../eg_internal.hpp"
+#include "codegen.hpp"
+
+namespace eg {
+namespace kd {
+
+namespace {
+
+constexpr long MAX_INNER = 64;     // floats of one tensor row kept in registers
+constexpr long SMALL_MAX = 4096;   // a "small" tensor (parameters, their gradients, scalars)
+constexpr long MAX_WORK = 2048;    // unrolled iterations of one kernel per sample
+
+long prodv(const std::vector<long>& s, size_t from = 0) {
+  long p = 1;
+  for (size_t i = from; i < s.size(); ++i) p *= s[i];
+  return p;
+}
+
+bool lin_has(const Lin& l, int reg) { return l.factor_of(reg) != 0; }
+
+bool op_has(const Op& op, int reg) {
+  for (auto& d : op.dims)
+    if (lin_has(d, reg)) return true;
+  return false;
+}
+
+std::string lin_text(const Lin& l, const std::map<int, std::string>& subst) {
+  std::string s = std::to_string(l.constant) + "L";
+  for (auto& f : l.factors) {
+    auto it = subst.find(f.first);
+    const std::string var = it != subst.end() ? it->second : "r" + std::to_string(f.first);
+    s += " + " + std::to_string(f.second) + "L * " + var;
+  }
+  return "(" + s + ")";
+}
+
+}  // namespace
+
+RowKernelInfo analyse_row_kernel(const Program& prog, const Kernel& k, const KernelInfo& info, const Shapes& shapes,
+                                 long B) {
+  RowKernelInfo r;
+  if (!info.ok || B <= 0) return r;
+  std::vector<const Op*> ops;
+  for (auto& rd : k.reads) ops.push_back(&rd);
+  ops.push_back(&k.write);
+  for (const Op* op : ops)
+    if (!shapes.count(op->tensor)) return r;
+  auto small = [&](const Op* op) { return prodv(shapes.at(op->tensor)) <= SMALL_MAX; };
+  auto state = [&](const Op* op) {
+    const TK kind = prog.tensors[op->tensor].kind;
+    return kind == TK::Param || kind == TK::Cache;
+  };
+
+  long other_work = 1;
+  for (size_t l = 0; l < k.loops.size(); ++l) other_work *= std::max(0L, info.bounds[l].second - info.bounds[l].first);
+
+  // the gradLoss seed and similar: no batch loop at all, everything small
+  if (k.is_seed) {
+    bool all_small = true;
+    for (const Op* op : ops) all_small = all_small && small(op);
+    if (all_small && other_work <= 64) {
+      r.ok = true;
+      r.small_only = true;
+      r.work = other_work;
+    }
+    return r;
+  }
+  if (!k.setup.empty()) return r;
+
+  for (size_t l = 0; l < k.loops.size(); ++l) {
+    const int y = k.loops[l].reg;
+    const long lo = info.bounds[l].first, hi = info.bounds[l].second;
+    if (lo != 0) continue;
+    bool ok = true, any = false;
+    bool raw = false;
+    long inner = 0;
+    // a raw iterator ({it}) shows in raw ops only; [B,1] tensors make its extent equal B as well
+    bool any_raw = false;
+    for (const Op* op : ops)
+      if (op_has(*op, y) && op->raw) any_raw = true;
+    if (hi == B && !any_raw) {
+      for (const Op* op : ops) {
+        if (!op_has(*op, y)) {
+          if (!small(op)) ok = false;
+          continue;
+        }
+        any = true;
+        const std::vector<long>& shp = shapes.at(op->tensor);
+        if (op->raw || state(op) || shp.empty() || shp[0] != B || op->dims[0].only_register() != y ||
+            prodv(shp, 1) > MAX_INNER)
+          ok = false;
+        for (size_t d = 1; ok && d < op->dims.size(); ++d)
+          if (lin_has(op->dims[d], y)) ok = false;
+      }
+    } else if (any_raw && hi >= B && hi % B == 0 && hi / B <= MAX_INNER) {
+      // raw iterator over B * S elements: it = y * S + j
+      raw = true;
+      inner = hi / B;
+      for (const Op* op : ops) {
+        if (!op_has(*op, y)) {
+          if (!small(op)) ok = false;
+          continue;
+        }
+        any = true;
+        const std::vector<long>& shp = shapes.at(op->tensor);
+        if (!op->raw || state(op) || op->dims.size() != 1 || op->dims[0].only_register() != y || shp.empty() ||
+            shp[0] != B || prodv(shp) != hi)
+          ok = false;
+      }
+    } else {
+      continue;
+    }
+    if (!ok || !any) continue;
+    // the iterator must not be used as a value by the expression (it only indexes)
+    for (auto& ins : k.instrs)
+      for (int a : ins.args)
+        if (a == y) ok = false;
+    if (!ok) continue;
+    const long span = hi - lo;
+    long work = span > 0 ? other_work / span : 0;
+    if (raw) work *= inner;
+    if (work > MAX_WORK) continue;
+    r.ok = true;
+    r.row_loop = (int)l;
+    r.raw = raw;
+    r.inner = inner;
+    r.work = work;
+    return r;
+  }
+  return r;
+}
+
+namespace {
+
+struct GroupEmitter {
+  const Program& prog;
+  const Shapes& shapes;
+  RowGroup& g;
+  std::string code;
+
+  std::string tname(int t) const { return "t" + std::to_string(t); }
+
+  // text of the element a tensor op refers to
+  std::string element(const Op& op, const RowKernelInfo& ri, const Kernel& k, const std::map<int, std::string>& subst,
+                      const std::string& raw_j) {
+    const RowGroupTensor& gt = g.tensors.at(op.tensor);
+    const std::vector<long>& shp = shapes.at(op.tensor);
+    const int yreg = ri.row_loop >= 0 ? k.loops[ri.row_loop].reg : 0;
+    const bool row_op = ri.row_loop >= 0 && op_has(op, yreg);
+    std::string idx;
+    if (row_op) {
+      if (ri.raw) {
+        idx = raw_j;
+      } else {
+        long stride = 1;
+        std::vector<std::string> terms;
+        for (size_t d = shp.size(); d-- > 1;) {
+          terms.push_back(std::to_string(stride) + "L * " + lin_text(op.dims[d], subst));
+          stride *= shp[d];
+        }
+        idx = "0L";
+        for (auto& t : terms) idx += " + " + t;
+      }
+      if (gt.role == RowGroupTensor::RowLocal) return "L" + std::to_string(op.tensor) + "[" + idx + "]";
+      return tname(op.tensor) + "[y * " + std::to_string(gt.inner) + "L + " + idx + "]";
+    }
+    // small tensor
+    if (op.raw) {
+      idx = lin_text(op.dims[0], subst);
+    } else {
+      long stride = 1;
+      idx = "0L";
+      for (size_t d = shp.size(); d-- > 0;) {
+        idx += " + " + std::to_string(stride) + "L * " + lin_text(op.dims[d], subst);
+        stride *= shp[d];
+      }
+    }
+    switch (gt.role) {
+      case RowGroupTensor::SmallLocal: return "S" + std::to_string(op.tensor) + "[" + idx + "]";
+      case RowGroupTensor::Reduction: return "R" + std::to_string(op.tensor) + "[" + idx + "]";
+      default: return tname(op.tensor) + "[" + idx + "]";
+    }
+  }
+
+  void emit_kernel(const Kernel& k, const KernelInfo& info, const RowKernelInfo& ri, int serial) {
+    const std::vector<Ty> ty = infer_types(k);
+    std::map<int, std::string> subst;
+    std::string raw_j;
+    code += "  if (active) {  // kernel " + std::to_string(serial) + ": " + to_text(k).substr(0, 90) + "\n";
+    for (auto& s : k.setup) {  // host-evaluated values become literals (shapes are fixed for this build)
+      code += "    const long r" + std::to_string(s.res) + " = " + std::to_string(info.vals.at(s.res)) + "L;\n";
+    }
+    int depth = 0;
+    for (size_t l = 0; l < k.loops.size(); ++l) {
+      const std::string r = "r" + std::to_string(k.loops[l].reg);
+      if ((int)l == ri.row_loop) {
+        if (ri.raw) {
+          raw_j = "j" + std::to_string(serial);
+          code += "    _Pragma(\"unroll\") for (long " + raw_j + " = 0; " + raw_j + " < " + std::to_string(ri.inner) + "L; ++" +
+                  raw_j + ") {\n";
+          ++depth;
+        }
+        continue;  // the batch iterator is the thread's row
+      }
+      code += "    _Pragma(\"unroll\") for (long " + r + " = " + std::to_string(info.bounds[l].first) + "L; " + r + " < " +
+              std::to_string(info.bounds[l].second) + "L; ++" + r + ") {\n";
+      ++depth;
+    }
+    for (auto& rd : k.reads)
+      code += "      const float r" + std::to_string(rd.reg) + " = " + element(rd, ri, k, subst, raw_j) + ";\n";
+    for (auto& ins : k.instrs) {
+      const Ty t = ty[ins.res];
+      const char* ctype = t == Ty::Scalar ? "float" : (t == Ty::Index ? "long" : "bool");
+      std::string special;
+      if (ins.kind == IK::Epoch) {
+        special = "EP";
+      } else if (ins.kind == IK::Shape || ins.kind == IK::Len || ins.kind == IK::ShapeLen) {
+        const std::vector<long>& shp = shapes.at(ins.tensor);
+        long v = 0;
+        if (ins.kind == IK::Len) v = prodv(shp);
+        else if (ins.kind == IK::ShapeLen) v = (long)shp.size();
+        else {
+          int d = ins.dim < 0 ? ins.dim + (int)shp.size() : ins.dim;
+          v = (d >= 0 && d < (int)shp.size()) ? shp[d] : 0;
+        }
+        special = std::to_string(v) + "L";
+      }
+      std::string e = instr_expression(ins, special, "r");
+      if (k.is_seed && ins.kind == IK::Scalar) e = "GS";  // gradLoss{i} = 1, times the data-parallel scale
+      code += std::string("      const ") + ctype + " r" + std::to_string(ins.res) + " = " + e + ";\n";
+    }
+    const std::string w = element(k.write, ri, k, subst, raw_j);
+    code += "      " + w + " = " + w + " + r" + std::to_string(k.result) + ";\n";
+    for (int d = 0; d < depth; ++d) code += "    }\n";
+    code += "  }\n";
+  }
+};
+
+}  // namespace
+
+int generate_row_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
+                       const Shapes& shapes, RowGroup& g) {
+  GroupEmitter em{prog, shapes, g, {}};
+  // pointer arguments: every tensor that touches memory
+  g.ptr_args.clear();
+  for (auto& kv : g.tensors) {
+    const RowGroupTensor& t = kv.second;
+    const bool mem = t.role == RowGroupTensor::RowExternal || t.role == RowGroupTensor::SmallExternal ||
+                     (t.role == RowGroupTensor::RowLocal && (t.load_first || t.store));
+    if (mem) g.ptr_args.push_back(kv.first);
+  }
+  std::string sig = "extern \"C\" __global__ void __launch_bounds__(256) " + g.name + "(float* __restrict__ partial";
+  for (int t : g.ptr_args) {
+    const RowGroupTensor& gt = g.tensors.at(t);
+    sig += gt.role == RowGroupTensor::RowLocal ? ", float* t" : ", const float* __restrict__ t";
+    sig += std::to_string(t);
+  }
+  sig += ", long B, float GS, long EP)";
+
+  std::string& c = em.code;
+  c += "  const long y = (long)blockIdx.x * 256 + threadIdx.x;\n  const bool active = y < B;\n";
+  for (auto& kv : g.tensors) {
+    const RowGroupTensor& t = kv.second;
+    const std::string id = std::to_string(kv.first);
+    if (t.role == RowGroupTensor::RowLocal) {
+      c += "  float L" + id + "[" + std::to_string(t.inner) + "];\n";
+      c += "  _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) L" + id + "[j] = ";
+      c += t.load_first ? "active ? t" + id + "[y * " + std::to_string(t.inner) + "L + j] : 0.0f;\n" : "0.0f;\n";
+    } else if (t.role == RowGroupTensor::SmallLocal || t.role == RowGroupTensor::Reduction) {
+      const char* p = t.role == RowGroupTensor::SmallLocal ? "S" : "R";
+      c += std::string("  float ") + p + id + "[" + std::to_string(t.inner) + "];\n";
+      c += "  _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) " + p + id + "[j] = 0.0f;\n";
+    }
+  }
+  for (size_t i = 0; i < g.kernel_index.size(); ++i)
+    em.emit_kernel(all[g.kernel_index[i]], infos[g.kernel_index[i]], g.infos[i], (int)i);
+  // rows that are needed after the group
+  for (auto& kv : g.tensors) {
+    const RowGroupTensor& t = kv.second;
+    if (t.role != RowGroupTensor::RowLocal || !t.store) continue;
+    const std::string id = std::to_string(kv.first);
+    c += "  if (active) { _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) t" + id + "[y * " +
+         std::to_string(t.inner) + "L + j] = L" + id + "[j]; }\n";
+  }
+  // batch reductions: wave shuffles, then the four wave totals through LDS, one partial row per block
+  if (g.red_total > 0) {
+    const std::string E = std::to_string(g.red_total);
+    c += "  __shared__ float red[4 * " + E + "];\n";
+    c += "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n";
+    for (auto& kv : g.tensors) {
+      const RowGroupTensor& t = kv.second;
+      if (t.role != RowGroupTensor::Reduction) continue;
+      const std::string id = std::to_string(kv.first);
+      c += "  _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) {\n";
+      c += "    float v = R" + id + "[j];\n";
+      c += "    _Pragma(\"unroll\") for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);\n";
+      c += "    if (lane == 0) red[wave * " + E + " + " + std::to_string(t.red_offset) + " + j] = v;\n  }\n";
+    }
+    c += "  __syncthreads();\n";
+    c += "  for (int e = threadIdx.x; e < " + E + "; e += 256)\n";
+    c += "    partial[(long)blockIdx.x * " + E + " + e] = (red[e] + red[" + E + " + e]) + (red[2 * " + E + " + e] + red[3 * " +
+         E + " + e]);\n";
+  }
+  g.source = sig + " {\n" + c + "}\n";
+  return EG_OK;
+}
+
+}  // namespace kd
+}  // namespace eg

@@ -1,0 +1,70 @@
+// Row fusion: run a chain of per-sample kernels as ONE generated kernel, one thread per sample.
+//
+// Role in the reference: fuseLoops (passes.nim:1929-2004, 2526-2549) merges consecutive kernels
+// that share their leading loop — on the CPU target dense + bias + activation become one `y`
+// loop.  The reference's GPU target does not benefit (each lowered kernel is still its own
+// launch, llvmgen.nim:455-500).  Here the idea is taken further for the launch-bound small-width
+// chains of the hot path (the whole forward + backward of the XOR net: 15 kernels over [B,4] /
+// [B,1] tensors; the softmax / cross-entropy gradient chain of the dense net over [B,10]):
+//   * a kernel is a "row kernel" if it has one loop over the batch B that indexes dimension 0 of
+//     every batch-major tensor it touches ([B, inner...], inner size <= 64), all its other loops
+//     are short, and everything else it touches is small (parameters, their gradients);
+//   * a run of consecutive row kernels is specialised for the current shapes (all extents become
+//     literals, loops fully unroll) and emitted as one kernel: thread y keeps the rows of the
+//     intermediate tensors in registers, tensors needed later are stored once, tensors that are
+//     dead after the run never touch memory;
+//   * writes that reduce over the batch (bias / weight gradients, losses) accumulate in
+//     registers, are folded across the block with wave shuffles + LDS, and one small `finalize`
+//     launch adds the per-block partials into the destination tensors in fixed order
+//     (deterministic, no float atomics).
+#pragma once
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "kd.hpp"
+
+namespace eg {
+namespace kd {
+
+struct RowKernelInfo {
+  bool ok = false;
+  int row_loop = -1;     // index into k.loops of the batch iterator (or of the raw iterator)
+  bool raw = false;      // the batch iterator is a raw `{it}` index over B * inner elements
+  long inner = 0;        // raw: inner size S (it = y * S + j)
+  bool small_only = false;  // touches only small tensors and has no batch loop (the gradLoss seed)
+  long work = 0;         // unrolled iterations per sample
+};
+
+// Can `k` run as part of a row group over batch size B?
+RowKernelInfo analyse_row_kernel(const Program& prog, const Kernel& k, const KernelInfo& info, const Shapes& shapes,
+                                 long B);
+
+struct RowGroupTensor {
+  int tensor = 0;
+  enum Role { RowLocal, RowExternal, SmallExternal, SmallLocal, Reduction } role = RowExternal;
+  long inner = 0;          // elements per row (row tensors) or total elements (small tensors)
+  bool load_first = false;  // RowLocal: written before the group too, start from memory
+  bool store = false;       // RowLocal: needed after the group
+  bool accumulate = false;  // Reduction: add to the destination instead of overwriting it
+  long red_offset = 0;      // Reduction: column offset inside the partial rows
+};
+
+struct RowGroup {
+  std::vector<int> kernel_index;  // indices into target.all, in execution order
+  std::vector<RowKernelInfo> infos;
+  std::map<int, RowGroupTensor> tensors;
+  long B = 0;
+  long red_total = 0;  // partial row length
+  std::string name, source;
+  std::vector<int> ptr_args;  // tensor ids in pointer-argument order (after `partial`)
+};
+
+// Emit the fused kernel.  Arguments of the generated kernel:
+//   (float* partial, float* / const float* t<ids>..., long B, float grad_scale, long epoch)
+int generate_row_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
+                       const Shapes& shapes, RowGroup& group);
+
+}  // namespace kd
+}  // namespace eg

@@ -156,6 +156,33 @@ int colsum_with_scratch(eg_ctx* ctx, long rows, long cols, const float* in, floa
   return EG_OK;
 }
 
+__global__ __launch_bounds__(NT) void row_finalize_kernel(const float* __restrict__ partial, int nblocks, int E,
+                                                          RowFinalizeArgs a) {
+  __shared__ float red[4];
+  const int e = blockIdx.x;
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < nblocks; b += NT) acc += partial[(long)b * E + e];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float s = ((red[0] + red[1]) + red[2]) + red[3];
+    int seg = 0;
+    while (seg + 1 < a.nseg && e >= a.offset[seg + 1]) ++seg;
+    float* p = a.dst[seg] + (e - a.offset[seg]);
+    *p = a.accumulate[seg] ? *p + s : s;
+  }
+}
+
+int row_finalize(eg_ctx* ctx, const float* partial, int nblocks, int E, const RowFinalizeArgs& args) {
+  if (E <= 0) return EG_OK;
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  hipLaunchKernelGGL(row_finalize_kernel, dim3((unsigned)E), dim3(NT), 0, ctx->stream, partial, nblocks, E, args);
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
 }  // namespace eg
 
 extern "C" {
