@@ -144,7 +144,7 @@ bool match_conv(const Kernel& k, ConvMatch& m) {
   return false;
 }
 
-enum class StepKind { Gemm, Conv, Seed, GenericA, GenericB, RowFused };
+enum class StepKind { Gemm, Conv, Seed, GenericA, GenericB, RowFused, SmallFused };
 
 struct Generic {
   GenericSource src;
@@ -194,6 +194,12 @@ struct PlanRowGroup {
   std::vector<int> red_tensors;  // reduction destinations, in segment order
 };
 
+// A run of small-tensor kernels (optimizer updates) fused into one single-block kernel.
+struct PlanSmallGroup {
+  SmallGroup g;
+  eg_kernel* handle = nullptr;
+};
+
 struct DevTensor {
   float* ptr = nullptr;
   long count = 0;
@@ -214,6 +220,7 @@ struct Plan {
   // HIP graph on its second execution and replayed afterwards: the small-batch targets are
   // launch-latency bound (19 kernels for the XOR step), a replay costs one submission.
   std::vector<std::unique_ptr<PlanRowGroup>> row_groups;
+  std::vector<std::unique_ptr<PlanSmallGroup>> small_groups;
   struct Captured {
     hipGraphExec_t exec = nullptr;
     std::string key;  // everything baked into the captured kernel arguments
@@ -642,6 +649,40 @@ int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<
     plan.row_groups.push_back(std::move(pg));
     p = q;
   }
+  // ---- small-kernel groups among what is left (encoded as -2 - index in group_of)
+  p = 0;
+  while (p < n) {
+    auto eligible = [&](int s) {
+      if (group_of[s] != -1 || ts.lowered[s].absorbed || ts.lowered[s].bias_tensor) return false;
+      return is_small_kernel(m->prog, t.all[t.live[s]], infos[t.live[s]], shapes);
+    };
+    if (!eligible(p)) {
+      ++p;
+      continue;
+    }
+    int q = p;
+    while (q < n && eligible(q) && !(q != p && q == t.first_update)) ++q;
+    if (q - p >= 2) {
+      std::unique_ptr<PlanSmallGroup> sg(new PlanSmallGroup());
+      for (int s = p; s < q; ++s) sg->g.kernel_index.push_back(t.live[s]);
+      char name[64];
+      snprintf(name, sizeof(name), "eg_small%d", m->kernel_serial++);
+      sg->g.name = name;
+      int rc = generate_small_group(m->prog, t.all, infos, shapes, sg->g);
+      if (rc) return rc;
+      rc = eg_kernel_compile(m->ctx, sg->g.name.c_str(), sg->g.source.c_str(), &sg->handle);
+      if (rc) {
+        std::string msg = eg_last_error();
+        set_error("%s\n--- generated source ---\n%s", msg.c_str(), sg->g.source.c_str());
+        return rc;
+      }
+      m->kernels.push_back(sg->handle);
+      const int gi = (int)plan.small_groups.size();
+      for (int s = p; s < q; ++s) group_of[s] = -2 - gi;
+      plan.small_groups.push_back(std::move(sg));
+    }
+    p = std::max(q, p + 1);
+  }
   return EG_OK;
 }
 
@@ -733,6 +774,18 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   plan.n_backward = -1;
   for (size_t p = 0; p < t.live.size(); ++p) {
     if ((int)p == t.first_update) plan.n_backward = (int)plan.launches.size();
+    if (group_of[p] <= -2) {
+      const int wt = t.all[t.live[p]].write.tensor;  // small groups always accumulate
+      if (m->prog.tensors[wt].kind == TK::Result && first_writer[wt] == (int)p) needs_zero.insert(wt);
+      if (p == 0 || group_of[p - 1] != group_of[p]) {
+        Launch L;
+        L.lowered = (int)p;
+        L.kind = StepKind::SmallFused;
+        L.row_group = -2 - group_of[p];
+        plan.launches.push_back(L);
+      }
+      continue;
+    }
     if (group_of[p] >= 0) {
       if (p == 0 || group_of[p - 1] != group_of[p]) {  // first kernel of the group: one launch for all
         Launch L;
@@ -906,6 +959,18 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
     case StepKind::Conv:
       return eg_conv2_nhwc(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, tensor_ptr(m, ts, plan, L.a_tensor),
                            tensor_ptr(m, ts, plan, L.b_tensor), tensor_ptr(m, ts, plan, L.c_tensor), L.accumulate);
+    case StepKind::SmallFused: {
+      PlanSmallGroup& sg = *plan.small_groups[L.row_group];
+      std::vector<float*> ptrs;
+      for (int tid : sg.g.ptr_args) ptrs.push_back(tensor_ptr(m, ts, plan, tid));
+      std::vector<void*> args;
+      for (auto& p : ptrs) args.push_back(&p);
+      float GS = m->grad_scale;
+      long EP = m->epoch;
+      args.push_back(&GS);
+      args.push_back(&EP);
+      return eg::kernel_launch_raw(sg.handle, 1, 1, 1, 256, args.data());
+    }
     case StepKind::RowFused: {
       PlanRowGroup& pg = *plan.row_groups[L.row_group];
       std::vector<float*> ptrs;

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <set>
 
 #include "../eg_internal.hpp"
 #include "codegen.hpp"
@@ -305,6 +306,116 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
     c += "  for (int e = threadIdx.x; e < " + E + "; e += 256)\n";
     c += "    partial[(long)blockIdx.x * " + E + " + e] = (red[e] + red[" + E + " + e]) + (red[2 * " + E + " + e] + red[3 * " +
          E + " + e]);\n";
+  }
+  g.source = sig + " {\n" + c + "}\n";
+  return EG_OK;
+}
+
+// ---------------------------------------------------------------------------------- small groups
+
+bool is_small_kernel(const Program& prog, const Kernel& k, const KernelInfo& info, const Shapes& shapes) {
+  if (!info.ok) return false;
+  if (!k.setup.empty() && !k.is_seed) return false;
+  std::vector<const Op*> ops;
+  for (auto& rd : k.reads) ops.push_back(&rd);
+  ops.push_back(&k.write);
+  for (const Op* op : ops) {
+    auto it = shapes.find(op->tensor);
+    if (it == shapes.end() || prodv(it->second) > SMALL_MAX) return false;
+  }
+  long work = 1;
+  for (size_t l = 0; l < k.loops.size(); ++l) work *= std::max(0L, info.bounds[l].second - info.bounds[l].first);
+  if (work > 65536) return false;
+  std::vector<int> indep, red;
+  bool scatter;
+  split_loops(k, indep, red, scatter);
+  return !scatter;
+}
+
+int generate_small_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
+                         const Shapes& shapes, SmallGroup& g) {
+  (void)prog;
+  std::set<int> written, touched;
+  for (int ki : g.kernel_index) {
+    written.insert(all[ki].write.tensor);
+    touched.insert(all[ki].write.tensor);
+    for (auto& rd : all[ki].reads) touched.insert(rd.tensor);
+  }
+  g.ptr_args.assign(touched.begin(), touched.end());
+  std::string sig = "extern \"C\" __global__ void __launch_bounds__(256) " + g.name + "(";
+  for (size_t i = 0; i < g.ptr_args.size(); ++i) {
+    const int t = g.ptr_args[i];
+    sig += (i ? ", " : "") + std::string(written.count(t) ? "float* t" : "const float* t") + std::to_string(t);
+  }
+  sig += std::string(g.ptr_args.empty() ? "" : ", ") + "float GS, long EP)";
+  std::string c;
+  const std::map<int, std::string> no_subst;
+  for (size_t gi = 0; gi < g.kernel_index.size(); ++gi) {
+    const Kernel& k = all[g.kernel_index[gi]];
+    const KernelInfo& info = infos[g.kernel_index[gi]];
+    const std::vector<Ty> ty = infer_types(k);
+    std::vector<int> indep, red;
+    bool scatter;
+    split_loops(k, indep, red, scatter);
+    long total = 1;
+    for (int l : indep) total *= std::max(0L, info.bounds[l].second - info.bounds[l].first);
+    auto element = [&](const Op& op) {
+      const std::vector<long>& shp = shapes.at(op.tensor);
+      std::string idx;
+      if (op.raw) {
+        idx = lin_text(op.dims[0], no_subst);
+      } else {
+        long stride = 1;
+        idx = "0L";
+        for (size_t d = shp.size(); d-- > 0;) {
+          idx += " + " + std::to_string(stride) + "L * " + lin_text(op.dims[d], no_subst);
+          stride *= shp[d];
+        }
+      }
+      return "t" + std::to_string(op.tensor) + "[" + idx + "]";
+    };
+    c += "  // kernel " + std::to_string(gi) + ": " + to_text(k).substr(0, 90) + "\n";
+    c += "  for (long idx = threadIdx.x; idx < " + std::to_string(total) + "L; idx += 256) {\n";
+    for (auto& s : k.setup) c += "    const long r" + std::to_string(s.res) + " = " + std::to_string(info.vals.at(s.res)) + "L;\n";
+    c += "    long rem = idx;\n";
+    for (size_t i = indep.size(); i-- > 0;) {
+      const int l = indep[i];
+      const long ext = info.bounds[l].second - info.bounds[l].first;
+      c += "    const long r" + std::to_string(k.loops[l].reg) + " = " + std::to_string(info.bounds[l].first) + "L + rem % " +
+           std::to_string(ext) + "L; rem /= " + std::to_string(ext) + "L;\n";
+    }
+    c += "    float acc = 0.0f;\n";
+    for (int l : red) {
+      const std::string r = "r" + std::to_string(k.loops[l].reg);
+      c += "    for (long " + r + " = " + std::to_string(info.bounds[l].first) + "L; " + r + " < " +
+           std::to_string(info.bounds[l].second) + "L; ++" + r + ") {\n";
+    }
+    for (auto& rd : k.reads) c += "      const float r" + std::to_string(rd.reg) + " = " + element(rd) + ";\n";
+    for (auto& ins : k.instrs) {
+      const Ty t = ty[ins.res];
+      const char* ctype = t == Ty::Scalar ? "float" : (t == Ty::Index ? "long" : "bool");
+      std::string special;
+      if (ins.kind == IK::Epoch) {
+        special = "EP";
+      } else if (ins.kind == IK::Shape || ins.kind == IK::Len || ins.kind == IK::ShapeLen) {
+        const std::vector<long>& shp = shapes.at(ins.tensor);
+        long v = 0;
+        if (ins.kind == IK::Len) v = prodv(shp);
+        else if (ins.kind == IK::ShapeLen) v = (long)shp.size();
+        else {
+          int d = ins.dim < 0 ? ins.dim + (int)shp.size() : ins.dim;
+          v = (d >= 0 && d < (int)shp.size()) ? shp[d] : 0;
+        }
+        special = std::to_string(v) + "L";
+      }
+      std::string e = instr_expression(ins, special, "r");
+      if (k.is_seed && ins.kind == IK::Scalar) e = "GS";
+      c += std::string("      const ") + ctype + " r" + std::to_string(ins.res) + " = " + e + ";\n";
+    }
+    c += "      acc = acc + r" + std::to_string(k.result) + ";\n";
+    for (size_t i = 0; i < red.size(); ++i) c += "    }\n";
+    const std::string w = element(k.write);
+    c += "    " + w + " = " + w + " + acc;\n  }\n  __syncthreads();\n";
   }
   g.source = sig + " {\n" + c + "}\n";
   return EG_OK;

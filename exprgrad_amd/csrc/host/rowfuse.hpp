@@ -66,5 +66,23 @@ struct RowGroup {
 int generate_row_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
                        const Shapes& shapes, RowGroup& group);
 
+// ---- small-kernel fusion -------------------------------------------------------------------------
+// Consecutive kernels that touch only small tensors (the optimizer updates: gradientDescent's
+// `param{it} ++= -grad{it} * rate` per parameter, adam's m / v / param chain, base.nim:37-53) run as
+// ONE single-block kernel: each kernel's independent iterations are strided over the 256 threads,
+// `__syncthreads()` separates the kernels.  Four launches of ~5 us each become one.
+bool is_small_kernel(const Program& prog, const Kernel& k, const KernelInfo& info, const Shapes& shapes);
+
+struct SmallGroup {
+  std::vector<int> kernel_index;  // indices into target.all, in execution order
+  std::string name, source;
+  std::vector<int> ptr_args;      // tensor ids in pointer-argument order
+};
+
+// Arguments of the generated kernel: (float* / const float* t<ids>..., float grad_scale, long epoch).
+// Every kernel accumulates into its destination (the caller zeroes first-written results).
+int generate_small_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
+                         const Shapes& shapes, SmallGroup& group);
+
 }  // namespace kd
 }  // namespace eg
