@@ -116,7 +116,7 @@ double tile_cost(const TileCfg& t, long M, long N, long k_tiles, int cus, int& s
   // K = batch); every slice keeps at least 8 k-tiles
   int splits = 1;
   if (tiles < slots && k_tiles >= 32) {
-    long want = (slots + tiles - 1) / tiles;
+    long want = slots / tiles;  // floor: one more slice would spill a few blocks into a second round
     long max_by_k = k_tiles / 8;
     splits = (int)(want < max_by_k ? want : max_by_k);
     if (splits < 1) splits = 1;

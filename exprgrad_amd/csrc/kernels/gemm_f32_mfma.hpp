@@ -515,7 +515,33 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
                                                                  const float* __restrict__ bias, long M, long N,
                                                                  long ldc, int splits, int accumulate) {
   const long total = M * N;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+  const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (long)gridDim.x * blockDim.x;
+  if ((N & 3) == 0 && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(partial) & 15) == 0) {
+    // 16 bytes per lane: a 4-wide group never straddles a row
+    for (long i4 = tid; i4 < (total >> 2); i4 += nthreads) {
+      const long i = i4 << 2, m = i / N, n = i % N;
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      for (int z = 0; z < splits; ++z) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (long)z * total + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += v[j];
+      }
+      f32x4* p = reinterpret_cast<f32x4*>(C + m * ldc + n);
+      if (accumulate) {
+        const f32x4 o = *p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = o[j] + s[j];
+      }
+      if (bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] += bias[n + j];
+      }
+      *p = s;
+    }
+    return;
+  }
+  for (long i = tid; i < total; i += nthreads) {
     const long m = i / N, n = i % N;
     float s = 0.f;
     for (int z = 0; z < splits; ++z) s += partial[(long)z * total + i];
