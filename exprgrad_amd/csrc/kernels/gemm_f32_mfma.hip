@@ -130,7 +130,15 @@ double tile_cost(const TileCfg& t, long M, long N, long k_tiles, int cus, int& s
   const long blocks = tiles * splits;
   const long rounds = (blocks + slots - 1) / slots;
   const double eff = t.bm * t.bn >= 256 * 256 ? 1.05 : (t.bm * t.bn >= 128 * 128 ? 1.0 : 0.9);
-  double cost = (double)rounds * t.blocks_per_cu * t.bm * t.bn * (double)per / eff;
+  // edge tiles skip their empty 32x32 sub-blocks; co-resident blocks of a CU share the matrix
+  // pipe, so with several blocks per CU the saved work shortens the round
+  double fill = 1.0;
+  if (t.blocks_per_cu > 1) {
+    const double m32 = (double)((M + 31) / 32 * 32), n32 = (double)((N + 31) / 32 * 32);
+    // only the matrix work shrinks (operand staging does not): credit half of it
+    fill = 0.5 + 0.5 * (m32 * n32) / ((double)tm * t.bm * (double)tn * t.bn);
+  }
+  double cost = (double)rounds * t.blocks_per_cu * t.bm * t.bn * (double)per * fill / eff;
   if (splits > 1) cost += (double)M * N * splits * 0.02;  // second pass traffic
   return cost;
 }
@@ -176,7 +184,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, bool conv, bool v
   // per-element serial walk over hundreds of slabs is latency bound, so the slabs are folded
   // with the tree column-sum instead of the serial second pass.
   const long total = M * N;
-  const bool tree_reduce = splits > 1 && total <= 4096 && args.ldc == N && args.bias == nullptr;
+  const bool tree_reduce = splits > 1 && (total <= 4096 || (splits >= 64 && total <= 65536)) && args.ldc == N && args.bias == nullptr;
   float* scratch = nullptr;
   if (splits > 1) {
     const size_t slab_floats = ((size_t)splits * total + 3) & ~(size_t)3;

@@ -209,6 +209,21 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
   const int a_off = (lane >> 5) * SA + wm0 + (lane & 31);
   const int b_off = (lane >> 5) * SB + wn0 + (lane & 31);
 
+  // Edge tiles: 32x32 sub-blocks of the wave tile that lie completely outside the problem are
+  // skipped (wave-uniform branch), so a ragged M or N costs matrix work at 32-row granularity
+  // instead of tile granularity (M = 784 with 128-row tiles: 800 rows of work, not 896).
+  unsigned live = 0xffffffffu;
+  if (E) {
+    const long m_w = __builtin_amdgcn_readfirstlane((int)min(a.M - m_blk - wm0, (long)BM));
+    const long n_w = __builtin_amdgcn_readfirstlane((int)min(a.N - n_blk - wn0, (long)BN));
+    live = 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+        if (i * 32 < m_w && j * 32 < n_w) live |= 1u << (i * NI + j);
+  }
+
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     const bool more = (ABL & 2) ? false : kt + 1 < nk;
@@ -244,7 +259,8 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i], bv[c][j], acc[i][j], 0, 0, 0);
+          if (!E || (live >> (i * NI + j) & 1))
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c][i], bv[c][j], acc[i][j], 0, 0, 0);
     }
     if (more && !(ABL & 8)) {
       la.store(lds + (cur ^ 1) * BUF, tid);
