@@ -14,6 +14,7 @@ One "step" is one pass of the hot path over one batch of synthetic input already
 when the timed region starts.  Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -30,6 +31,16 @@ DENSE = dict(n_in=784, n_hidden=512, n_out=10, rate=0.01, batch=65536)
 # forward 2 GEMMs, backward 3 (input gradient of the first layer is eliminated)
 DENSE_FLOPS_PER_SAMPLE = 2 * (2 * 784 * 512) + 3 * (2 * 512 * 10)
 XOR_BYTES_PER_SAMPLE = 72 * 4  # kernel-list traffic of the XOR train target
+
+
+def measured_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/summarize_profile.py: 2 x FETCH_SIZE + WRITE_SIZE); None when no profile covers the workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            return json.load(f)[key]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def parse():
@@ -65,13 +76,21 @@ class Timer:
         self.sync()
         starts = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+        gc.collect()
+        gc.disable()  # a generation-2 collection inside a 25 us step would dominate it
         t0 = time.perf_counter()
+        marks = []
         for i in range(steps):
             starts[i].record(self.stream)
             step()
             ends[i].record(self.stream)
+            marks.append(time.perf_counter())
         self.sync()
         elapsed = time.perf_counter() - t0
+        gc.enable()
+        if os.environ.get("EG_BENCH_DEBUG"):
+            host = [round((b - a) * 1e6) for a, b in zip([t0] + marks[:-1], marks)]
+            print(f"[bench] host us/step: {host} tail sync {round((t0 + elapsed - marks[-1]) * 1e6)}", file=sys.stderr)
         if self.world > 1:
             t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -154,7 +173,8 @@ def run_matmul(args, env):
                                "(MFMA + LDS tiled HIP kernel), A, B ~ U[0,1) resident in HBM",
                    "parallelism": "single" if env["world"] == 1 else f"{env['world']} independent replicas"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                     "traffic": measured_traffic("matmul4096") if n == 4096 else None,
                      "kernel": "eg::gemm::gemm_f32_mfma_kernel<256,256,16,128,64,NN,DMA>", "flops_per_launch": flops,
                      "kernel_ms_avg": round(ev_avg, 4), "kernel_ms_min": round(ev_min, 4)},
     }
@@ -201,7 +221,8 @@ def run_train(args, env):
                    "parallelism": f"dp{world}" if world > 1 else "single",
                    "grad_bucket_floats": model.grad_bucket("train")[1]},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                     "traffic": measured_traffic("train") if batch == DENSE["batch"] else None,
                      "kernel": "whole train step on one GPU (5 contractions dominate: gemm_f32_mfma_kernel)",
                      "flops_per_launch": step_flops, "kernel_ms_avg": round(ev_avg, 4),
                      "kernel_ms_min": round(ev_min, 4)},
@@ -226,8 +247,9 @@ def run_xor(args, env):
     return {"metric": "train steps/s XOR net (examples/xor_from_scratch) batch 65536", "value": round(steps / elapsed, 1),
             "unit": "steps/s", "samples_per_s": round(batch * steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "whole step (19 kernels; launch-latency bound)",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "traffic": measured_traffic("xor") if batch == 65536 else None,
+                         "kernel": "whole step (19 kernels fused into 4 launches replayed as HIP graphs; launch-latency bound)",
                          "bytes_per_launch": XOR_BYTES_PER_SAMPLE * batch, "kernel_ms_avg": round(ev_avg, 4)}}
 
 
@@ -247,8 +269,9 @@ def run_conv2(args, env):
     return {"metric": "GFLOP/s conv2 3x3 256x256x64->64 f32", "value": round(flops * steps / elapsed / 1e9, 1),
             "unit": "GFLOP/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                         "kernel": "gemm_f32_mfma_kernel<128,64,64,32,NT,conv>", "flops_per_launch": flops,
+                         "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": measured_traffic("conv2"),
+                         "kernel": "gemm_f32_mfma_kernel<64,64,32,32,32,NT,conv,DMA gather>", "flops_per_launch": flops,
                          "kernel_ms_avg": round(ev_avg, 4)}}
 
 
