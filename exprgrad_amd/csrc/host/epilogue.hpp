@@ -1,0 +1,37 @@
+// Epilogue fusion: an elementwise kernel that consumes the output of a contraction runs on the
+// accumulator registers of the matrix kernel instead of as its own launch.
+//
+// Role in the reference: fuseLoops (passes.nim:1929-2004) merges `dense` and the activation that
+// follows it into one loop nest on the CPU target; its GPU target launches every kernel separately
+// (llvmgen.nim:455-500).  Here, for `h = x * W + b; a{it} ++= f(h{it})` the contraction writes h
+// (only if something later reads it) and a from the same registers; for the backward pair
+// `ga = gz * W2^T; gh{it} ++= select(..h{it}.., ga{it}, ..)` ga never exists in memory.
+// The generated functor is spliced into gemm_block<..., Epi> (kernels/gemm_fused.hpp).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "kd.hpp"
+
+namespace eg {
+namespace kd {
+
+struct EpilogueSpec {
+  std::string struct_name;     // "EgEpi"
+  std::string struct_code;     // the functor definition
+  std::vector<int> operands;   // tensor ids bound to a.epi[i], in order
+};
+
+// Can `k` (with inferred bounds `info`) run as the epilogue of a contraction that produces
+// `c_tensor` = [M, N] (dense rows)?  Requirements: no reduction, every operand is addressed by the
+// same flat element index, that index enumerates 0 .. M*N-1 exactly once, the kernel reads
+// c_tensor and writes a different tensor it does not read.
+bool epilogue_capable(const Kernel& k, const KernelInfo& info, const Shapes& shapes, int c_tensor, long M, long N);
+
+// store_c: also write the contraction result itself (it is read again later).
+// accumulate: the consumer adds to its destination instead of overwriting it.
+int generate_epilogue(const Kernel& k, const KernelInfo& info, const Shapes& shapes, int c_tensor, bool store_c,
+                      bool accumulate, EpilogueSpec& out);
+
+}  // namespace kd
+}  // namespace eg

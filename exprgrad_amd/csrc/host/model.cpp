@@ -23,7 +23,9 @@
 #include <sstream>
 
 #include "../eg_internal.hpp"
+#include "../kernels/gemm_fused.hpp"
 #include "codegen.hpp"
+#include "epilogue.hpp"
 #include "kd.hpp"
 #include "rowfuse.hpp"
 
@@ -144,7 +146,7 @@ bool match_conv(const Kernel& k, ConvMatch& m) {
   return false;
 }
 
-enum class StepKind { Gemm, Conv, Seed, GenericA, GenericB, RowFused, SmallFused };
+enum class StepKind { Gemm, Conv, Seed, GenericA, GenericB, RowFused, SmallFused, GemmFused };
 
 struct Generic {
   GenericSource src;
@@ -183,6 +185,7 @@ struct Launch {
   long partial_rows = 0, partial_cols = 0;  // mode B second stage
   std::vector<int> epoch_slots;             // params refreshed from Model.epoch at every launch
   int row_group = -1;                       // RowFused: index into Plan::row_groups
+  int epilogue = -1;                        // GemmFused: index into Plan::epilogues
 };
 
 // A run of per-sample kernels fused into one generated kernel (rowfuse.hpp), built per plan.
@@ -198,6 +201,13 @@ struct PlanRowGroup {
 struct PlanSmallGroup {
   SmallGroup g;
   eg_kernel* handle = nullptr;
+};
+
+// A contraction whose elementwise consumer runs as its epilogue (epilogue.hpp), built per plan.
+struct PlanEpilogue {
+  EpilogueSpec spec;
+  Launch consumer;                          // the consumer as its own launch (split-K fallback)
+  std::map<std::string, eg_kernel*> built;  // by template variant (tile shape, alignment class)
 };
 
 struct DevTensor {
@@ -221,6 +231,7 @@ struct Plan {
   // launch-latency bound (19 kernels for the XOR step), a replay costs one submission.
   std::vector<std::unique_ptr<PlanRowGroup>> row_groups;
   std::vector<std::unique_ptr<PlanSmallGroup>> small_groups;
+  std::vector<std::unique_ptr<PlanEpilogue>> epilogues;
   struct Captured {
     hipGraphExec_t exec = nullptr;
     std::string key;  // everything baked into the captured kernel arguments
@@ -262,6 +273,7 @@ struct eg_model {
   long epoch = 0;
   int kernel_serial = 0;
   std::string plan_text;
+  std::string launch_text;
   std::vector<eg_kernel*> kernels;
 };
 
@@ -686,6 +698,88 @@ int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<
   return EG_OK;
 }
 
+// Contraction + elementwise consumer -> one launch (epilogue.hpp).  Only large outputs: the
+// fused kernel is built at run time from the matrix kernel's source (seconds), which pays when
+// the saved round trip through HBM is megabytes; small chains are launch bound and handled by
+// row fusion / graphs.  EG_EPILOGUE_MIN_ELEMS overrides the threshold, EG_NO_EPILOGUE=1 disables.
+int fuse_epilogues(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos) {
+  static const bool off = [] {
+    const char* e = getenv("EG_NO_EPILOGUE");
+    return e && e[0] && e[0] != '0';
+  }();
+  if (off) return EG_OK;
+  long min_elems = 1L << 20;
+  if (const char* e = getenv("EG_EPILOGUE_MIN_ELEMS")) min_elems = atol(e);
+  Target& t = *ts.target;
+  plan.epilogues.clear();
+  for (size_t i = 0; i + 1 < plan.launches.size(); ++i) {
+    Launch& G = plan.launches[i];
+    if (G.kind != StepKind::Gemm || G.accumulate) continue;
+    if (G.ldc != G.N || G.M * G.N < min_elems || G.M * G.N <= 0) continue;
+    // the consumer: the first later launch that reads the contraction result.  It need not be
+    // adjacent (derive emits the other gradient contraction of a layer in between), as long as
+    // moving it up to the contraction is legal.
+    size_t j = i + 1;
+    bool found = false;
+    for (; j < plan.launches.size() && j <= i + 4; ++j) {
+      const Launch& X = plan.launches[j];
+      if (X.kind == StepKind::RowFused || X.kind == StepKind::SmallFused || X.kind == StepKind::GemmFused) break;
+      const Kernel& kx = t.all[ts.lowered[X.lowered].all_index];
+      bool reads_c = false;
+      for (auto& rd : kx.reads)
+        if (rd.tensor == G.c_tensor) reads_c = true;
+      if (reads_c) {
+        found = X.kind == StepKind::GenericA;
+        break;
+      }
+    }
+    if (!found) continue;
+    if (plan.n_backward > (int)i && plan.n_backward <= (int)j) continue;  // straddles the backward / update boundary
+    Launch& E = plan.launches[j];
+    const Lowered& le = ts.lowered[E.lowered];
+    const Kernel& ke = t.all[le.all_index];
+    const KernelInfo& ie = infos[le.all_index];
+    if (!epilogue_capable(ke, ie, plan.shapes, G.c_tensor, G.M, G.N)) continue;
+    bool legal = true;
+    for (int p = plan.launches[i + 1].lowered; p < E.lowered && j > i + 1; ++p) {
+      const Kernel& kx = t.all[t.live[p]];
+      if (kx.write.tensor == ke.write.tensor) legal = false;
+      for (auto& rd : ke.reads)
+        if (rd.tensor == kx.write.tensor) legal = false;
+      for (auto& rd : kx.reads)
+        if (rd.tensor == ke.write.tensor) legal = false;
+    }
+    if (!legal) continue;
+    eg::gemm::FusedLaunch probe;
+    float* aligned = reinterpret_cast<float*>(uintptr_t(256));
+    if (eg::gemm::plan_fused(m->ctx, G.trans_a, G.trans_b, G.M, G.N, G.K, aligned, G.lda, aligned, G.ldb, aligned, G.ldc,
+                             nullptr, probe)) {
+      eg::clear_error();
+      continue;
+    }
+    if (probe.splits > 1) continue;
+    // is the contraction result itself needed by anything but the consumer?
+    bool store_c = G.c_tensor == t.output || ts.bucket_offset.count(G.c_tensor) != 0;
+    for (size_t p = (size_t)G.lowered + 1; p < t.live.size() && !store_c; ++p) {
+      if ((int)p == E.lowered) continue;
+      const Kernel& k = t.all[t.live[p]];
+      if (k.write.tensor == G.c_tensor && !ts.lowered[p].absorbed) store_c = true;
+      for (auto& rd : k.reads)
+        if (rd.tensor == G.c_tensor) store_c = true;
+    }
+    auto pe = std::make_unique<PlanEpilogue>();
+    int rc = generate_epilogue(ke, ie, plan.shapes, G.c_tensor, store_c, E.accumulate, pe->spec);
+    if (rc) return rc;
+    pe->consumer = E;
+    G.kind = StepKind::GemmFused;
+    G.epilogue = (int)plan.epilogues.size();
+    plan.epilogues.push_back(std::move(pe));
+    plan.launches.erase(plan.launches.begin() + j);
+    if (plan.n_backward > (int)j) plan.n_backward--;
+  }
+  return EG_OK;
+}
+
 int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   Target& t = *ts.target;
   Shapes& shapes = plan.shapes;
@@ -921,6 +1015,10 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   }
   if (plan.n_backward < 0) plan.n_backward = (int)plan.launches.size();
   if (t.output && m->prog.tensors[t.output].kind == TK::Result && !first_writer.count(t.output)) needs_zero.insert(t.output);
+  {
+    int rc = fuse_epilogues(m, ts, plan, infos);
+    if (rc) return rc;
+  }
 
   // arena layout: tensors that need zeroing first (one memset), then the rest
   plan.arena_offset.clear();
@@ -956,6 +1054,40 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       return eg_sgemm(ctx, L.trans_a, L.trans_b, L.M, L.N, L.K, tensor_ptr(m, ts, plan, L.a_tensor), L.lda,
                       tensor_ptr(m, ts, plan, L.b_tensor), L.ldb, tensor_ptr(m, ts, plan, L.c_tensor), L.ldc,
                       L.accumulate, L.bias_tensor ? tensor_ptr(m, ts, plan, L.bias_tensor) : nullptr);
+    case StepKind::GemmFused: {
+      PlanEpilogue& pe = *plan.epilogues[L.epilogue];
+      const float* bias = L.bias_tensor ? tensor_ptr(m, ts, plan, L.bias_tensor) : nullptr;
+      eg::gemm::FusedLaunch f;
+      int rc = eg::gemm::plan_fused(ctx, L.trans_a, L.trans_b, L.M, L.N, L.K, tensor_ptr(m, ts, plan, L.a_tensor), L.lda,
+                                    tensor_ptr(m, ts, plan, L.b_tensor), L.ldb, tensor_ptr(m, ts, plan, L.c_tensor), L.ldc,
+                                    bias, f);
+      if (rc) return rc;
+      if (f.splits > 1) {  // cannot happen for the shapes the plan was made for; stay correct anyway
+        rc = eg_sgemm(ctx, L.trans_a, L.trans_b, L.M, L.N, L.K, tensor_ptr(m, ts, plan, L.a_tensor), L.lda,
+                      tensor_ptr(m, ts, plan, L.b_tensor), L.ldb, tensor_ptr(m, ts, plan, L.c_tensor), L.ldc, 0, bias);
+        if (rc) return rc;
+        return run_launch(m, ts, plan, pe.consumer);
+      }
+      const std::string variant = eg::gemm::fused_variant(f);
+      eg_kernel*& handle = pe.built[variant];
+      if (!handle) {
+        const std::string name = "eg_gemm_epi" + std::to_string(m->kernel_serial++);
+        const std::string src = eg::gemm::fused_source(f, pe.spec.struct_code, pe.spec.struct_name, name);
+        rc = eg_kernel_compile(ctx, name.c_str(), src.c_str(), &handle);
+        if (rc) {
+          std::string msg = eg_last_error();
+          set_error("%s\n--- generated epilogue (%s) ---\n%s", msg.c_str(), variant.c_str(), pe.spec.struct_code.c_str());
+          handle = nullptr;
+          return rc;
+        }
+        m->kernels.push_back(handle);
+      }
+      void* operands[eg::gemm::MAX_EPILOGUE_OPERANDS] = {};
+      for (size_t o = 0; o < pe.spec.operands.size(); ++o) operands[o] = tensor_ptr(m, ts, plan, pe.spec.operands[o]);
+      eg::gemm::set_epilogue_operands(f, operands, (int)pe.spec.operands.size(), m->grad_scale, m->epoch);
+      void* args[] = {f.args};
+      return eg::kernel_launch_raw(handle, f.grid, 1, 1, (unsigned)f.nt, args);
+    }
     case StepKind::Conv:
       return eg_conv2_nhwc(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, tensor_ptr(m, ts, plan, L.a_tensor),
                            tensor_ptr(m, ts, plan, L.b_tensor), tensor_ptr(m, ts, plan, L.c_tensor), L.accumulate);
@@ -1254,6 +1386,50 @@ int eg_model_free(eg_model* m) {
 }
 
 const char* eg_model_plan_text(eg_model* m) { return m ? m->plan_text.c_str() : ""; }
+
+const char* eg_model_launch_text(eg_model* m, const char* target) {
+  if (!m || !target) return "";
+  auto it = m->targets.find(target);
+  if (it == m->targets.end() || !it->second.last) return "";
+  TargetState& ts = it->second;
+  Plan& plan = *ts.last;
+  std::ostringstream os;
+  for (size_t i = 0; i < plan.launches.size(); ++i) {
+    const Launch& L = plan.launches[i];
+    if ((int)i == plan.n_backward) os << "-- update --\n";
+    os << "[" << i << "] ";
+    switch (L.kind) {
+      case StepKind::Seed: os << "seed-fill t" << L.c_tensor; break;
+      case StepKind::Gemm:
+      case StepKind::GemmFused:
+        os << (L.kind == StepKind::GemmFused ? "gemm+epilogue " : "gemm ") << (L.trans_a ? "T" : "N") << (L.trans_b ? "T" : "N")
+           << " " << L.M << "x" << L.N << "x" << L.K << " -> t" << L.c_tensor << (L.bias_tensor ? " +bias" : "")
+           << (L.accumulate ? " accumulate" : "");
+        if (L.kind == StepKind::GemmFused) {
+          const PlanEpilogue& pe = *plan.epilogues[L.epilogue];
+          os << " | consumer kernel " << pe.consumer.lowered << " operands";
+          for (int t : pe.spec.operands) os << " t" << t;
+        }
+        break;
+      case StepKind::Conv: os << "conv2 -> t" << L.c_tensor; break;
+      case StepKind::GenericA: os << "generated(map) kernel " << L.lowered << " -> t" << L.c_tensor; break;
+      case StepKind::GenericB: os << "generated(split-reduce) kernel " << L.lowered << " -> t" << L.c_tensor; break;
+      case StepKind::RowFused: {
+        const PlanRowGroup& pg = *plan.row_groups[L.row_group];
+        os << "row-fused " << pg.g.kernel_index.size() << " kernels";
+        break;
+      }
+      case StepKind::SmallFused: {
+        const PlanSmallGroup& sg = *plan.small_groups[L.row_group];
+        os << "small-fused " << sg.g.kernel_index.size() << " kernels";
+        break;
+      }
+    }
+    os << "\n";
+  }
+  m->launch_text = os.str();
+  return m->launch_text.c_str();
+}
 
 int eg_model_kernel_count(eg_model* m, const char* target) {
   if (!m || !target) return -1;

@@ -11,6 +11,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 
 #include "../eg_internal.hpp"
 
@@ -28,7 +30,8 @@ template <int BM, int BN, int WM, int WN, int MINB>
 int launch_config(eg_ctx* ctx, bool a_kc, bool b_kc, const GemmArgs& args, int splits, bool vec, bool edge,
                   bool conv) {
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
-  dim3 grid((unsigned)(args.tiles_m * args.tiles_n), 1, (unsigned)splits);
+  const long rows_m = args.edge_splits > 0 ? args.tiles_m - 1 : args.tiles_m;
+  dim3 grid((unsigned)(rows_m * args.tiles_n * splits + (long)args.tiles_n * args.edge_splits), 1, 1);
   dim3 block(NT);
   hipStream_t s = ctx->stream;
   // 16-byte aligned operands: interior tiles run the LDS-DMA loop (gemm_f32_mfma.hpp)
@@ -105,6 +108,15 @@ int run_conv(eg_ctx* ctx, GemmArgs args, bool vec) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Time of a ragged last-row tile relative to a full one per k-tile (it skips its empty 32x32
+// sub-blocks and loads only its valid rows, but stages the whole B tile).  Calibrated on
+// 784 x 512 x 65536 (TN): 128-row tiles 0.55, 256-row tiles 0.4.
+double ragged_tile_share(int bm, long m_rest) {
+  const double live = (double)((m_rest + 31) / 32 * 32) / bm;
+  const double floor = bm >= 256 ? 0.4 : 0.55;
+  return live > floor ? live : floor;
+}
+
 // Relative cost of running the problem with a given tile: (block rounds on the chip) x (work of
 // the co-resident blocks of one CU), slightly favouring the larger tile whose measured
 // efficiency is higher (tools/gemm_tune.hip: 135 vs 128 TFLOP/s at 4096^3).
@@ -129,7 +141,10 @@ double tile_cost(const TileCfg& t, long M, long N, long k_tiles, int cus, int& s
   splits_out = splits;
   const long blocks = tiles * splits;
   const long rounds = (blocks + slots - 1) / slots;
-  const double eff = t.bm * t.bn >= 256 * 256 ? 1.05 : (t.bm * t.bn >= 128 * 128 ? 1.0 : 0.9);
+  // short K: the launch is bound by writing the output, which wants many waves in flight rather
+  // than the 8-wave 256x256 block (one per CU)
+  const double big = k_tiles >= 8 ? 1.05 : 0.8;
+  const double eff = t.bm * t.bn >= 256 * 256 ? big : (t.bm * t.bn >= 128 * 128 ? 1.0 : 0.9);
   // edge tiles skip their empty 32x32 sub-blocks; co-resident blocks of a CU share the matrix
   // pipe, so with several blocks per CU the saved work shortens the round
   double fill = 1.0;
@@ -139,13 +154,19 @@ double tile_cost(const TileCfg& t, long M, long N, long k_tiles, int cus, int& s
     fill = 0.5 + 0.5 * (m32 * n32) / ((double)tm * t.bm * (double)tn * t.bn);
   }
   double cost = (double)rounds * t.blocks_per_cu * t.bm * t.bn * (double)per * fill / eff;
+  // split-K with a ragged last tile row: run_gemm cuts those tiles into fewer slices, the k-slices
+  // of the full tiles shrink accordingly
+  const long m_rest = M % t.bm;
+  if (splits > 1 && rounds == 1 && m_rest != 0 && m_rest * 2 <= t.bm && tm >= 2) {
+    const double share = ((double)(tm - 1) * tn + tn * ragged_tile_share(t.bm, m_rest)) / (double)tiles;
+    cost = cost / fill * share;
+  }
   if (splits > 1) cost += (double)M * N * splits * 0.02;  // second pass traffic
   return cost;
 }
 
-// Shared host-side planning: tile shape, split-K, vector/edge variant, launch, second pass.
-int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, bool conv, bool vec_ok) {
-  const long M = args.M, N = args.N, K = args.K;
+// Tile shape and split count for an M x N x K contraction on this device.
+void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& splits) {
   const long k_tiles = (K + BK - 1) / BK;
   // Candidates: 256x256 (16 waves, 1 block/CU) for large outputs, 128x128 (4 waves, 4 blocks/CU),
   // and narrow tiles for bias-sized N (the N = 1/4/10 layers of the XOR and dense nets, F = 64
@@ -171,23 +192,62 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, bool conv, bool v
       best_splits = sp;
     }
   }
-  const int BM = cfgs[best].bm, BN = cfgs[best].bn;
-  const int splits = best_splits;
+  bm = cfgs[best].bm;
+  bn = cfgs[best].bn;
+  splits = best_splits;
+}
+
+// Shared host-side planning: tile shape, split-K, vector/edge variant, launch, second pass.
+int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, bool conv, bool vec_ok) {
+  const long M = args.M, N = args.N, K = args.K;
+  const long k_tiles = (K + BK - 1) / BK;
+  int BM, BN, splits;
+  choose_tile(ctx, M, N, K, BM, BN, splits);
   args.tiles_m = (int)((M + BM - 1) / BM);
   args.tiles_n = (int)((N + BN - 1) / BN);
   args.partial = nullptr;
   long tiles_per_split = (k_tiles + splits - 1) / splits;
   if (tiles_per_split < 1) tiles_per_split = 1;
   args.k_per_split = tiles_per_split * BK;
+  args.splits = splits;
 
   // Tiny outputs split many ways (the XOR net's [2,4] and [4,1] weight gradients): a
   // per-element serial walk over hundreds of slabs is latency bound, so the slabs are folded
   // with the tree column-sum instead of the serial second pass.
   const long total = M * N;
   const bool tree_reduce = splits > 1 && (total <= 4096 || (splits >= 64 && total <= 65536)) && args.ldc == N && args.bias == nullptr;
+  // Ragged last tile row (M = 784 with 128-row tiles: 16 rows): its blocks run a fraction of the
+  // matrix work but, cut like the others, would occupy their CU slots just as long.  Give them
+  // fewer, longer slices so every block carries about the same work; the freed slots go to the
+  // full tiles.  Needs the LDS-DMA loop (cheap ragged tiles) and the serial second pass.
+  long edge_row = M;
+  int edge_splits = 0;
+  const long m_rest = M % BM;
+  if (splits > 1 && !tree_reduce && !conv && vec_ok && m_rest != 0 && m_rest * 2 <= BM && args.tiles_m >= 2 &&
+      getenv("EG_GEMM_EVEN_SPLITS") == nullptr) {
+    const double frac = ragged_tile_share(BM, m_rest);
+    const long full_tiles = (long)(args.tiles_m - 1) * args.tiles_n;
+    const long slots = (long)ctx->compute_units * (BM * BN >= 256 * 256 ? 1 : (BM == 256 ? 2 : 4));
+    long s_full = (long)((double)slots / ((double)full_tiles + args.tiles_n * frac));
+    const long max_by_k = k_tiles / 8;
+    if (s_full > max_by_k) s_full = max_by_k;
+    long s_edge = (long)(s_full * frac + 0.5);
+    if (s_full >= 2 && s_edge >= 1 && s_edge < s_full) {
+      long per_full = (k_tiles + s_full - 1) / s_full;
+      s_full = (k_tiles + per_full - 1) / per_full;
+      long per_edge = (k_tiles + s_edge - 1) / s_edge;
+      s_edge = (k_tiles + per_edge - 1) / per_edge;
+      args.k_per_split = per_full * BK;
+      args.splits = (int)s_full;
+      args.edge_splits = edge_splits = (int)s_edge;
+      args.k_per_split_edge = per_edge * BK;
+      edge_row = (long)(args.tiles_m - 1) * BM;
+    }
+  }
+  const int launch_splits = args.edge_splits > 0 ? args.splits : splits;
   float* scratch = nullptr;
   if (splits > 1) {
-    const size_t slab_floats = ((size_t)splits * total + 3) & ~(size_t)3;
+    const size_t slab_floats = ((size_t)launch_splits * total + 3) & ~(size_t)3;
     const size_t scratch_floats = tree_reduce ? (size_t)eg::colsum_scratch_floats(ctx, splits, total) : 0;
     int rc = eg::ensure_workspace(ctx, (slab_floats + scratch_floats) * sizeof(float));
     if (rc) return rc;
@@ -197,19 +257,20 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, bool conv, bool v
 
   const bool vec = vec_ok;
   const bool edge = conv || !(vec && M % BM == 0 && N % BN == 0 && K % BK == 0 && K > 0);
+
   int rc;
   if (BN == 32)
-    rc = launch_config<128, 32, 32, 32, 4>(ctx, a_kc, b_kc, args, splits, vec, edge, conv);
+    rc = launch_config<128, 32, 32, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else if (BN == 64 && BM == 256)
-    rc = launch_config<256, 64, 64, 32, 2>(ctx, a_kc, b_kc, args, splits, vec, edge, conv);
+    rc = launch_config<256, 64, 64, 32, 2>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else if (BN == 64 && BM == 64)
-    rc = launch_config<64, 64, 32, 32, 4>(ctx, a_kc, b_kc, args, splits, vec, edge, conv);
+    rc = launch_config<64, 64, 32, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else if (BN == 64)
-    rc = launch_config<128, 64, 64, 32, 4>(ctx, a_kc, b_kc, args, splits, vec, edge, conv);
+    rc = launch_config<128, 64, 64, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else if (BN == 128)
-    rc = launch_config<128, 128, 64, 64, 4>(ctx, a_kc, b_kc, args, splits, vec, edge, conv);
+    rc = launch_config<128, 128, 64, 64, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else
-    rc = launch_config<256, 256, 128, 64, 1>(ctx, a_kc, b_kc, args, splits, vec, edge, conv);
+    rc = launch_config<256, 256, 128, 64, 1>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   if (rc) return rc;
 
   if (splits > 1) {
@@ -217,7 +278,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, bool conv, bool v
     long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, args.partial,
-                       args.C, args.bias, M, N, args.ldc, splits, args.accumulate);
+                       args.C, args.bias, M, N, args.ldc, launch_splits, args.accumulate, edge_row, edge_splits);
     EG_HIP_CHECK(hipGetLastError());
   }
   return EG_OK;
@@ -299,3 +360,99 @@ extern "C" int eg_conv2_nhwc(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64
   if (rc >= 0) return rc;
   return run_gemm(ctx, true, true, args, /*conv=*/true, vec);
 }
+
+// ---- contraction with a generated epilogue (gemm_fused.hpp) ----------------------------------------
+#include "gemm_fused.hpp"
+
+namespace {
+const char* const kGemmHeaderText =
+#include "gemm_src.inc"
+    ;
+}
+
+namespace eg {
+namespace gemm {
+
+static_assert(sizeof(GemmArgs) <= sizeof(FusedLaunch::args), "FusedLaunch::args too small");
+static_assert(MAX_EPILOGUE_OPERANDS == sizeof(GemmArgs::epi) / sizeof(void*), "epilogue operand count");
+
+int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, const float* A, long lda, const float* B,
+               long ldb, float* C, long ldc, const float* bias, FusedLaunch& out) {
+  EG_REQUIRE(ctx && M > 0 && N > 0 && K >= 0 && C, EG_ERR_INVALID, "plan_fused: bad problem");
+  const bool a_kc = !trans_a, b_kc = trans_b != 0;
+  int bm, bn, splits;
+  choose_tile(ctx, M, N, K, bm, bn, splits);
+  out = FusedLaunch();
+  out.bm = bm;
+  out.bn = bn;
+  out.bk = BK;
+  out.splits = splits;
+  if (bn == 32) { out.wm = 32; out.wn = 32; out.minb = 4; }
+  else if (bn == 64 && bm == 256) { out.wm = 64; out.wn = 32; out.minb = 2; }
+  else if (bn == 64 && bm == 64) { out.wm = 32; out.wn = 32; out.minb = 4; }
+  else if (bn == 64) { out.wm = 64; out.wn = 32; out.minb = 4; }
+  else if (bn == 128) { out.wm = 64; out.wn = 64; out.minb = 4; }
+  else { out.wm = 128; out.wn = 64; out.minb = 1; }
+  out.nt = (bm / out.wm) * (bn / out.wn) * 64;
+  out.a_kc = a_kc;
+  out.b_kc = b_kc;
+  const long a_contig = a_kc ? K : M, b_contig = b_kc ? K : N;
+  const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (a_contig % 4 == 0) && (b_contig % 4 == 0) && aligned16(A) &&
+                   aligned16(B);
+  out.edge = !(vec && M % bm == 0 && N % bn == 0 && K % BK == 0 && K > 0);
+  out.vec = (!out.edge || vec) ? 4 : 1;
+  out.dma = out.vec == 4;
+  GemmArgs args = {};
+  args.A = A;
+  args.B = B;
+  args.C = C;
+  args.bias = bias;
+  args.M = M;
+  args.N = N;
+  args.K = K;
+  args.lda = lda;
+  args.ldb = ldb;
+  args.ldc = ldc;
+  args.accumulate = 0;
+  args.tiles_m = (int)((M + bm - 1) / bm);
+  args.tiles_n = (int)((N + bn - 1) / bn);
+  args.partial = nullptr;
+  args.k_per_split = ((K + BK - 1) / BK) * BK;
+  if (args.k_per_split < BK) args.k_per_split = BK;
+  out.grid = (unsigned)(args.tiles_m * args.tiles_n);
+  memcpy(out.args, &args, sizeof(args));
+  out.args_size = sizeof(args);
+  return EG_OK;
+}
+
+void set_epilogue_operands(FusedLaunch& f, void* const* ptrs, int count, float grad_scale, long epoch) {
+  GemmArgs* a = reinterpret_cast<GemmArgs*>(f.args);
+  for (int i = 0; i < MAX_EPILOGUE_OPERANDS; ++i) a->epi[i] = i < count ? ptrs[i] : nullptr;
+  a->epi_gs = grad_scale;
+  a->epi_ep = epoch;
+}
+
+std::string fused_variant(const FusedLaunch& f) {
+  char buf[96];
+  snprintf(buf, sizeof(buf), "%dx%dx%d_%dx%d_%d_%c%c_v%d%s%s", f.bm, f.bn, f.bk, f.wm, f.wn, f.minb, f.a_kc ? 'k' : 'm',
+           f.b_kc ? 'k' : 'n', f.vec, f.edge ? "_edge" : "", f.dma ? "_dma" : "");
+  return buf;
+}
+
+std::string fused_source(const FusedLaunch& f, const std::string& epi_struct, const std::string& epi_name,
+                         const std::string& kernel_name) {
+  std::string s = kGemmHeaderText;
+  s += "\n" + epi_struct + "\n";
+  char buf[512];
+  const int waves = f.nt / 64;
+  snprintf(buf, sizeof(buf),
+           "extern \"C\" __global__ __launch_bounds__(%d, %d) void %s(eg::gemm::GemmArgs a) {\n"
+           "  eg::gemm::gemm_block<%d, %d, %d, %d, %d, %s, %s, %d, %s, false, 0, %s, %s>(a);\n}\n",
+           f.nt, (f.minb * waves + 3) / 4, kernel_name.c_str(), f.bm, f.bn, f.bk, f.wm, f.wn, f.a_kc ? "true" : "false",
+           f.b_kc ? "true" : "false", f.vec, f.edge ? "true" : "false", f.dma ? "true" : "false", epi_name.c_str());
+  s += buf;
+  return s;
+}
+
+}  // namespace gemm
+}  // namespace eg

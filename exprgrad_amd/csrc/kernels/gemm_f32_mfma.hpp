@@ -20,8 +20,10 @@
 //     remapped to give each XCD's private L2 a contiguous, squarish patch of output tiles.
 //   * split-K (grid.z) with a deterministic second pass for contractions whose output is small
 //     and whose K is the batch (the weight gradients): no float atomics, fixed summation order.
+#ifndef __HIPCC_RTC__  // hiprtc (kernels/gemm_fused.hpp) compiles this text as the main file, runtime built in
 #pragma once
 #include <hip/hip_runtime.h>
+#endif
 
 namespace eg {
 namespace gemm {
@@ -40,8 +42,32 @@ struct GemmArgs {
   long k_per_split;  // multiple of BK
   int tiles_m, tiles_n;
   int accumulate;
+  int splits;  // k-splits (grid = tiles_m * tiles_n * splits blocks); 0 / 1 = none
+  // Ragged last tile row with split-K: its tiles hold little matrix work (empty 32x32 sub-blocks
+  // are skipped), so they are cut into fewer, longer k-slices to finish with the full tiles.
+  // edge_splits > 0: tiles of row tiles_m - 1 use edge_splits slices of k_per_split_edge.
+  int edge_splits;
+  long k_per_split_edge;
   // Implicit-GEMM convolution (A gathered from an NHWC image): m = (n, y, x), k = (dy, dx, c).
   long cH, cW, cC, cFW, cHo, cWo;
+  // Operands of a generated epilogue (fused elementwise consumer, host/epilogue.cpp): tensors of
+  // the same [M, N] shape as C, the seed-gradient scale and the epoch.
+  void* epi[6];
+  float epi_gs;
+  long epi_ep;
+};
+
+// Epilogue functor of the library kernels: plain store.  A generated epilogue (ACTIVE = true)
+// receives every finished element v = acc + bias of a non-accumulating, non-split launch together
+// with its flat index m * ldc + n and is responsible for all stores, including C if it is needed.
+// The work is split in two so the kernel can issue the loads of all 16 elements of an accumulator
+// block before the first dependent store: prefetch() reads the NX other operands of the element,
+// apply() computes and stores.
+struct EpiNone {
+  static constexpr bool ACTIVE = false;
+  static constexpr int NX = 1;
+  __device__ __forceinline__ static void prefetch(const GemmArgs&, long, float (&)[1]) {}
+  __device__ __forceinline__ static void apply(const GemmArgs&, long, float, const float (&)[1]) {}
 };
 
 // Row stride (in floats) of an LDS operand tile [BK][stride].
@@ -292,7 +318,10 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
 // the slot permutation c ^ ((r >> 1) & 7), with the same conflict-free property.
 // CONV: the k-contiguous A operand is the virtual im2col matrix, its rows gathered from the NHWC
 // image (requires C % BK == 0 so that a k-tile lies inside one filter tap).
-template <int BMN, int BK, int NT, bool KC, bool CONV>
+// CLAMP (ragged M / N tiles): rows past the end of the operand re-read its last row (k-contiguous)
+// or its last 16-byte column chunk (m|n-contiguous) — always valid memory; what they produce lands
+// in accumulator rows / columns the epilogue never stores.
+template <int BMN, int BK, int NT, bool KC, bool CONV, bool CLAMP = false>
 struct DmaLoader {
   static constexpr int INSTRS = BK * BMN / 256;  // 1 KiB wave instructions per tile
   static constexpr int WAVES = NT / 64;
@@ -319,7 +348,7 @@ struct DmaLoader {
 
   // issue this wave's share of the tile whose origin is (mn0, k0) into `tile` (LDS, lane-linear)
   __device__ __forceinline__ void issue(const GemmArgs& a, const float* __restrict__ base, long ld, long mn0, long k0,
-                                        float* tile, int wave, int lane) const {
+                                        float* tile, int wave, int lane, long limit = 0) const {
     long tap_off = 0;
     if (CONV) {  // block-uniform: scalar work
       const unsigned C = (unsigned)a.cC, FW = (unsigned)a.cFW;
@@ -338,11 +367,11 @@ struct DmaLoader {
         if (CONV)
           src = base + row_off[t] + tap_off + c * 4;
         else
-          src = base + (mn0 + r) * ld + k0 + c * 4;
+          src = base + (CLAMP ? min(mn0 + r, limit - 1) : mn0 + r) * ld + k0 + c * 4;
       } else {
         constexpr int CPR = BMN / 4;
         const int k = q / CPR, col = (q % CPR) * 4;
-        src = base + (k0 + k) * ld + mn0 + col;
+        src = base + (k0 + k) * ld + (CLAMP ? min(mn0 + col, limit - 4) : mn0 + col);
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(tile + instr * 256), 16, 0, 0);
@@ -350,7 +379,7 @@ struct DmaLoader {
   }
 };
 
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool CONV>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool CONV, bool CL = false>
 __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32],
                                                   long m_blk, long n_blk, long k_begin, int nk, int tid, int wm0,
                                                   int wn0) {
@@ -358,18 +387,31 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int BUF = BK * (BM + BN);
-  using DmaA = DmaLoader<BM, BK, NT, A_KC, CONV>;
-  using DmaB = DmaLoader<BN, BK, NT, B_KC, false>;
+  using DmaA = DmaLoader<BM, BK, NT, A_KC, CONV, CL>;
+  using DmaB = DmaLoader<BN, BK, NT, B_KC, false, CL>;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, hi = lane >> 5;
+
+  // ragged tile: 32x32 sub-blocks of the wave tile that lie outside the problem are skipped
+  unsigned live = 0xffffffffu;
+  if (CL) {
+    const int m_w = __builtin_amdgcn_readfirstlane((int)min(a.M - m_blk - wm0, (long)BM));
+    const int n_w = __builtin_amdgcn_readfirstlane((int)min(a.N - n_blk - wn0, (long)BN));
+    live = 0;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        if (mi * 32 < m_w && ni * 32 < n_w) live |= 1u << (mi * NI + ni);
+  }
 
   DmaA da;
   DmaB db;
   da.init(a, m_blk, wave, lane);
   db.init(a, n_blk, wave, lane);
   if (nk > 0) {
-    da.issue(a, a.A, a.lda, m_blk, k_begin, lds, wave, lane);
-    db.issue(a, a.B, a.ldb, n_blk, k_begin, lds + BK * BM, wave, lane);
+    da.issue(a, a.A, a.lda, m_blk, k_begin, lds, wave, lane, a.M);
+    db.issue(a, a.B, a.ldb, n_blk, k_begin, lds + BK * BM, wave, lane, a.N);
   }
   __syncthreads();  // hipcc drains vmcnt before the barrier while an LDS-DMA is in flight
 
@@ -378,8 +420,8 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
     if (kt + 1 < nk) {
       const long k0 = k_begin + (long)(kt + 1) * BK;
       float* nxt = lds + (cur ^ 1) * BUF;
-      da.issue(a, a.A, a.lda, m_blk, k0, nxt, wave, lane);
-      db.issue(a, a.B, a.ldb, n_blk, k0, nxt + BK * BM, wave, lane);
+      da.issue(a, a.A, a.lda, m_blk, k0, nxt, wave, lane, a.M);
+      db.issue(a, a.B, a.ldb, n_blk, k0, nxt + BK * BM, wave, lane, a.N);
     }
     const float* As = lds + cur * BUF;
     const float* Bs = As + BK * BM;
@@ -422,7 +464,8 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+            if (!CL || (live >> (mi * NI + ni) & 1))
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -432,10 +475,9 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
 // EDGE kernels still run their interior tiles on the unpredicated loop.
 // DMA: interior tiles use the LDS-DMA loop (requires VEC == 4, BK in {16, 32}; with CONV the host
 // checks C % BK == 0).
-template <int BM, int BN, int BK, int WM, int WN, int MINB, bool A_KC, bool B_KC, int VEC, bool EDGE, bool CONV,
-          int ABL = 0, bool DMA = false>
-__global__ __launch_bounds__((Geometry<BM, BN, WM, WN>::NT), (MINB * Geometry<BM, BN, WM, WN>::WAVES + 3) / 4) void
-gemm_f32_mfma_kernel(GemmArgs a) {
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int VEC, bool EDGE, bool CONV, int ABL, bool DMA,
+          class Epi>
+__device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   constexpr int WAVES_N = BN / WN;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int SA = LdsStride<BM, BK, A_KC>::value, SB = LdsStride<BN, BK, B_KC>::value;
@@ -450,19 +492,39 @@ gemm_f32_mfma_kernel(GemmArgs a) {
 
   // ---- tile coordinates: XCD-contiguous ids, then 8-row groups so co-resident tiles share
   //      A row-panels and B column-panels inside one L2.
-  const int nwg = a.tiles_m * a.tiles_n;
-  const int wgid = xcd_remap(blockIdx.x, nwg);
-  constexpr int GROUP = 8;
-  const int per_group = GROUP * a.tiles_n;
-  const int group = wgid / per_group;
-  const int first_m = group * GROUP;
-  const int gsize = min(a.tiles_m - first_m, GROUP);
-  const int in_group = wgid % per_group;
-  const long m_blk = (long)(first_m + in_group % gsize) * BM;
-  const long n_blk = (long)(in_group / gsize) * BN;
+  // Work items are (k-split, tile) pairs, split-major.  xcd_remap hands every XCD a contiguous
+  // range of them, so the tiles of one k-split — which all stream the same rows of A and B — run
+  // on one XCD at the same time and share its L2 (with the splits spread round-robin over the
+  // XCDs a weight-gradient contraction fetched its operands 4.9x: 1.65 GB for 339 MB).
+  const int rows_m = a.edge_splits > 0 ? a.tiles_m - 1 : a.tiles_m;  // tile rows cut into a.splits slices
+  const int nwg = rows_m * a.tiles_n;
+  const int nsplit = a.splits > 1 ? a.splits : 1;
+  const int nfull = nwg * nsplit;
+  const int work = xcd_remap(blockIdx.x, nfull + a.tiles_n * a.edge_splits);
+  int split;
+  long m_blk, n_blk, k_slice;
+  if (work < nfull) {
+    split = work / nwg;
+    const int wgid = work - split * nwg;
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * a.tiles_n;
+    const int group = wgid / per_group;
+    const int first_m = group * GROUP;
+    const int gsize = min(rows_m - first_m, GROUP);
+    const int in_group = wgid % per_group;
+    m_blk = (long)(first_m + in_group % gsize) * BM;
+    n_blk = (long)(in_group / gsize) * BN;
+    k_slice = a.k_per_split;
+  } else {
+    const int w = work - nfull;
+    split = w / a.tiles_n;
+    m_blk = (long)rows_m * BM;
+    n_blk = (long)(w - split * a.tiles_n) * BN;
+    k_slice = a.k_per_split_edge;
+  }
 
-  const long k_begin = (long)blockIdx.z * a.k_per_split;
-  const long k_end = min(a.K, k_begin + a.k_per_split);
+  const long k_begin = (long)split * k_slice;
+  const long k_end = min(a.K, k_begin + k_slice);
   const int nk = (int)((k_end - k_begin + BK - 1) / BK);
 
   f32x16 acc[MI][NI];
@@ -476,6 +538,10 @@ gemm_f32_mfma_kernel(GemmArgs a) {
   static_assert(!DMA || VEC == 4, "LDS-DMA loop: 16-byte aligned operands");
   if (DMA && (!EDGE || (m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0))) {
     gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
+  } else if (DMA && EDGE && !CONV && (k_end - k_begin) % BK == 0) {
+    // ragged in M or N only: still the LDS-DMA loop, with clamped row addresses
+    gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, false, true>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0,
+                                                                     wn0);
   } else if (EDGE) {
     const bool interior = m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0;
     if (interior)
@@ -492,7 +558,7 @@ gemm_f32_mfma_kernel(GemmArgs a) {
   // ---- epilogue.  32x32 accumulator block: register r of lane l holds
   //      row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31.
   const bool to_partial = a.partial != nullptr;
-  float* out = to_partial ? a.partial + (long)blockIdx.z * a.M * a.N : a.C;
+  float* out = to_partial ? a.partial + (long)split * a.M * a.N : a.C;
   const long ldo = to_partial ? a.N : a.ldc;
   const bool accumulate = !to_partial && a.accumulate;
   const bool has_bias = !to_partial && a.bias != nullptr;
@@ -506,7 +572,24 @@ gemm_f32_mfma_kernel(GemmArgs a) {
       if (has_bias && n_ok) bias = a.bias[n];
       const long m_base = m_blk + wm0 + i * 32 + 4 * (lane >> 5);
       float* col = out + n;
-      if (accumulate) {
+      if (Epi::ACTIVE) {
+        float x[16][Epi::NX];
+        if (!EDGE || (m_blk + BM <= a.M && n_blk + BN <= a.N)) {  // whole tile inside: branch-free, loads batched
+#pragma unroll
+          for (int r = 0; r < 16; ++r) Epi::prefetch(a, (m_base + (r & 3) + 8 * (r >> 2)) * ldo + n, x[r]);
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            Epi::apply(a, (m_base + (r & 3) + 8 * (r >> 2)) * ldo + n, acc[i][j][r] + bias, x[r]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const long m = m_base + (r & 3) + 8 * (r >> 2);
+            if (m >= a.M || !n_ok) continue;
+            Epi::prefetch(a, m * ldo + n, x[r]);
+            Epi::apply(a, m * ldo + n, acc[i][j][r] + bias, x[r]);
+          }
+        }
+      } else if (accumulate) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const long m = m_base + (r & 3) + 8 * (r >> 2);
@@ -525,20 +608,30 @@ gemm_f32_mfma_kernel(GemmArgs a) {
   }
 }
 
+template <int BM, int BN, int BK, int WM, int WN, int MINB, bool A_KC, bool B_KC, int VEC, bool EDGE, bool CONV,
+          int ABL = 0, bool DMA = false>
+__global__ __launch_bounds__((Geometry<BM, BN, WM, WN>::NT), (MINB * Geometry<BM, BN, WM, WN>::WAVES + 3) / 4) void
+gemm_f32_mfma_kernel(GemmArgs a) {
+  gemm_block<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, EDGE, CONV, ABL, DMA, EpiNone>(a);
+}
+
 // Second pass of split-K: C[m,n] = (accumulate ? C : 0) + sum_z partial[z][m][n] + bias[n],
 // slabs added in increasing z (fixed order => run-to-run deterministic).
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial, float* C,
                                                                  const float* __restrict__ bias, long M, long N,
-                                                                 long ldc, int splits, int accumulate) {
+                                                                 long ldc, int splits, int accumulate,
+                                                                 long edge_row, int edge_splits) {
+  // rows >= edge_row were cut into edge_splits slices only (GemmArgs::edge_splits)
   const long total = M * N;
   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (long)gridDim.x * blockDim.x;
-  if ((N & 3) == 0 && (ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
-      (reinterpret_cast<uintptr_t>(partial) & 15) == 0) {
+  if ((N & 3) == 0 && (ldc & 3) == 0 && (reinterpret_cast<unsigned long>(C) & 15) == 0 &&
+      (reinterpret_cast<unsigned long>(partial) & 15) == 0) {
     // 16 bytes per lane: a 4-wide group never straddles a row
     for (long i4 = tid; i4 < (total >> 2); i4 += nthreads) {
       const long i = i4 << 2, m = i / N, n = i % N;
       f32x4 s = {0.f, 0.f, 0.f, 0.f};
-      for (int z = 0; z < splits; ++z) {
+      const int nz = m >= edge_row ? edge_splits : splits;
+      for (int z = 0; z < nz; ++z) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (long)z * total + i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) s[j] += v[j];
@@ -560,7 +653,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
   for (long i = tid; i < total; i += nthreads) {
     const long m = i / N, n = i % N;
     float s = 0.f;
-    for (int z = 0; z < splits; ++z) s += partial[(long)z * total + i];
+    const int nz = m >= edge_row ? edge_splits : splits;
+    for (int z = 0; z < nz; ++z) s += partial[(long)z * total + i];
     float* p = C + m * ldc + n;
     if (accumulate) s = *p + s;
     if (bias) s += bias[n];

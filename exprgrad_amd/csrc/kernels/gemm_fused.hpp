@@ -1,0 +1,46 @@
+// Contraction with a generated epilogue: the host plans the launch exactly as eg_sgemm would, the
+// kernel is gemm_block<..., Epi> from gemm_f32_mfma.hpp compiled at run time (hiprtc) together with
+// the `Epi` functor that host/epilogue.cpp generates from the fused consumer kernel.
+//
+// Role in the reference: none on its GPU target — every lowered kernel is its own launch
+// (llvmgen.nim:455-500); on the CPU target fuseLoops (passes.nim:1929-2004) merges `dense` with
+// the following activation into one loop nest.  Here the activation (and, in the backward pass,
+// the activation gradient) runs on the accumulator registers of the matrix kernel, so the
+// intermediate tensor is written at most once and never re-read.
+#pragma once
+#include <string>
+
+#include "../eg_internal.hpp"
+
+namespace eg {
+namespace gemm {
+
+struct FusedLaunch {
+  int bm = 0, bn = 0, bk = 0, wm = 0, wn = 0, minb = 0, nt = 0;
+  bool a_kc = false, b_kc = false, edge = false, dma = false;
+  int vec = 1;
+  int splits = 1;   // > 1: the problem needs split-K, run it unfused
+  unsigned grid = 0;
+  alignas(8) unsigned char args[320];  // the kernel's GemmArgs (opaque to host-only translation units)
+  unsigned args_size = 0;
+};
+constexpr int MAX_EPILOGUE_OPERANDS = 6;
+
+// Plan C = op(A) * op(B) (+ bias) like eg_sgemm(accumulate = 0).  `out.args` is ready to launch
+// except for the epilogue operands.
+int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, const float* A, long lda, const float* B,
+               long ldb, float* C, long ldc, const float* bias, FusedLaunch& out);
+
+// Tensors the generated epilogue reads / writes (a.epi[i]), the seed-gradient scale and the epoch.
+void set_epilogue_operands(FusedLaunch& f, void* const* ptrs, int count, float grad_scale, long epoch);
+
+// Identifies the template instantiation (cache key / kernel name suffix).
+std::string fused_variant(const FusedLaunch& f);
+
+// Complete hiprtc translation unit: the kernel header, `epi_struct` (which must define
+// `struct <epi_name>` with ACTIVE and apply) and an extern "C" kernel `kernel_name(GemmArgs)`.
+std::string fused_source(const FusedLaunch& f, const std::string& epi_struct, const std::string& epi_name,
+                         const std::string& kernel_name);
+
+}  // namespace gemm
+}  // namespace eg

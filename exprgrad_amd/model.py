@@ -81,6 +81,11 @@ class Model:
 
     emitIr = emit_ir
 
+    def launch_plan(self, target):
+        """The launch sequence the target last ran with (fusion groups, fused epilogues), one line per launch."""
+        from . import _lib
+        return (_lib.lib().eg_model_launch_text(self.handle, target.encode()) or b"").decode()
+
     def kernel_count(self, target):
         return call("eg_model_kernel_count", self.handle, target.encode())
 

@@ -184,6 +184,10 @@ int eg_model_free(eg_model* model);
 /* Introspection (model.emitIr, model.nim:262-264: the lowered plan as text). Returned pointer
  * is owned by the model and valid until the next call of the same function. */
 const char* eg_model_plan_text(eg_model* model);
+/* The launch sequence of the plan the target last ran with (shape dependent: fusion groups,
+ * contractions with a fused epilogue, graph ranges), one line per launch; "" before the first
+ * run.  Same ownership rule. */
+const char* eg_model_launch_text(eg_model* model, const char* target);
 /* Number of kernels in a target after autodiff + elimination, or -1. */
 int eg_model_kernel_count(eg_model* model, const char* target);
 

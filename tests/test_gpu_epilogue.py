@@ -1,0 +1,108 @@
+"""Contractions with a generated epilogue (csrc/host/epilogue.cpp, kernels/gemm_fused.hpp): the
+activation after `dense` and the activation gradient after the backward contraction run on the
+accumulator registers of the matrix kernel.  Parity with the oracle, and with the unfused path.
+"""
+import numpy as np
+import pytest
+
+import refcases
+from conftest import TOL, rel_err
+from exprgrad_amd import dsl, layers
+from exprgrad_amd import model as egm
+
+pytestmark = pytest.mark.gpu
+
+ACTS = {"relu": layers.relu, "leaky_relu": layers.leaky_relu, "sigmoid": layers.sigmoid, "tanh": layers.tanh}
+
+
+def mlp(act="relu", dims=(96, 80, 72, 8), rate=0.05):  # hidden widths > 64: not row-fusable
+    net = dsl.input("x")
+    for i in range(len(dims) - 1):
+        net = layers.dense(net, dims[i], dims[i + 1])
+        if i + 2 < len(dims):
+            net = ACTS[act](net)
+    net = net.target("predict")
+    net = layers.mse(net, dsl.input("y")).target("loss")
+    return [net.backprop(layers.gradient_descent(rate)).target("train")]
+
+
+def build(gpu_ctx, monkeypatch, min_elems, **kw):
+    from oracle import kd
+    monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", str(min_elems))
+    gpu = egm.compile(*mlp(**kw), gpu=gpu_ctx)
+    ref = kd.Model(refcases.program_text(mlp(**kw)), threads=4)
+    rng = np.random.default_rng(5)
+    for tid in sorted(ref.params):
+        v = (rng.random(ref.params[tid].shape, dtype=np.float32) * 0.6 - 0.3).astype(np.float32)
+        ref.params[tid][...] = v
+        gpu.params[tid] = v
+    return gpu, ref
+
+
+@pytest.mark.parametrize("act", sorted(ACTS))
+@pytest.mark.parametrize("batch", [64, 37, 300])
+def test_fused_epilogue_matches_the_oracle(gpu_ctx, monkeypatch, act, batch):
+    gpu, ref = build(gpu_ctx, monkeypatch, 0, act=act)
+    rng = np.random.default_rng(batch)
+    x = (rng.random((batch, 96), dtype=np.float32) - 0.5).astype(np.float32)
+    y = rng.random((batch, 8), dtype=np.float32)
+    assert rel_err(gpu.call("predict", {"x": x}), ref.call("predict", {"x": x})) <= TOL
+    assert gpu.launch_plan("predict").count("gemm+epilogue") == 2     # both hidden layers
+    assert rel_err(gpu.call("loss", {"x": x, "y": y}), ref.call("loss", {"x": x, "y": y})) <= TOL
+    before = {t: ref.params[t].copy() for t in ref.params}
+    for _ in range(2):  # the second step replays the captured graph
+        gpu.apply("train", {"x": x, "y": y})
+        ref.apply("train", {"x": x, "y": y})
+    plan = gpu.launch_plan("train")
+    # 2 forward + the backward ones (at batch 37 the [37, 72] gradients are "small" tensors and the
+    # activation gradients join a single-block small-kernel group instead)
+    assert plan.count("gemm+epilogue") >= (3 if batch >= 64 else 2), plan
+    for tid in sorted(ref.params):
+        du_gpu, du_ref = gpu.params[tid] - before[tid], ref.params[tid] - before[tid]
+        assert rel_err(du_gpu, du_ref) <= 2e-5 + 1e-7 / max(np.abs(du_ref).max(), 1e-30), (tid, plan)
+    gpu.close()
+
+
+def test_fused_and_unfused_paths_agree_bit_for_bit(gpu_ctx, monkeypatch):
+    # same matrix kernel, same scalar expression: fusing must not change a single bit
+    rng = np.random.default_rng(9)
+    x = (rng.random((200, 96), dtype=np.float32) - 0.5).astype(np.float32)
+    y = rng.random((200, 8), dtype=np.float32)
+    results = []
+    for min_elems in (0, 1 << 40):
+        gpu, _ = build(gpu_ctx, monkeypatch, min_elems, act="leaky_relu")
+        out = gpu.call("predict", {"x": x})
+        gpu.apply("train", {"x": x, "y": y})
+        fused = "gemm+epilogue" in gpu.launch_plan("train")
+        assert fused == (min_elems == 0)
+        results.append((out, {t: gpu.params[t].copy() for t in sorted(gpu.params)}))
+        gpu.close()
+    assert np.array_equal(results[0][0], results[1][0])
+    for t in results[0][1]:
+        assert np.array_equal(results[0][1][t], results[1][1][t]), t
+
+
+def test_large_layers_fuse_by_default(gpu_ctx, monkeypatch):
+    # >= 2^20 output elements: no environment override needed (the cfg-5 shapes at a reduced batch)
+    monkeypatch.delenv("EG_EPILOGUE_MIN_ELEMS", raising=False)
+    from oracle import kd
+    graphs = lambda: refcases.dense_softmax_net(n_in=64, n_hidden=512, n_out=10)
+    gpu = egm.compile(*graphs(), gpu=gpu_ctx)
+    ref = kd.Model(refcases.program_text(graphs()), threads=8)
+    rng = np.random.default_rng(1)
+    for tid in sorted(ref.params):
+        v = (rng.random(ref.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+        ref.params[tid][...] = v
+        gpu.params[tid] = v
+    batch = 2048
+    x = rng.random((batch, 64), dtype=np.float32)
+    y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, size=batch)]
+    before = {t: ref.params[t].copy() for t in ref.params}
+    gpu.apply("train", {"x": x, "y": y})
+    ref.apply("train", {"x": x, "y": y})
+    plan = gpu.launch_plan("train")
+    assert plan.count("gemm+epilogue") == 2, plan     # relu forward, relu backward
+    for tid in sorted(ref.params):
+        du_gpu, du_ref = gpu.params[tid] - before[tid], ref.params[tid] - before[tid]
+        assert rel_err(du_gpu, du_ref) <= 2e-5 + 1e-7 / max(np.abs(du_ref).max(), 1e-30), tid
+    gpu.close()

@@ -66,6 +66,19 @@ def test_ragged_shapes_all_layouts(gpu_ctx, refcpu, shape, layout):
     assert err <= TOL
 
 
+@pytest.mark.parametrize("shape", [(784, 512, 8192), (300, 256, 20000), (144, 128, 40000), (272, 200, 12000),
+                                   (520, 516, 4096)])
+@pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
+def test_split_k_with_a_ragged_last_tile_row(gpu_ctx, refcpu, shape, layout):
+    # weight-gradient shapes (K = batch): split-K with the ragged last tile row cut into fewer, longer
+    # slices, ragged tiles on the LDS-DMA loop with clamped rows, empty 32x32 sub-blocks skipped
+    ta, tb = layout[0] == "t", layout[1] == "t"
+    err, _, _ = gemm_case(gpu_ctx, refcpu, *shape, trans_a=ta, trans_b=tb, seed=11)
+    assert err <= TOL
+    err, _, _ = gemm_case(gpu_ctx, refcpu, *shape, trans_a=ta, trans_b=tb, accumulate=True, bias=True, seed=12)
+    assert err <= TOL
+
+
 @pytest.mark.parametrize("layout", ["nn", "nt", "tn"])
 def test_accumulate_and_bias(gpu_ctx, refcpu, layout):
     ta, tb = layout[0] == "t", layout[1] == "t"
