@@ -73,6 +73,8 @@ _SIGS = {
     "eg_map": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_void_p, c_f32, c_int]),
     "eg_map_grad": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_void_p, c_void_p, c_f32, c_int]),
     "eg_conv2_nhwc": (c_int, [c_void_p] + [c_i64] * 7 + [c_void_p, c_void_p, c_void_p, c_int]),
+    "eg_conv2_nhwc_grad_filter": (c_int, [c_void_p] + [c_i64] * 7 + [c_void_p, c_void_p, c_void_p, c_int]),
+    "eg_conv2_nhwc_grad_image": (c_int, [c_void_p] + [c_i64] * 7 + [c_void_p, c_void_p, c_void_p, c_int]),
     "eg_model_compile": (c_int, [c_void_p, c_char_p, P(c_void_p)]),
     "eg_model_free": (c_int, [c_void_p]),
     "eg_model_plan_text": (c_char_p, [c_void_p]),

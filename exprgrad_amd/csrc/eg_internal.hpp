@@ -43,6 +43,10 @@ struct eg_ctx {
   // Scratch for split-K partials and two-stage reductions; grown on demand, never shrunk.
   void* workspace = nullptr;
   size_t workspace_bytes = 0;
+  // Second scratch block for operands a library call prepares for an inner call that may itself
+  // grow the workspace (padded output gradient + flipped filters of the convolution's image gradient).
+  void* aux = nullptr;
+  size_t aux_bytes = 0;
   int compute_units = 256;
   std::string arch;
 };
@@ -59,6 +63,7 @@ struct eg_buf {
 namespace eg {
 // Ensure ctx->workspace holds at least `bytes`; synchronises the stream if it has to grow.
 int ensure_workspace(eg_ctx* ctx, size_t bytes);
+int ensure_aux(eg_ctx* ctx, size_t bytes);
 // Launch a hiprtc-built kernel with an explicit argument array (bypasses the sticky arguments).
 int kernel_launch_raw(eg_kernel* kernel, unsigned gx, unsigned gy, unsigned gz, unsigned block, void** args);
 // Column sum with caller-provided scratch (colsum_scratch_floats(...) floats); see reduce.hip.

@@ -100,34 +100,41 @@ bool match_bias(const Kernel& k, int tensor) {
 }
 
 struct ConvMatch {
-  int img_read = 0, flt_read = 0;
+  // which operand plays which part: -1 = the written tensor, 0 / 1 = k.reads[i]
+  int out_op = -1, img_op = 0, flt_op = 1;
   bool batched = true;
+  enum Role { Forward, GradImage, GradFilter } role = Forward;
 };
 
 // out[n,y,x,f] += img[n,y+dy,x+dx,c] * flt[f,dy,dx,c]   dnn.nim:45-49 (4-D) / conv2.nim:128-132 (3-D)
+// and the two kernels derive (passes.nim:383-549) makes of it, which are the same loop nest with
+// another of the three tensors written:
+//   gimg[n,y+dy,x+dx,c] += gout[n,y,x,f] * flt[f,dy,dx,c]      gflt[f,dy,dx,c] += gout[n,y,x,f] * img[n,y+dy,x+dx,c]
 bool match_conv(const Kernel& k, ConvMatch& m) {
   if (k.instrs.size() != 1 || k.instrs[0].kind != IK::Mul || k.result != k.instrs[0].res || k.reads.size() != 2) return false;
-  if (!k.setup.empty() || k.write.raw) return false;
+  if (!k.setup.empty() || k.write.raw || k.reads[0].raw || k.reads[1].raw) return false;
+  const std::vector<int>& args = k.instrs[0].args;
+  if (!((args[0] == k.reads[0].reg && args[1] == k.reads[1].reg) || (args[0] == k.reads[1].reg && args[1] == k.reads[0].reg)))
+    return false;
   for (auto& lp : k.loops)
     if (lp.has_bounds) return false;
-  const size_t nd = k.write.dims.size();
-  if (nd != 4 && nd != 3) return false;
-  const bool batched = nd == 4;
-  if (k.loops.size() != (batched ? 7u : 6u)) return false;
-  std::vector<int> w;
-  for (auto& d : k.write.dims) {
-    int r = d.only_register();
-    if (!r) return false;
-    w.push_back(r);
-  }
-  const int off = batched ? 1 : 0;
-  const int n = batched ? w[0] : 0, y = w[off], x = w[off + 1], f = w[off + 2];
-  for (int a = 0; a < 2; ++a) {
-    const Op& img = k.reads[a];
-    const Op& flt = k.reads[1 - a];
-    if (img.raw || flt.raw || img.dims.size() != nd || flt.dims.size() != 4) continue;
-    int ff = flt.dims[0].only_register(), dy = flt.dims[1].only_register(), dx = flt.dims[2].only_register(),
-        c = flt.dims[3].only_register();
+  const Op* ops[3] = {&k.write, &k.reads[0], &k.reads[1]};  // operand index + 1
+  static const int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+  for (auto& pm : perms) {
+    const Op& out = *ops[pm[0]];
+    const Op& img = *ops[pm[1]];
+    const Op& flt = *ops[pm[2]];
+    const size_t nd = out.dims.size();
+    if ((nd != 4 && nd != 3) || img.dims.size() != nd || flt.dims.size() != 4) continue;
+    const bool batched = nd == 4;
+    if (k.loops.size() != (batched ? 7u : 6u)) continue;
+    std::vector<int> w;
+    for (auto& d : out.dims) w.push_back(d.only_register());
+    const int off = batched ? 1 : 0;
+    const int n = batched ? w[0] : 0, y = w[off], x = w[off + 1], f = w[off + 2];
+    if (!y || !x || !f || (batched && !n)) continue;
+    const int ff = flt.dims[0].only_register(), dy = flt.dims[1].only_register(), dx = flt.dims[2].only_register(),
+              c = flt.dims[3].only_register();
     if (ff != f || !dy || !dx || !c) continue;
     std::set<int> all = {y, x, f, dy, dx, c};
     if (batched) all.insert(n);
@@ -138,15 +145,17 @@ bool match_conv(const Kernel& k, ConvMatch& m) {
     if (batched && img.dims[0].only_register() != n) continue;
     if (!pair_sum(img.dims[off], y, dy) || !pair_sum(img.dims[off + 1], x, dx) || img.dims[off + 2].only_register() != c)
       continue;
-    m.img_read = a;
-    m.flt_read = 1 - a;
+    m.out_op = pm[0] - 1;
+    m.img_op = pm[1] - 1;
+    m.flt_op = pm[2] - 1;
     m.batched = batched;
+    m.role = pm[0] == 0 ? ConvMatch::Forward : (pm[1] == 0 ? ConvMatch::GradImage : ConvMatch::GradFilter);
     return true;
   }
   return false;
 }
 
-enum class StepKind { Gemm, Conv, Seed, GenericA, GenericB, RowFused, SmallFused, GemmFused };
+enum class StepKind { Gemm, Conv, ConvGradImage, ConvGradFilter, Seed, GenericA, GenericB, RowFused, SmallFused, GemmFused };
 
 struct Generic {
   GenericSource src;
@@ -327,7 +336,9 @@ int lower_target(eg_model* m, TargetState& ts) {
       continue;
     }
     if (match_conv(k, lo.conv)) {
-      lo.kind = StepKind::Conv;
+      lo.kind = lo.conv.role == ConvMatch::Forward     ? StepKind::Conv
+                : lo.conv.role == ConvMatch::GradImage ? StepKind::ConvGradImage
+                                                       : StepKind::ConvGradFilter;
       continue;
     }
     lo.kind = StepKind::GenericA;
@@ -935,11 +946,14 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
       L.trans_a = g.trans_a;
       L.trans_b = g.trans_b;
       L.bias_tensor = lo.bias_tensor;
-    } else if (lo.kind == StepKind::Conv) {
-      const Op& img = k.reads[lo.conv.img_read];
-      const Op& flt = k.reads[lo.conv.flt_read];
+    } else if (lo.kind == StepKind::Conv || lo.kind == StepKind::ConvGradImage || lo.kind == StepKind::ConvGradFilter) {
+      auto operand = [&](int which) -> const Op& { return which < 0 ? k.write : k.reads[which]; };
+      const Op& img = operand(lo.conv.img_op);
+      const Op& flt = operand(lo.conv.flt_op);
+      const Op& out = operand(lo.conv.out_op);
       const std::vector<long>& is = shapes.at(img.tensor);
       const std::vector<long>& fs = shapes.at(flt.tensor);
+      const std::vector<long>& os = shapes.at(out.tensor);
       const int off = lo.conv.batched ? 1 : 0;
       L.cN = lo.conv.batched ? is[0] : 1;
       L.cH = is[off];
@@ -952,8 +966,29 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
         set_error("conv2: image has %ld channels, filters have %ld", L.cC, fs[3]);
         return EG_ERR_SHAPE;
       }
-      L.a_tensor = img.tensor;
-      L.b_tensor = flt.tensor;
+      if (lo.kind != StepKind::Conv) {
+        // the gradient kernels cover their destination completely only if the three shapes are
+        // the ones of a valid convolution
+        const bool ok = os.size() == is.size() && (!lo.conv.batched || os[0] == L.cN) && os[off] == L.cH - L.cFH + 1 &&
+                        os[off + 1] == L.cW - L.cFW + 1 && os[off + 2] == L.cF;
+        if (!ok) {
+          set_error("conv2 gradient: output gradient shape does not match image and filter shapes");
+          return EG_ERR_SHAPE;
+        }
+        if (first) overwrite = true;
+      }
+      // a_tensor: image (forward, filter gradient) or filters (image gradient); b_tensor: filters
+      // (forward) or the output gradient
+      if (lo.kind == StepKind::Conv) {
+        L.a_tensor = img.tensor;
+        L.b_tensor = flt.tensor;
+      } else if (lo.kind == StepKind::ConvGradFilter) {
+        L.a_tensor = img.tensor;
+        L.b_tensor = out.tensor;
+      } else {
+        L.a_tensor = flt.tensor;
+        L.b_tensor = out.tensor;
+      }
       L.c_tensor = wt;
     } else {
       // generic: choose the template
@@ -1088,6 +1123,14 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       void* args[] = {f.args};
       return eg::kernel_launch_raw(handle, f.grid, 1, 1, (unsigned)f.nt, args);
     }
+    case StepKind::ConvGradFilter:
+      return eg_conv2_nhwc_grad_filter(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, tensor_ptr(m, ts, plan, L.a_tensor),
+                                       tensor_ptr(m, ts, plan, L.b_tensor), tensor_ptr(m, ts, plan, L.c_tensor),
+                                       L.accumulate);
+    case StepKind::ConvGradImage:
+      return eg_conv2_nhwc_grad_image(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, tensor_ptr(m, ts, plan, L.a_tensor),
+                                      tensor_ptr(m, ts, plan, L.b_tensor), tensor_ptr(m, ts, plan, L.c_tensor),
+                                      L.accumulate);
     case StepKind::Conv:
       return eg_conv2_nhwc(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, tensor_ptr(m, ts, plan, L.a_tensor),
                            tensor_ptr(m, ts, plan, L.b_tensor), tensor_ptr(m, ts, plan, L.c_tensor), L.accumulate);
@@ -1229,7 +1272,7 @@ int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool
   std::ostringstream key;
   for (auto& in : m->inputs)
     if (in.second.bound) key << in.first << "=" << (const void*)in.second.device << ";";
-  key << "w" << m->ctx->workspace << "b" << (void*)ts.bucket << "g" << m->grad_scale << "e" << m->epoch;
+  key << "w" << m->ctx->workspace << "x" << m->ctx->aux << "b" << (void*)ts.bucket << "g" << m->grad_scale << "e" << m->epoch;
   const std::string k = key.str();
   if (cap.exec && cap.key == k) {
     EG_HIP_CHECK(hipGraphLaunch(cap.exec, m->ctx->stream));
@@ -1293,6 +1336,8 @@ void describe(eg_model* m) {
       const char* kind = lo.absorbed ? "fused-into-previous"
                          : lo.kind == StepKind::Gemm ? (lo.bias_tensor ? "gemm+bias" : "gemm")
                          : lo.kind == StepKind::Conv ? "conv2"
+                         : lo.kind == StepKind::ConvGradImage ? "conv2-grad-image"
+                         : lo.kind == StepKind::ConvGradFilter ? "conv2-grad-filter"
                          : lo.kind == StepKind::Seed ? "seed-fill"
                          : (lo.b_capable ? "generic(map|split-reduce)" : "generic(map)");
       os << "  [" << p << "] " << kind;
@@ -1411,7 +1456,9 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
           for (int t : pe.spec.operands) os << " t" << t;
         }
         break;
-      case StepKind::Conv: os << "conv2 -> t" << L.c_tensor; break;
+      case StepKind::Conv: os << "conv2 -> t" << L.c_tensor << (L.accumulate ? " accumulate" : ""); break;
+      case StepKind::ConvGradImage: os << "conv2-grad-image -> t" << L.c_tensor << (L.accumulate ? " accumulate" : ""); break;
+      case StepKind::ConvGradFilter: os << "conv2-grad-filter -> t" << L.c_tensor << (L.accumulate ? " accumulate" : ""); break;
       case StepKind::GenericA: os << "generated(map) kernel " << L.lowered << " -> t" << L.c_tensor; break;
       case StepKind::GenericB: os << "generated(split-reduce) kernel " << L.lowered << " -> t" << L.c_tensor; break;
       case StepKind::RowFused: {

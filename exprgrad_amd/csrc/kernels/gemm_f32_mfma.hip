@@ -9,6 +9,7 @@
 // tile shape, split-K, vector/edge variant, launch, deterministic second pass.
 #include "gemm_f32_mfma.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,7 +29,7 @@ struct TileCfg {
 
 template <int BM, int BN, int WM, int WN, int MINB>
 int launch_config(eg_ctx* ctx, bool a_kc, bool b_kc, const GemmArgs& args, int splits, bool vec, bool edge,
-                  bool conv) {
+                  int conv) {
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
   const long rows_m = args.edge_splits > 0 ? args.tiles_m - 1 : args.tiles_m;
   dim3 grid((unsigned)(rows_m * args.tiles_n * splits + (long)args.tiles_n * args.edge_splits), 1, 1);
@@ -36,22 +37,27 @@ int launch_config(eg_ctx* ctx, bool a_kc, bool b_kc, const GemmArgs& args, int s
   hipStream_t s = ctx->stream;
   // 16-byte aligned operands: interior tiles run the LDS-DMA loop (gemm_f32_mfma.hpp)
 #define EG_GEMM_LAUNCH(AKC, BKC, V, E, CV)                                                                        \
-  hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, MINB, AKC, BKC, V, E, CV, 0, (V == 4 && !CV)>), grid, \
+  hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, MINB, AKC, BKC, V, E, CV, 0, (V == 4 && CV == 0)>), grid, \
                      block, 0, s, args)
 #define EG_GEMM_LAYOUT(AKC, BKC)                  \
   do {                                            \
     if (!edge)                                    \
-      EG_GEMM_LAUNCH(AKC, BKC, 4, false, false);  \
+      EG_GEMM_LAUNCH(AKC, BKC, 4, false, 0);  \
     else if (vec)                                 \
-      EG_GEMM_LAUNCH(AKC, BKC, 4, true, false);   \
+      EG_GEMM_LAUNCH(AKC, BKC, 4, true, 0);   \
     else                                          \
-      EG_GEMM_LAUNCH(AKC, BKC, 1, true, false);   \
+      EG_GEMM_LAUNCH(AKC, BKC, 1, true, 0);   \
   } while (0)
-  if (conv) {
+  if (conv == 2) {  // filter gradient: A = gOut [pixels][F], B = im2col gathered from the image
     if (vec)
-      EG_GEMM_LAUNCH(true, true, 4, true, true);
+      EG_GEMM_LAUNCH(false, false, 4, true, 2);
     else
-      EG_GEMM_LAUNCH(true, true, 1, true, true);
+      EG_GEMM_LAUNCH(false, false, 1, true, 2);
+  } else if (conv) {
+    if (vec)
+      EG_GEMM_LAUNCH(true, true, 4, true, 1);
+    else
+      EG_GEMM_LAUNCH(true, true, 1, true, 1);
   } else if (a_kc && !b_kc) {
     EG_GEMM_LAYOUT(true, false);  // NN
   } else if (a_kc && b_kc) {
@@ -198,7 +204,7 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
 }
 
 // Shared host-side planning: tile shape, split-K, vector/edge variant, launch, second pass.
-int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, bool conv, bool vec_ok) {
+int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool vec_ok) {
   const long M = args.M, N = args.N, K = args.K;
   const long k_tiles = (K + BK - 1) / BK;
   int BM, BN, splits;
@@ -318,7 +324,7 @@ extern "C" int eg_sgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_
   const long a_contig = a_kc ? K : M, b_contig = b_kc ? K : N;
   const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (a_contig % 4 == 0) && (b_contig % 4 == 0) &&
                    (A == nullptr || aligned16(A)) && (B == nullptr || aligned16(B));
-  return run_gemm(ctx, a_kc, b_kc, args, /*conv=*/false, vec);
+  return run_gemm(ctx, a_kc, b_kc, args, /*conv=*/0, vec);
 }
 
 // Direct convolution as an implicit GEMM:  M = N*Ho*Wo output pixels, N = F filters,
@@ -358,7 +364,127 @@ extern "C" int eg_conv2_nhwc(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64
   const bool vec = (C % 4 == 0) && aligned16(img) && aligned16(flt);
   rc = run_conv(ctx, args, vec);
   if (rc >= 0) return rc;
-  return run_gemm(ctx, true, true, args, /*conv=*/true, vec);
+  return run_gemm(ctx, true, true, args, /*conv=*/1, vec);
+}
+
+// ---- convolution gradients ------------------------------------------------------------------------
+// What derive (passes.nim:383-549) produces for conv2 (dnn.nim:45-49):
+//   gFlt[f,dy,dx,c]     ++= gOut[n,y,x,f] * img[n,y+dy,x+dx,c]
+//   gImg[n,y+dy,x+dx,c] ++= gOut[n,y,x,f] * flt[f,dy,dx,c]
+// The reference runs both as the same 7-deep loop nest as the forward pass (the second one as a
+// scatter).  Here both are contractions on the matrix cores.
+
+namespace {
+
+// gOut [N,Ho,Wo,F] -> zero-bordered [N, Ho + 2(FH-1), Wo + 2(FW-1), F]
+__global__ __launch_bounds__(256) void pad_gradient_kernel(const float* __restrict__ g, float* __restrict__ out, long N,
+                                                           long Ho, long Wo, long F, long ph, long pw) {
+  const long Hp = Ho + 2 * ph, Wp = Wo + 2 * pw;
+  const long total = N * Hp * Wp * F;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long f = i % F, p = i / F;
+    const long x = p % Wp - pw, q = p / Wp;
+    const long y = q % Hp - ph, n = q / Hp;
+    out[i] = (y >= 0 && y < Ho && x >= 0 && x < Wo) ? g[((n * Ho + y) * Wo + x) * F + f] : 0.f;
+  }
+}
+
+// flt [F,FH,FW,C] -> [C,FH,FW,F] with both spatial axes reversed
+__global__ __launch_bounds__(256) void flip_filter_kernel(const float* __restrict__ flt, float* __restrict__ out, long F,
+                                                          long FH, long FW, long C) {
+  const long total = F * FH * FW * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long f = i % F, p = i / F;
+    const long dx = p % FW, q = p / FW;
+    const long dy = q % FH, c = q / FH;
+    out[i] = flt[((f * FH + (FH - 1 - dy)) * FW + (FW - 1 - dx)) * C + c];
+  }
+}
+
+}  // namespace
+
+// Filter gradient as ONE contraction over all output pixels:
+//   gFlt[F, FH*FW*C] (+)= gOut^T [F, P] * im2col(img) [P, FH*FW*C],  P = N*Ho*Wo
+// A = gOut is a plain [P][F] matrix (m-contiguous); B is gathered from the image inside the tile
+// loader (CONV = 2), never materialised.  K = P is long and the output small: split-K.
+extern "C" int eg_conv2_nhwc_grad_filter(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64_t C, int64_t F, int64_t FH,
+                                         int64_t FW, const float* img, const float* gout, float* gflt,
+                                         int accumulate) {
+  EG_REQUIRE(ctx, EG_ERR_INVALID, "eg_conv2_nhwc_grad_filter: ctx is NULL");
+  EG_REQUIRE(N >= 0 && H >= 0 && W >= 0 && C >= 0 && F >= 0 && FH >= 1 && FW >= 1, EG_ERR_INVALID,
+             "eg_conv2_nhwc_grad_filter: bad extent");
+  const long Ho = H - FH + 1, Wo = W - FW + 1;
+  EG_REQUIRE(Ho >= 0 && Wo >= 0, EG_ERR_SHAPE, "eg_conv2_nhwc_grad_filter: filter larger than image");
+  if (F == 0 || C == 0) return EG_OK;
+  EG_REQUIRE(gflt, EG_ERR_INVALID, "eg_conv2_nhwc_grad_filter: NULL tensor");
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  const long P = N * Ho * Wo;
+  if (P == 0) {
+    if (!accumulate) return eg_fill_f32(ctx, F * FH * FW * C, 0.f, gflt);
+    return EG_OK;
+  }
+  EG_REQUIRE(img && gout, EG_ERR_INVALID, "eg_conv2_nhwc_grad_filter: NULL tensor");
+  EG_REQUIRE(P < (1L << 31) && FH * FW * C < (1L << 31), EG_ERR_INVALID,
+             "eg_conv2_nhwc_grad_filter: more than 2^31 output pixels or taps");
+  GemmArgs args = {};
+  args.A = gout;
+  args.B = img;
+  args.C = gflt;
+  args.M = F;
+  args.N = FH * FW * C;
+  args.K = P;
+  args.lda = F;
+  args.ldb = 0;
+  args.ldc = args.N;
+  args.accumulate = accumulate;
+  args.cH = H;
+  args.cW = W;
+  args.cC = C;
+  args.cFW = FW;
+  args.cHo = Ho;
+  args.cWo = Wo;
+  const bool vec = (C % 4 == 0) && (F % 4 == 0) && aligned16(img) && aligned16(gout);
+  return run_gemm(ctx, false, false, args, /*conv=*/2, vec);
+}
+
+// Image gradient = "full" correlation of gOut with the flipped, channel-transposed filters:
+//   gImg[n,yy,xx,c] = sum_{dy,dx,f} pad(gOut)[n, yy+dy', xx+dx', f] * fltT[c, dy', dx', f],
+//   dy' = FH-1-dy, dx' = FW-1-dx, pad = (FH-1, FW-1) zeros on every side.
+// That is exactly a forward convolution with F and C exchanged, so it runs on eg_conv2_nhwc
+// (LDS-DMA gather and all); the padded gradient and the flipped bank live in the context's
+// auxiliary scratch.
+extern "C" int eg_conv2_nhwc_grad_image(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64_t C, int64_t F, int64_t FH,
+                                        int64_t FW, const float* flt, const float* gout, float* gimg, int accumulate) {
+  EG_REQUIRE(ctx, EG_ERR_INVALID, "eg_conv2_nhwc_grad_image: ctx is NULL");
+  EG_REQUIRE(N >= 0 && H >= 0 && W >= 0 && C >= 0 && F >= 0 && FH >= 1 && FW >= 1, EG_ERR_INVALID,
+             "eg_conv2_nhwc_grad_image: bad extent");
+  const long Ho = H - FH + 1, Wo = W - FW + 1;
+  EG_REQUIRE(Ho >= 0 && Wo >= 0, EG_ERR_SHAPE, "eg_conv2_nhwc_grad_image: filter larger than image");
+  if (N == 0 || H == 0 || W == 0 || C == 0) return EG_OK;
+  EG_REQUIRE(gimg, EG_ERR_INVALID, "eg_conv2_nhwc_grad_image: NULL tensor");
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  if (F == 0 || Ho == 0 || Wo == 0) {
+    if (!accumulate) return eg_fill_f32(ctx, N * H * W * C, 0.f, gimg);
+    return EG_OK;
+  }
+  EG_REQUIRE(flt && gout, EG_ERR_INVALID, "eg_conv2_nhwc_grad_image: NULL tensor");
+  const long Hp = Ho + 2 * (FH - 1), Wp = Wo + 2 * (FW - 1);
+  const size_t pad_floats = ((size_t)(N * Hp * Wp * F) + 3) & ~(size_t)3;
+  const size_t flt_floats = (size_t)(C * FH * FW * F);
+  rc = eg::ensure_aux(ctx, (pad_floats + flt_floats) * sizeof(float));
+  if (rc) return rc;
+  float* padded = static_cast<float*>(ctx->aux);
+  float* flipped = padded + pad_floats;
+  const long blocks = std::min<long>(((long)pad_floats + 255) / 256, 8L * ctx->compute_units);
+  hipLaunchKernelGGL(pad_gradient_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, gout, padded, (long)N, Ho,
+                     Wo, (long)F, (long)FH - 1, (long)FW - 1);
+  const long fblocks = std::min<long>(((long)flt_floats + 255) / 256, 8L * ctx->compute_units);
+  hipLaunchKernelGGL(flip_filter_kernel, dim3((unsigned)fblocks), dim3(256), 0, ctx->stream, flt, flipped, (long)F,
+                     (long)FH, (long)FW, (long)C);
+  EG_HIP_CHECK(hipGetLastError());
+  return eg_conv2_nhwc(ctx, N, Hp, Wp, F, C, FH, FW, padded, flipped, gimg, accumulate);
 }
 
 // ---- contraction with a generated epilogue (gemm_fused.hpp) ----------------------------------------

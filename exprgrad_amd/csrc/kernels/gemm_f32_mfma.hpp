@@ -83,12 +83,13 @@ struct LdsStride {
 // One operand tile: BMN rows/cols along m|n, BK along k.
 //   KC == true : global element (mn, k) at  base[mn * ld + k]   (k contiguous)
 //   KC == false: global element (mn, k) at  base[k * ld + mn]   (m|n contiguous)
-//   CONV (KC only): element (m, k) of the virtual im2col matrix, read straight from the image:
+//   CONV && KC : element (m, k) of the virtual im2col matrix, read straight from the image:
 //       base[((n*H + y + dy)*W + x + dx)*C + c],  m = (n*Ho + y)*Wo + x,  k = (dy*FW + dx)*C + c
 //     (dnn.nim:45-49: images[image, y + dy, x + dx, chan], valid padding, stride 1).
+//   CONV && !KC: the same matrix as the k x n operand of the filter-gradient contraction
+//     gF[f, (dy,dx,c)] = sum_pixels gOut[pixel, f] * im2col[pixel, (dy,dx,c)]: k = pixel, n = tap.
 template <int BMN, int BK, int NT, bool KC, int VEC, bool EDGE, bool CONV>
 struct TileLoader {
-  static_assert(!CONV || KC, "the gathered operand is k(channel)-contiguous");
   static constexpr int STRIDE = LdsStride<BMN, BK, KC>::value;
   static constexpr int ELEMS = BMN * BK;
   static constexpr int CHUNKS = ELEMS / VEC;
@@ -120,7 +121,13 @@ struct TileLoader {
         const long img = m / (a.cHo * a.cWo);
         const unsigned rem = (unsigned)(m - img * (a.cHo * a.cWo));
         const unsigned y = rem / (unsigned)a.cWo, x = rem % (unsigned)a.cWo;
-        row_off[i] = ((img * a.cH + y) * a.cW + x) * a.cC;
+        if (KC) {
+          row_off[i] = ((img * a.cH + y) * a.cW + x) * a.cC;
+        } else {  // n = (dy*FW + dx)*C + c is fixed per thread: its offset inside the window
+          const unsigned C = (unsigned)a.cC, FW = (unsigned)a.cFW;
+          const unsigned tap = (unsigned)m / C, c = (unsigned)m % C;
+          row_off[i] = (long)((tap / FW) * (unsigned)a.cW + tap % FW) * C + c;
+        }
       }
     }
   }
@@ -135,7 +142,13 @@ struct TileLoader {
       coords(idx, mn, k);
       const long gmn = mn0 + mn, gk = k0 + k;
       const float* p;
-      if (CONV) {
+      if (CONV && !KC) {
+        // k -> output pixel (n, y, x) -> offset of its window's top-left input pixel
+        const unsigned hw = (unsigned)(a.cHo * a.cWo);
+        const unsigned img = (unsigned)gk / hw, rem = (unsigned)gk % hw;
+        const unsigned y = rem / (unsigned)a.cWo, x = rem % (unsigned)a.cWo;
+        p = base + (((long)img * a.cH + y) * a.cW + x) * a.cC + row_off[i];
+      } else if (CONV) {
         // k -> (dy, dx, c).  The k-tile origin k0 is block-uniform: when C is a multiple of BK the
         // whole tile lies inside one filter tap and the split is scalar work; otherwise a
         // 32-bit division per chunk (64-bit division is a ~100 instruction software routine).
@@ -209,13 +222,13 @@ struct Geometry {
 // ABL (tuning harness only; the library always instantiates 0): bit 0 = no LDS fragment reads in
 // the k loop, bit 1 = no global loads / LDS stores after the first tile, bit 2 = no barriers,
 // bit 3 = no LDS stores only, bit 4 = no global loads only.
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int VEC, bool E, bool CONV, int ABL>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int VEC, bool E, int CONV, int ABL>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32], long m_blk,
                                               long n_blk, long k_begin, long k_end, int nk, int tid, int wm0, int wn0) {
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
   constexpr int MI = WM / 32, NI = WN / 32;
-  using LoadA = TileLoader<BM, BK, NT, A_KC, VEC, E, CONV>;
-  using LoadB = TileLoader<BN, BK, NT, B_KC, VEC, E, false>;
+  using LoadA = TileLoader<BM, BK, NT, A_KC, VEC, E, CONV == 1>;
+  using LoadB = TileLoader<BN, BK, NT, B_KC, VEC, E, CONV == 2>;
   constexpr int SA = LoadA::STRIDE, SB = LoadB::STRIDE;
   constexpr int BUF = BK * (SA + SB);  // one stage: A tile then B tile
   const int lane = tid & 63;
@@ -475,7 +488,9 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
 // EDGE kernels still run their interior tiles on the unpredicated loop.
 // DMA: interior tiles use the LDS-DMA loop (requires VEC == 4, BK in {16, 32}; with CONV the host
 // checks C % BK == 0).
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int VEC, bool EDGE, bool CONV, int ABL, bool DMA,
+// CONV: 0 = plain operands, 1 = A is the im2col matrix of an NHWC image (forward convolution),
+// 2 = B is (filter-gradient contraction; register-staged loop only).
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int VEC, bool EDGE, int CONV, int ABL, bool DMA,
           class Epi>
 __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   constexpr int WAVES_N = BN / WN;
@@ -537,7 +552,8 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
 
   static_assert(!DMA || VEC == 4, "LDS-DMA loop: 16-byte aligned operands");
   if (DMA && (!EDGE || (m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0))) {
-    gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
+    static_assert(!DMA || CONV != 2, "the filter-gradient gather runs on the register-staged loop");
+    gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV == 1>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
   } else if (DMA && EDGE && !CONV && (k_end - k_begin) % BK == 0) {
     // ragged in M or N only: still the LDS-DMA loop, with clamped row addresses
     gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, false, true>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0,
@@ -608,7 +624,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int MINB, bool A_KC, bool B_KC, int VEC, bool EDGE, bool CONV,
+template <int BM, int BN, int BK, int WM, int WN, int MINB, bool A_KC, bool B_KC, int VEC, bool EDGE, int CONV,
           int ABL = 0, bool DMA = false>
 __global__ __launch_bounds__((Geometry<BM, BN, WM, WN>::NT), (MINB * Geometry<BM, BN, WM, WN>::WAVES + 3) / 4) void
 gemm_f32_mfma_kernel(GemmArgs a) {

@@ -48,6 +48,19 @@ int ensure_workspace(eg_ctx* ctx, size_t bytes) {
   ctx->workspace_bytes = want;
   return EG_OK;
 }
+
+int ensure_aux(eg_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->aux_bytes) return EG_OK;
+  EG_HIP_CHECK(hipSetDevice(ctx->device));
+  EG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+  if (ctx->aux) EG_HIP_CHECK(hipFree(ctx->aux));
+  ctx->aux = nullptr;
+  ctx->aux_bytes = 0;
+  size_t want = bytes + bytes / 4;
+  EG_HIP_CHECK(hipMalloc(&ctx->aux, want));
+  ctx->aux_bytes = want;
+  return EG_OK;
+}
 }  // namespace eg
 
 using eg::set_error;
@@ -168,6 +181,7 @@ int eg_ctx_destroy(eg_ctx* ctx) {
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
   if (ctx->workspace) hipFree(ctx->workspace);
+  if (ctx->aux) hipFree(ctx->aux);
   if (ctx->owns_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return EG_OK;

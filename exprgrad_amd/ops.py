@@ -62,3 +62,13 @@ def map_grad(ctx, op, n, x, gout, gin, param=0.0, accumulate=False):
 
 def conv2_nhwc(ctx, N, H, W, C, F, FH, FW, img, flt, out, accumulate=False):
     call("eg_conv2_nhwc", ctx.handle, N, H, W, C, F, FH, FW, _p(img), _p(flt), _p(out), int(accumulate))
+
+
+def conv2_nhwc_grad_filter(ctx, N, H, W, C, F, FH, FW, img, gout, gflt, accumulate=False):
+    """gflt[f,dy,dx,c] (+)= sum gout[n,y,x,f] * img[n,y+dy,x+dx,c]  (derived from dnn.nim:45-49)."""
+    call("eg_conv2_nhwc_grad_filter", ctx.handle, N, H, W, C, F, FH, FW, _p(img), _p(gout), _p(gflt), int(accumulate))
+
+
+def conv2_nhwc_grad_image(ctx, N, H, W, C, F, FH, FW, flt, gout, gimg, accumulate=False):
+    """gimg[n,y+dy,x+dx,c] (+)= sum gout[n,y,x,f] * flt[f,dy,dx,c]  (derived from dnn.nim:45-49)."""
+    call("eg_conv2_nhwc_grad_image", ctx.handle, N, H, W, C, F, FH, FW, _p(flt), _p(gout), _p(gimg), int(accumulate))

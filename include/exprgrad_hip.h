@@ -169,6 +169,17 @@ int eg_map_grad(eg_ctx* ctx, int op, int64_t n, const float* in, const float* go
 int eg_conv2_nhwc(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64_t C, int64_t F, int64_t FH,
                   int64_t FW, const float* img, const float* flt, float* out, int accumulate);
 
+/* The two gradients derive (passes.nim:383-549) produces for conv2 (dnn.nim:45-49), which the
+ * reference runs as the forward loop nest with the roles of the tensors exchanged:
+ *   grad_filter: gflt[f,dy,dx,c]     (+)= sum_{n,y,x}   gout[n,y,x,f] * img[n,y+dy,x+dx,c]
+ *   grad_image:  gimg[n,y+dy,x+dx,c] (+)= sum_{f}       gout[n,y,x,f] * flt[f,dy,dx,c]
+ * img / gimg [N,H,W,C], flt / gflt [F,FH,FW,C], gout [N,H-FH+1,W-FW+1,F]; accumulate = 0 overwrites
+ * the whole destination. */
+int eg_conv2_nhwc_grad_filter(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64_t C, int64_t F, int64_t FH,
+                              int64_t FW, const float* img, const float* gout, float* gflt, int accumulate);
+int eg_conv2_nhwc_grad_image(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64_t C, int64_t F, int64_t FH,
+                             int64_t FW, const float* flt, const float* gout, float* gimg, int accumulate);
+
 /* ------------------------------------------------------------------ group 3: model ---- */
 /* A program is the text form of exprgrad's `Program` (ir.nim:247-270) before `generate`:
  * tensors, targets, and per target the ordered list of `++=` kernel descriptions

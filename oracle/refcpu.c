@@ -344,3 +344,43 @@ EXPORT void ref_dgemm_from_f32(int trans_a, int trans_b, int64_t M, int64_t N, i
       C[m * ldc + n] = s;
     }
 }
+
+/* The two kernels derive (passes.nim:383-549) produces from conv2 (dnn.nim:45-49), as plain loop
+ * nests with the iterators of the forward kernel (n, y, x, f, dy, dx, c), separate float multiply
+ * and add, accumulating into the destination like every `++=` kernel:
+ *   gflt[f,dy,dx,c]     += gout[n,y,x,f] * img[n,y+dy,x+dx,c]
+ *   gimg[n,y+dy,x+dx,c] += gout[n,y,x,f] * flt[f,dy,dx,c]
+ * Single threaded (scatter / reduction over every loop): test sizes only. */
+EXPORT void ref_conv2_nhwc_grad_filter(int64_t N, int64_t H, int64_t W, int64_t C, int64_t F, int64_t FH, int64_t FW,
+                                       const float* img, const float* gout, float* gflt) {
+  const int64_t Ho = H - FH + 1, Wo = W - FW + 1;
+  for (int64_t n = 0; n < N; ++n)
+    for (int64_t y = 0; y < Ho; ++y)
+      for (int64_t x = 0; x < Wo; ++x)
+        for (int64_t f = 0; f < F; ++f) {
+          const float g = gout[((n * Ho + y) * Wo + x) * F + f];
+          for (int64_t dy = 0; dy < FH; ++dy)
+            for (int64_t dx = 0; dx < FW; ++dx) {
+              const float* ip = img + ((n * H + y + dy) * W + x + dx) * C;
+              float* gp = gflt + ((f * FH + dy) * FW + dx) * C;
+              for (int64_t c = 0; c < C; ++c) gp[c] += g * ip[c];
+            }
+        }
+}
+
+EXPORT void ref_conv2_nhwc_grad_image(int64_t N, int64_t H, int64_t W, int64_t C, int64_t F, int64_t FH, int64_t FW,
+                                      const float* flt, const float* gout, float* gimg) {
+  const int64_t Ho = H - FH + 1, Wo = W - FW + 1;
+  for (int64_t n = 0; n < N; ++n)
+    for (int64_t y = 0; y < Ho; ++y)
+      for (int64_t x = 0; x < Wo; ++x)
+        for (int64_t f = 0; f < F; ++f) {
+          const float g = gout[((n * Ho + y) * Wo + x) * F + f];
+          for (int64_t dy = 0; dy < FH; ++dy)
+            for (int64_t dx = 0; dx < FW; ++dx) {
+              const float* fp = flt + ((f * FH + dy) * FW + dx) * C;
+              float* gp = gimg + ((n * H + y + dy) * W + x + dx) * C;
+              for (int64_t c = 0; c < C; ++c) gp[c] += g * fp[c];
+            }
+        }
+}

@@ -52,10 +52,12 @@ def lib():
         _lib.ref_map.argtypes = [cint, i64, f32p, f32p, f32]
         _lib.ref_map_grad.argtypes = [cint, i64, f32p, f32p, f32p, f32]
         _lib.ref_conv2_nhwc.argtypes = [i64] * 7 + [f32p, f32p, f32p, cint, cint]
+        _lib.ref_conv2_nhwc_grad_filter.argtypes = [i64] * 7 + [f32p, f32p, f32p]
+        _lib.ref_conv2_nhwc_grad_image.argtypes = [i64] * 7 + [f32p, f32p, f32p]
         _lib.ref_dgemm_from_f32.argtypes = [cint, cint, i64, i64, i64, f32p, i64, f32p, i64, f64p, i64]
         for name in ("ref_sgemm", "ref_bias_add", "ref_colsum", "ref_rowsum", "ref_sum",
                      "ref_gradient_descent", "ref_axpy", "ref_map", "ref_map_grad",
-                     "ref_conv2_nhwc", "ref_dgemm_from_f32"):
+                     "ref_conv2_nhwc", "ref_conv2_nhwc_grad_filter", "ref_conv2_nhwc_grad_image", "ref_dgemm_from_f32"):
             getattr(_lib, name).restype = None
     return _lib
 
@@ -167,4 +169,24 @@ def conv2_nhwc(img, flt, out=None, threads_n=1, threads_y=1):
     if out is None:
         out = np.zeros((N, H - FH + 1, W - FW + 1, F), dtype=np.float32)
     lib().ref_conv2_nhwc(N, H, W, C, F, FH, FW, _p(img), _p(flt), _p(out), threads_n, threads_y)
+    return out
+
+
+def conv2_nhwc_grad_filter(img, gout, flt_shape, out=None):
+    img, gout = _f32(img), _f32(gout)
+    N, H, W, C = img.shape
+    F, FH, FW, _ = flt_shape
+    if out is None:
+        out = np.zeros(flt_shape, dtype=np.float32)
+    lib().ref_conv2_nhwc_grad_filter(N, H, W, C, F, FH, FW, _p(img), _p(gout), _p(out))
+    return out
+
+
+def conv2_nhwc_grad_image(flt, gout, img_shape, out=None):
+    flt, gout = _f32(flt), _f32(gout)
+    N, H, W, C = img_shape
+    F, FH, FW, _ = flt.shape
+    if out is None:
+        out = np.zeros(img_shape, dtype=np.float32)
+    lib().ref_conv2_nhwc_grad_image(N, H, W, C, F, FH, FW, _p(flt), _p(gout), _p(out))
     return out

@@ -1,0 +1,104 @@
+"""The two gradients of conv2 as library kernels (eg_conv2_nhwc_grad_filter / _grad_image) against
+the oracle's loop nests (oracle/refcpu.c), and through the model path (derive -> matcher -> the
+same kernels) against the oracle's graph executor."""
+import numpy as np
+import pytest
+
+import refcases
+from conftest import TOL, rel_err
+from exprgrad_amd import dsl, layers, ops
+from exprgrad_amd import model as egm
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(ctx, arr):
+    t = ctx.allocTensor(arr.shape)
+    t.write(arr)
+    return t
+
+
+SHAPES = [  # N, H, W, C, F, FH, FW
+    (1, 8, 8, 4, 4, 3, 3), (2, 12, 10, 8, 16, 3, 3), (1, 9, 7, 3, 5, 2, 3), (2, 20, 20, 32, 64, 3, 3),
+    (1, 34, 34, 64, 64, 3, 3), (3, 6, 6, 4, 8, 1, 1), (1, 5, 5, 4, 4, 5, 5), (2, 7, 9, 5, 6, 3, 2),
+    (1, 40, 36, 16, 32, 5, 5), (4, 16, 16, 64, 32, 3, 3),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv2_gradients_against_the_oracle(gpu_ctx, refcpu, shape):
+    N, H, W, C, F, FH, FW = shape
+    rng = np.random.default_rng(sum(shape))
+    img = rng.random((N, H, W, C), dtype=np.float32)
+    flt = (rng.random((F, FH, FW, C), dtype=np.float32) * 2 - 1).astype(np.float32)
+    gout = (rng.random((N, H - FH + 1, W - FW + 1, F), dtype=np.float32) - 0.5).astype(np.float32)
+    dimg, dflt, dg = dev(gpu_ctx, img), dev(gpu_ctx, flt), dev(gpu_ctx, gout)
+
+    gflt = gpu_ctx.allocTensor(flt.shape)
+    gflt.write(np.full(flt.shape, 7.0, dtype=np.float32))            # must be overwritten
+    ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dg, gflt)
+    want = refcpu.conv2_nhwc_grad_filter(img, gout, flt.shape)
+    assert rel_err(gflt.read(), want) <= TOL
+    base = rng.random(flt.shape, dtype=np.float32)
+    gflt.write(base)
+    ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dg, gflt, accumulate=True)
+    assert rel_err(gflt.read(), refcpu.conv2_nhwc_grad_filter(img, gout, flt.shape, out=base.copy())) <= TOL
+
+    gimg = gpu_ctx.allocTensor(img.shape)
+    gimg.write(np.full(img.shape, -3.0, dtype=np.float32))
+    ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dg, gimg)
+    want = refcpu.conv2_nhwc_grad_image(flt, gout, img.shape)
+    assert rel_err(gimg.read(), want) <= TOL
+    base = rng.random(img.shape, dtype=np.float32)
+    gimg.write(base)
+    ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dg, gimg, accumulate=True)
+    assert rel_err(gimg.read(), refcpu.conv2_nhwc_grad_image(flt, gout, img.shape, out=base.copy())) <= TOL
+
+
+def test_gradient_kernels_are_deterministic(gpu_ctx):
+    N, H, W, C, F, FH, FW = 2, 40, 40, 16, 32, 3, 3      # split-K over 2888 pixels
+    rng = np.random.default_rng(0)
+    dimg = dev(gpu_ctx, rng.random((N, H, W, C), dtype=np.float32))
+    dg = dev(gpu_ctx, rng.random((N, H - 2, W - 2, F), dtype=np.float32))
+    outs = []
+    for _ in range(2):
+        gflt = gpu_ctx.allocTensor((F, FH, FW, C))
+        ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dg, gflt)
+        outs.append(gflt.read())
+    assert np.array_equal(outs[0], outs[1])
+
+
+def cnn(c_in=4, f1=8, f2=16, rate=0.05):
+    """conv2 -> relu -> conv2 -> mse -> gradientDescent: both gradient forms appear in `train`
+    (filter gradients of both layers, image gradient of the second)."""
+    x = dsl.input("x")
+    net = layers.conv2(x, dsl.param([f1, 3, 3, c_in], name="k1"))
+    net = layers.relu(net)
+    net = layers.conv2(net, dsl.param([f2, 3, 3, f1], name="k2")).target("predict")
+    net = layers.mse(net, dsl.input("y")).target("loss")
+    return [net.backprop(layers.gradient_descent(rate)).target("train")]
+
+
+@pytest.mark.parametrize("dims", [(2, 24, 24, 4, 8, 16), (1, 40, 36, 3, 5, 6), (2, 14, 14, 32, 64, 32)])
+def test_cnn_train_step_matches_the_oracle(gpu_ctx, dims):
+    from oracle import kd
+    n, h, w, c_in, f1, f2 = dims
+    gpu = egm.compile(*cnn(c_in, f1, f2), gpu=gpu_ctx)
+    ref = kd.Model(refcases.program_text(cnn(c_in, f1, f2)), threads=4)
+    rng = np.random.default_rng(h * w)
+    for tid in sorted(ref.params):
+        v = (rng.random(ref.params[tid].shape, dtype=np.float32) * 0.4 - 0.2).astype(np.float32)
+        ref.params[tid][...] = v
+        gpu.params[tid] = v
+    x = rng.random((n, h, w, c_in), dtype=np.float32)
+    y = rng.random((n, h - 4, w - 4, f2), dtype=np.float32)
+    assert rel_err(gpu.call("predict", {"x": x}), ref.call("predict", {"x": x})) <= TOL
+    before = {t: ref.params[t].copy() for t in ref.params}
+    gpu.apply("train", {"x": x, "y": y})
+    ref.apply("train", {"x": x, "y": y})
+    plan = gpu.launch_plan("train")
+    assert plan.count("conv2-grad-filter") == 2 and plan.count("conv2-grad-image") == 1, plan
+    for tid in sorted(ref.params):
+        du_gpu, du_ref = gpu.params[tid] - before[tid], ref.params[tid] - before[tid]
+        assert rel_err(du_gpu, du_ref) <= 2e-5 + 1e-7 / max(np.abs(du_ref).max(), 1e-30), (tid, plan)
+    gpu.close()
