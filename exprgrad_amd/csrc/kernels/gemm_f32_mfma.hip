@@ -159,7 +159,16 @@ double tile_cost(const TileCfg& t, long M, long N, long k_tiles, int cus, int& s
     // only the matrix work shrinks (operand staging does not): credit half of it
     fill = 0.5 + 0.5 * (m32 * n32) / ((double)tm * t.bm * (double)tn * t.bn);
   }
-  double cost = (double)rounds * t.blocks_per_cu * t.bm * t.bn * (double)per * fill / eff;
+  // a partial last round: its blocks have their CU (almost) to themselves and finish sooner than a
+  // full round of co-resident blocks — but never faster than about 1.3 / blocks_per_cu of it
+  const long tail = blocks % slots;
+  double eff_rounds = (double)(blocks / slots);
+  if (tail) {
+    const double alone = 1.3 / t.blocks_per_cu < 1.0 ? 1.3 / t.blocks_per_cu : 1.0;
+    const double share = (double)tail / (double)slots;
+    eff_rounds += share > alone ? share : alone;
+  }
+  double cost = eff_rounds * t.blocks_per_cu * t.bm * t.bn * (double)per * fill / eff;
   // split-K with a ragged last tile row: run_gemm cuts those tiles into fewer slices, the k-slices
   // of the full tiles shrink accordingly
   const long m_rest = M % t.bm;

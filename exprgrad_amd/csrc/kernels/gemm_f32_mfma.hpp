@@ -331,9 +331,10 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
 // the slot permutation c ^ ((r >> 1) & 7), with the same conflict-free property.
 // CONV: the k-contiguous A operand is the virtual im2col matrix, its rows gathered from the NHWC
 // image (requires C % BK == 0 so that a k-tile lies inside one filter tap).
-// CLAMP (ragged M / N tiles): rows past the end of the operand re-read its last row (k-contiguous)
-// or its last 16-byte column chunk (m|n-contiguous) — always valid memory; what they produce lands
-// in accumulator rows / columns the epilogue never stores.
+// CLAMP (ragged tiles): rows past the end of the operand re-read its last row (k-contiguous) or
+// its last 16-byte column chunk (m|n-contiguous) — always valid memory; what they produce lands
+// in accumulator rows / columns the epilogue never stores.  Past the end of K both operands re-read
+// their last k, and the main loop zeroes the A side of those k in LDS.
 template <int BMN, int BK, int NT, bool KC, bool CONV, bool CLAMP = false>
 struct DmaLoader {
   static constexpr int INSTRS = BK * BMN / 256;  // 1 KiB wave instructions per tile
@@ -361,7 +362,7 @@ struct DmaLoader {
 
   // issue this wave's share of the tile whose origin is (mn0, k0) into `tile` (LDS, lane-linear)
   __device__ __forceinline__ void issue(const GemmArgs& a, const float* __restrict__ base, long ld, long mn0, long k0,
-                                        float* tile, int wave, int lane, long limit = 0) const {
+                                        float* tile, int wave, int lane, long limit = 0, long k_lim = 0) const {
     long tap_off = 0;
     if (CONV) {  // block-uniform: scalar work
       const unsigned C = (unsigned)a.cC, FW = (unsigned)a.cFW;
@@ -380,11 +381,11 @@ struct DmaLoader {
         if (CONV)
           src = base + row_off[t] + tap_off + c * 4;
         else
-          src = base + (CLAMP ? min(mn0 + r, limit - 1) : mn0 + r) * ld + k0 + c * 4;
+          src = base + (CLAMP ? min(mn0 + r, limit - 1) : mn0 + r) * ld + (CLAMP ? min(k0 + c * 4, k_lim - 4) : k0 + c * 4);
       } else {
         constexpr int CPR = BMN / 4;
         const int k = q / CPR, col = (q % CPR) * 4;
-        src = base + (k0 + k) * ld + (CLAMP ? min(mn0 + col, limit - 4) : mn0 + col);
+        src = base + (CLAMP ? min(k0 + k, k_lim - 1) : k0 + k) * ld + (CLAMP ? min(mn0 + col, limit - 4) : mn0 + col);
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(tile + instr * 256), 16, 0, 0);
@@ -395,7 +396,7 @@ struct DmaLoader {
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool CONV, bool CL = false>
 __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32],
                                                   long m_blk, long n_blk, long k_begin, int nk, int tid, int wm0,
-                                                  int wn0) {
+                                                  int wn0, long k_end = 0) {
   static_assert(BK == 16 || BK == 32, "LDS-DMA loop: BK is 16 or 32");
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
   constexpr int MI = WM / 32, NI = WN / 32;
@@ -423,9 +424,10 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
   da.init(a, m_blk, wave, lane);
   db.init(a, n_blk, wave, lane);
   if (nk > 0) {
-    da.issue(a, a.A, a.lda, m_blk, k_begin, lds, wave, lane, a.M);
-    db.issue(a, a.B, a.ldb, n_blk, k_begin, lds + BK * BM, wave, lane, a.N);
+    da.issue(a, a.A, a.lda, m_blk, k_begin, lds, wave, lane, a.M, k_end);
+    db.issue(a, a.B, a.ldb, n_blk, k_begin, lds + BK * BM, wave, lane, a.N, k_end);
   }
+  const int k_tail = CL ? (int)((k_end - k_begin) % BK) : 0;  // valid k of a ragged last k-tile (0 = full)
   __syncthreads();  // hipcc drains vmcnt before the barrier while an LDS-DMA is in flight
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -433,8 +435,23 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
     if (kt + 1 < nk) {
       const long k0 = k_begin + (long)(kt + 1) * BK;
       float* nxt = lds + (cur ^ 1) * BUF;
-      da.issue(a, a.A, a.lda, m_blk, k0, nxt, wave, lane, a.M);
-      db.issue(a, a.B, a.ldb, n_blk, k0, nxt + BK * BM, wave, lane, a.N);
+      da.issue(a, a.A, a.lda, m_blk, k0, nxt, wave, lane, a.M, k_end);
+      db.issue(a, a.B, a.ldb, n_blk, k0, nxt + BK * BM, wave, lane, a.N, k_end);
+    }
+    if (CL && k_tail != 0 && kt == nk - 1) {
+      // ragged end of K: the loaders re-read the last valid k for the missing ones; zero them on
+      // the A side so they contribute nothing
+      float* At = lds + cur * BUF;
+      const int width = BK - k_tail;
+      for (int e = tid; e < BM * width; e += NT) {
+        if (A_KC) {
+          const int r = e / width, k = k_tail + e % width;
+          At[r * BK + (((k >> 2) ^ DmaA::swizzle(r)) << 2) + (k & 3)] = 0.f;
+        } else {
+          At[k_tail * BM + e] = 0.f;
+        }
+      }
+      __syncthreads();
     }
     const float* As = lds + cur * BUF;
     const float* Bs = As + BK * BM;
@@ -554,10 +571,10 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   if (DMA && (!EDGE || (m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0))) {
     static_assert(!DMA || CONV != 2, "the filter-gradient gather runs on the register-staged loop");
     gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV == 1>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
-  } else if (DMA && EDGE && !CONV && (k_end - k_begin) % BK == 0) {
-    // ragged in M or N only: still the LDS-DMA loop, with clamped row addresses
+  } else if (DMA && EDGE && !CONV) {
+    // ragged in M, N or K: still the LDS-DMA loop, with clamped addresses and a zeroed K tail
     gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, false, true>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0,
-                                                                     wn0);
+                                                                     wn0, k_end);
   } else if (EDGE) {
     const bool interior = m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0;
     if (interior)
@@ -578,6 +595,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   const long ldo = to_partial ? a.N : a.ldc;
   const bool accumulate = !to_partial && a.accumulate;
   const bool has_bias = !to_partial && a.bias != nullptr;
+  const bool whole_tile = m_blk + BM <= a.M && n_blk + BN <= a.N;
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -590,7 +608,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
       float* col = out + n;
       if (Epi::ACTIVE) {
         float x[16][Epi::NX];
-        if (!EDGE || (m_blk + BM <= a.M && n_blk + BN <= a.N)) {  // whole tile inside: branch-free, loads batched
+        if (!EDGE || whole_tile) {  // whole tile inside: branch-free, loads batched
 #pragma unroll
           for (int r = 0; r < 16; ++r) Epi::prefetch(a, (m_base + (r & 3) + 8 * (r >> 2)) * ldo + n, x[r]);
 #pragma unroll
@@ -605,18 +623,29 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
             Epi::apply(a, m * ldo + n, acc[i][j][r] + bias, x[r]);
           }
         }
+      } else if (!EDGE || whole_tile) {  // branch-free: the 16 stores (and loads) of a block are issued back to back
+        if (accumulate) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const long m = m_base + (r & 3) + 8 * (r >> 2);
+            col[m * ldo] = (col[m * ldo] + acc[i][j][r]) + bias;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) col[(m_base + (r & 3) + 8 * (r >> 2)) * ldo] = acc[i][j][r] + bias;
+        }
       } else if (accumulate) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const long m = m_base + (r & 3) + 8 * (r >> 2);
-          if (EDGE && (m >= a.M || !n_ok)) continue;
+          if (m >= a.M || !n_ok) continue;
           col[m * ldo] = (col[m * ldo] + acc[i][j][r]) + bias;
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const long m = m_base + (r & 3) + 8 * (r >> 2);
-          if (EDGE && (m >= a.M || !n_ok)) continue;
+          if (m >= a.M || !n_ok) continue;
           col[m * ldo] = acc[i][j][r] + bias;
         }
       }
@@ -624,9 +653,21 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   }
 }
 
+// Waves per SIMD the register allocator must leave room for.  The ragged-tile variants of the
+// 64-wide tiles need a few registers more than the 128 that four waves allow (they spilled 2-38
+// VGPRs to scratch): three waves there.
+// The unaligned (VEC = 1) variants stage element by element and need far more: two waves.
+template <int BM, int BN, int WM, int WN, int MINB, bool EDGE, int VEC>
+struct WavesPerSimd {
+  static constexpr int plain = (MINB * Geometry<BM, BN, WM, WN>::WAVES + 3) / 4;
+  static constexpr int value = (EDGE && VEC == 1 && BM * BN >= 128 * 64 && plain > 2) ? 2
+                               : (EDGE && BN == 64 && BM >= 128 && plain == 4)        ? 3
+                                                                                       : plain;
+};
+
 template <int BM, int BN, int BK, int WM, int WN, int MINB, bool A_KC, bool B_KC, int VEC, bool EDGE, int CONV,
           int ABL = 0, bool DMA = false>
-__global__ __launch_bounds__((Geometry<BM, BN, WM, WN>::NT), (MINB * Geometry<BM, BN, WM, WN>::WAVES + 3) / 4) void
+__global__ __launch_bounds__((Geometry<BM, BN, WM, WN>::NT), (WavesPerSimd<BM, BN, WM, WN, MINB, EDGE, VEC>::value)) void
 gemm_f32_mfma_kernel(GemmArgs a) {
   gemm_block<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, EDGE, CONV, ABL, DMA, EpiNone>(a);
 }
