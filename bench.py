@@ -266,13 +266,23 @@ def run_conv2(args, env):
         lambda: ops.conv2_nhwc(ctx, N, H, W, C, F, FH, FW, img, flt, out), steps, args.warmup)
     flops = 2.0 * N * (H - FH + 1) * (W - FW + 1) * F * FH * FW * C
     achieved = flops / (ev_avg * 1e-3) / 1e12
+    # the two gradients derive makes of conv2 (same FLOP count each), for the record
+    gout = torch.rand(out.shape, device="cuda", generator=gen) - 0.5
+    gflt, gimg = torch.empty_like(flt), torch.empty_like(img)
+    _, gf_avg, _ = env["timer"].run(
+        lambda: ops.conv2_nhwc_grad_filter(ctx, N, H, W, C, F, FH, FW, img, gout, gflt), steps, args.warmup)
+    _, gi_avg, _ = env["timer"].run(
+        lambda: ops.conv2_nhwc_grad_image(ctx, N, H, W, C, F, FH, FW, flt, gout, gimg), steps, args.warmup)
+    backward = {"grad_filter_ms": round(gf_avg, 4), "grad_filter_tflops": round(flops / (gf_avg * 1e-3) / 1e12, 2),
+                "grad_image_ms": round(gi_avg, 4), "grad_image_tflops": round(flops / (gi_avg * 1e-3) / 1e12, 2)}
     return {"metric": "GFLOP/s conv2 3x3 256x256x64->64 f32", "value": round(flops * steps / elapsed / 1e9, 1),
             "unit": "GFLOP/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": measured_traffic("conv2"),
                          "kernel": "gemm_f32_mfma_kernel<64,64,32,32,32,NT,conv,DMA gather>", "flops_per_launch": flops,
-                         "kernel_ms_avg": round(ev_avg, 4)}}
+                         "kernel_ms_avg": round(ev_avg, 4)},
+            "backward": backward}
 
 
 def main():

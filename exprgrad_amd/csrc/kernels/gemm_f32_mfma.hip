@@ -195,7 +195,9 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
   for (int c = 0; c < NCFG; ++c) {
     if (forced_bm && (cfgs[c].bm != forced_bm || cfgs[c].bn != forced_bn)) continue;
     if (!forced_bm) {
-      if (cfgs[c].bn == 64 && N > 64) continue;
+      // 64-wide tiles: narrow outputs, or a single tile row (M <= BM: the filter gradient of a
+      // convolution, M = F)
+      if (cfgs[c].bn == 64 && N > 64 && M > cfgs[c].bm) continue;
       if (cfgs[c].bn == 32 && N > 32) continue;
       if (cfgs[c].bn >= 128 && N <= 64) continue;
     }
