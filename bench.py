@@ -205,6 +205,20 @@ def run_train(args, env):
     model, dp, x, y = build_dense(env, batch)
     world = env["world"]
     inputs = [("x", x), ("y", y)]
+    single = None
+    if world > 1:
+        # the same step on this GPU's shard without the gradient exchange, in the same run: the
+        # 1-GPU point of the scaling series (the N = 1 invocation reports matmul as its primary metric)
+        eng = dp.engine
+
+        def alone():
+            eng.set_grad_scale(1.0)
+            eng.run_backward(inputs)
+            eng.run_update()
+        k1 = min(args.steps, 20)
+        t1, _, _ = env["timer"].run(alone, k1, 3)
+        single = {"value": round(batch * k1 / t1, 1), "unit": "samples/s", "ms_per_step": round(t1 / k1 * 1e3, 4),
+                  "note": "one GPU's shard, no all-reduce, slowest rank; N-GPU value / (N x this) = scaling efficiency"}
     elapsed, ev_avg, ev_min = env["timer"].run(lambda: dp.step(inputs), args.steps, args.warmup)
     samples = batch * world * args.steps
     step_flops = DENSE_FLOPS_PER_SAMPLE * batch
@@ -227,6 +241,8 @@ def run_train(args, env):
                      "flops_per_launch": step_flops, "kernel_ms_avg": round(ev_avg, 4),
                      "kernel_ms_min": round(ev_min, 4)},
     }
+    if single:
+        out["single_gpu_reference"] = single
     return out, model
 
 
@@ -293,9 +309,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hook (one-GPU boxes): EG_BENCH_ONE_GPU=1 puts every rank on cuda:0 and exchanges over gloo,
+    # which exercises the N > 1 code path (sharding, barrier, max over ranks) without RCCL
+    one_gpu = os.environ.get("EG_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import exprgrad_amd as eg
     from exprgrad_amd import ops
@@ -337,6 +361,9 @@ def main():
             extra["xor"] = run_xor(small, env)
             extra["conv2"] = run_conv2(small, env)
             line["extra"] = extra
+            # the --gpus N > 1 invocations report the data-parallel train step; its 1-GPU point:
+            line["scaling_series_n1"] = {"metric": extra["train"]["metric"], "value": extra["train"]["value"],
+                                         "unit": extra["train"]["unit"], "ms_per_step": extra["train"]["ms_per_step"]}
         if not args.no_cpu_baseline:
             if workload == "matmul":
                 line["cpu_baseline"] = cpu_baseline_matmul(args.size)
