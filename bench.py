@@ -296,7 +296,7 @@ def run_conv2(args, env):
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": measured_traffic("conv2"),
-                         "kernel": "gemm_f32_mfma_kernel<64,64,32,32,32,NT,conv,DMA gather>", "flops_per_launch": flops,
+                         "kernel": "conv2_halo_kernel<9,3,3> (LDS-resident 10x34 halo, 8x32 patch x 64 filters per block)", "flops_per_launch": flops,
                          "kernel_ms_avg": round(ev_avg, 4)},
             "backward": backward}
 

@@ -80,6 +80,9 @@ struct RowFinalizeArgs {
   int nseg;
 };
 int row_finalize(eg_ctx* ctx, const float* partial, int nblocks, int E, const RowFinalizeArgs& args);
+// LDS-halo convolution (kernels/conv2_halo.hip); *launched = false when the problem does not suit it.
+int conv2_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
+                   const float* flt, float* out, int accumulate, bool* launched);
 inline int set_device(eg_ctx* ctx) {
   EG_HIP_CHECK(hipSetDevice(ctx->device));
   return EG_OK;

@@ -354,6 +354,11 @@ extern "C" int eg_conv2_nhwc(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64
   EG_REQUIRE(out && (C == 0 || (img && flt)), EG_ERR_INVALID, "eg_conv2_nhwc: NULL tensor");
   int rc = eg::set_device(ctx);
   if (rc) return rc;
+  if (C > 0) {  // 3x3-class filters on full-sized images: the LDS-halo kernel
+    bool launched = false;
+    rc = eg::conv2_halo_try(ctx, N, H, W, C, F, FH, FW, img, flt, out, accumulate, &launched);
+    if (rc || launched) return rc;
+  }
   GemmArgs args = {};
   args.A = img;
   args.B = flt;

@@ -102,3 +102,28 @@ def test_cnn_train_step_matches_the_oracle(gpu_ctx, dims):
         du_gpu, du_ref = gpu.params[tid] - before[tid], ref.params[tid] - before[tid]
         assert rel_err(du_gpu, du_ref) <= 2e-5 + 1e-7 / max(np.abs(du_ref).max(), 1e-30), (tid, plan)
     gpu.close()
+
+
+HALO_SHAPES = [  # N, H, W, C, F, FH, FW — at least 128 patches of 16x16 pixels: the LDS-halo kernel
+    (8, 66, 66, 16, 64, 3, 3), (2, 130, 70, 32, 64, 3, 3), (9, 64, 64, 16, 96, 1, 1), (3, 100, 120, 48, 40, 2, 3),
+    (1, 250, 131, 16, 128, 3, 1),
+]
+
+
+@pytest.mark.parametrize("shape", HALO_SHAPES)
+def test_halo_convolution_against_the_oracle(gpu_ctx, refcpu, monkeypatch, shape):
+    N, H, W, C, F, FH, FW = shape
+    rng = np.random.default_rng(sum(shape))
+    img = rng.random((N, H, W, C), dtype=np.float32)
+    flt = (rng.random((F, FH, FW, C), dtype=np.float32) * 2 - 1).astype(np.float32)
+    want = refcpu.conv2_nhwc(img, flt, threads_n=N, threads_y=max(1, 16 // N))
+    dimg, dflt = dev(gpu_ctx, img), dev(gpu_ctx, flt)
+    out = gpu_ctx.allocTensor(want.shape)
+    out.write(np.full(want.shape, 5.0, dtype=np.float32))
+    ops.conv2_nhwc(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dflt, out)
+    got = out.read()
+    assert rel_err(got, want) <= TOL
+    base = rng.random(want.shape, dtype=np.float32)
+    out.write(base)
+    ops.conv2_nhwc(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dflt, out, accumulate=True)
+    assert rel_err(out.read(), want + base) <= TOL
