@@ -354,6 +354,8 @@ extern "C" int eg_conv2_nhwc(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64
   EG_REQUIRE(out && (C == 0 || (img && flt)), EG_ERR_INVALID, "eg_conv2_nhwc: NULL tensor");
   int rc = eg::set_device(ctx);
   if (rc) return rc;
+  if (FH == 1 && FW == 1 && C > 0)  // a 1x1 filter bank is a plain contraction over the channels: out[P,F] = img[P,C] * flt[F,C]^T
+    return eg_sgemm(ctx, 0, 1, N * H * W, F, C, img, C, flt, C, out, F, accumulate, nullptr);
   if (C > 0) {  // 3x3-class filters on full-sized images: the LDS-halo kernel
     bool launched = false;
     rc = eg::conv2_halo_try(ctx, N, H, W, C, F, FH, FW, img, flt, out, accumulate, &launched);
@@ -441,6 +443,8 @@ extern "C" int eg_conv2_nhwc_grad_filter(eg_ctx* ctx, int64_t N, int64_t H, int6
     return EG_OK;
   }
   EG_REQUIRE(img && gout, EG_ERR_INVALID, "eg_conv2_nhwc_grad_filter: NULL tensor");
+  if (FH == 1 && FW == 1)  // plain contraction: gflt[F,C] = gout[P,F]^T * img[P,C]
+    return eg_sgemm(ctx, 1, 0, F, C, P, gout, F, img, C, gflt, C, accumulate, nullptr);
   EG_REQUIRE(P < (1L << 31) && FH * FW * C < (1L << 31), EG_ERR_INVALID,
              "eg_conv2_nhwc_grad_filter: more than 2^31 output pixels or taps");
   GemmArgs args = {};
@@ -486,6 +490,8 @@ extern "C" int eg_conv2_nhwc_grad_image(eg_ctx* ctx, int64_t N, int64_t H, int64
     return EG_OK;
   }
   EG_REQUIRE(flt && gout, EG_ERR_INVALID, "eg_conv2_nhwc_grad_image: NULL tensor");
+  if (FH == 1 && FW == 1)  // plain contraction: gimg[P,C] = gout[P,F] * flt[F,C]
+    return eg_sgemm(ctx, 0, 0, N * H * W, C, F, gout, F, flt, C, gimg, C, accumulate, nullptr);
   const long Hp = Ho + 2 * (FH - 1), Wp = Wo + 2 * (FW - 1);
   const size_t pad_floats = ((size_t)(N * Hp * Wp * F) + 3) & ~(size_t)3;
   const size_t flt_floats = (size_t)(C * FH * FW * F);
