@@ -394,16 +394,28 @@ extern "C" int eg_conv2_nhwc(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64
 
 namespace {
 
-// gOut [N,Ho,Wo,F] -> zero-bordered [N, Ho + 2(FH-1), Wo + 2(FW-1), F]
-__global__ __launch_bounds__(256) void pad_gradient_kernel(const float* __restrict__ g, float* __restrict__ out, long N,
-                                                           long Ho, long Wo, long F, long ph, long pw) {
-  const long Hp = Ho + 2 * ph, Wp = Wo + 2 * pw;
-  const long total = N * Hp * Wp * F;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long f = i % F, p = i / F;
-    const long x = p % Wp - pw, q = p / Wp;
-    const long y = q % Hp - ph, n = q / Hp;
-    out[i] = (y >= 0 && y < Ho && x >= 0 && x < Wo) ? g[((n * Ho + y) * Wo + x) * F + f] : 0.f;
+// gOut [N,Ho,Wo,F] -> zero-bordered [N, Ho + 2(FH-1), Wo + 2(FW-1), F].  One thread per VEC floats
+// of one padded pixel; 32-bit index arithmetic (the host checks the sizes).
+template <int VEC>
+__global__ __launch_bounds__(256) void pad_gradient_kernel(const float* __restrict__ g, float* __restrict__ out,
+                                                           unsigned pixels, unsigned Hp, unsigned Wp, unsigned Ho,
+                                                           unsigned Wo, unsigned F, unsigned ph, unsigned pw) {
+  const unsigned per_pixel = F / VEC;
+  const unsigned total = pixels * per_pixel;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const unsigned p = i / per_pixel, f = (i - p * per_pixel) * VEC;
+    const unsigned xp = p % Wp, q = p / Wp;
+    const unsigned yp = q % Hp, n = q / Hp;
+    const unsigned y = yp - ph, x = xp - pw;  // wraps to a huge value left of / above the image
+    const bool inside = y < Ho && x < Wo;
+    const size_t src = ((size_t)(n * Ho + y) * Wo + x) * F + f;
+    if (VEC == 4) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (inside) v = *reinterpret_cast<const f32x4*>(g + src);
+      *reinterpret_cast<f32x4*>(out + (size_t)p * F + f) = v;
+    } else {
+      out[(size_t)p * F + f] = inside ? g[src] : 0.f;
+    }
   }
 }
 
@@ -499,9 +511,18 @@ extern "C" int eg_conv2_nhwc_grad_image(eg_ctx* ctx, int64_t N, int64_t H, int64
   if (rc) return rc;
   float* padded = static_cast<float*>(ctx->aux);
   float* flipped = padded + pad_floats;
-  const long blocks = std::min<long>(((long)pad_floats + 255) / 256, 8L * ctx->compute_units);
-  hipLaunchKernelGGL(pad_gradient_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, gout, padded, (long)N, Ho,
-                     Wo, (long)F, (long)FH - 1, (long)FW - 1);
+  EG_REQUIRE(N * Hp * Wp * F < (1L << 32), EG_ERR_INVALID, "eg_conv2_nhwc_grad_image: padded gradient exceeds 2^32 elements");
+  const bool vec4 = F % 4 == 0 && aligned16(gout);
+  const long work = N * Hp * Wp * (vec4 ? F / 4 : F);
+  const long blocks = std::min<long>((work + 255) / 256, 16L * ctx->compute_units);
+  if (vec4)
+    hipLaunchKernelGGL(pad_gradient_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, gout, padded,
+                       (unsigned)(N * Hp * Wp), (unsigned)Hp, (unsigned)Wp, (unsigned)Ho, (unsigned)Wo, (unsigned)F,
+                       (unsigned)(FH - 1), (unsigned)(FW - 1));
+  else
+    hipLaunchKernelGGL(pad_gradient_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, gout, padded,
+                       (unsigned)(N * Hp * Wp), (unsigned)Hp, (unsigned)Wp, (unsigned)Ho, (unsigned)Wo, (unsigned)F,
+                       (unsigned)(FH - 1), (unsigned)(FW - 1));
   const long fblocks = std::min<long>(((long)flt_floats + 255) / 256, 8L * ctx->compute_units);
   hipLaunchKernelGGL(flip_filter_kernel, dim3((unsigned)fblocks), dim3(256), 0, ctx->stream, flt, flipped, (long)F,
                      (long)FH, (long)FW, (long)C);

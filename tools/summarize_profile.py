@@ -34,7 +34,8 @@ def short(name):
 
 
 def ours(name):
-    return name.startswith("eg") or "colsum" in name or "rowsum" in name or "eg::" in name or "eg_" in name
+    return (name.startswith("eg") or "eg::" in name or "eg_" in name or
+            any(k in name for k in ("colsum", "rowsum", "conv2_halo", "pad_gradient", "flip_filter")))
 
 
 def main():
