@@ -80,11 +80,22 @@ class Timer:
         ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
         gc.collect()
         gc.disable()  # a generation-2 collection inside a 25 us step would dominate it
-        t_end = time.perf_counter() + 0.2
-        while time.perf_counter() < t_end:
-            for _ in range(8):
-                step()
-            torch.cuda.synchronize()
+        # The number of spin-up steps must be the same on every rank (a step may contain a
+        # collective): time 8 steps, agree on the slowest rank's estimate, derive the count from it.
+        t_probe = time.perf_counter()
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        per_step = (time.perf_counter() - t_probe) / 8
+        if self.world > 1:
+            t = torch.tensor([per_step], device="cuda", dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            per_step = float(t.item())
+        spin = min(4096, max(8, int(0.2 / max(per_step, 1e-6))))
+        for i in range(spin):
+            step()
+            if i % 64 == 63:
+                torch.cuda.synchronize()
         for _ in range(warmup):
             step()
         self.sync()
