@@ -71,6 +71,9 @@ struct Emitter {
 
   // loads + expression, at indentation of the innermost body
   void emit_body(std::string& out) {
+    // computed indices first (`y div 2`): Index instructions over iterators and host values
+    for (auto& ins : k.index_instrs)
+      out += "      const long " + reg(ins.res) + " = " + instr_expression(ins, "0L", "r") + ";\n";
     for (size_t i = 0; i < k.reads.size(); ++i) {
       const Op& r = k.reads[i];
       out += "      const float " + reg(r.reg) + " = t" + std::to_string(r.tensor) + "[" + flat_index(r, (int)i) + "];\n";
@@ -199,12 +202,17 @@ void split_loops(const Kernel& k, std::vector<int>& indep, std::vector<int>& red
     if (!ind_regs.count(k.loops[l].reg)) red.push_back((int)l);
   scatter = false;
   for (auto& d : k.write.dims)
-    for (auto& f : d.factors)
+    for (auto& f : d.factors) {
       for (int l : red)
         if (k.loops[l].reg == f.first) scatter = true;
+      // a computed index (`y div 2`) moves with the iterators it is computed from
+      for (auto& ins : k.index_instrs)
+        if (ins.res == f.first) scatter = true;
+    }
 }
 
 bool split_reduction_capable(const Kernel& k) {
+  if (!k.index_instrs.empty()) return false;
   std::vector<int> indep, red;
   bool scatter;
   split_loops(k, indep, red, scatter);
@@ -229,6 +237,11 @@ bool split_reduction_capable(const Kernel& k) {
 }
 
 int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out) {
+  for (auto& ins : k.index_instrs)
+    if (ins.kind == IK::Shape || ins.kind == IK::Len || ins.kind == IK::ShapeLen || ins.kind == IK::Epoch) {
+      set_error("shape()/len()/epoch() inside a computed tensor index is not supported");
+      return EG_ERR_UNSUPPORTED;
+    }
   Emitter em(k);
   out = GenericSource();
   out.name = name;

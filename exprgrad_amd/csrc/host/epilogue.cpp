@@ -42,7 +42,7 @@ bool flat_index(const Op& op, const std::vector<long>& shape, std::map<int, long
 }  // namespace
 
 bool epilogue_capable(const Kernel& k, const KernelInfo& info, const Shapes& shapes, int c_tensor, long M, long N) {
-  if (!info.ok || k.is_seed || k.gen != Gen::None) return false;
+  if (!info.ok || k.is_seed || k.gen != Gen::None || !k.index_instrs.empty()) return false;
   std::vector<int> indep, red;
   bool scatter;
   split_loops(k, indep, red, scatter);

@@ -175,7 +175,8 @@ int parse(const char* text, Program& prog) {
   std::string line;
   Target* target = nullptr;
   Kernel* kernel = nullptr;
-  Kernel cur;
+  Kernel cur, grad_cur;    // grad_cur: a kernel of cur's customgrad block
+  bool in_custom = false;
   int lineno = 0;
   bool header = false;
   while (std::getline(in, line)) {
@@ -241,17 +242,40 @@ int parse(const char* text, Program& prog) {
       target = &prog.targets.back();
     } else if (kw == "endtarget") {
       target = nullptr;
+    } else if (kw == "shapesetup") {
+      long a;
+      if (!tk.next_long(a)) P_FAIL("kd line %d: bad shapesetup", lineno);
+      Instr ins;
+      int rc = parse_instr(tk, ins);
+      if (rc) return rc;
+      prog.shape_setup[(int)a].push_back(ins);
     } else if (kw == "kernel") {
       if (!target) P_FAIL("kd line %d: kernel outside a target", lineno);
-      cur = Kernel();
+      if (kernel) P_FAIL("kd line %d: kernel inside a kernel (missing customgrad?)", lineno);
+      Kernel& dst = in_custom ? grad_cur : cur;
+      dst = Kernel();
       long n;
       if (!tk.next_long(n)) P_FAIL("kd line %d: bad register count", lineno);
-      cur.nregs = (int)n;
-      kernel = &cur;
+      dst.nregs = (int)n;
+      kernel = &dst;
     } else if (kw == "endkernel") {
       if (!kernel || !target) P_FAIL("kd line %d: stray endkernel", lineno);
-      target->source.push_back(cur);
+      if (kernel == &grad_cur) {
+        cur.custom_grad.push_back(grad_cur);
+        kernel = nullptr;
+      } else {
+        target->source.push_back(cur);
+        kernel = nullptr;
+      }
+    } else if (kw == "customgrad") {
+      if (kernel != &cur || in_custom) P_FAIL("kd line %d: customgrad outside a kernel", lineno);
+      cur.has_custom_grad = true;
+      in_custom = true;
       kernel = nullptr;
+    } else if (kw == "endcustomgrad") {
+      if (!in_custom || kernel) P_FAIL("kd line %d: stray endcustomgrad", lineno);
+      in_custom = false;
+      kernel = &cur;
     } else if (kw == "backwards" || kw == "gradient") {
       if (!target) P_FAIL("kd line %d: generator outside a target", lineno);
       Kernel g;
@@ -286,6 +310,10 @@ int parse(const char* text, Program& prog) {
         Op op;
         rc = parse_op(tk, op);
         kernel->reads.push_back(op);
+      } else if (kw == "idx") {
+        Instr ins;
+        rc = parse_instr(tk, ins);
+        kernel->index_instrs.push_back(ins);
       } else if (kw == "ins") {
         Instr ins;
         rc = parse_instr(tk, ins);
@@ -317,6 +345,13 @@ int parse(const char* text, Program& prog) {
       for (auto& r : k.reads)
         if (!check_tid(r.tensor)) P_FAIL("target '%s': kernel reads unknown tensor %d", t.name.c_str(), r.tensor);
       if (k.result < 1 || k.result > k.nregs) P_FAIL("target '%s': kernel result register out of range", t.name.c_str());
+      for (auto& g : k.custom_grad) {  // gradient placeholders: -t for an existing tensor t
+        auto ok = [&](int tid) { return check_tid(tid < 0 ? -tid : tid); };
+        if (!ok(g.write.tensor)) P_FAIL("target '%s': custom gradient writes unknown tensor %d", t.name.c_str(), g.write.tensor);
+        for (auto& r : g.reads)
+          if (!ok(r.tensor)) P_FAIL("target '%s': custom gradient reads unknown tensor %d", t.name.c_str(), r.tensor);
+        if (g.result < 1 || g.result > g.nregs) P_FAIL("target '%s': custom gradient result register out of range", t.name.c_str());
+      }
     }
   }
   return EG_OK;
@@ -332,7 +367,11 @@ std::vector<Ty> infer_types(const Kernel& k) {
   for (auto& lp : k.loops) set(lp.reg, Ty::Index);
   for (auto& s : k.setup) set(s.res, Ty::Index);
   for (auto& r : k.reads) set(r.reg, Ty::Scalar);
-  for (auto& ins : k.instrs) {
+  std::vector<const Instr*> order;
+  for (auto& ins : k.index_instrs) order.push_back(&ins);
+  for (auto& ins : k.instrs) order.push_back(&ins);
+  for (const Instr* pins : order) {
+    const Instr& ins = *pins;
     Ty t = Ty::Scalar;
     switch (ins.kind) {
       case IK::Scalar: t = Ty::Scalar; break;
@@ -495,6 +534,14 @@ void dead_code_elim(Kernel& k) {
         for (auto& f : d.factors) use(f.first);
     }
   k.reads.swap(reads);
+  std::vector<Instr> kept_idx;
+  for (auto it = k.index_instrs.rbegin(); it != k.index_instrs.rend(); ++it)
+    if (used[it->res]) {
+      kept_idx.push_back(*it);
+      for (int a : it->args) use(a);
+    }
+  std::reverse(kept_idx.begin(), kept_idx.end());
+  k.index_instrs.swap(kept_idx);
   std::vector<Loop> loops;
   for (auto& lp : k.loops)
     if (used[lp.reg]) {
@@ -598,6 +645,28 @@ int generate(Program& prog, Target& t) {
             grad_tensors[read.tensor] = gt;
           }
         if (!grad_tensors.count(k2.write.tensor)) continue;  // does not influence the loss
+        if (k2.has_custom_grad) {  // 626-634: the user's gradient kernels, last first, placeholders bound
+          for (size_t g = k2.custom_grad.size(); g-- > 0;) {
+            Kernel gk = k2.custom_grad[g];
+            gk.has_custom_grad = false;
+            gk.custom_grad.clear();
+            auto bind = [&](Op& op) {
+              if (op.tensor >= 0) return true;
+              auto it = grad_tensors.find(-op.tensor);
+              if (it == grad_tensors.end()) return false;
+              op.tensor = it->second;
+              return true;
+            };
+            bool ok = bind(gk.write);
+            for (auto& rd : gk.reads) ok = bind(rd) && ok;
+            if (!ok) {
+              set_error("custom gradient refers to the gradient of a tensor the kernel does not touch");
+              return EG_ERR_INVALID;
+            }
+            grads.push_back(gk);
+          }
+          continue;
+        }
         int rc = derive_kernel(k2, grad_tensors, grads);
         if (rc) return rc;
       }
@@ -660,11 +729,14 @@ static long prod(const std::vector<long>& s) {
   return p;
 }
 
-int infer_kernel(const Program& prog, const Kernel& k, Shapes& shapes, long epoch, KernelInfo& out) {
-  out = KernelInfo();
-  std::map<int, long>& vals = out.vals;
-  for (auto& s : k.setup) {
+// Host evaluation of shape()/len()/index arithmetic (kernel setup, shape-constraint setup).
+static int eval_host_instrs(const std::vector<Instr>& instrs, const Shapes& shapes, long epoch, std::map<int, long>& vals) {
+  for (auto& s : instrs) {
     long v = 0;
+    auto arg = [&](size_t i) -> long {
+      auto it = i < s.args.size() ? vals.find(s.args[i]) : vals.end();
+      return it == vals.end() ? 0 : it->second;
+    };
     switch (s.kind) {
       case IK::Shape: {
         auto it = shapes.find(s.tensor);
@@ -691,12 +763,55 @@ int infer_kernel(const Program& prog, const Kernel& k, Shapes& shapes, long epoc
       }
       case IK::Index: v = (long)s.lit; break;
       case IK::Epoch: v = epoch; break;
+      case IK::Add: v = arg(0) + arg(1); break;
+      case IK::Sub: v = arg(0) - arg(1); break;
+      case IK::Mul: v = arg(0) * arg(1); break;
+      case IK::Negate: v = -arg(0); break;
+      case IK::IndexDiv: v = arg(1) ? arg(0) / arg(1) : 0; break;  // sdiv: truncation toward zero
+      case IK::Mod: v = arg(1) ? arg(0) % arg(1) : 0; break;
       default:
-        set_error("unsupported setup instruction %s", ik_name(s.kind));
+        set_error("unsupported host instruction %s", ik_name(s.kind));
         return EG_ERR_UNSUPPORTED;
     }
     vals[s.res] = v;
   }
+  return EG_OK;
+}
+
+// withShape / reshape dims of `tid`, if they can be evaluated now.  Registers of the dims come from
+// the constraint's own host instructions (shapesetup) or, failing that, from the writing kernel's.
+static bool user_shape(const Program& prog, int tid, const Shapes& shapes, long epoch, const std::map<int, long>& kernel_vals,
+                       std::vector<long>& shape_out) {
+  auto sd = prog.shape_dims.find(tid);
+  if (sd == prog.shape_dims.end()) return false;
+  std::map<int, long> vals = kernel_vals;
+  auto ss = prog.shape_setup.find(tid);
+  if (ss != prog.shape_setup.end() && eval_host_instrs(ss->second, shapes, epoch, vals) != EG_OK) {
+    eg::clear_error();
+    return false;
+  }
+  shape_out.clear();
+  for (auto& l : sd->second) {
+    long v = l.constant;
+    for (auto& f : l.factors) {
+      auto it = vals.find(f.first);
+      if (it == vals.end()) return false;
+      v += f.second * it->second;
+    }
+    shape_out.push_back(v);
+  }
+  return true;
+}
+
+int infer_kernel(const Program& prog, const Kernel& k, Shapes& shapes, long epoch, KernelInfo& out) {
+  out = KernelInfo();
+  std::map<int, long>& vals = out.vals;
+  {
+    int rc = eval_host_instrs(k.setup, shapes, epoch, vals);
+    if (rc) return rc;
+  }
+  std::set<int> idx_regs;  // computed indices never bound a loop
+  for (auto& ins : k.index_instrs) idx_regs.insert(ins.res);
   auto lin_const = [&](const Lin& l) {
     long v = l.constant;
     for (auto& f : l.factors) v += f.second * vals.at(f.first);
@@ -711,15 +826,9 @@ int infer_kernel(const Program& prog, const Kernel& k, Shapes& shapes, long epoc
   // user constraints (withShape / copyShape, parser.nim:683-697) fix the written tensor's shape
   // before its loops are bounded: PriorityUser outranks the inferred constraints
   if (!shapes.count(k.write.tensor)) {
-    auto sd = prog.shape_dims.find(k.write.tensor);
     auto sc = prog.shape_copy.find(k.write.tensor);
-    bool constant = sd != prog.shape_dims.end();
-    if (constant)
-      for (auto& l : sd->second)
-        if (!l.factors.empty()) constant = false;
-    if (constant) {
-      std::vector<long> shp;
-      for (auto& l : sd->second) shp.push_back(l.constant);
+    std::vector<long> shp;
+    if (user_shape(prog, k.write.tensor, shapes, epoch, vals, shp)) {
       shapes[k.write.tensor] = shp;
     } else if (sc != prog.shape_copy.end() && shapes.count(sc->second)) {
       shapes[k.write.tensor] = shapes[sc->second];
@@ -752,6 +861,10 @@ int infer_kernel(const Program& prog, const Kernel& k, Shapes& shapes, long epoc
       if (it == shapes.end() || op->raw) continue;
       for (size_t d = 0; d < op->dims.size(); ++d) {
         const Lin& lin = op->dims[d];
+        bool computed = false;
+        for (auto& f : lin.factors)
+          if (idx_regs.count(f.first)) computed = true;
+        if (computed) continue;
         int unknown = 0, n_unknown = 0;
         for (auto& f : lin.factors)
           if (!bounds.count(f.first) && !vals.count(f.first)) {
@@ -787,13 +900,9 @@ int infer_kernel(const Program& prog, const Kernel& k, Shapes& shapes, long epoc
     auto sc = prog.shape_copy.find(wt);
     if (sd != prog.shape_dims.end()) {
       std::vector<long> shp;
-      for (auto& l : sd->second) {
-        for (auto& f : l.factors)
-          if (!vals.count(f.first)) {
-            set_error("withShape of tensor %d uses a value this kernel does not define", wt);
-            return EG_ERR_SHAPE;
-          }
-        shp.push_back(lin_const(l));
+      if (!user_shape(prog, wt, shapes, epoch, vals, shp)) {
+        set_error("withShape of tensor %d uses a value that is not known yet", wt);
+        return EG_ERR_SHAPE;
       }
       shapes[wt] = shp;
     } else if (sc != prog.shape_copy.end() && shapes.count(sc->second)) {
@@ -809,6 +918,11 @@ int infer_kernel(const Program& prog, const Kernel& k, Shapes& shapes, long epoc
     } else {
       std::vector<long> shp;
       for (auto& lin : k.write.dims) {
+        for (auto& f : lin.factors)
+          if (idx_regs.count(f.first)) {
+            set_error("shape of tensor %d is under-constrained (computed write index; use withShape)", wt);
+            return EG_ERR_SHAPE;
+          }
         long hi = lin.constant;
         for (auto& f : lin.factors) {
           if (vals.count(f.first))
@@ -863,18 +977,23 @@ std::string to_text(const Kernel& k) {
   for (size_t i = 0; i < k.loops.size(); ++i) s += (i ? "," : "") + k.loops[i].name + ":r" + std::to_string(k.loops[i].reg);
   s += ") reads(";
   for (size_t i = 0; i < k.reads.size(); ++i) s += (i ? ", " : "") + ("r" + std::to_string(k.reads[i].reg) + "=" + op_text(k.reads[i]));
-  s += ") instrs(";
-  for (size_t i = 0; i < k.instrs.size(); ++i) {
-    const Instr& ins = k.instrs[i];
-    s += (i ? "; " : "") + ("r" + std::to_string(ins.res) + "=" + ik_name(ins.kind));
-    for (int a : ins.args) s += " r" + std::to_string(a);
-    if (ins.kind == IK::Scalar || ins.kind == IK::Index) {
-      char buf[48];
-      snprintf(buf, sizeof(buf), " %g", ins.lit);
-      s += buf;
-    }
-  }
   s += ")";
+  auto list = [&](const char* title, const std::vector<Instr>& instrs) {
+    s += std::string(" ") + title + "(";
+    for (size_t i = 0; i < instrs.size(); ++i) {
+      const Instr& ins = instrs[i];
+      s += (i ? "; " : "") + ("r" + std::to_string(ins.res) + "=" + ik_name(ins.kind));
+      for (int a : ins.args) s += " r" + std::to_string(a);
+      if (ins.kind == IK::Scalar || ins.kind == IK::Index) {
+        char buf[48];
+        snprintf(buf, sizeof(buf), " %g", ins.lit);
+        s += buf;
+      }
+    }
+    s += ")";
+  };
+  if (!k.index_instrs.empty()) list("index", k.index_instrs);
+  list("instrs", k.instrs);
   return s;
 }
 

@@ -62,10 +62,19 @@ struct Kernel {
   int nregs = 0;
   std::vector<Instr> setup;  // host-evaluated: shape()/len() terms of explicit loop bounds
   std::vector<Loop> loops;
+  // Index instructions evaluated inside the loop nest before the reads: the non-affine parts of
+  // tensor indices (`y div 2`; LinearIndex.setup in the reference, ir.nim:120-123).  Their result
+  // registers appear in the Lin dims of the operands like iterators do.
+  std::vector<Instr> index_instrs;
   std::vector<Op> reads;
   std::vector<Instr> instrs;
   int result = 0;
   Op write;
+  // KernelGradient(isCustom) ir.nim:203-209: gradient kernels written by the user (maxpool2,
+  // dnn.nim:59-71), used by generate instead of derive.  In them tensor id -t stands for the
+  // gradient tensor of t.
+  bool has_custom_grad = false;
+  std::vector<Kernel> custom_grad;
   Gen gen = Gen::None;
   int gen_tensor = 0;  // Backwards: the loss; Gradient: differentiate with respect to this tensor
   int gen_dest = 0;    // Gradient: tensor that receives the gradient
@@ -96,6 +105,7 @@ struct Program {
   std::vector<TensorDef> tensors;  // 1-based: tensors[0] is unused
   std::map<int, int> shape_copy;   // dest -> src      (ShapeCopy, ir.nim:186-187)
   std::map<int, std::vector<Lin>> shape_dims;  // dest -> dims (ShapeDims)
+  std::map<int, std::vector<Instr>> shape_setup;  // dest -> host instructions defining the registers of shape_dims
   std::vector<Target> targets;
   std::map<std::string, int> inputs;
   Target* find_target(const std::string& name);

@@ -55,6 +55,7 @@ int loop_index(const Kernel& k, int reg) {
 
 // c[i,j] += a(i,k) * b(k,j)      base.nim:27-28 and its two derived forms (passes.nim:519-549)
 bool match_gemm(const Kernel& k, GemmMatch& m) {
+  if (!k.index_instrs.empty()) return false;
   if (k.instrs.size() != 1 || k.instrs[0].kind != IK::Mul || k.result != k.instrs[0].res) return false;
   if (k.reads.size() != 2 || k.loops.size() != 3 || !k.setup.empty()) return false;
   for (auto& lp : k.loops)
@@ -89,6 +90,7 @@ bool match_gemm(const Kernel& k, GemmMatch& m) {
 
 // out[y,x] += bias[x] on the tensor the preceding contraction wrote   dnn.nim:22-24
 bool match_bias(const Kernel& k, int tensor) {
+  if (!k.index_instrs.empty()) return false;
   if (!k.instrs.empty() || k.reads.size() != 1 || k.result != k.reads[0].reg || k.write.tensor != tensor) return false;
   if (k.loops.size() != 2 || !k.setup.empty()) return false;
   for (auto& lp : k.loops)
@@ -111,6 +113,7 @@ struct ConvMatch {
 // another of the three tensors written:
 //   gimg[n,y+dy,x+dx,c] += gout[n,y,x,f] * flt[f,dy,dx,c]      gflt[f,dy,dx,c] += gout[n,y,x,f] * img[n,y+dy,x+dx,c]
 bool match_conv(const Kernel& k, ConvMatch& m) {
+  if (!k.index_instrs.empty()) return false;
   if (k.instrs.size() != 1 || k.instrs[0].kind != IK::Mul || k.result != k.instrs[0].res || k.reads.size() != 2) return false;
   if (!k.setup.empty() || k.write.raw || k.reads[0].raw || k.reads[1].raw) return false;
   const std::vector<int>& args = k.instrs[0].args;

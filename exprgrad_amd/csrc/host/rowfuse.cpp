@@ -45,7 +45,7 @@ std::string lin_text(const Lin& l, const std::map<int, std::string>& subst) {
 RowKernelInfo analyse_row_kernel(const Program& prog, const Kernel& k, const KernelInfo& info, const Shapes& shapes,
                                  long B) {
   RowKernelInfo r;
-  if (!info.ok || B <= 0) return r;
+  if (!info.ok || B <= 0 || !k.index_instrs.empty()) return r;
   std::vector<const Op*> ops;
   for (auto& rd : k.reads) ops.push_back(&rd);
   ops.push_back(&k.write);
@@ -314,7 +314,7 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
 // ---------------------------------------------------------------------------------- small groups
 
 bool is_small_kernel(const Program& prog, const Kernel& k, const KernelInfo& info, const Shapes& shapes) {
-  if (!info.ok) return false;
+  if (!info.ok || !k.index_instrs.empty()) return false;
   if (!k.setup.empty() && !k.is_seed) return false;
   std::vector<const Op*> ops;
   for (auto& rd : k.reads) ops.push_back(&rd);

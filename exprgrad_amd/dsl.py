@@ -262,12 +262,34 @@ class Fun:
         tgt = acc.target
         if tgt.tensor is not self or tgt.is_raw != is_raw or len(tgt.children) != len(dims):
             raise ParserError("`+=` target mismatch")
+        if self.kind == "gradarg":
+            # `grad(t)[idx] ++= value` inside a customGrad block (parser.nim:498, 585)
+            if not _custom_grad_stack:
+                raise ParserError("grad_of(t)[...] += ... is only valid inside `with fun.custom_grad():`")
+            block = _custom_grad_stack[-1]
+            block.kernels.append(_KernelBuilder(self, dims, is_raw, acc.value))
+            _collect_children(acc.value, block.fun)
+            return
         if self.kind not in ("result", "effect"):
             raise ParserError("Unable to add a kernel to a " + self.kind)  # parser.nim:437-438
         if self.locked:
             raise ParserError("tensor is locked")
         self.kernels.append(_KernelBuilder(self, dims, is_raw, acc.value))
         _collect_children(acc.value, self)  # parser.nim:430-441
+
+    def custom_grad(self):
+        """`do: customGrad: ...` of the statement added last (parser.nim:498, 585; used by maxpool2,
+        dnn.nim:59-71): the gradient kernels written inside the block replace derive for it.
+
+            with result.custom_grad():
+                grad_of(images)[n, y, x, c] += select(...grad_of(result)[n, y // 2, x // 2, c]...)
+        """
+        if not self.kernels:
+            raise ParserError("custom_grad() follows the statement it belongs to")
+        return _CustomGrad(self)
+
+    def reshape(self, shape):
+        return reshape(self, shape)
 
     # ---- shape constraints (parser.nim:683-697) --------------------------------------------
     def copy_shape(self, src):
@@ -318,8 +340,56 @@ def _collect_children(expr, fun):
     if expr.bounds:
         for b in expr.bounds:
             _collect_children(b, fun)
-    if expr.tensor is not None and expr.tensor is not fun and expr.tensor not in fun.children:
-        fun.children.append(expr.tensor)
+    t = expr.tensor
+    if t is not None and t.kind == "gradarg":
+        t = t.children[0]  # the gradient placeholder stands for a tensor of the graph
+    if t is not None and t is not fun and t not in fun.children:
+        fun.children.append(t)
+
+
+_custom_grad_stack = []
+
+
+class _CustomGrad:
+    def __init__(self, fun):
+        self.fun, self.kernels = fun, []
+
+    def __enter__(self):
+        _custom_grad_stack.append(self)
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        _custom_grad_stack.pop()
+        if exc_type is None:
+            self.fun.kernels[-1].grads = self.kernels
+        return False
+
+
+def grad_of(fun):
+    """`grad(fun)` inside a customGrad block (FunGradientArg, parser.nim:70, 142-146, 784): the
+    gradient tensor of `fun`, bound when the backward pass is generated."""
+    return Fun("gradarg", children=[fun])
+
+
+def _tensor_id(fun):
+    return -fun.children[0].tensor if fun.kind == "gradarg" else fun.tensor
+
+
+def reshape(fun, shape):
+    """reshape (parser.nim:786-793; GenReshape, passes.nim:643-688): a raw copy into a tensor whose
+    shape is given, one extent may be -1 (= len / product of the others)."""
+    shape = [int(d) for d in shape]
+    if sum(1 for d in shape if d < 0) > 1:
+        raise ParserError("reshape: at most one extent may be -1")
+    prod = 1
+    for d in shape:
+        if d >= 0:
+            prod *= d
+    it = iter_in("reshape.it", 0, fun.len())
+    r = Fun(name="reshape")
+    r.raw[it] += fun.raw[it]
+    r.with_shape(*[literal(d) if d >= 0 else fun.len() // prod for d in shape])
+    return r
 
 
 def input(name, shape=()):  # noqa: A001 - parser.nim:724-731
@@ -383,6 +453,7 @@ def grad(gradients, fun):
 class _KernelBuilder:
     def __init__(self, target, dims, is_raw, value):
         self.target, self.dims, self.is_raw, self.value = target, dims, is_raw, value
+        self.grads = None  # custom gradient statements (KernelBuilder.grads, parser.nim:57)
 
 
 class LinearIndex:
@@ -405,10 +476,13 @@ class Kernel:
         self.loops = []    # (iter_reg, name, bounds or None)
         self.setup = []    # instrs evaluated on the host: shape/len terms of explicit bounds
         self.reads = []    # (tensor_id, reg, is_raw, [LinearIndex])
+        self.index_instrs = []  # like instrs, Index typed, evaluated inside the loop nest before the
+                                # reads: the non-affine parts of tensor indices (`y div 2`)
         self.instrs = []   # (kind, res, [args], extra)
         self.result = 0
         self.write = None  # (tensor_id, reg, is_raw, [LinearIndex])
         self.generator = None  # ("backwards", tid) | ("gradient", of_tid, dest_tid)
+        self.custom_grad = None  # [Kernel]: used instead of derive (ir.nim:203-209); tensor id -t = gradient of t
 
     def alloc(self):
         self.nregs += 1
@@ -434,7 +508,7 @@ def _build(expr, instrs, block, ctx):
     if expr.kind == "read":
         dims = [_build_linear(d, ctx) for d in expr.children]
         res = k.alloc()
-        k.reads.append((expr.tensor.tensor, res, expr.is_raw, dims))
+        k.reads.append((_tensor_id(expr.tensor), res, expr.is_raw, dims))
     elif expr.kind == "iter":
         if expr.iter not in ctx.iters:
             reg = k.alloc()
@@ -501,12 +575,27 @@ def _fold(expr, ctx):
     return None
 
 
-def _build_linear(expr, ctx):
+def _build_linear(expr, ctx, host=False):
+    """An index expression as a LinearIndex.  Affine parts fold into constant + factors; any other
+    Index sub-expression (`y div 2`, `x mod 3`: LinearIndex.setup in the reference, ir.nim:120-123)
+    becomes index instructions of the kernel whose result register enters with factor 1.
+    host=True (shape constraints, loop bounds): the instructions go to the host-evaluated setup."""
     lin = _fold(expr, ctx)
-    if lin is None:
-        raise ParserError("tensor indices must be affine in the iterators for the GPU hot path "
-                          "(`div`/`mod` indices, used by maxpool2/upsample2, are out of scope)")
-    return lin
+    if lin is not None:
+        return lin
+    if expr.kind == "instr" and expr.instr in ("add", "sub"):
+        a, b = _build_linear(expr.children[0], ctx, host), _build_linear(expr.children[1], ctx, host)
+        sign = 1 if expr.instr == "add" else -1
+        out = LinearIndex(a.constant + sign * b.constant, a.factors)
+        for r, f in b.factors.items():
+            out.factors[r] = out.factors.get(r, 0) + sign * f
+        out.factors = {r: f for r, f in out.factors.items() if f != 0}
+        return out
+    if expr.typ != INDEX:
+        raise ParserError("tensor indices must be Index expressions")
+    sink = ctx.kernel.setup if host else ctx.kernel.index_instrs
+    reg = _build(expr, sink, -2 if host else -3, ctx)
+    return LinearIndex(0, {reg: 1})
 
 
 def _clear(expr):
@@ -543,8 +632,10 @@ def _build_kernel(kb):
     k = ctx.kernel
     k.result = _build(kb.value, k.instrs, ctx.block(), ctx)
     wdims = [_build_linear(d, ctx) for d in kb.dims]
-    k.write = (kb.target.tensor, k.result, kb.is_raw, wdims)
+    k.write = (_tensor_id(kb.target), k.result, kb.is_raw, wdims)
     _dedup_reads(k)
+    if kb.grads is not None:
+        k.custom_grad = [_build_kernel(g) for g in kb.grads]
     return k
 
 
@@ -587,36 +678,49 @@ class Program:
                 for d in c[2]:
                     toks += d.tokens()
                 out.append(" ".join(toks))
+                for ins in (c[3] if len(c) > 3 else ()):
+                    out.append(f"shapesetup {c[1]} " + _ins_text(ins))
         for name, tgt in self.targets.items():
             out.append(f"target {name} {tgt.output}")
             for k in tgt.kernels:
                 if k.generator:
                     out.append(" ".join(str(x) for x in k.generator))
                     continue
-                out.append(f"kernel {k.nregs}")
-                for ins in k.setup:
-                    out.append("setup " + _ins_text(ins))
-                for (reg, nm, bounds) in k.loops:
-                    if bounds:
-                        out.append(" ".join(["loop", str(reg), nm, "1"] + bounds[0].tokens() + bounds[1].tokens()))
-                    else:
-                        out.append(f"loop {reg} {nm} 0")
-                for (tid, reg, raw, dims) in k.reads:
-                    toks = ["read", str(tid), str(reg), "1" if raw else "0", str(len(dims))]
-                    for d in dims:
-                        toks += d.tokens()
-                    out.append(" ".join(toks))
-                for ins in k.instrs:
-                    out.append("ins " + _ins_text(ins))
-                out.append(f"result {k.result}")
-                tid, reg, raw, dims = k.write
-                toks = ["write", str(tid), str(reg), "1" if raw else "0", str(len(dims))]
-                for d in dims:
-                    toks += d.tokens()
-                out.append(" ".join(toks))
-                out.append("endkernel")
+                _kernel_text(k, out)
             out.append("endtarget")
         return "\n".join(out) + "\n"
+
+
+def _kernel_text(k, out):
+    out.append(f"kernel {k.nregs}")
+    for ins in k.setup:
+        out.append("setup " + _ins_text(ins))
+    for (reg, nm, bounds) in k.loops:
+        if bounds:
+            out.append(" ".join(["loop", str(reg), nm, "1"] + bounds[0].tokens() + bounds[1].tokens()))
+        else:
+            out.append(f"loop {reg} {nm} 0")
+    for ins in k.index_instrs:
+        out.append("idx " + _ins_text(ins))
+    for (tid, reg, raw, dims) in k.reads:
+        toks = ["read", str(tid), str(reg), "1" if raw else "0", str(len(dims))]
+        for d in dims:
+            toks += d.tokens()
+        out.append(" ".join(toks))
+    for ins in k.instrs:
+        out.append("ins " + _ins_text(ins))
+    out.append(f"result {k.result}")
+    tid, reg, raw, dims = k.write
+    toks = ["write", str(tid), str(reg), "1" if raw else "0", str(len(dims))]
+    for d in dims:
+        toks += d.tokens()
+    out.append(" ".join(toks))
+    if k.custom_grad is not None:
+        out.append("customgrad")
+        for g in k.custom_grad:
+            _kernel_text(g, out)
+        out.append("endcustomgrad")
+    out.append("endkernel")
 
 
 def _ins_text(ins):
@@ -681,9 +785,14 @@ def _flatten(fun, target, program):
             if fun.shape_constr[0] == "copy":
                 c = ("copy", fun.tensor, fun.shape_constr[1].tensor)
             else:
+                # the dims are evaluated on the host from the shapes of the tensors they name; their
+                # instructions travel with the constraint (ShapeConstraint.dims[].setup in the reference)
                 ctx = _Ctx()
-                c = ("dims", fun.tensor, [_build_linear(d, ctx) for d in fun.shape_constr[1]])
-            if c not in program.shape_constraints:
+                for d in fun.shape_constr[1]:
+                    _clear(d)
+                dims = [_build_linear(d, ctx, host=True) for d in fun.shape_constr[1]]
+                c = ("dims", fun.tensor, dims, tuple(ctx.kernel.setup))
+            if all(c[:2] != o[:2] for o in program.shape_constraints):
                 program.shape_constraints.append(c)
     elif fun.kind == "backwards":
         k = Kernel()

@@ -64,3 +64,22 @@ def conv2_3d():
     return [r.target("conv2")]
 
 
+
+
+def fashion_mnist_net(eta=0.01, size=28, f1=8, f2=16, classes=10):
+    """examples/fashion_mnist/fashion_mnist.nim:39-57: reshape -> conv2(1,5,5,8) -> leakyRelu -> maxpool2
+    -> conv2(8,3,3,16) -> leakyRelu -> maxpool2 -> reshape -> dense -> softmax -> crossEntropy -> adam."""
+    s1 = (size - 4) // 2          # 5x5 valid convolution, then 2x2 pooling
+    s2 = (s1 - 2) // 2            # 3x3 valid convolution, then 2x2 pooling
+    net = dsl.reshape(dsl.input("x"), [-1, size, size, 1])
+    net = layers.conv2(net, 1, 5, 5, f1)
+    net = layers.leaky_relu(net)
+    net = layers.maxpool2(net)
+    net = layers.conv2(net, f1, 3, 3, f2)
+    net = layers.leaky_relu(net)
+    net = layers.maxpool2(net)
+    net = dsl.reshape(net, [-1, f2 * s2 * s2])
+    net = layers.dense(net, f2 * s2 * s2, classes)
+    net = layers.softmax(net).target("predict")
+    net = layers.cross_entropy(net, dsl.input("y")).target("loss")
+    return [net.backwards().optimize(layers.adam(eta=eta)).target("fit")]

@@ -2,8 +2,7 @@
 
 Sources: exprgrad/layers/base.nim:19-67 and exprgrad/layers/dnn.nim:19-100.  Iterator
 declaration order after `|` does not affect the lowered kernel (loops are created on first
-use, parser.nim:183-196), so it is not reproduced.  Layers outside the hot path (maxpool2 /
-avgpool2 / upsample2 / dropout: non-affine indices or random tensors) are not provided.
+use, parser.nim:183-196), so it is not reproduced.  `dropout` (a random tensor) is not provided.
 """
 from . import dsl
 from .dsl import Fun, iters, param, select, sq, to_scalar
@@ -184,6 +183,41 @@ def conv2(images, filters, w=None, h=None, nfilters=None):
     r = _layer("conv2")
     r[image, y, x, flt] += images[image, y + dy, x + dx, chan] * filters[flt, dy, dx, chan]
     return r
+
+
+def maxpool2(images):
+    """dnn.nim:56-71: 2x2 max pooling with a hand-written gradient (the maximum's position gets the
+    output gradient; computed indices `y div 2`)."""
+    image, y, x, chan = iters("image y x chan")
+    r = _layer("maxpool2")
+    r[image, y, x, chan] += dsl.max(dsl.max(images[image, y * 2, x * 2, chan], images[image, y * 2 + 1, x * 2, chan]),
+                                    dsl.max(images[image, y * 2, x * 2 + 1, chan], images[image, y * 2 + 1, x * 2 + 1, chan]))
+    with r.custom_grad():
+        dsl.grad_of(images)[image, y, x, chan] += select(
+            images[image, y, x, chan].eq(r[image, y // 2, x // 2, chan]),
+            dsl.grad_of(r)[image, y // 2, x // 2, chan], 0.0)
+    r.lock()
+    return r
+
+
+def avgpool2(images):
+    image, y, x, chan = iters("image y x chan")
+    r = _layer("avgpool2")                                              # dnn.nim:73-79
+    r[image, y, x, chan] += (images[image, y * 2, x * 2, chan] + images[image, y * 2 + 1, x * 2, chan] +
+                             images[image, y * 2, x * 2 + 1, chan] + images[image, y * 2 + 1, x * 2 + 1, chan]) / 4.0
+    return r
+
+
+def upsample2(images):
+    image, y, x, chan = iters("image y x chan")
+    r = _layer("upsample2")                                             # dnn.nim:81-88
+    r[image, y, x, chan] += images[image, y // 2, x // 2, chan]
+    r.with_shape(images.shape[0], images.shape[1] * 2, images.shape[2] * 2, images.shape[3])
+    return r
+
+
+def reshape(fun, shape):
+    return dsl.reshape(fun, shape)                                      # parser.nim:786-793
 
 
 def softmax(inp):

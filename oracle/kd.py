@@ -65,10 +65,13 @@ class Kernel:
     def __init__(self):
         self.nregs = 0
         self.setup, self.loops, self.reads, self.instrs = [], [], [], []
+        self.index_instrs = []   # Index instructions evaluated inside the loop nest before the reads
+                                 # (LinearIndex.setup of the reference, ir.nim:120-123): `y div 2`
         self.result = 0
         self.write = None
         self.generator = None
         self.is_seed = False
+        self.custom_grad = None  # KernelGradient(isCustom) ir.nim:203-209: kernels; tensor -t = grad of t
 
     def alloc(self):
         self.nregs += 1
@@ -81,8 +84,10 @@ class Kernel:
         k.loops = list(self.loops)
         k.reads = list(self.reads)
         k.instrs = list(self.instrs)
+        k.index_instrs = list(self.index_instrs)
         k.result, k.write, k.generator = self.result, self.write, self.generator
         k.is_seed = self.is_seed
+        k.custom_grad = self.custom_grad
         return k
 
 
@@ -91,6 +96,7 @@ class Program:
         self.tensors = {}       # id -> dict(kind, name, shape, range)
         self.shape_copy = {}    # dest -> src
         self.shape_dims = {}    # dest -> [Lin]
+        self.shape_setup = {}   # dest -> [Instr] evaluated on the host for the Lin registers of shape_dims
         self.targets = {}       # name -> (output, [Kernel])
         self.inputs = {}
 
@@ -139,6 +145,7 @@ def parse(text):
     prog = Program()
     cur_target = None
     cur = None
+    stack = []   # kernels whose customgrad block is open
     for line in text.splitlines():
         toks = line.split()
         if not toks or toks[0].startswith("#"):
@@ -164,17 +171,31 @@ def parse(text):
                 d, pos = _lin(toks, pos)
                 dims.append(d)
             prog.shape_dims[int(toks[1])] = dims
+        elif t == "shapesetup":
+            prog.shape_setup.setdefault(int(toks[1]), []).append(_instr(toks[2:]))
         elif t == "target":
             cur_target = (int(toks[2]), [])
             prog.targets[toks[1]] = cur_target
         elif t == "endtarget":
             cur_target = None
         elif t == "kernel":
-            cur = Kernel()
+            cur = Kernel()                 # inside an open customgrad block: a gradient kernel of stack[-1]
             cur.nregs = int(toks[1])
         elif t == "endkernel":
-            cur_target[1].append(cur)
+            if stack:
+                stack[-1].custom_grad.append(cur)
+                cur = None
+            else:
+                cur_target[1].append(cur)
+                cur = None
+        elif t == "customgrad":
+            cur.custom_grad = []
+            stack.append(cur)
             cur = None
+        elif t == "endcustomgrad":
+            cur = stack.pop()
+        elif t == "idx":
+            cur.index_instrs.append(_instr(toks[1:]))
         elif t == "setup":
             cur.setup.append(_instr(toks[1:]))
         elif t == "loop":
@@ -321,6 +342,12 @@ def dead_code_elim(k):
             for d in r.dims:
                 used.update(d.factors)
     k.reads = reads
+    kept_idx = []
+    for ins in reversed(k.index_instrs):
+        if ins.res in used:
+            kept_idx.append(ins)
+            used.update(ins.args)
+    k.index_instrs = kept_idx[::-1]
     # loops are kept only if their iterator is used (passes.nim:280-289)
     loops = []
     for lp in k.loops:
@@ -388,7 +415,11 @@ def generate(prog, kernels):
                         grad_tensors[read.tensor] = gt
                 if k2.write.tensor not in grad_tensors:
                     continue  # does not influence the loss (the reference would raise KeyError)
-                grad_kernels.extend(derive_kernel(k2, grad_tensors))
+                if k2.custom_grad is not None:              # 626-634: the user's kernels, last first
+                    for gk in reversed(k2.custom_grad):
+                        grad_kernels.append(_substitute_grads(gk, grad_tensors))
+                else:
+                    grad_kernels.extend(derive_kernel(k2, grad_tensors))
             kernels[i:i + 1] = grad_kernels
             i += len(grad_kernels)
         elif k.generator and k.generator[0] == "gradient":
@@ -396,6 +427,17 @@ def generate(prog, kernels):
         else:
             i += 1
     return kernels
+
+
+def _substitute_grads(kernel, grad_tensors):
+    """A customGrad kernel with its gradient placeholders (tensor -t) bound to gradTensors[t]."""
+    def sub(op):
+        return Op(grad_tensors[-op.tensor], op.reg, op.raw, op.dims) if op.tensor < 0 else op
+    gk = kernel.clone()
+    gk.custom_grad = None
+    gk.reads = [sub(r) for r in gk.reads]
+    gk.write = sub(gk.write)
+    return gk
 
 
 def _alloc_tensor(prog, kind, name):
@@ -473,10 +515,50 @@ class ShapeError(Exception):
     pass
 
 
+def _sdiv(a, b):
+    if b == 0:
+        return 0
+    q = abs(a) // abs(b)
+    return q if (a >= 0) == (b >= 0) else -q
+
+
 def _eval_setup(k, shapes, epoch):
+    return _eval_host_instrs(k.setup, shapes, epoch)
+
+
+def _user_shape(prog, tid, shapes, epoch, kernel_vals):
+    """withShape / reshape dims of `tid` if they can be evaluated now, else None.  Registers of the
+    dims come from the constraint's own host instructions (shapesetup) or, failing that, from the
+    writing kernel's setup."""
+    dims = prog.shape_dims.get(tid)
+    if dims is None:
+        return None
+    vals = dict(kernel_vals)
+    try:
+        vals.update(_eval_host_instrs(prog.shape_setup.get(tid, []), shapes, epoch))
+        return [_lin_const(d, vals) for d in dims]
+    except (KeyError, TypeError):
+        return None
+
+
+def _eval_host_instrs(instrs, shapes, epoch):
     vals = {}
-    for s in k.setup:
-        if s.kind == "shape":
+    for s in instrs:
+        if s.kind in ("add", "sub", "mul", "indexdiv", "mod", "negate"):
+            a = [vals[r] for r in s.args]
+            if s.kind == "add":
+                vals[s.res] = a[0] + a[1]
+            elif s.kind == "sub":
+                vals[s.res] = a[0] - a[1]
+            elif s.kind == "mul":
+                vals[s.res] = a[0] * a[1]
+            elif s.kind == "negate":
+                vals[s.res] = -a[0]
+            elif s.kind == "indexdiv":           # sdiv (llvmgen.nim:236): truncation toward zero
+                vals[s.res] = _sdiv(a[0], a[1])
+            else:                                # srem
+                vals[s.res] = a[0] - _sdiv(a[0], a[1]) * a[1]
+        elif s.kind == "shape":
             tid, dim = s.extra
             vals[s.res] = shapes[tid][dim]
         elif s.kind == "len":
@@ -511,11 +593,13 @@ def infer_kernel(prog, k, shapes, epoch=0):
     # before its loops are bounded (PriorityUser outranks inferred constraints)
     wt0 = k.write.tensor
     if shapes.get(wt0) is None:
-        if wt0 in prog.shape_dims and all(not d.factors for d in prog.shape_dims[wt0]):
-            shapes[wt0] = [d.constant for d in prog.shape_dims[wt0]]
+        user = _user_shape(prog, wt0, shapes, epoch, vals)
+        if user is not None:
+            shapes[wt0] = user
         elif wt0 in prog.shape_copy and shapes.get(prog.shape_copy[wt0]) is not None:
             shapes[wt0] = list(shapes[prog.shape_copy[wt0]])
     ops = list(k.reads) + [k.write]
+    idx_regs = {i.res for i in k.index_instrs}   # computed indices never bound a loop
     for op in ops:
         shp = shapes.get(op.tensor)
         if shp is None:
@@ -535,6 +619,8 @@ def infer_kernel(prog, k, shapes, epoch=0):
             if shp is None or op.raw:
                 continue
             for d, lin in enumerate(op.dims):
+                if any(r in idx_regs for r in lin.factors):
+                    continue
                 unknown = [r for r in lin.factors if r not in bounds and r not in vals]
                 if len(unknown) == 1 and lin.factors[unknown[0]] > 0:
                     rest = lin.constant
@@ -555,7 +641,10 @@ def infer_kernel(prog, k, shapes, epoch=0):
     wt = k.write.tensor
     if shapes.get(wt) is None:
         if wt in prog.shape_dims:
-            shapes[wt] = [_lin_const(d, vals) for d in prog.shape_dims[wt]]
+            user = _user_shape(prog, wt, shapes, epoch, vals)
+            if user is None:
+                raise ShapeError(f"withShape of tensor {wt} uses a value that is not known yet")
+            shapes[wt] = user
         elif wt in prog.shape_copy and shapes.get(prog.shape_copy[wt]) is not None:
             shapes[wt] = list(shapes[prog.shape_copy[wt]])
         elif k.write.raw:
@@ -566,6 +655,8 @@ def infer_kernel(prog, k, shapes, epoch=0):
         else:
             shp = []
             for lin in k.write.dims:
+                if any(r in idx_regs for r in lin.factors):
+                    raise ShapeError(f"shape of tensor {wt} is under-constrained (computed write index; use withShape)")
                 hi = lin.constant
                 for r, f in lin.factors.items():
                     if r in vals:
@@ -597,7 +688,7 @@ def infer_types(k, vals):
         typ[r] = INDEX
     for rd in k.reads:
         typ[rd.reg] = SCALAR
-    for ins in k.instrs:
+    for ins in list(k.index_instrs) + list(k.instrs):
         kd = ins.kind
         if kd == "scalar":
             t = SCALAR
@@ -615,7 +706,91 @@ def infer_types(k, vals):
     return typ
 
 
+def _encode_instrs(instrs, typ, shapes, epoch):
+    """Instruction list -> (5 x int32 words, literal per instruction) for refinterp.c."""
+    words, lits = [], []
+    for ins in instrs:
+        kd = ins.kind
+        lit = 0.0
+        if kd in ("shape", "len", "shapelen", "epoch"):
+            # host-evaluated builtins (model.nim:83-104) become index literals
+            if kd == "shape":
+                lit = shapes[ins.extra[0]][ins.extra[1]]
+            elif kd == "len":
+                lit = int(np.prod(shapes[ins.extra[0]], dtype=np.int64))
+            elif kd == "shapelen":
+                lit = len(shapes[ins.extra[0]])
+            else:
+                lit = epoch
+            code = 1
+        elif kd in ("scalar", "index", "boolean"):
+            code = _OPC[kd]
+            lit = float(ins.extra)
+        elif (kd, typ[ins.args[0]] if ins.args else None) in _OPC:
+            code = _OPC[(kd, typ[ins.args[0]])]
+        else:
+            code = _OPC[kd]
+        a = ins.args + [0, 0, 0]
+        words += [code, ins.res, a[0], a[1], a[2]]
+        lits.append(lit)
+    return words, lits
+
+
+def _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch):
+    """Kernels with computed (non-affine) indices: flat index of an operand = constant +
+    sum(coefficient * register) over iterator AND index-instruction registers (ref_interp_kernel2)."""
+    lib = refcpu.lib()
+    lib.ref_interp_kernel2.restype = ctypes.c_int
+    typ = infer_types(k, vals)
+    c_i64, c_i32 = ctypes.c_int64, ctypes.c_int32
+    nl = len(k.loops)
+
+    def terms(op):
+        shp = shapes[op.tensor]
+        if op.raw:
+            strides = [1]
+        else:
+            strides = [1] * len(shp)
+            for d in range(len(shp) - 2, -1, -1):
+                strides[d] = strides[d + 1] * shp[d + 1]
+        const, coef = 0, {}
+        for d, lin in enumerate(op.dims):
+            const += strides[d] * lin.constant
+            for r, f in lin.factors.items():
+                if r in vals:
+                    const += strides[d] * f * vals[r]
+                else:
+                    coef[r] = coef.get(r, 0) + strides[d] * f
+        out = [const, len(coef)]
+        for r, f in coef.items():
+            out += [r, f]
+        return out
+
+    packed, offsets = [], []
+    for op in list(k.reads) + [k.write]:
+        offsets.append(len(packed))
+        packed += terms(op)
+    idx_words, idx_lits = _encode_instrs(k.index_instrs, typ, shapes, epoch)
+    words, lits = _encode_instrs(k.instrs, typ, shapes, epoch)
+    nreads = len(k.reads)
+    out = tensors[k.write.tensor]
+    arr = lambda t, v: (t * max(len(v), 1))(*v)
+    rc = lib.ref_interp_kernel2(
+        nl, arr(c_i64, [bounds[lp.reg][0] for lp in k.loops]), arr(c_i64, [bounds[lp.reg][1] for lp in k.loops]),
+        arr(c_i32, [lp.reg for lp in k.loops]), k.nregs + 1,
+        len(k.index_instrs), arr(c_i32, idx_words), arr(ctypes.c_double, idx_lits),
+        nreads, arr(ctypes.c_void_p, [tensors[r.tensor].ctypes.data for r in k.reads]),
+        arr(c_i32, [r.reg for r in k.reads]), arr(c_i64, packed), arr(c_i32, offsets),
+        len(k.instrs), arr(c_i32, words), arr(ctypes.c_double, lits), k.result,
+        ctypes.c_void_p(out.ctypes.data), arr(c_i64, [int(np.prod(shapes[op.tensor], dtype=np.int64))
+                                                      for op in list(k.reads) + [k.write]]))
+    if rc != 0:
+        raise RuntimeError(f"ref_interp_kernel2 failed ({rc})")
+
+
 def run_kernel(k, bounds, vals, shapes, tensors, epoch=0):
+    if k.index_instrs:
+        return _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch)
     lib = refcpu.lib()
     if not hasattr(lib, "_interp_ready"):
         lib.ref_interp_kernel.restype = ctypes.c_int

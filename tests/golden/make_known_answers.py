@@ -126,6 +126,10 @@ xl = np.array([1, 2, -1, -2, 0, 3], dtype=f32)
 case("leakyReluGpu", "tests/test_gpu.nim:238-246",
      [call("y", {"x": T(xl)}, T(np.where(xl > 0, xl, f32(0.01) * xl)))])
 
+case("customGrad", "tests/test_model.nim:196-214",
+     [call("identity", {"inp": T([1, 2, 3, 4], [2, 2])}, T([1, 2, 3, 4], [2, 2])),
+      call("grad", {"inp": T([1, 2, 3, 4], [2, 2])}, T([2, 4, 6, 8], [2, 2]))])
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "known_answers.json")
 with open(out, "w") as f:
     json.dump(cases, f, indent=1)

@@ -223,6 +223,17 @@ def leaky_relu_gpu():
     return [y.target("y")]
 
 
+def custom_grad():
+    # tests/test_model.nim:196-214: identity with a hand-written gradient inp * 2 * grad(identity)
+    x = iters("x")
+    inp = dsl.input("inp")
+    ident = Fun()
+    ident.raw[x] += inp.raw[x]
+    with ident.custom_grad():
+        dsl.grad_of(inp).raw[x] += inp.raw[x] * 2.0 * dsl.grad_of(ident).raw[x]
+    return [ident.target("identity").backwards().grad(inp).target("grad")]
+
+
 BUILDERS = {
     "identity": identity, "double": double, "matmul": matmul, "relu": relu,
     "meanSquaredError": mean_squared_error, "transpose": transpose, "max": maximum, "conv1": conv1,
@@ -231,7 +242,7 @@ BUILDERS = {
     "derive/trigonometry": derive_trigonometry, "derive/exp": derive_exp, "derive/log": derive_log,
     "increment": increment, "sumPositive": sum_positive, "multiple": linear,
     "multiplyAndSquare": multiply_and_square, "leakyReluGpu": leaky_relu_gpu, "matmulTalks": matmul,
-    "matmulExample": matmul,
+    "matmulExample": matmul, "customGrad": custom_grad,
 }
 
 

@@ -1,0 +1,134 @@
+"""reshape, maxpool2 (hand-written gradient with computed indices `y div 2`), avgpool2, upsample2 and
+the reference's fashion_mnist network (examples/fashion_mnist/fashion_mnist.nim:39-57).
+
+CPU part: the oracle against closed forms in numpy (the reference pins the customGrad mechanism with
+tests/test_model.nim:196-214, which is in tests/golden/known_answers.json; reshape with
+tests/test_tensors.nim:111-117).  GPU part: the product against the oracle."""
+import numpy as np
+import pytest
+
+import refcases
+from conftest import TOL, rel_err
+from exprgrad_amd import dsl, examples, layers
+
+
+def oracle(graphs, threads=2):
+    from oracle import kd
+    return kd.Model(refcases.program_text(graphs), threads=threads)
+
+
+def pool_graphs(kind):
+    img = dsl.input("img")
+    layer = {"max": layers.maxpool2, "avg": layers.avgpool2, "up": layers.upsample2}[kind](img)
+    it = dsl.iters("it")
+    loss = dsl.Fun()
+    loss[0] += layer.raw[it] * layer.raw[it]
+    return [layer.target("out"), loss.target("loss").backwards().grad(img).target("grad")]
+
+
+def pool_reference(kind, a):
+    n, h, w, c = a.shape
+    if kind == "up":
+        out = a.repeat(2, axis=1).repeat(2, axis=2)
+        grad = (2 * out).reshape(n, h, 2, w, 2, c).sum(axis=(2, 4))
+        return out, grad
+    blocks = a.reshape(n, h // 2, 2, w // 2, 2, c)
+    if kind == "avg":
+        out = blocks.sum(axis=(2, 4)) / 4
+        grad = (2 * out / 4).repeat(2, axis=1).repeat(2, axis=2)
+        return out, grad
+    out = blocks.max(axis=(2, 4))
+    big = out.repeat(2, axis=1).repeat(2, axis=2)
+    return out, np.where(a == big, 2 * big, 0)
+
+
+@pytest.mark.parametrize("kind", ["max", "avg", "up"])
+def test_oracle_pooling_forward_and_gradient(kind):
+    a = np.random.default_rng(3).random((2, 4, 6, 3), dtype=np.float32)
+    m = oracle(pool_graphs(kind))
+    out, grad = pool_reference(kind, a.astype(np.float64))
+    assert rel_err(m.call("out", {"img": a}), out) <= TOL
+    assert rel_err(m.call("grad", {"img": a}), grad) <= TOL
+
+
+def test_oracle_reshape_known_answers():
+    # tests/test_tensors.nim:111-117 (host-tensor reshape; the graph version must agree)
+    b = np.arange(6, dtype=np.float32)
+    for shape, want in (([2, 3], (2, 3)), ([2, -1], (2, 3)), ([-1, 3], (2, 3)), ([-1], (6,)), ([-1, 2, 3], (1, 2, 3))):
+        m = oracle([dsl.reshape(dsl.input("a"), shape).target("r")])
+        got = m.call("r", {"a": b.reshape(3, 2)})
+        assert got.shape == want and np.array_equal(got.ravel(), b)
+
+
+def test_oracle_fashion_mnist_network_learns():
+    m = oracle(examples.fashion_mnist_net(size=12, f1=4, f2=8, eta=0.02), threads=4)
+    rng = np.random.default_rng(0)
+    for tid in m.params:
+        m.params[tid][...] = (rng.random(m.params[tid].shape, dtype=np.float32) * 0.4 - 0.2)
+    x = rng.random((8, 144), dtype=np.float32)
+    y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 8)]
+    first = float(m.call("loss", {"x": x, "y": y})[0])
+    for epoch in range(1, 9):
+        m.epoch = epoch           # Model.fit bumps the epoch before every pass (model.nim:436)
+        m.apply("fit", {"x": x, "y": y})
+    assert float(m.call("loss", {"x": x, "y": y})[0]) < 0.8 * first
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["max", "avg", "up"])
+@pytest.mark.parametrize("shape", [(2, 4, 6, 3), (3, 16, 20, 8)])
+def test_gpu_pooling_matches_the_oracle(gpu_ctx, kind, shape):
+    from exprgrad_amd import model as egm
+    a = np.random.default_rng(sum(shape)).random(shape, dtype=np.float32)
+    ref = oracle(pool_graphs(kind))
+    gpu = egm.compile(*pool_graphs(kind), gpu=gpu_ctx)
+    assert np.array_equal(gpu.call("out", {"img": a}), ref.call("out", {"img": a}))
+    assert rel_err(gpu.call("grad", {"img": a}), ref.call("grad", {"img": a})) <= TOL
+    gpu.close()
+
+
+@pytest.mark.gpu
+def test_gpu_reshape_and_custom_grad(gpu_ctx):
+    from exprgrad_amd import model as egm
+    b = np.arange(24, dtype=np.float32)
+    for shape in ([4, 6], [2, -1], [-1, 3], [-1], [-1, 2, 3]):
+        gpu = egm.compile(dsl.reshape(dsl.input("a"), shape).target("r"), gpu=gpu_ctx)
+        got = gpu.call("r", {"a": b.reshape(3, 8)})
+        assert got.shape == tuple(b.reshape(shape).shape) and np.array_equal(got.ravel(), b)
+        gpu.close()
+    gpu = egm.compile(*refcases.custom_grad(), gpu=gpu_ctx)
+    t = np.array([[1, 2], [3, 4]], dtype=np.float32)
+    assert np.array_equal(gpu.call("identity", {"inp": t}), t)          # tests/test_model.nim:212-213
+    assert np.array_equal(gpu.call("grad", {"inp": t}), t * 2)
+    gpu.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [(12, 4, 8, 8), (28, 8, 16, 32)])
+def test_gpu_fashion_mnist_network_matches_the_oracle(gpu_ctx, dims):
+    from exprgrad_amd import model as egm
+    size, f1, f2, batch = dims
+    graphs = lambda: examples.fashion_mnist_net(size=size, f1=f1, f2=f2)
+    gpu = egm.compile(*graphs(), gpu=gpu_ctx)
+    ref = oracle(graphs(), threads=8)
+    rng = np.random.default_rng(size)
+    for tid in sorted(ref.params):
+        v = (rng.random(ref.params[tid].shape, dtype=np.float32) * 0.4 - 0.2).astype(np.float32)
+        ref.params[tid][...] = v
+        gpu.params[tid] = v
+    x = rng.random((batch, size * size), dtype=np.float32)
+    y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, batch)]
+    assert rel_err(gpu.call("predict", {"x": x}), ref.call("predict", {"x": x})) <= TOL
+    assert rel_err(gpu.call("loss", {"x": x, "y": y}), ref.call("loss", {"x": x, "y": y})) <= TOL
+    before = {t: ref.params[t].copy() for t in ref.params}
+    gpu.epoch = ref.epoch = 1
+    gpu.apply("fit", {"x": x, "y": y})
+    ref.apply("fit", {"x": x, "y": y})
+    for tid in sorted(ref.params):
+        du_gpu, du_ref = gpu.params[tid] - before[tid], ref.params[tid] - before[tid]
+        # adam's first step is eta * g / (|g| + eps): tiny gradients amplify rounding; compare where it is resolved
+        assert rel_err(du_gpu, du_ref) <= 2e-3, tid
+        assert rel_err(gpu.params[tid], ref.params[tid]) <= 1e-4, tid
+    gpu.close()
