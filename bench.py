@@ -322,6 +322,34 @@ def run_conv2(args, env):
             "backward": backward}
 
 
+def run_fashion_fit(args, env):
+    """One epoch of Model.fit on the reference's flagship network (examples/fashion_mnist/fashion_mnist.nim:
+    39-57: reshape-conv2-leakyRelu-maxpool2 x2, dense, softmax, crossEntropy, adam) with synthetic data of
+    the data set's shape, at the reference's default batch size of 32 and at 4096."""
+    import numpy as np
+    from exprgrad_amd import examples as refcases
+    from exprgrad_amd import model as egm
+    torch = env["torch"]
+    model = egm.compile(*refcases.fashion_mnist_net(), gpu=env["ctx"])
+    rng = np.random.default_rng(6)
+    samples = 60000
+    x = rng.random((samples, 784), dtype=np.float32)
+    y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, samples)]
+    out = {"metric": "Model.fit samples/s, fashion_mnist network (reference flagship example), one epoch of 60000",
+           "unit": "samples/s", "data": "synthetic 28x28 images, host arrays (H2D copy per batch included)"}
+    for batch in (32, 4096):
+        model.fit("fit", {"x": x[:batch * 4], "y": y[:batch * 4]}, batch_size=batch)   # builds, captures
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.fit("fit", {"x": x, "y": y}, batch_size=batch)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[f"batch_{batch}"] = {"value": round(samples // batch * batch / dt, 1), "epoch_ms": round(dt * 1e3, 2),
+                                 "us_per_batch": round(dt / (samples // batch) * 1e6, 1)}
+    out["value"] = out["batch_32"]["value"]
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -381,6 +409,7 @@ def main():
             extra["train"], model = run_train(small, env)
             extra["xor"] = run_xor(small, env)
             extra["conv2"] = run_conv2(small, env)
+            extra["fashion_mnist_fit"] = run_fashion_fit(small, env)
             line["extra"] = extra
             # the --gpus N > 1 invocations report the data-parallel train step; its 1-GPU point:
             line["scaling_series_n1"] = {"metric": extra["train"]["metric"], "value": extra["train"]["value"],

@@ -233,6 +233,9 @@ struct Plan {
   Shapes shapes;
   std::vector<Launch> launches;
   int n_backward = 0;  // launches before the first parameter update
+  // Result tensors that are a whole-tensor raw copy of another tensor (reshape, passes.nim:643-688,
+  // and the gradient of one) share its storage instead of being copied: dest -> source.
+  std::map<int, int> alias;
   std::map<int, long> arena_offset;  // result tensor -> float offset in the arena
   long arena_floats = 0;
   long zero_floats = 0;  // leading part of the arena that is zeroed before every run
@@ -357,6 +360,7 @@ int lower_target(eg_model* m, TargetState& ts) {
 }
 
 float* tensor_ptr(eg_model* m, TargetState& ts, Plan& plan, int tid) {
+  for (auto al = plan.alias.find(tid); al != plan.alias.end(); al = plan.alias.find(tid)) tid = al->second;
   const TensorDef& d = m->prog.tensors[tid];
   if (d.kind == TK::Param || d.kind == TK::Cache) return m->params[tid].ptr;
   if (d.kind == TK::Input) {
@@ -712,6 +716,33 @@ int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<
   return EG_OK;
 }
 
+// Is live kernel p a whole-tensor raw copy `dst{it} ++= src{it}` whose destination can simply share
+// the source's storage?  (reshape and its gradient.)  Requires: dst is written by this kernel only,
+// src is complete by then (no later writer), same element count, dst not in the gradient bucket.
+bool copy_can_alias(eg_model* m, TargetState& ts, const Kernel& k, const KernelInfo& info, const Shapes& shapes, int p) {
+  static const bool off = [] {
+    const char* e = getenv("EG_NO_ALIAS");
+    return e && e[0] && e[0] != '0';
+  }();
+  if (off || !info.ok) return false;
+  if (k.reads.size() != 1 || !k.instrs.empty() || !k.index_instrs.empty() || k.loops.size() != 1) return false;
+  const Op& rd = k.reads[0];
+  if (k.result != rd.reg || !k.write.raw || !rd.raw || k.write.dims.size() != 1 || rd.dims.size() != 1) return false;
+  const int it = k.loops[0].reg;
+  if (k.write.dims[0].only_register() != it || rd.dims[0].only_register() != it) return false;
+  const int dst = k.write.tensor, src = rd.tensor;
+  if (dst == src || ts.bucket_offset.count(dst) || m->prog.tensors[dst].kind != TK::Result) return false;
+  const long n = prod(shapes.at(dst));
+  if (info.bounds[0].first != 0 || info.bounds[0].second != n || prod(shapes.at(src)) != n) return false;
+  const Target& t = *ts.target;
+  for (size_t q = 0; q < t.live.size(); ++q) {
+    const Kernel& o = t.all[t.live[q]];
+    if ((int)q != p && o.write.tensor == dst) return false;   // another contribution to dst
+    if ((int)q > p && o.write.tensor == src) return false;    // src still changes after the copy
+  }
+  return true;
+}
+
 // Contraction + elementwise consumer -> one launch (epilogue.hpp).  Only large outputs: the
 // fused kernel is built at run time from the matrix kernel's source (seconds), which pays when
 // the saved round trip through HBM is megabytes; small chains are launch bound and handled by
@@ -913,6 +944,10 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
     const bool is_result = m->prog.tensors[wt].kind == TK::Result;
     const bool first = is_result && first_writer[wt] == (int)p;
     const std::vector<long>& wshape = shapes.at(wt);
+    if (lo.kind == StepKind::GenericA && first && copy_can_alias(m, ts, k, info, shapes, (int)p)) {
+      plan.alias[wt] = k.reads[0].tensor;
+      continue;
+    }
     Launch L;
     L.lowered = (int)p;
     L.kind = lo.kind;
@@ -1064,6 +1099,7 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   long off = 0;
   for (int pass = 0; pass < 2; ++pass) {
     for (int tid : result_tensors) {
+      if (plan.alias.count(tid)) continue;  // lives in its source's storage
       if (ts.bucket_offset.count(tid)) {
         if (pass == 0 && needs_zero.count(tid)) plan.bucket_zero.push_back(tid);
         continue;
