@@ -713,6 +713,42 @@ int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<
     }
     p = std::max(q, p + 1);
   }
+  // ---- map groups: runs of raw elementwise kernels of any size among what is still separate (the
+  //      per-parameter optimizer kernels); same encoding and launch path as the small groups
+  p = 0;
+  while (p < n) {
+    auto eligible = [&](int s) {
+      if (group_of[s] != -1 || ts.lowered[s].absorbed || ts.lowered[s].kind != StepKind::GenericA) return false;
+      long count = 0;
+      return is_map_kernel(m->prog, t.all[t.live[s]], infos[t.live[s]], shapes, count);
+    };
+    if (!eligible(p)) {
+      ++p;
+      continue;
+    }
+    int q = p;
+    while (q < n && eligible(q) && !(q != p && q == t.first_update)) ++q;
+    if (q - p >= 2) {
+      std::unique_ptr<PlanSmallGroup> sg(new PlanSmallGroup());
+      for (int s = p; s < q; ++s) sg->g.kernel_index.push_back(t.live[s]);
+      char name[64];
+      snprintf(name, sizeof(name), "eg_maps%d", m->kernel_serial++);
+      sg->g.name = name;
+      int rc = generate_map_group(m->prog, t.all, infos, shapes, sg->g);
+      if (rc) return rc;
+      rc = eg_kernel_compile(m->ctx, sg->g.name.c_str(), sg->g.source.c_str(), &sg->handle);
+      if (rc) {
+        std::string msg = eg_last_error();
+        set_error("%s\n--- generated source ---\n%s", msg.c_str(), sg->g.source.c_str());
+        return rc;
+      }
+      m->kernels.push_back(sg->handle);
+      const int gi = (int)plan.small_groups.size();
+      for (int s = p; s < q; ++s) group_of[s] = -2 - gi;
+      plan.small_groups.push_back(std::move(sg));
+    }
+    p = std::max(q, p + 1);
+  }
   return EG_OK;
 }
 
@@ -1183,7 +1219,7 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       long EP = m->epoch;
       args.push_back(&GS);
       args.push_back(&EP);
-      return eg::kernel_launch_raw(sg.handle, 1, 1, 1, 256, args.data());
+      return eg::kernel_launch_raw(sg.handle, (unsigned)sg.g.blocks, 1, 1, 256, args.data());
     }
     case StepKind::RowFused: {
       PlanRowGroup& pg = *plan.row_groups[L.row_group];
@@ -1507,7 +1543,7 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
       }
       case StepKind::SmallFused: {
         const PlanSmallGroup& sg = *plan.small_groups[L.row_group];
-        os << "small-fused " << sg.g.kernel_index.size() << " kernels";
+        os << (sg.g.blocks > 1 ? "map-fused " : "small-fused ") << sg.g.kernel_index.size() << " kernels";
         break;
       }
     }

@@ -421,5 +421,98 @@ int generate_small_group(const Program& prog, const std::vector<Kernel>& all, co
   return EG_OK;
 }
 
+bool is_map_kernel(const Program& prog, const Kernel& k, const KernelInfo& info, const Shapes& shapes, long& count) {
+  (void)prog;
+  if (!info.ok || !k.index_instrs.empty() || k.loops.size() != 1 || k.gen != Gen::None) return false;
+  if (!k.setup.empty() && !k.is_seed) return false;
+  const int it = k.loops[0].reg;
+  std::vector<const Op*> ops;
+  for (auto& rd : k.reads) ops.push_back(&rd);
+  ops.push_back(&k.write);
+  auto ws = shapes.find(k.write.tensor);
+  if (ws == shapes.end()) return false;
+  count = prodv(ws->second);
+  if (count <= 0 || info.bounds[0].first != 0 || info.bounds[0].second != count) return false;
+  for (const Op* op : ops) {
+    auto sh = shapes.find(op->tensor);
+    if (sh == shapes.end() || prodv(sh->second) != count) return false;
+    if (!op->raw || op->dims.size() != 1 || op->dims[0].only_register() != it) return false;
+  }
+  return true;
+}
+
+int generate_map_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
+                       const Shapes& shapes, SmallGroup& g) {
+  std::set<int> written, touched;
+  std::vector<long> counts;  // distinct element counts, in order of first appearance = the segments
+  std::vector<long> of_kernel;
+  for (int ki : g.kernel_index) {
+    long n = 0;
+    if (!is_map_kernel(prog, all[ki], infos[ki], shapes, n)) {
+      set_error("internal: kernel %d is not an elementwise map", ki);
+      return EG_ERR_INVALID;
+    }
+    of_kernel.push_back(n);
+    if (std::find(counts.begin(), counts.end(), n) == counts.end()) counts.push_back(n);
+    written.insert(all[ki].write.tensor);
+    touched.insert(all[ki].write.tensor);
+    for (auto& rd : all[ki].reads) touched.insert(rd.tensor);
+  }
+  g.ptr_args.assign(touched.begin(), touched.end());
+  std::string sig = "extern \"C\" __global__ void __launch_bounds__(256) " + g.name + "(";
+  for (size_t i = 0; i < g.ptr_args.size(); ++i) {
+    const int t = g.ptr_args[i];
+    sig += (i ? ", " : "") + std::string(written.count(t) ? "float* t" : "const float* t") + std::to_string(t);
+  }
+  sig += std::string(g.ptr_args.empty() ? "" : ", ") + "float GS, long EP)";
+  std::string c = "  const long block = blockIdx.x;\n";
+  long first_block = 0;
+  for (size_t seg = 0; seg < counts.size(); ++seg) {
+    const long n = counts[seg], nblocks = (n + 255) / 256;
+    c += std::string(seg ? "  else if" : "  if") + " (block < " + std::to_string(first_block + nblocks) + "L) {  // " +
+         std::to_string(n) + " elements\n";
+    c += "    const long idx = (block - " + std::to_string(first_block) + "L) * 256 + threadIdx.x;\n";
+    c += "    if (idx < " + std::to_string(n) + "L) {\n";
+    for (size_t gi = 0; gi < g.kernel_index.size(); ++gi) {
+      if (of_kernel[gi] != n) continue;
+      const Kernel& k = all[g.kernel_index[gi]];
+      const KernelInfo& info = infos[g.kernel_index[gi]];
+      const std::vector<Ty> ty = infer_types(k);
+      c += "      {  // " + to_text(k).substr(0, 100) + "\n";
+      for (auto& s : k.setup) c += "        const long r" + std::to_string(s.res) + " = " + std::to_string(info.vals.at(s.res)) + "L;\n";
+      c += "        const long r" + std::to_string(k.loops[0].reg) + " = idx;\n";
+      for (auto& rd : k.reads) c += "        const float r" + std::to_string(rd.reg) + " = t" + std::to_string(rd.tensor) + "[idx];\n";
+      for (auto& ins : k.instrs) {
+        const Ty t = ty[ins.res];
+        const char* ctype = t == Ty::Scalar ? "float" : (t == Ty::Index ? "long" : "bool");
+        std::string special;
+        if (ins.kind == IK::Epoch) {
+          special = "EP";
+        } else if (ins.kind == IK::Shape || ins.kind == IK::Len || ins.kind == IK::ShapeLen) {
+          const std::vector<long>& shp = shapes.at(ins.tensor);
+          long v = 0;
+          if (ins.kind == IK::Len) v = prodv(shp);
+          else if (ins.kind == IK::ShapeLen) v = (long)shp.size();
+          else {
+            int d = ins.dim < 0 ? ins.dim + (int)shp.size() : ins.dim;
+            v = (d >= 0 && d < (int)shp.size()) ? shp[d] : 0;
+          }
+          special = std::to_string(v) + "L";
+        }
+        std::string e = instr_expression(ins, special, "r");
+        if (k.is_seed && ins.kind == IK::Scalar) e = "GS";
+        c += std::string("        const ") + ctype + " r" + std::to_string(ins.res) + " = " + e + ";\n";
+      }
+      const std::string w = "t" + std::to_string(k.write.tensor) + "[idx]";
+      c += "        " + w + " = " + w + " + (0.0f + r" + std::to_string(k.result) + ");\n      }\n";
+    }
+    c += "    }\n  }\n";
+    first_block += nblocks;
+  }
+  g.blocks = first_block;
+  g.source = sig + " {\n" + c + "}\n";
+  return EG_OK;
+}
+
 }  // namespace kd
 }  // namespace eg

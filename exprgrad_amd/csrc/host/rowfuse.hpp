@@ -77,12 +77,24 @@ struct SmallGroup {
   std::vector<int> kernel_index;  // indices into target.all, in execution order
   std::string name, source;
   std::vector<int> ptr_args;      // tensor ids in pointer-argument order
+  long blocks = 1;                // grid size (1 for a small group, sum over the segments of a map group)
 };
 
 // Arguments of the generated kernel: (float* / const float* t<ids>..., float grad_scale, long epoch).
 // Every kernel accumulates into its destination (the caller zeroes first-written results).
 int generate_small_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
                          const Shapes& shapes, SmallGroup& group);
+
+// ---- map groups ------------------------------------------------------------------------------------
+// Consecutive raw elementwise kernels over whole tensors of ANY size (`p{it} ++= -g{it} * rate` for
+// every parameter: gradientDescent, base.nim:37-38; adam's m / v / p chains) run as one launch: the
+// kernels are grouped into segments by element count, a block belongs to one segment (block ranges
+// are literals in the generated source) and a thread runs, for its element, every kernel of the
+// segment in order.  Kernels of different segments cannot share a tensor (each covers its tensors
+// completely), so segments are independent.  Same kernel arguments as a small group.
+bool is_map_kernel(const Program& prog, const Kernel& k, const KernelInfo& info, const Shapes& shapes, long& count);
+int generate_map_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
+                       const Shapes& shapes, SmallGroup& group);
 
 }  // namespace kd
 }  // namespace eg
