@@ -132,3 +132,26 @@ def test_gpu_fashion_mnist_network_matches_the_oracle(gpu_ctx, dims):
         assert rel_err(du_gpu, du_ref) <= 2e-3, tid
         assert rel_err(gpu.params[tid], ref.params[tid]) <= 1e-4, tid
     gpu.close()
+
+
+def test_front_end_errors_of_the_new_constructs():
+    x = dsl.input("x")
+    it = dsl.iters("it")
+    with pytest.raises(dsl.ParserError):
+        dsl.grad_of(x).raw[it] += x.raw[it]            # grad(...) ++= outside a customGrad block
+    with pytest.raises(dsl.ParserError):
+        dsl.reshape(x, [-1, -1])                       # one free extent at most
+    f = dsl.Fun()
+    with pytest.raises(dsl.ParserError):
+        f.custom_grad()                                # nothing to attach the gradient to
+    pooled = layers.maxpool2(x)
+    with pytest.raises(dsl.ParserError):
+        pooled.raw[it] += x.raw[it]                    # maxpool2 locks its result (dnn.nim:71)
+
+
+def test_kernel_description_text_of_the_new_constructs():
+    text = refcases.program_text(pool_graphs("max"))
+    assert "customgrad" in text and "endcustomgrad" in text and "\nidx indexdiv" in text
+    assert " -" in [l for l in text.splitlines() if l.startswith("write")][1]   # gradient placeholder: negative id
+    text = refcases.program_text([dsl.reshape(dsl.input("a"), [-1, 3]).target("r")])
+    assert "shapesetup" in text and "indexdiv" in text
