@@ -411,11 +411,22 @@ def backwards(fun):
     return Fun("backwards", children=[fun])
 
 
+def cond(branches, otherwise=None):
+    """cond({target name: fun, ...}, otherwise) (parser.nim:812-817): a node that stands for a
+    different sub-graph depending on the target being built — the GAN example feeds its
+    discriminator the generator's output in `fit.gen` and an input elsewhere (gan.nim:44)."""
+    branches = dict(branches)
+    return Fun("cond", cond=branches, cond_else=otherwise)
+
+
 def params(fun, stop=frozenset()):
     """parser.nim:742-756.  (The reference returns a HashSet; here: discovery order, deterministic.)"""
     out = []
     if not (fun.kind == "target" and fun.name in stop):
-        for c in fun.children:
+        subs = list(fun.children)
+        if fun.kind == "cond":                               # parser.nim:747-751
+            subs += list(fun.cond.values()) + ([fun.cond_else] if fun.cond_else is not None else [])
+        for c in subs:
             for p in params(c, stop):
                 if p not in out:
                     out.append(p)
@@ -763,6 +774,11 @@ def _alloc_tensors(fun, program):
             if src.get("shape") is None:
                 raise ParserError("cache() needs a tensor with a static shape (a parameter)")
             fun.tensor = program.alloc_tensor(kind="cache", name=fun.name, shape=list(src["shape"]))
+        elif k == "cond":                                    # parser.nim:302-307
+            for child in fun.cond.values():
+                _alloc_tensors(child, program)
+            if fun.cond_else is not None:
+                _alloc_tensors(fun.cond_else, program)
         for c in fun.children:
             _alloc_tensors(c, program)
         if k == "target":
@@ -794,6 +810,12 @@ def _flatten(fun, target, program):
                 c = ("dims", fun.tensor, dims, tuple(ctx.kernel.setup))
             if all(c[:2] != o[:2] for o in program.shape_constraints):
                 program.shape_constraints.append(c)
+    elif fun.kind == "cond":                                 # parser.nim:368-377
+        child = fun.cond.get(target.name, fun.cond_else)
+        if child is None:
+            raise ParserError(f'Conditional node does not have a branch for the target "{target.name}"')
+        _flatten(child, target, program)
+        fun.tensor = child.tensor
     elif fun.kind == "backwards":
         k = Kernel()
         k.generator = ("backwards", fun.children[0].tensor)
@@ -813,6 +835,11 @@ def _collect_targets(fun, targets):
                                   "within a model. Choose a different name every target.")
             return
         targets[fun.name] = fun
+    if fun.kind == "cond":                                   # parser.nim:395-399
+        for child in fun.cond.values():
+            _collect_targets(child, targets)
+        if fun.cond_else is not None:
+            _collect_targets(fun.cond_else, targets)
     for c in fun.children:
         _collect_targets(c, targets)
     if fun.kind == "effect":

@@ -83,3 +83,32 @@ def fashion_mnist_net(eta=0.01, size=28, f1=8, f2=16, classes=10):
     net = layers.softmax(net).target("predict")
     net = layers.cross_entropy(net, dsl.input("y")).target("loss")
     return [net.backwards().optimize(layers.adam(eta=eta)).target("fit")]
+
+
+def gan(seed_dim=32, h1=64, h2=128, pixels=28 * 28, rate=0.1):
+    """examples/gan/gan.nim:35-61: generator and discriminator MLPs; `cond` feeds the discriminator the
+    generator's output in the generator's targets and the `samples` input elsewhere; each side is
+    optimised over its own parameters only."""
+    it = iters("it")
+
+    def gen_loss(labels):
+        r = Fun()
+        r[0] += sq(labels.raw[it]) / dsl.to_scalar(labels.shape[0])                  # gan.nim:35-36
+        return r
+
+    gen = layers.dense(dsl.input("seed"), seed_dim, h1)
+    gen = layers.leaky_relu(gen, 0.01)
+    gen = layers.dense(gen, h1, h2)
+    gen = layers.leaky_relu(gen, 0.01)
+    gen = layers.sigmoid(layers.dense(gen, h2, pixels)).target("gen")
+    discr = dsl.cond({"fit.gen": gen, "loss.gen": gen}, dsl.input("samples"))
+    discr = layers.leaky_relu(layers.dense(discr, pixels, h2), 0.01)
+    discr = layers.leaky_relu(layers.dense(discr, h2, h1), 0.01)
+    discr = layers.sigmoid(layers.dense(discr, h1, 1)).target("discr")
+    gen_params = gen.params()
+    fit_gen = gen_loss(discr).target("loss.gen").backwards().optimize(gen_params, layers.gradient_descent(rate))
+    fit_gen = fit_gen.target("fit.gen")
+    discr_params = [p for p in discr.params() if p not in gen_params]
+    fit_discr = layers.mse(discr, dsl.input("labels")).target("loss.discr").backwards()
+    fit_discr = fit_discr.optimize(discr_params, layers.gradient_descent(rate)).target("fit.discr")
+    return [gen, discr, fit_gen, fit_discr]
