@@ -183,8 +183,11 @@ int eg_conv2_nhwc_grad_image(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64
 /* ------------------------------------------------------------------ group 3: model ---- */
 /* A program is the text form of exprgrad's `Program` (ir.nim:247-270) before `generate`:
  * tensors, targets, and per target the ordered list of `++=` kernel descriptions
- * (loops + reads + expr + write, ir.nim:211-230) plus the GenBackwards / GenGradient
- * placeholders (ir.nim:196-209).  Grammar: DESIGN.md "Kernel-description text".
+ * (loops + reads + expr + write, ir.nim:211-230; computed index parts of an operand —
+ * LinearIndex.setup, ir.nim:120-123 — as `idx` instructions; a customGrad block, ir.nim:203-209,
+ * as nested kernels) plus the GenBackwards / GenGradient placeholders (ir.nim:196-204); reshape
+ * (GenReshape) arrives as the copy kernel + shape constraint generate makes of it
+ * (passes.nim:643-688).  Grammar: DESIGN.md "Kernel-description text".
  *
  * eg_model_compile does what newModel does for a CompileGpu target (model.nim:232-251):
  * autodiff + dead-kernel elimination, pattern-match every kernel to a library kernel or
