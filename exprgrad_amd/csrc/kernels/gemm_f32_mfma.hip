@@ -37,7 +37,7 @@ int launch_config(eg_ctx* ctx, bool a_kc, bool b_kc, const GemmArgs& args, int s
   hipStream_t s = ctx->stream;
   // 16-byte aligned operands: interior tiles run the LDS-DMA loop (gemm_f32_mfma.hpp)
 #define EG_GEMM_LAUNCH(AKC, BKC, V, E, CV)                                                                        \
-  hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, MINB, AKC, BKC, V, E, CV, 0, (V == 4 && CV == 0)>), grid, \
+  hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, MINB, AKC, BKC, V, E, CV, 0, (V == 4 && CV != 1)>), grid, \
                      block, 0, s, args)
 #define EG_GEMM_LAYOUT(AKC, BKC)                  \
   do {                                            \

@@ -346,8 +346,8 @@ struct DmaLoader {
 
   __device__ __forceinline__ static int swizzle(int r) { return BK == 16 ? (r >> 2) & 3 : (r >> 1) & 7; }
 
-  __device__ __forceinline__ void init(const GemmArgs& a, long mn0, int wave, int lane) {
-    if (CONV) {
+  __device__ __forceinline__ void init(const GemmArgs& a, long mn0, int wave, int lane, long limit = 0) {
+    if (CONV && KC) {
 #pragma unroll
       for (int t = 0; t < PER_WAVE; ++t) {
         const int q = (wave + t * WAVES) * 64 + lane;
@@ -357,6 +357,19 @@ struct DmaLoader {
         const unsigned y = rem / (unsigned)a.cWo, x = rem % (unsigned)a.cWo;
         row_off[t] = ((img * a.cH + y) * a.cW + x) * a.cC;
       }
+    } else if (CONV) {
+      // filter-gradient operand (k = output pixel, n = (dy, dx, c)): this lane's n is fixed, so is
+      // its offset inside the window
+#pragma unroll
+      for (int t = 0; t < PER_WAVE; ++t) {
+        constexpr int CPR = BMN / 4;
+        const int q = (wave + t * WAVES) * 64 + lane;
+        long n = mn0 + (q % CPR) * 4;
+        if (CLAMP) n = min(n, limit - 4);
+        const unsigned C = (unsigned)a.cC, FW = (unsigned)a.cFW;
+        const unsigned tap = (unsigned)n / C, c = (unsigned)n % C;
+        row_off[t] = (long)((tap / FW) * (unsigned)a.cW + tap % FW) * C + c;
+      }
     }
   }
 
@@ -364,7 +377,7 @@ struct DmaLoader {
   __device__ __forceinline__ void issue(const GemmArgs& a, const float* __restrict__ base, long ld, long mn0, long k0,
                                         float* tile, int wave, int lane, long limit = 0, long k_lim = 0) const {
     long tap_off = 0;
-    if (CONV) {  // block-uniform: scalar work
+    if (CONV && KC) {  // block-uniform: scalar work
       const unsigned C = (unsigned)a.cC, FW = (unsigned)a.cFW;
       const unsigned tap = (unsigned)k0 / C, c0 = (unsigned)k0 % C;
       tap_off = (long)((tap / FW) * (unsigned)a.cW + tap % FW) * C + c0;
@@ -385,7 +398,15 @@ struct DmaLoader {
       } else {
         constexpr int CPR = BMN / 4;
         const int k = q / CPR, col = (q % CPR) * 4;
-        src = base + (CLAMP ? min(k0 + k, k_lim - 1) : k0 + k) * ld + (CLAMP ? min(mn0 + col, limit - 4) : mn0 + col);
+        if (CONV) {  // k -> output pixel (n, y, x) -> its window's top-left input pixel
+          const unsigned gk = (unsigned)(CLAMP ? min(k0 + k, k_lim - 1) : k0 + k);
+          const unsigned hw = (unsigned)(a.cHo * a.cWo);
+          const unsigned img = gk / hw, rem = gk % hw;
+          const unsigned y = rem / (unsigned)a.cWo, x = rem % (unsigned)a.cWo;
+          src = base + (((long)img * a.cH + y) * a.cW + x) * a.cC + row_off[t];
+        } else {
+          src = base + (CLAMP ? min(k0 + k, k_lim - 1) : k0 + k) * ld + (CLAMP ? min(mn0 + col, limit - 4) : mn0 + col);
+        }
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(tile + instr * 256), 16, 0, 0);
@@ -393,7 +414,7 @@ struct DmaLoader {
   }
 };
 
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool CONV, bool CL = false>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int CONV, bool CL = false>
 __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32],
                                                   long m_blk, long n_blk, long k_begin, int nk, int tid, int wm0,
                                                   int wn0, long k_end = 0) {
@@ -401,8 +422,8 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int BUF = BK * (BM + BN);
-  using DmaA = DmaLoader<BM, BK, NT, A_KC, CONV, CL>;
-  using DmaB = DmaLoader<BN, BK, NT, B_KC, false, CL>;
+  using DmaA = DmaLoader<BM, BK, NT, A_KC, CONV == 1, CL>;
+  using DmaB = DmaLoader<BN, BK, NT, B_KC, CONV == 2, CL>;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, hi = lane >> 5;
 
@@ -421,8 +442,8 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
 
   DmaA da;
   DmaB db;
-  da.init(a, m_blk, wave, lane);
-  db.init(a, n_blk, wave, lane);
+  da.init(a, m_blk, wave, lane, a.M);
+  db.init(a, n_blk, wave, lane, a.N);
   if (nk > 0) {
     da.issue(a, a.A, a.lda, m_blk, k_begin, lds, wave, lane, a.M, k_end);
     db.issue(a, a.B, a.ldb, n_blk, k_begin, lds + BK * BM, wave, lane, a.N, k_end);
@@ -506,7 +527,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
 // DMA: interior tiles use the LDS-DMA loop (requires VEC == 4, BK in {16, 32}; with CONV the host
 // checks C % BK == 0).
 // CONV: 0 = plain operands, 1 = A is the im2col matrix of an NHWC image (forward convolution),
-// 2 = B is (filter-gradient contraction; register-staged loop only).
+// 2 = B is that matrix with k = output pixel, n = tap (filter-gradient contraction).
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int VEC, bool EDGE, int CONV, int ABL, bool DMA,
           class Epi>
 __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
@@ -569,12 +590,11 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
 
   static_assert(!DMA || VEC == 4, "LDS-DMA loop: 16-byte aligned operands");
   if (DMA && (!EDGE || (m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0))) {
-    static_assert(!DMA || CONV != 2, "the filter-gradient gather runs on the register-staged loop");
-    gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV == 1>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
-  } else if (DMA && EDGE && !CONV) {
+    gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
+  } else if (DMA && EDGE && CONV != 1) {
     // ragged in M, N or K: still the LDS-DMA loop, with clamped addresses and a zeroed K tail
-    gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, false, true>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0,
-                                                                     wn0, k_end);
+    gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, true>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0,
+                                                                    k_end);
   } else if (EDGE) {
     const bool interior = m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0;
     if (interior)
