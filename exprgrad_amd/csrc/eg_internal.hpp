@@ -64,6 +64,9 @@ namespace eg {
 // Ensure ctx->workspace holds at least `bytes`; synchronises the stream if it has to grow.
 int ensure_workspace(eg_ctx* ctx, size_t bytes);
 int ensure_aux(eg_ctx* ctx, size_t bytes);
+// Build several kernels (extern "C" names) from one source text in a single hiprtc program.
+int kernels_compile_batch(eg_ctx* ctx, const char* label, const char* source, const std::vector<std::string>& names,
+                          std::vector<eg_kernel*>& out);
 // Launch a hiprtc-built kernel with an explicit argument array (bypasses the sticky arguments).
 int kernel_launch_raw(eg_kernel* kernel, unsigned gx, unsigned gy, unsigned gz, unsigned block, void** args);
 // Column sum with caller-provided scratch (colsum_scratch_floats(...) floats); see reduce.hip.

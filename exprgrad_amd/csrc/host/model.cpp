@@ -289,6 +289,7 @@ struct eg_model {
   int kernel_serial = 0;
   std::string plan_text;
   std::string launch_text;
+  std::vector<Generic*> pending;  // generated kernels not built yet (eg_model_compile builds them together)
   std::vector<eg_kernel*> kernels;
 };
 
@@ -353,9 +354,36 @@ int lower_target(eg_model* m, TargetState& ts) {
     snprintf(name, sizeof(name), "eg_k%d_a", m->kernel_serial++);
     int rc = generate_mode_a(k, name, lo.mode_a.src);
     if (rc) return rc;
-    rc = build_generic(m, lo.mode_a);
-    if (rc) return rc;
+    m->pending.push_back(&lo.mode_a);  // built together with the model's other generated kernels
   }
+  return EG_OK;
+}
+
+// All template-A kernels of the model in one hiprtc program (seconds -> fractions of a second for a
+// 40-kernel network); if the program fails to build, build one by one to name the culprit.
+int build_pending(eg_model* m) {
+  if (m->pending.empty()) return EG_OK;
+  std::string source;
+  std::vector<std::string> names;
+  for (Generic* g : m->pending) {
+    source += g->src.source + "\n";
+    names.push_back(g->src.name);
+  }
+  std::vector<eg_kernel*> built;
+  int rc = eg::kernels_compile_batch(m->ctx, "eg_model_kernels", source.c_str(), names, built);
+  if (rc) {
+    eg::clear_error();
+    for (Generic* g : m->pending) {
+      rc = build_generic(m, *g);
+      if (rc) return rc;
+    }
+  } else {
+    for (size_t i = 0; i < built.size(); ++i) {
+      m->pending[i]->handle = built[i];
+      m->kernels.push_back(built[i]);
+    }
+  }
+  m->pending.clear();
   return EG_OK;
 }
 
@@ -1477,6 +1505,8 @@ int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out) {
     rc = lower_target(m.get(), ts);
     if (rc) return rc;
   }
+  rc = build_pending(m.get());
+  if (rc) return rc;
   describe(m.get());
   *out = m.release();
   return EG_OK;

@@ -65,9 +65,21 @@ int ensure_aux(eg_ctx* ctx, size_t bytes) {
 
 using eg::set_error;
 
+// A loaded code object; several kernels built in one hiprtc program share it.
+struct eg_module {
+  int device = 0;
+  hipModule_t handle = nullptr;
+  ~eg_module() {
+    if (handle) {
+      hipSetDevice(device);
+      hipModuleUnload(handle);
+    }
+  }
+};
+
 struct eg_kernel {
   eg_ctx* ctx = nullptr;
-  hipModule_t module = nullptr;
+  std::shared_ptr<eg_module> module;
   hipFunction_t fn = nullptr;
   std::string name;
   // Sticky arguments, 8 bytes each (pointers, int64, double) or 4 (float).
@@ -84,6 +96,64 @@ int kernel_launch_raw(eg_kernel* kernel, unsigned gx, unsigned gy, unsigned gz, 
   if (gx == 0 || gy == 0 || gz == 0) return EG_OK;
   EG_HIP_CHECK(hipSetDevice(kernel->ctx->device));
   EG_HIP_CHECK(hipModuleLaunchKernel(kernel->fn, gx, gy, gz, block, 1, 1, 0, kernel->ctx->stream, args, nullptr));
+  return EG_OK;
+}
+}  // namespace eg
+
+namespace eg {
+// One hiprtc program, one code object, one handle per kernel name (a model's generated kernels are
+// built together: the per-program overhead of hiprtc dominates small kernels).
+int kernels_compile_batch(eg_ctx* ctx, const char* label, const char* source, const std::vector<std::string>& names,
+                          std::vector<eg_kernel*>& out) {
+  out.clear();
+  EG_HIP_CHECK(hipSetDevice(ctx->device));
+  hiprtcProgram prog;
+  hiprtcResult r = hiprtcCreateProgram(&prog, source, label, 0, nullptr, nullptr);
+  if (r != HIPRTC_SUCCESS) {
+    set_error("hiprtcCreateProgram failed: %s", hiprtcGetErrorString(r));
+    return EG_ERR_COMPILE;
+  }
+  // Arch comes from the device (e.g. "gfx950:sramecc+:xnack-").  contract=off keeps the
+  // generated scalar code inside the reference's no-fast-math arithmetic (llvm.nim:486-491).
+  std::string arch_opt = "--offload-arch=" + ctx->arch;
+  const char* opts[] = {arch_opt.c_str(), "-O3", "-ffp-contract=off", "-std=c++17"};
+  r = hiprtcCompileProgram(prog, 4, opts);
+  if (r != HIPRTC_SUCCESS) {
+    size_t log_size = 0;
+    hiprtcGetProgramLogSize(prog, &log_size);
+    std::string log(log_size, '\0');
+    if (log_size) hiprtcGetProgramLog(prog, &log[0]);
+    hiprtcDestroyProgram(&prog);
+    // cl.nim:163-171
+    if (log_size > 1)
+      set_error("Failed to build program: %s", log.c_str());
+    else
+      set_error("Failed to build program");
+    return EG_ERR_COMPILE;
+  }
+  size_t code_size = 0;
+  hiprtcGetCodeSize(prog, &code_size);
+  std::vector<char> code(code_size);
+  hiprtcGetCode(prog, code.data());
+  hiprtcDestroyProgram(&prog);
+
+  std::shared_ptr<eg_module> mod(new eg_module());
+  mod->device = ctx->device;
+  EG_HIP_CHECK(hipModuleLoadData(&mod->handle, code.data()));
+  std::vector<std::unique_ptr<eg_kernel>> built;
+  for (auto& name : names) {
+    std::unique_ptr<eg_kernel> k(new eg_kernel());
+    k->ctx = ctx;
+    k->name = name;
+    k->module = mod;
+    hipError_t e = hipModuleGetFunction(&k->fn, mod->handle, name.c_str());
+    if (e != hipSuccess) {
+      set_error("kernel '%s' not found in compiled module: %s", name.c_str(), hipGetErrorString(e));
+      return EG_ERR_COMPILE;
+    }
+    built.push_back(std::move(k));
+  }
+  for (auto& k : built) out.push_back(k.release());
   return EG_OK;
 }
 }  // namespace eg
@@ -310,48 +380,10 @@ int eg_buf_fill(eg_buf* buf, const void* pattern, size_t pattern_bytes) {
 
 int eg_kernel_compile(eg_ctx* ctx, const char* name, const char* source, eg_kernel** out) {
   EG_REQUIRE(ctx && name && source && out, EG_ERR_INVALID, "eg_kernel_compile: NULL argument");
-  EG_HIP_CHECK(hipSetDevice(ctx->device));
-  hiprtcProgram prog;
-  hiprtcResult r = hiprtcCreateProgram(&prog, source, name, 0, nullptr, nullptr);
-  if (r != HIPRTC_SUCCESS) {
-    set_error("hiprtcCreateProgram failed: %s", hiprtcGetErrorString(r));
-    return EG_ERR_COMPILE;
-  }
-  // Arch comes from the device (e.g. "gfx950:sramecc+:xnack-").  contract=off keeps the
-  // generated scalar code inside the reference's no-fast-math arithmetic (llvm.nim:486-491).
-  std::string arch_opt = "--offload-arch=" + ctx->arch;
-  const char* opts[] = {arch_opt.c_str(), "-O3", "-ffp-contract=off", "-std=c++17"};
-  r = hiprtcCompileProgram(prog, 4, opts);
-  if (r != HIPRTC_SUCCESS) {
-    size_t log_size = 0;
-    hiprtcGetProgramLogSize(prog, &log_size);
-    std::string log(log_size, '\0');
-    if (log_size) hiprtcGetProgramLog(prog, &log[0]);
-    hiprtcDestroyProgram(&prog);
-    // cl.nim:163-171
-    if (log_size > 1)
-      set_error("Failed to build program: %s", log.c_str());
-    else
-      set_error("Failed to build program");
-    return EG_ERR_COMPILE;
-  }
-  size_t code_size = 0;
-  hiprtcGetCodeSize(prog, &code_size);
-  std::vector<char> code(code_size);
-  hiprtcGetCode(prog, code.data());
-  hiprtcDestroyProgram(&prog);
-
-  std::unique_ptr<eg_kernel> k(new eg_kernel());
-  k->ctx = ctx;
-  k->name = name;
-  EG_HIP_CHECK(hipModuleLoadData(&k->module, code.data()));
-  hipError_t e = hipModuleGetFunction(&k->fn, k->module, name);
-  if (e != hipSuccess) {
-    hipModuleUnload(k->module);
-    set_error("kernel '%s' not found in compiled module: %s", name, hipGetErrorString(e));
-    return EG_ERR_COMPILE;
-  }
-  *out = k.release();
+  std::vector<eg_kernel*> built;
+  int rc = eg::kernels_compile_batch(ctx, name, source, {std::string(name)}, built);
+  if (rc) return rc;
+  *out = built[0];
   return EG_OK;
 }
 
@@ -359,8 +391,7 @@ int eg_kernel_free(eg_kernel* kernel) {
   if (!kernel) return EG_OK;
   hipSetDevice(kernel->ctx->device);
   hipStreamSynchronize(kernel->ctx->stream);
-  if (kernel->module) hipModuleUnload(kernel->module);
-  delete kernel;
+  delete kernel;  // the code object goes with the last kernel that shares it
   return EG_OK;
 }
 
