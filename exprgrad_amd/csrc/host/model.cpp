@@ -247,6 +247,12 @@ struct Plan {
   std::vector<std::unique_ptr<PlanRowGroup>> row_groups;
   std::vector<std::unique_ptr<PlanSmallGroup>> small_groups;
   std::vector<std::unique_ptr<PlanEpilogue>> epilogues;
+  // generated kernels of this plan waiting for the one hiprtc program make_plan builds at its end
+  struct PendingKernel {
+    std::string name, source;
+    eg_kernel** slot;
+  };
+  std::vector<PendingKernel> pending;
   struct Captured {
     hipGraphExec_t exec = nullptr;
     std::string key;  // everything baked into the captured kernel arguments
@@ -356,6 +362,44 @@ int lower_target(eg_model* m, TargetState& ts) {
     if (rc) return rc;
     m->pending.push_back(&lo.mode_a);  // built together with the model's other generated kernels
   }
+  return EG_OK;
+}
+
+// The kernels generated for one plan (row / small / map groups, split reductions): one program.
+int build_plan_kernels(eg_model* m, Plan& plan) {
+  if (plan.pending.empty()) return EG_OK;
+  std::string source;
+  std::vector<std::string> names;
+  for (auto& pk : plan.pending) {
+    if (*pk.slot) continue;  // the same split-reduction kernel requested twice
+    bool dup = false;
+    for (auto& n : names) dup = dup || n == pk.name;
+    if (dup) continue;
+    source += pk.source + "\n";
+    names.push_back(pk.name);
+  }
+  std::vector<eg_kernel*> built;
+  int rc = names.empty() ? EG_OK : eg::kernels_compile_batch(m->ctx, "eg_plan_kernels", source.c_str(), names, built);
+  if (rc) {  // name the culprit
+    eg::clear_error();
+    for (auto& pk : plan.pending) {
+      if (*pk.slot) continue;
+      rc = eg_kernel_compile(m->ctx, pk.name.c_str(), pk.source.c_str(), pk.slot);
+      if (rc) {
+        std::string msg = eg_last_error();
+        set_error("%s\n--- generated source ---\n%s", msg.c_str(), pk.source.c_str());
+        return rc;
+      }
+      m->kernels.push_back(*pk.slot);
+    }
+  } else {
+    for (size_t i = 0; i < built.size(); ++i) {
+      m->kernels.push_back(built[i]);
+      for (auto& pk : plan.pending)
+        if (pk.name == names[i]) *pk.slot = built[i];
+    }
+  }
+  plan.pending.clear();
   return EG_OK;
 }
 
@@ -690,13 +734,7 @@ int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<
     g.name = name;
     int rc = generate_row_group(m->prog, t.all, infos, shapes, g);
     if (rc) return rc;
-    rc = eg_kernel_compile(m->ctx, g.name.c_str(), g.source.c_str(), &pg->handle);
-    if (rc) {
-      std::string msg = eg_last_error();
-      set_error("%s\n--- generated source ---\n%s", msg.c_str(), g.source.c_str());
-      return rc;
-    }
-    m->kernels.push_back(pg->handle);
+    plan.pending.push_back({g.name, g.source, &pg->handle});
     pg->nblocks = (int)((B + 255) / 256);
     if (g.red_total > 0) {
       EG_HIP_CHECK(hipSetDevice(m->ctx->device));
@@ -728,13 +766,7 @@ int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<
       sg->g.name = name;
       int rc = generate_small_group(m->prog, t.all, infos, shapes, sg->g);
       if (rc) return rc;
-      rc = eg_kernel_compile(m->ctx, sg->g.name.c_str(), sg->g.source.c_str(), &sg->handle);
-      if (rc) {
-        std::string msg = eg_last_error();
-        set_error("%s\n--- generated source ---\n%s", msg.c_str(), sg->g.source.c_str());
-        return rc;
-      }
-      m->kernels.push_back(sg->handle);
+      plan.pending.push_back({sg->g.name, sg->g.source, &sg->handle});
       const int gi = (int)plan.small_groups.size();
       for (int s = p; s < q; ++s) group_of[s] = -2 - gi;
       plan.small_groups.push_back(std::move(sg));
@@ -764,13 +796,7 @@ int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<
       sg->g.name = name;
       int rc = generate_map_group(m->prog, t.all, infos, shapes, sg->g);
       if (rc) return rc;
-      rc = eg_kernel_compile(m->ctx, sg->g.name.c_str(), sg->g.source.c_str(), &sg->handle);
-      if (rc) {
-        std::string msg = eg_last_error();
-        set_error("%s\n--- generated source ---\n%s", msg.c_str(), sg->g.source.c_str());
-        return rc;
-      }
-      m->kernels.push_back(sg->handle);
+      plan.pending.push_back({sg->g.name, sg->g.source, &sg->handle});
       const int gi = (int)plan.small_groups.size();
       for (int s = p; s < q; ++s) group_of[s] = -2 - gi;
       plan.small_groups.push_back(std::move(sg));
@@ -1114,8 +1140,7 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
           snprintf(name, sizeof(name), "eg_k%d_b%d", m->kernel_serial++, tx);
           int rc = generate_mode_b(k, name, tx, g.src);
           if (rc) return rc;
-          rc = build_generic(m, g);
-          if (rc) return rc;
+          plan.pending.push_back({g.src.name, g.src.source, &g.handle});
         }
         const int ty = 256 / tx;
         const long col_tiles = (total + tx - 1) / tx;
@@ -1157,6 +1182,10 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
     if (rc) return rc;
   }
 
+  {
+    int rc = build_plan_kernels(m, plan);
+    if (rc) return rc;
+  }
   // arena layout: tensors that need zeroing first (one memset), then the rest
   plan.arena_offset.clear();
   plan.bucket_zero.clear();
