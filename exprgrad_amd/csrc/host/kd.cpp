@@ -200,6 +200,7 @@ int parse(const char* text, Program& prog) {
       else if (kind == "param") d.kind = TK::Param;
       else if (kind == "result") d.kind = TK::Result;
       else if (kind == "cache") d.kind = TK::Cache;
+      else if (kind == "random") d.kind = TK::Random;
       else P_FAIL("kd line %d: unknown tensor kind '%s'", lineno, kind.c_str());
       d.name = tk.next();
       if (d.name == "-") d.name.clear();
@@ -216,6 +217,8 @@ int parse(const char* text, Program& prog) {
         if (!d.has_shape) P_FAIL("kd line %d: a parameter needs a static shape", lineno);
         if (!tk.next_double(d.lo) || !tk.next_double(d.hi)) P_FAIL("kd line %d: bad init range", lineno);
       }
+      if (d.kind == TK::Random && (!tk.next_double(d.lo) || !tk.next_double(d.hi)))
+        P_FAIL("kd line %d: a random tensor needs its range", lineno);
       if (d.kind == TK::Cache && !d.has_shape) P_FAIL("kd line %d: a cache tensor needs a static shape", lineno);
       if (d.kind == TK::Input) prog.inputs[d.name] = (int)id;
       prog.tensors.push_back(d);

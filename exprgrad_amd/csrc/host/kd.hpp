@@ -82,14 +82,14 @@ struct Kernel {
   int alloc() { return ++nregs; }
 };
 
-enum class TK : uint8_t { Input, Param, Result, Cache };  // ir.nim:232-245
+enum class TK : uint8_t { Input, Param, Result, Cache, Random };  // ir.nim:232-245
 
 struct TensorDef {
   TK kind = TK::Result;
   std::string name;
   bool has_shape = false;
   std::vector<long> shape;  // static shape; -1 = unknown extent
-  double lo = 0, hi = 0;    // TensorParam.initRange
+  double lo = 0, hi = 0;    // TensorParam.initRange / TensorRandom.randomRange
 };
 
 struct Target {

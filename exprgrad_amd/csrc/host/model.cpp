@@ -236,6 +236,7 @@ struct Plan {
   // Result tensors that are a whole-tensor raw copy of another tensor (reshape, passes.nim:643-688,
   // and the gradient of one) share its storage instead of being copied: dest -> source.
   std::map<int, int> alias;
+  std::vector<int> random_tensors;   // TensorRandom tensors the live kernels read: refilled on every run
   std::map<int, long> arena_offset;  // result tensor -> float offset in the arena
   long arena_floats = 0;
   long zero_floats = 0;  // leading part of the arena that is zeroed before every run
@@ -296,6 +297,7 @@ struct eg_model {
   std::string plan_text;
   std::string launch_text;
   std::vector<Generic*> pending;  // generated kernels not built yet (eg_model_compile builds them together)
+  uint64_t* rng_state = nullptr;  // device: {seed, fills drawn so far} for the TensorRandom tensors (eg_fill_uniform)
   std::vector<eg_kernel*> kernels;
 };
 
@@ -361,6 +363,19 @@ int lower_target(eg_model* m, TargetState& ts) {
     int rc = generate_mode_a(k, name, lo.mode_a.src);
     if (rc) return rc;
     m->pending.push_back(&lo.mode_a);  // built together with the model's other generated kernels
+  }
+  return EG_OK;
+}
+
+// Device-resident generator state of the model's TensorRandom tensors: {seed, fills drawn so far}.
+int ensure_rng(eg_model* m, uint64_t seed = 0x5eed5eed5eed5eedULL, bool reseed = false) {
+  EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+  const bool fresh = m->rng_state == nullptr;
+  if (fresh) EG_HIP_CHECK(hipMalloc((void**)&m->rng_state, 2 * sizeof(uint64_t)));
+  if (fresh || reseed) {
+    const uint64_t init[2] = {seed, 0};
+    EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    EG_HIP_CHECK(hipMemcpy(m->rng_state, init, sizeof(init), hipMemcpyHostToDevice));
   }
   return EG_OK;
 }
@@ -942,6 +957,11 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
     const Kernel& k = t.all[i];
     bool ready = true;
     int missing = 0;
+    for (auto& r : k.reads)  // TensorRandom: shaped like the tensor `rand` was given (parser.nim:378-383)
+      if (m->prog.tensors[r.tensor].kind == TK::Random && !shapes.count(r.tensor)) {
+        auto sc = m->prog.shape_copy.find(r.tensor);
+        if (sc != m->prog.shape_copy.end() && shapes.count(sc->second)) shapes[r.tensor] = shapes[sc->second];
+      }
     for (auto& r : k.reads)
       if (!shapes.count(r.tensor)) {
         ready = false;
@@ -1204,6 +1224,18 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
     }
     if (pass == 0) plan.zero_floats = off;
   }
+  plan.random_tensors.clear();
+  for (int p : t.live)
+    for (auto& rd : t.all[p].reads)
+      if (m->prog.tensors[rd.tensor].kind == TK::Random && !plan.arena_offset.count(rd.tensor)) {
+        plan.arena_offset[rd.tensor] = off;
+        off += align4(prod(shapes.at(rd.tensor)));
+        plan.random_tensors.push_back(rd.tensor);
+      }
+  if (!plan.random_tensors.empty()) {
+    int rc = ensure_rng(m);
+    if (rc) return rc;
+  }
   plan.arena_floats = off;
   if (off > 0) {
     EG_HIP_CHECK(hipSetDevice(m->ctx->device));
@@ -1378,6 +1410,19 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
     for (int tid : plan.bucket_zero)
       EG_HIP_CHECK(hipMemsetAsync(ts.bucket + ts.bucket_offset[tid], 0, (size_t)prod(plan.shapes.at(tid)) * sizeof(float),
                                   m->ctx->stream));
+    // fresh random tensors for this call (model.nim:310-314 does it on the host); the draw counter
+    // is bumped on the device so a captured sequence advances on every replay
+    for (size_t r = 0; r < plan.random_tensors.size(); ++r) {
+      const int tid = plan.random_tensors[r];
+      const TensorDef& d = m->prog.tensors[tid];
+      int rc = eg_fill_uniform(m->ctx, prod(plan.shapes.at(tid)), (float)d.lo, (float)d.hi, m->rng_state, (uint64_t)tid,
+                               plan.arena + plan.arena_offset[tid]);
+      if (rc) return rc;
+    }
+    if (!plan.random_tensors.empty()) {
+      int rc = eg_rng_advance(m->ctx, m->rng_state);
+      if (rc) return rc;
+    }
   }
   for (int i = begin; i < end; ++i) {
     int rc = run_launch(m, ts, plan, plan.launches[i]);
@@ -1559,6 +1604,7 @@ int eg_model_free(eg_model* m) {
     if (p.second.ptr) hipFree(p.second.ptr);
   for (auto& in : m->inputs)
     if (in.second.owned) hipFree(in.second.owned);
+  if (m->rng_state) hipFree(m->rng_state);
   for (eg_kernel* k : m->kernels) eg_kernel_free(k);
   delete m;
   return EG_OK;
@@ -1874,5 +1920,10 @@ int eg_model_set_epoch(eg_model* m, int64_t epoch) {
 }
 
 int64_t eg_model_epoch(eg_model* m) { return m ? m->epoch : 0; }
+
+int eg_model_set_seed(eg_model* m, uint64_t seed) {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  return ensure_rng(m, seed, true);
+}
 
 }  // extern "C"

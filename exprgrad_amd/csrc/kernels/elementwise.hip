@@ -239,6 +239,27 @@ __global__ __launch_bounds__(NT) void fill_kernel(float value, float* __restrict
 
 }  // namespace
 
+// splitmix64 finaliser: a bijective 64-bit mix with full avalanche
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+
+// state[0] = seed, state[1] = number of fills drawn so far; `stream` separates the random tensors
+// filled from the same state in one run
+__global__ __launch_bounds__(NT) void fill_uniform_kernel(float lo, float hi, const uint64_t* __restrict__ state,
+                                                          unsigned long long stream, float* __restrict__ out, long n) {
+  const unsigned long long key = mix64(state[0] + 0x9e3779b97f4a7c15ULL * (state[1] + 1)) ^ mix64(stream + 0x632be59bd9b4e019ULL);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const unsigned long long bits = mix64(key + 0x9e3779b97f4a7c15ULL * (unsigned long long)(i + 1));
+    const float u = (float)(bits >> 40) * 0x1.0p-24f;  // 24 random bits: [0, 1), exactly representable
+    out[i] = lo + (hi - lo) * u;
+  }
+}
+
+__global__ void rng_advance_kernel(uint64_t* state) { state[1] += 1; }
+
 extern "C" {
 
 int eg_map(eg_ctx* ctx, int op, int64_t n, const float* in, float* out, float param, int accumulate) {
@@ -332,6 +353,34 @@ int eg_fill_f32(eg_ctx* ctx, int64_t n, float value, float* out) {
   const int vec = aligned16(out);
   hipLaunchKernelGGL(fill_kernel, dim3(grid_for(ctx, vec ? (n + 3) / 4 : n)), dim3(NT), 0, ctx->stream, value, out,
                      (long)n, vec);
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
+// Uniform random fill of TensorRandom tensors (`rand`, parser.nim:732-736; dropout's mask,
+// dnn.nim:96-100).  The reference fills them on the host with Nim's RNG and uploads them on every
+// call (model.nim:310-314); here a counter-based generator runs on the device: element i of
+// fill number c of a stream seeded s is hash(s, c, i) — reproducible, order independent, no state
+// per element.  The fill counter lives in device memory (state[1]) so that a captured launch
+// sequence draws fresh numbers on every replay: eg_rng_advance bumps it.
+int eg_fill_uniform(eg_ctx* ctx, int64_t n, float lo, float hi, const uint64_t* state, uint64_t stream, float* out) {
+  EG_REQUIRE(ctx, EG_ERR_INVALID, "eg_fill_uniform: ctx is NULL");
+  EG_REQUIRE(n >= 0, EG_ERR_INVALID, "eg_fill_uniform: negative length");
+  if (n == 0) return EG_OK;
+  EG_REQUIRE(out && state, EG_ERR_INVALID, "eg_fill_uniform: NULL pointer");
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid_for(ctx, n)), dim3(NT), 0, ctx->stream, lo, hi, state,
+                     (unsigned long long)stream, out, (long)n);
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
+int eg_rng_advance(eg_ctx* ctx, uint64_t* state) {
+  EG_REQUIRE(ctx && state, EG_ERR_INVALID, "eg_rng_advance: NULL argument");
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, ctx->stream, state);
   EG_HIP_CHECK(hipGetLastError());
   return EG_OK;
 }

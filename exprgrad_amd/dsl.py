@@ -407,6 +407,12 @@ def cache(fun, name=""):
     return Fun("effect", effect=Fun("cache", name, cache=fun))
 
 
+def rand(fun, lo=0.0, hi=1.0):
+    """rand(fun, range) (parser.nim:732-736): a tensor shaped like `fun`, refilled with uniform random
+    numbers in [lo, hi) on every call (TensorRandom, ir.nim:233-240)."""
+    return Fun("random", children=[fun], random_range=(float(lo), float(hi)))
+
+
 def backwards(fun):
     return Fun("backwards", children=[fun])
 
@@ -678,7 +684,7 @@ class Program:
                 line.append("-1")
             else:
                 line += [str(len(shape))] + [str(s) for s in shape]
-            if t["kind"] == "param":
+            if t["kind"] in ("param", "random"):
                 line += [repr(t["range"][0]), repr(t["range"][1])]
             out.append(" ".join(line))
         for c in self.shape_constraints:
@@ -764,6 +770,8 @@ def _alloc_tensors(fun, program):
             fun.tensor = program.alloc_tensor(kind="param", name=fun.name, shape=list(fun.param_shape), range=fun.init_range)
         elif k in ("result", "gradient"):
             fun.tensor = program.alloc_tensor(kind="result", name=fun.name)
+        elif k == "random":                                  # parser.nim:281-285
+            fun.tensor = program.alloc_tensor(kind="random", name=fun.name, range=fun.random_range)
         elif k == "effect":
             _alloc_tensors(fun.effect, program)
             fun.tensor = fun.effect.tensor
@@ -810,6 +818,10 @@ def _flatten(fun, target, program):
                 c = ("dims", fun.tensor, dims, tuple(ctx.kernel.setup))
             if all(c[:2] != o[:2] for o in program.shape_constraints):
                 program.shape_constraints.append(c)
+    elif fun.kind == "random":                               # parser.nim:378-383: shaped like its argument
+        c = ("copy", fun.tensor, fun.children[0].tensor)
+        if all(c[:2] != o[:2] for o in program.shape_constraints):
+            program.shape_constraints.append(c)
     elif fun.kind == "cond":                                 # parser.nim:368-377
         child = fun.cond.get(target.name, fun.cond_else)
         if child is None:

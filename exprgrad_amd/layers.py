@@ -2,7 +2,7 @@
 
 Sources: exprgrad/layers/base.nim:19-67 and exprgrad/layers/dnn.nim:19-100.  Iterator
 declaration order after `|` does not affect the lowered kernel (loops are created on first
-use, parser.nim:183-196), so it is not reproduced.  `dropout` (a random tensor) is not provided.
+use, parser.nim:183-196), so it is not reproduced.
 """
 from . import dsl
 from .dsl import Fun, iters, param, select, sq, to_scalar
@@ -213,6 +213,17 @@ def upsample2(images):
     r = _layer("upsample2")                                             # dnn.nim:81-88
     r[image, y, x, chan] += images[image, y // 2, x // 2, chan]
     r.with_shape(images.shape[0], images.shape[1] * 2, images.shape[2] * 2, images.shape[3])
+    return r
+
+
+def dropout(inp, prob):
+    """dnn.nim:96-100: keep an element with probability 1 - prob and rescale it, mask drawn per call."""
+    it = iters("it")
+    mask = dsl.rand(inp, 0.0, 1.0)
+    mask.name = "dropout.rand"
+    r = _layer("dropout")
+    r.raw[it] += select(dsl.literal(float(prob)) <= mask.raw[it], inp.raw[it] / (1.0 - prob), 0.0)
+    r.copy_shape(inp)
     return r
 
 

@@ -98,6 +98,11 @@ class Model:
     def epoch(self, v):
         call("eg_model_set_epoch", self.handle, int(v))
 
+    def set_seed(self, seed):
+        """Seed of the model's random tensors (`rand`, dropout masks); the reference uses Nim's global
+        generator (`randomize(seed)`)."""
+        call("eg_model_set_seed", self.handle, int(seed) & 0xFFFFFFFFFFFFFFFF)
+
     # ---- inputs ------------------------------------------------------------------------------
     def _bind(self, name, tensor):
         if hasattr(tensor, "data_ptr"):  # device tensor: borrow

@@ -143,6 +143,14 @@ int eg_axpy(eg_ctx* ctx, int64_t n, float alpha, const float* x, float* y);
 /* out[i] = value             — result zeroing (model.nim:318, 383), gradLoss = 1 (passes.nim:575-606). */
 int eg_fill_f32(eg_ctx* ctx, int64_t n, float value, float* out);
 
+/* Uniform fill in [lo, hi) of a TensorRandom tensor (`rand`, parser.nim:732-736; the reference
+ * fills these on the host and uploads them on every call, model.nim:310-314).  Counter-based:
+ * element i = hash(state[0] = seed, state[1] = fills drawn so far, stream, i).  `state` is two
+ * uint64 in DEVICE memory; eg_rng_advance increments state[1] on the stream, so a captured launch
+ * sequence draws fresh numbers on every replay. */
+int eg_fill_uniform(eg_ctx* ctx, int64_t n, float lo, float hi, const uint64_t* state, uint64_t stream, float* out);
+int eg_rng_advance(eg_ctx* ctx, uint64_t* state);
+
 /* Fixed-function elementwise maps of the layer library (raw-indexed `{it}` kernels). */
 enum eg_map_op {
   EG_MAP_IDENTITY = 0,
@@ -258,6 +266,9 @@ int eg_model_tensor_ptr(eg_model* model, const char* target, int tensor_id, floa
 /* Model.epoch (model.nim:39, bumped by fit at model.nim:436). */
 int eg_model_set_epoch(eg_model* model, int64_t epoch);
 int64_t eg_model_epoch(eg_model* model);
+/* Seed of the model's random tensors (`rand` / dropout; the reference draws them from Nim's global
+ * generator, `randomize(seed)`): same seed, same call sequence -> same numbers.  Resets the draw counter. */
+int eg_model_set_seed(eg_model* model, uint64_t seed);
 
 #ifdef __cplusplus
 }

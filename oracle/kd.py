@@ -158,8 +158,8 @@ def parse(text):
             d = {"kind": kind, "name": "" if name == "-" else name, "shape": None}
             if rank >= 0:
                 d["shape"] = [int(x) for x in toks[5:5 + rank]]
-            if kind == "param":
-                d["range"] = (float(toks[5 + rank]), float(toks[6 + rank]))
+            if kind in ("param", "random"):
+                d["range"] = (float(toks[5 + max(rank, 0)]), float(toks[6 + max(rank, 0)]))
             prog.tensors[tid] = d
             if kind == "input":
                 prog.inputs[d["name"]] = tid
@@ -908,6 +908,11 @@ class Model:
         self.threads = threads
         self.last = {}
         self.caches = {}
+        # TensorRandom (`rand`, dropout's mask): the reference refills them from Nim's global RNG on
+        # every call (model.nim:286-294) — unpinned.  Here: numpy's generator, or, for parity tests,
+        # the numbers another implementation drew (random_override[tensor id]).
+        self.rng = np.random.default_rng(0)
+        self.random_override = {}
         for tid, t in self.prog.tensors.items():
             if t["kind"] == "param":
                 self.params[tid] = np.zeros(t["shape"], dtype=np.float32)
@@ -973,6 +978,16 @@ class Model:
         live = {id(k) for k in kernels}
         infos = {}
         for k in all_kernels:
+            for r in k.reads:                  # random tensors: shaped like their source, drawn per call
+                t = self.prog.tensors[r.tensor]
+                src = self.prog.shape_copy.get(r.tensor)
+                if t["kind"] == "random" and r.tensor not in shapes and src in shapes:
+                    shapes[r.tensor] = list(shapes[src])
+                    if r.tensor in self.random_override:
+                        tensors[r.tensor] = np.ascontiguousarray(self.random_override[r.tensor], dtype=np.float32)
+                    else:
+                        lo, hi = t["range"]
+                        tensors[r.tensor] = (lo + (hi - lo) * self.rng.random(shapes[r.tensor], dtype=np.float32)).astype(np.float32)
             if any(r.tensor not in shapes for r in k.reads):
                 if id(k) in live:
                     missing = [r.tensor for r in k.reads if r.tensor not in shapes]
