@@ -589,23 +589,29 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   static_assert(!DMA || VEC == 4, "LDS-DMA loop: 16-byte aligned operands");
-  if (DMA && (!EDGE || (m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0))) {
-    gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
-  } else if (DMA && EDGE && CONV != 1) {
-    // ragged in M, N or K: still the LDS-DMA loop, with clamped addresses and a zeroed K tail
-    gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, true>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0,
-                                                                    k_end);
-  } else if (EDGE) {
-    const bool interior = m_blk + BM <= a.M && n_blk + BN <= a.N && (k_end - k_begin) % BK == 0;
-    if (interior)
-      gemm_mainloop<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, false, CONV, ABL>(a, lds, acc, m_blk, n_blk, k_begin, k_end, nk,
-                                                                          tid, wm0, wn0);
-    else
-      gemm_mainloop<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, true, CONV, ABL>(a, lds, acc, m_blk, n_blk, k_begin, k_end, nk,
-                                                                         tid, wm0, wn0);
-  } else {
-    gemm_mainloop<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, false, CONV, ABL>(a, lds, acc, m_blk, n_blk, k_begin, k_end, nk,
-                                                                        tid, wm0, wn0);
+  const bool whole_k = (k_end - k_begin) % BK == 0;
+  const bool interior = m_blk + BM <= a.M && n_blk + BN <= a.N && whole_k;
+  bool done = false;
+  if constexpr (DMA) {  // kernels without the DMA loop (tuning harness: BK = 8) never instantiate it
+    if (!EDGE || interior) {
+      gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
+      done = true;
+    } else if (CONV != 1) {
+      // ragged in M, N or K: still the LDS-DMA loop, with clamped addresses and a zeroed K tail
+      gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, true>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0,
+                                                                      k_end);
+      done = true;
+    }
+  }
+  if constexpr (!DMA || (EDGE && CONV == 1)) {  // register-staged loop: unaligned operands, ragged im2col tiles
+    if (!done) {
+      if (EDGE && !interior)
+        gemm_mainloop<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, true, CONV, ABL>(a, lds, acc, m_blk, n_blk, k_begin, k_end, nk,
+                                                                           tid, wm0, wn0);
+      else
+        gemm_mainloop<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, false, CONV, ABL>(a, lds, acc, m_blk, n_blk, k_begin, k_end, nk,
+                                                                            tid, wm0, wn0);
+    }
   }
 
   // ---- epilogue.  32x32 accumulator block: register r of lane l holds

@@ -128,13 +128,14 @@ int main(int argc, char** argv) {
       long k_tiles = K / v.bk, per = (k_tiles + splits - 1) / splits;
       a.k_per_split = per * v.bk;
       a.partial = splits > 1 ? P : nullptr;
-      dim3 grid(a.tiles_m * a.tiles_n, 1, splits);
+      a.splits = splits;
+      dim3 grid(a.tiles_m * a.tiles_n * splits, 1, 1);
       const int reps = round < 0 ? 1 : 5;
       CHECK(hipEventRecord(e0, s));
       for (int r = 0; r < reps; ++r) {
         v.launch(a, grid, s);
         if (splits > 1)
-          hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(2048), dim3(256), 0, s, P, C, (const float*)nullptr, M, N, N, splits, 0);
+          hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(2048), dim3(256), 0, s, P, C, (const float*)nullptr, M, N, N, splits, 0, M, 0);
       }
       CHECK(hipEventRecord(e1, s));
       CHECK(hipStreamSynchronize(s));
