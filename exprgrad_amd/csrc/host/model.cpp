@@ -1528,9 +1528,21 @@ void describe(eg_model* m) {
 }  // namespace
 
 // ---- helpers implemented next to the group-1 / group-2 code ------------------------------------
+// No C++ exception may cross the C ABI (std::bad_alloc, a failed .at() on a malformed program):
+// every entry point that touches the STL turns it into a status + eg_last_error().
+#define EG_CATCH_ALL                                           \
+  catch (const std::exception& e) {                            \
+    eg::set_error("internal error: %s", e.what());             \
+    return EG_ERR_RUNTIME;                                     \
+  }                                                            \
+  catch (...) {                                                \
+    eg::set_error("internal error");                           \
+    return EG_ERR_RUNTIME;                                     \
+  }
+
 extern "C" {
 
-int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out) {
+int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out) try {
   EG_REQUIRE(ctx && program_text && out, EG_ERR_INVALID, "eg_model_compile: NULL argument");
   std::unique_ptr<eg_model> m(new eg_model());
   m->ctx = ctx;
@@ -1585,8 +1597,9 @@ int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out) {
   *out = m.release();
   return EG_OK;
 }
+EG_CATCH_ALL
 
-int eg_model_free(eg_model* m) {
+int eg_model_free(eg_model* m) try {
   if (!m) return EG_OK;
   hipSetDevice(m->ctx->device);
   hipStreamSynchronize(m->ctx->stream);
@@ -1609,6 +1622,7 @@ int eg_model_free(eg_model* m) {
   delete m;
   return EG_OK;
 }
+EG_CATCH_ALL
 
 const char* eg_model_plan_text(eg_model* m) { return m ? m->plan_text.c_str() : ""; }
 
@@ -1658,16 +1672,17 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
   return m->launch_text.c_str();
 }
 
-int eg_model_kernel_count(eg_model* m, const char* target) {
+int eg_model_kernel_count(eg_model* m, const char* target) try {
   if (!m || !target) return -1;
   auto it = m->targets.find(target);
   return it == m->targets.end() ? -1 : (int)it->second.target->live.size();
 }
+EG_CATCH_ALL
 
 int eg_model_tensor_count(eg_model* m) { return m ? (int)m->prog.tensors.size() - 1 : 0; }
 
 int eg_model_param_info(eg_model* m, int tensor_id, int* kind, int* rank, int64_t* shape8, char* name,
-                        size_t name_cap) {
+                        size_t name_cap) try {
   EG_REQUIRE(m && tensor_id >= 1 && tensor_id < (int)m->prog.tensors.size(), EG_ERR_INVALID, "bad tensor id %d", tensor_id);
   const TensorDef& d = m->prog.tensors[tensor_id];
   if (kind) *kind = (int)d.kind;
@@ -1679,8 +1694,9 @@ int eg_model_param_info(eg_model* m, int tensor_id, int* kind, int* rank, int64_
   }
   return EG_OK;
 }
+EG_CATCH_ALL
 
-int eg_model_param_write(eg_model* m, int tensor_id, const float* host, int64_t count) {
+int eg_model_param_write(eg_model* m, int tensor_id, const float* host, int64_t count) try {
   EG_REQUIRE(m && host, EG_ERR_INVALID, "eg_model_param_write: NULL argument");
   auto it = m->params.find(tensor_id);
   EG_REQUIRE(it != m->params.end(), EG_ERR_INVALID, "tensor %d is not a parameter", tensor_id);
@@ -1692,8 +1708,9 @@ int eg_model_param_write(eg_model* m, int tensor_id, const float* host, int64_t 
   EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
   return EG_OK;
 }
+EG_CATCH_ALL
 
-int eg_model_param_read(eg_model* m, int tensor_id, float* host, int64_t count) {
+int eg_model_param_read(eg_model* m, int tensor_id, float* host, int64_t count) try {
   EG_REQUIRE(m && host, EG_ERR_INVALID, "eg_model_param_read: NULL argument");
   auto it = m->params.find(tensor_id);
   EG_REQUIRE(it != m->params.end(), EG_ERR_INVALID, "tensor %d is not a parameter", tensor_id);
@@ -1705,8 +1722,9 @@ int eg_model_param_read(eg_model* m, int tensor_id, float* host, int64_t count) 
   EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
   return EG_OK;
 }
+EG_CATCH_ALL
 
-int eg_model_param_ptr(eg_model* m, int tensor_id, float** device_ptr, int64_t* count) {
+int eg_model_param_ptr(eg_model* m, int tensor_id, float** device_ptr, int64_t* count) try {
   EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
   auto it = m->params.find(tensor_id);
   EG_REQUIRE(it != m->params.end(), EG_ERR_INVALID, "tensor %d is not a parameter", tensor_id);
@@ -1714,8 +1732,9 @@ int eg_model_param_ptr(eg_model* m, int tensor_id, float** device_ptr, int64_t* 
   if (count) *count = it->second.count;
   return EG_OK;
 }
+EG_CATCH_ALL
 
-int eg_model_grad_bucket(eg_model* m, const char* target, float** device_ptr, int64_t* count) {
+int eg_model_grad_bucket(eg_model* m, const char* target, float** device_ptr, int64_t* count) try {
   EG_REQUIRE(m && target, EG_ERR_INVALID, "NULL argument");
   auto it = m->targets.find(target);
   EG_REQUIRE(it != m->targets.end(), EG_ERR_RUNTIME, "%s is not a target of the model", target);
@@ -1723,8 +1742,9 @@ int eg_model_grad_bucket(eg_model* m, const char* target, float** device_ptr, in
   if (count) *count = it->second.bucket_floats;
   return EG_OK;
 }
+EG_CATCH_ALL
 
-int eg_model_bind_grad_bucket(eg_model* m, const char* target, float* device_ptr, int64_t count) {
+int eg_model_bind_grad_bucket(eg_model* m, const char* target, float* device_ptr, int64_t count) try {
   EG_REQUIRE(m && target && device_ptr, EG_ERR_INVALID, "NULL argument");
   auto it = m->targets.find(target);
   EG_REQUIRE(it != m->targets.end(), EG_ERR_RUNTIME, "%s is not a target of the model", target);
@@ -1738,6 +1758,7 @@ int eg_model_bind_grad_bucket(eg_model* m, const char* target, float* device_ptr
   ts.bucket_owned = false;
   return EG_OK;
 }
+EG_CATCH_ALL
 
 static int bind_input(eg_model* m, const char* name, const float* device, const float* host, int rank,
                       const int64_t* shape) {
@@ -1773,17 +1794,19 @@ static int bind_input(eg_model* m, const char* name, const float* device, const 
   return EG_OK;
 }
 
-int eg_model_set_input_host(eg_model* m, const char* name, const float* host, int rank, const int64_t* shape) {
+int eg_model_set_input_host(eg_model* m, const char* name, const float* host, int rank, const int64_t* shape) try {
   EG_REQUIRE(host || rank == 0, EG_ERR_INVALID, "NULL host pointer");
   static const float dummy = 0;
   return bind_input(m, name, nullptr, host ? host : &dummy, rank, shape);
 }
+EG_CATCH_ALL
 
-int eg_model_set_input_device(eg_model* m, const char* name, const float* device_ptr, int rank, const int64_t* shape) {
+int eg_model_set_input_device(eg_model* m, const char* name, const float* device_ptr, int rank, const int64_t* shape) try {
   return bind_input(m, name, device_ptr, nullptr, rank, shape);
 }
+EG_CATCH_ALL
 
-int eg_model_clear_inputs(eg_model* m) {
+int eg_model_clear_inputs(eg_model* m) try {
   EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
   // Host-staged inputs keep their staging buffer (reused by the next host bind); only the
   // bindings are forgotten.  No synchronisation: nothing is freed.
@@ -1799,36 +1822,41 @@ int eg_model_clear_inputs(eg_model* m) {
   }
   return EG_OK;
 }
+EG_CATCH_ALL
 
-int eg_model_run(eg_model* m, const char* target) {
+int eg_model_run(eg_model* m, const char* target) try {
   TargetState* ts;
   Plan* plan;
   int rc = get_plan(m, target, &ts, &plan);
   if (rc) return rc;
   return run_range(m, *ts, *plan, 0, (int)plan->launches.size(), true, 0);
 }
+EG_CATCH_ALL
 
-int eg_model_run_backward(eg_model* m, const char* target) {
+int eg_model_run_backward(eg_model* m, const char* target) try {
   TargetState* ts;
   Plan* plan;
   int rc = get_plan(m, target, &ts, &plan);
   if (rc) return rc;
   return run_range(m, *ts, *plan, 0, plan->n_backward, true, 1);
 }
+EG_CATCH_ALL
 
-int eg_model_run_update(eg_model* m, const char* target) {
+int eg_model_run_update(eg_model* m, const char* target) try {
   TargetState* ts;
   Plan* plan;
   int rc = get_plan(m, target, &ts, &plan);
   if (rc) return rc;
   return run_range(m, *ts, *plan, plan->n_backward, (int)plan->launches.size(), false, 2);
 }
+EG_CATCH_ALL
 
-int eg_model_set_grad_scale(eg_model* m, float scale) {
+int eg_model_set_grad_scale(eg_model* m, float scale) try {
   EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
   m->grad_scale = scale;
   return EG_OK;
 }
+EG_CATCH_ALL
 
 static int find_tensor(eg_model* m, const char* target, int* tid, TargetState** ts) {
   auto it = m->targets.find(target);
@@ -1865,7 +1893,7 @@ static int read_tensor(eg_model* m, TargetState& ts, int tid, float* host, int64
   return EG_OK;
 }
 
-int eg_model_output_shape(eg_model* m, const char* target, int* rank, int64_t* shape8) {
+int eg_model_output_shape(eg_model* m, const char* target, int* rank, int64_t* shape8) try {
   EG_REQUIRE(m && target, EG_ERR_INVALID, "NULL argument");
   int tid;
   TargetState* ts;
@@ -1873,8 +1901,9 @@ int eg_model_output_shape(eg_model* m, const char* target, int* rank, int64_t* s
   if (rc) return rc;
   return tensor_shape(m, *ts, tid, rank, shape8);
 }
+EG_CATCH_ALL
 
-int eg_model_read_output(eg_model* m, const char* target, float* host, int64_t count) {
+int eg_model_read_output(eg_model* m, const char* target, float* host, int64_t count) try {
   EG_REQUIRE(m && target, EG_ERR_INVALID, "NULL argument");
   int tid;
   TargetState* ts;
@@ -1882,27 +1911,30 @@ int eg_model_read_output(eg_model* m, const char* target, float* host, int64_t c
   if (rc) return rc;
   return read_tensor(m, *ts, tid, host, count);
 }
+EG_CATCH_ALL
 
 static TargetState* last_target(eg_model* m, const char* target) {
   auto it = m->targets.find(target ? target : "");
   return it == m->targets.end() ? nullptr : &it->second;
 }
 
-int eg_model_tensor_shape(eg_model* m, const char* target, int tensor_id, int* rank, int64_t* shape8) {
+int eg_model_tensor_shape(eg_model* m, const char* target, int tensor_id, int* rank, int64_t* shape8) try {
   EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
   TargetState* ts = last_target(m, target);
   EG_REQUIRE(ts, EG_ERR_RUNTIME, "%s is not a target of the model", target ? target : "(null)");
   return tensor_shape(m, *ts, tensor_id, rank, shape8);
 }
+EG_CATCH_ALL
 
-int eg_model_read_tensor(eg_model* m, const char* target, int tensor_id, float* host, int64_t count) {
+int eg_model_read_tensor(eg_model* m, const char* target, int tensor_id, float* host, int64_t count) try {
   EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
   TargetState* ts = last_target(m, target);
   EG_REQUIRE(ts, EG_ERR_RUNTIME, "%s is not a target of the model", target ? target : "(null)");
   return read_tensor(m, *ts, tensor_id, host, count);
 }
+EG_CATCH_ALL
 
-int eg_model_tensor_ptr(eg_model* m, const char* target, int tensor_id, float** device_ptr, int64_t* count) {
+int eg_model_tensor_ptr(eg_model* m, const char* target, int tensor_id, float** device_ptr, int64_t* count) try {
   EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
   TargetState* ts = last_target(m, target);
   EG_REQUIRE(ts && ts->last, EG_ERR_RUNTIME, "target has not been run");
@@ -1912,18 +1944,21 @@ int eg_model_tensor_ptr(eg_model* m, const char* target, int tensor_id, float** 
   if (count) *count = prod(s->second);
   return EG_OK;
 }
+EG_CATCH_ALL
 
-int eg_model_set_epoch(eg_model* m, int64_t epoch) {
+int eg_model_set_epoch(eg_model* m, int64_t epoch) try {
   EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
   m->epoch = epoch;
   return EG_OK;
 }
+EG_CATCH_ALL
 
 int64_t eg_model_epoch(eg_model* m) { return m ? m->epoch : 0; }
 
-int eg_model_set_seed(eg_model* m, uint64_t seed) {
+int eg_model_set_seed(eg_model* m, uint64_t seed) try {
   EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
   return ensure_rng(m, seed, true);
 }
+EG_CATCH_ALL
 
 }  // extern "C"
