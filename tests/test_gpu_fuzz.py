@@ -1,0 +1,166 @@
+"""Differential fuzzing: random layer chains built with the Python front-end run through the product
+(GPU: pattern matcher, generated kernels, row / map / small fusion, fused epilogues, graphs) and
+through the oracle's independent restatement of generate / derive / shape inference / execution.
+Seeds are fixed: the cases are reproducible."""
+import random
+
+import numpy as np
+import pytest
+
+import refcases
+from conftest import rel_err
+from exprgrad_amd import dsl, layers
+from exprgrad_amd.dsl import Fun, iters
+
+pytestmark = pytest.mark.gpu
+
+
+def unary(rng, x):
+    it = iters("it")
+    r = Fun()
+    kind = rng.choice(["relu", "leaky", "sigmoid", "tanh", "scale", "square", "softsign", "sin", "clip"])
+    v = x.raw[it]
+    if kind == "relu":
+        r.raw[it] += dsl.select(v > 0.0, v, 0.0)
+    elif kind == "leaky":
+        r.raw[it] += dsl.select(v > 0.0, v, v * 0.1)
+    elif kind == "sigmoid":
+        r.raw[it] += 1.0 / (1.0 + dsl.exp(-v))
+    elif kind == "tanh":
+        return layers.tanh(x)
+    elif kind == "scale":
+        r.raw[it] += v * rng.choice([0.5, -1.5, 2.0]) + rng.choice([0.0, 0.25])
+    elif kind == "square":
+        r.raw[it] += v * v * 0.5
+    elif kind == "softsign":
+        r.raw[it] += v / (1.0 + dsl.select(v > 0.0, v, -v))
+    elif kind == "sin":
+        r.raw[it] += dsl.sin(v)
+    else:
+        r.raw[it] += dsl.min(dsl.max(v, -0.5), 0.5)
+    r.copy_shape(x)
+    return r
+
+
+def build(seed):
+    rng = random.Random(seed)
+    width = rng.choice([3, 8, 20, 70, 130])
+    net, dims = dsl.input("x"), width
+    for depth in range(rng.randint(2, 5)):
+        op = rng.choice(["dense", "dense", "unary", "unary", "residual", "rowscale"])
+        if op == "dense":
+            out = rng.choice([1, 4, 10, 33, 96])
+            net = layers.dense(net, dims, out, has_bias=rng.random() < 0.7)
+            dims = out
+        elif op == "unary":
+            net = unary(rng, net)
+        elif op == "residual":
+            total = layers.add(net, unary(rng, net))
+            total.copy_shape(net)      # a raw write with two reads has no inferred shape (passes.nim:1059-1066)
+            net = total
+        else:  # every row divided by (1 + its sum of squares): a per-row reduction feeding a map
+            y, x = iters("y x")
+            sums = Fun()
+            sums[y] += net[y, x] * net[y, x]
+            r = Fun()
+            r[y, x] += net[y, x] / (1.0 + sums[y])
+            net = r
+    predict = net.target("predict")
+    loss = layers.mse(predict, dsl.input("y")).target("loss")
+    opt = layers.gradient_descent(0.05) if rng.random() < 0.6 else layers.adam(eta=0.01)
+    return [loss.backprop(opt).target("train"), loss.backwards().grad(dsl.input("x")).target("gx")], width, dims
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_chain_matches_the_oracle(gpu_ctx, monkeypatch, seed):
+    from oracle import kd
+    from exprgrad_amd import model as egm
+    monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", "0" if seed % 2 else str(1 << 40))
+    graphs, width, out_dims = build(seed)
+    gpu = egm.compile(*graphs, gpu=gpu_ctx)
+    ref = kd.Model(refcases.program_text(build(seed)[0]), threads=2)
+    rng = np.random.default_rng(seed)
+    for tid in sorted(ref.params):
+        v = (rng.random(ref.params[tid].shape, dtype=np.float32) * 0.6 - 0.3).astype(np.float32)
+        ref.params[tid][...] = v
+        gpu.params[tid] = v
+    batch = [5, 64, 257, 1500][seed % 4]
+    x = (rng.random((batch, width), dtype=np.float32) - 0.5).astype(np.float32)
+    y = rng.random((batch, out_dims), dtype=np.float32)
+    tol = 2e-5
+    assert rel_err(gpu.call("predict", {"x": x}), ref.call("predict", {"x": x})) <= tol, gpu.launch_plan("predict")
+    assert rel_err(gpu.call("loss", {"x": x, "y": y}), ref.call("loss", {"x": x, "y": y})) <= tol
+    gx_g, gx_r = gpu.call("gx", {"x": x, "y": y}), ref.call("gx", {"x": x, "y": y})
+    assert rel_err(gx_g, gx_r) <= 5e-5 + 1e-7 / max(np.abs(gx_r).max(), 1e-30), gpu.launch_plan("gx")
+    gpu.epoch = ref.epoch = 1
+    before = {t: ref.params[t].copy() for t in ref.params}
+    for _ in range(2):
+        gpu.apply("train", {"x": x, "y": y})
+        ref.apply("train", {"x": x, "y": y})
+    for tid in sorted(ref.params):
+        # adam divides by sqrt(v) + eps: where the gradient is ~0 its step amplifies rounding; compare parameters
+        assert rel_err(gpu.params[tid], ref.params[tid]) <= 2e-4, (tid, gpu.launch_plan("train"))
+        du_g, du_r = gpu.params[tid] - before[tid], ref.params[tid] - before[tid]
+        assert rel_err(du_g, du_r) <= 2e-2, (tid, gpu.launch_plan("train"))
+    gpu.close()
+
+
+def build_cnn(seed):
+    rng = random.Random(1000 + seed)
+    chans = rng.choice([1, 3, 4, 16])
+    size = rng.choice([8, 12, 18])
+    net = dsl.input("x")
+    h = w = size
+    for depth in range(rng.randint(1, 3)):
+        op = rng.choice(["conv", "conv", "unary", "maxpool", "avgpool", "upsample"])
+        if op == "conv" and min(h, w) >= 4:
+            f = rng.choice([2, 8, 16, 64])
+            kh, kw = rng.choice([(1, 1), (3, 3), (2, 3), (3, 1)])
+            net = layers.conv2(net, dsl.param([f, kh, kw, chans], name="filters"))
+            chans, h, w = f, h - kh + 1, w - kw + 1
+        elif op == "maxpool" and h % 2 == 0 and w % 2 == 0:
+            net, h, w = layers.maxpool2(net), h // 2, w // 2
+        elif op == "avgpool" and h % 2 == 0 and w % 2 == 0:
+            net, h, w = layers.avgpool2(net), h // 2, w // 2
+        elif op == "upsample" and h * w <= 100:
+            net, h, w = layers.upsample2(net), h * 2, w * 2
+        else:
+            net = unary(rng, net)
+    net = dsl.reshape(net, [-1, h * w * chans])
+    net = layers.dense(net, h * w * chans, rng.choice([1, 5, 10]))
+    predict = net.target("predict")
+    loss = layers.mse(predict, dsl.input("y")).target("loss")
+    return [loss.backprop(layers.gradient_descent(0.02)).target("train"),
+            loss.backwards().grad(dsl.input("x")).target("gx")], (size, size, chans_in(seed)), None
+
+
+def chans_in(seed):
+    return random.Random(1000 + seed).choice([1, 3, 4, 16])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_cnn_matches_the_oracle(gpu_ctx, seed):
+    from oracle import kd
+    from exprgrad_amd import model as egm
+    graphs, (h, w, c), _ = build_cnn(seed)
+    gpu = egm.compile(*graphs, gpu=gpu_ctx)
+    ref = kd.Model(refcases.program_text(build_cnn(seed)[0]), threads=4)
+    rng = np.random.default_rng(seed)
+    for tid in sorted(ref.params):
+        v = (rng.random(ref.params[tid].shape, dtype=np.float32) * 0.6 - 0.3).astype(np.float32)
+        ref.params[tid][...] = v
+        gpu.params[tid] = v
+    batch = [2, 9, 40][seed % 3]
+    x = (rng.random((batch, h, w, c), dtype=np.float32) - 0.5).astype(np.float32)
+    out_r = ref.call("predict", {"x": x})
+    y = rng.random(out_r.shape, dtype=np.float32)
+    assert rel_err(gpu.call("predict", {"x": x}), out_r) <= 2e-5, gpu.launch_plan("predict")
+    gx_g, gx_r = gpu.call("gx", {"x": x, "y": y}), ref.call("gx", {"x": x, "y": y})
+    assert rel_err(gx_g, gx_r) <= 5e-5 + 1e-7 / max(np.abs(gx_r).max(), 1e-30), gpu.launch_plan("gx")
+    before = {t: ref.params[t].copy() for t in ref.params}
+    gpu.apply("train", {"x": x, "y": y})
+    ref.apply("train", {"x": x, "y": y})
+    for tid in sorted(ref.params):
+        du_g, du_r = gpu.params[tid] - before[tid], ref.params[tid] - before[tid]
+        assert rel_err(du_g, du_r) <= 1e-4 + 1e-7 / max(np.abs(du_r).max(), 1e-30), (tid, gpu.launch_plan("train"))
+    gpu.close()
