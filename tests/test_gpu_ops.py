@@ -295,3 +295,31 @@ def test_runtime_mirror(gpu_ctx):
         kernel.run([], [])
     c.fill(3.0)
     assert np.array_equal(c.read(), np.full(32, 3.0, dtype=np.float32))
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_contraction_shapes(gpu_ctx, seed):
+    # tile choice, split-K (even and uneven), ragged M / N / K on the DMA loop, unaligned operands:
+    # random problems against a float64 product (the oracle's loop nest is too slow for the long-K cases)
+    rng = np.random.default_rng(1000 + seed)
+    M = int(rng.choice([1, 7, 33, 64, 100, 257, 784, 1000, 2048]))
+    N = int(rng.choice([1, 4, 10, 32, 65, 130, 512, 1000]))
+    K = int(rng.choice([1, 3, 16, 50, 400, 784, 4096, 20000, 65536]))
+    if M * N * K > 3e9:
+        K = max(1, int(3e9 // (M * N)))
+    ta, tb = bool(rng.integers(2)), bool(rng.integers(2))
+    acc, bias = bool(rng.integers(2)), bool(rng.integers(2))
+    a = (rng.random((K, M) if ta else (M, K), dtype=np.float32) - 0.5).astype(np.float32)
+    b = (rng.random((N, K) if tb else (K, N), dtype=np.float32) - 0.5).astype(np.float32)
+    c0 = rng.random((M, N), dtype=np.float32) if acc else np.zeros((M, N), dtype=np.float32)
+    bv = (rng.random((N,), dtype=np.float32) - 0.5).astype(np.float32) if bias else None
+    want = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64) + c0
+    if bias:
+        want = want + bv
+    da, db, dc = dev(gpu_ctx, a), dev(gpu_ctx, b), dev(gpu_ctx, c0)
+    dbias = dev(gpu_ctx, bv) if bias else None
+    ops.sgemm(gpu_ctx, M, N, K, da, a.shape[1], db, b.shape[1], dc, N, ta, tb, acc, dbias)
+    got = dc.read()
+    # error budget: every output is a sum of K products of magnitude <= 0.25
+    scale = max(np.abs(want).max(), 0.25 * np.sqrt(K) * 0.3)
+    assert np.abs(got - want).max() <= 2e-5 * scale, (M, N, K, ta, tb, acc, bias)
