@@ -127,3 +127,29 @@ def test_halo_convolution_against_the_oracle(gpu_ctx, refcpu, monkeypatch, shape
     out.write(base)
     ops.conv2_nhwc(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dflt, out, accumulate=True)
     assert rel_err(out.read(), want + base) <= TOL
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_convolution_problems(gpu_ctx, refcpu, seed):
+    # forward (halo kernel / implicit GEMM / 1x1 contraction chosen by shape) and both gradients
+    rng = np.random.default_rng(500 + seed)
+    C = int(rng.choice([1, 3, 8, 16, 32, 48]))
+    F = int(rng.choice([2, 8, 24, 64, 72]))
+    FH, FW = [(1, 1), (3, 3), (3, 3), (2, 2), (5, 5), (1, 3)][int(rng.integers(6))]
+    big = C % 16 == 0 and FH <= 3 and FW <= 3 and rng.random() < 0.6       # enough patches for the halo kernel
+    N = int(rng.choice([8, 10])) if big else int(rng.choice([1, 2, 5]))
+    H = int(rng.choice([66, 70])) if big else int(rng.integers(FH + 1, 20))
+    W = int(rng.choice([66, 100])) if big else int(rng.integers(FW + 1, 24))
+    img = rng.random((N, H, W, C), dtype=np.float32)
+    flt = (rng.random((F, FH, FW, C), dtype=np.float32) * 2 - 1).astype(np.float32)
+    gout = (rng.random((N, H - FH + 1, W - FW + 1, F), dtype=np.float32) - 0.5).astype(np.float32)
+    dimg, dflt, dg = dev(gpu_ctx, img), dev(gpu_ctx, flt), dev(gpu_ctx, gout)
+    out = gpu_ctx.allocTensor(gout.shape)
+    ops.conv2_nhwc(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dflt, out)
+    assert rel_err(out.read(), refcpu.conv2_nhwc(img, flt, threads_n=N, threads_y=4)) <= TOL, (N, H, W, C, F, FH, FW)
+    gflt = gpu_ctx.allocTensor(flt.shape)
+    ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dg, gflt)
+    assert rel_err(gflt.read(), refcpu.conv2_nhwc_grad_filter(img, gout, flt.shape)) <= TOL, (N, H, W, C, F, FH, FW)
+    gimg = gpu_ctx.allocTensor(img.shape)
+    ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dg, gimg)
+    assert rel_err(gimg.read(), refcpu.conv2_nhwc_grad_image(flt, gout, img.shape)) <= TOL, (N, H, W, C, F, FH, FW)
