@@ -290,6 +290,32 @@ def run_xor(args, env):
                          "bytes_per_launch": XOR_BYTES_PER_SAMPLE * batch, "kernel_ms_avg": round(ev_avg, 4)}}
 
 
+def run_xor_dp(args, env):
+    """BASELINE configs[2] data parallel (weak: 65536 samples per GPU): the 17-float gradient bucket makes the
+    step a pure latency test of the all-reduce — reported for completeness next to the dense step."""
+    from exprgrad_amd import examples as refcases
+    from exprgrad_amd import model as egm
+    from exprgrad_amd.parallel import DataParallel, GpuEngine
+    torch = env["torch"]
+    batch = 65536
+    model = egm.compile(*refcases.xor_from_scratch(), gpu=env["ctx"])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    for tid in model.params.ids():
+        model.params[tid] = (torch.rand(model._param_shapes[tid], device="cuda", generator=gen) * 0.2 - 0.1).cpu().numpy()
+    gen.manual_seed(300 + env["rank"])
+    x = torch.randint(0, 2, (batch, 2), device="cuda", generator=gen).to(torch.float32)
+    y = (x[:, :1] != x[:, 1:]).to(torch.float32).contiguous()
+    dp = DataParallel(GpuEngine(model, "train"), reduction="sum")   # the XOR loss is a plain sum (xor_from_scratch.nim:28)
+    inputs = [("x", x), ("y", y)]
+    steps = max(args.steps, 50)
+    elapsed, ev_avg, _ = env["timer"].run(lambda: dp.step(inputs), steps, args.warmup)
+    world = env["world"]
+    return {"metric": "train steps/s XOR net (data parallel, 65536 samples per GPU)", "value": round(steps / elapsed, 1),
+            "unit": "steps/s", "samples_per_s": round(batch * world * steps / elapsed, 1),
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "grad_bucket_floats": model.grad_bucket("train")[1]}
+
+
 def run_conv2(args, env):
     torch, ops, ctx = env["torch"], env["ops"], env["ctx"]
     N, H, W, C, F, FH, FW = 1, 256, 256, 64, 64, 3, 3  # BASELINE configs[3]
@@ -400,6 +426,14 @@ def main():
     line = {**{k: line[k] for k in ("metric", "value", "unit")}, **base,
             **{k: v for k, v in line.items() if k not in ("metric", "value", "unit")}}
 
+    if world > 1 and workload == "train" and not args.no_extra:
+        # secondary figure; never allowed to take the primary line down with it (every rank runs it:
+        # it contains collectives)
+        try:
+            small = argparse.Namespace(**{**vars(args), "steps": min(args.steps, 50), "warmup": 3, "batch": 0})
+            line["extra"] = {"xor": run_xor_dp(small, env)}
+        except Exception as exc:  # noqa: BLE001
+            line["extra"] = {"xor": {"error": repr(exc)}}
     if rank == 0 and world == 1:
         if not args.no_extra and args.workload == "auto":
             # single-GPU numbers of the other BASELINE configs, same run (reference point for the
