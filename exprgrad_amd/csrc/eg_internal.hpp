@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,8 @@ struct eg_ctx {
   size_t aux_bytes = 0;
   int compute_units = 256;
   std::string arch;
+  // kernels a library call specialises at run time (hiprtc) and keeps: by name
+  std::map<std::string, eg_kernel*> jit;
 };
 
 struct eg_kernel;
@@ -83,6 +86,11 @@ struct RowFinalizeArgs {
   int nseg;
 };
 int row_finalize(eg_ctx* ctx, const float* partial, int nblocks, int E, const RowFinalizeArgs& args);
+// Direct per-pixel kernels for few input channels (kernels/conv2_direct.cpp), same convention.
+int conv2_direct_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
+                     const float* flt, float* out, int accumulate, bool* launched);
+int conv2_direct_grad_filter_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
+                                 const float* gout, float* gflt, int accumulate, bool* launched);
 // LDS-halo convolution (kernels/conv2_halo.hip); *launched = false when the problem does not suit it.
 int conv2_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
                    const float* flt, float* out, int accumulate, bool* launched);

@@ -356,6 +356,11 @@ extern "C" int eg_conv2_nhwc(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64
   if (rc) return rc;
   if (FH == 1 && FW == 1 && C > 0)  // a 1x1 filter bank is a plain contraction over the channels: out[P,F] = img[P,C] * flt[F,C]^T
     return eg_sgemm(ctx, 0, 1, N * H * W, F, C, img, C, flt, C, out, F, accumulate, nullptr);
+  if (C > 0 && C <= 4) {  // an image network's first layer: per-pixel kernel specialised for the filter geometry
+    bool launched = false;
+    rc = eg::conv2_direct_try(ctx, N, H, W, C, F, FH, FW, img, flt, out, accumulate, &launched);
+    if (rc || launched) return rc;
+  }
   if (C > 0) {  // 3x3-class filters on full-sized images: the LDS-halo kernel
     bool launched = false;
     rc = eg::conv2_halo_try(ctx, N, H, W, C, F, FH, FW, img, flt, out, accumulate, &launched);
@@ -457,6 +462,11 @@ extern "C" int eg_conv2_nhwc_grad_filter(eg_ctx* ctx, int64_t N, int64_t H, int6
   EG_REQUIRE(img && gout, EG_ERR_INVALID, "eg_conv2_nhwc_grad_filter: NULL tensor");
   if (FH == 1 && FW == 1)  // plain contraction: gflt[F,C] = gout[P,F]^T * img[P,C]
     return eg_sgemm(ctx, 1, 0, F, C, P, gout, F, img, C, gflt, C, accumulate, nullptr);
+  if (C <= 4) {
+    bool launched = false;
+    rc = eg::conv2_direct_grad_filter_try(ctx, N, H, W, C, F, FH, FW, img, gout, gflt, accumulate, &launched);
+    if (rc || launched) return rc;
+  }
   EG_REQUIRE(P < (1L << 31) && FH * FW * C < (1L << 31), EG_ERR_INVALID,
              "eg_conv2_nhwc_grad_filter: more than 2^31 output pixels or taps");
   GemmArgs args = {};

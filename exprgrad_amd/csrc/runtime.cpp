@@ -252,6 +252,7 @@ int eg_ctx_destroy(eg_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   if (ctx->workspace) hipFree(ctx->workspace);
   if (ctx->aux) hipFree(ctx->aux);
+  for (auto& kv : ctx->jit) delete kv.second;  // eg_kernel: the code object goes with it
   if (ctx->owns_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return EG_OK;

@@ -153,3 +153,33 @@ def test_random_convolution_problems(gpu_ctx, refcpu, seed):
     gimg = gpu_ctx.allocTensor(img.shape)
     ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dg, gimg)
     assert rel_err(gimg.read(), refcpu.conv2_nhwc_grad_image(flt, gout, img.shape)) <= TOL, (N, H, W, C, F, FH, FW)
+
+
+@pytest.mark.parametrize("shape", [(256, 28, 28, 1, 8, 5, 5), (64, 50, 50, 3, 4, 3, 3), (300, 24, 24, 2, 6, 2, 4)])
+def test_few_channel_convolutions_use_the_direct_kernels(gpu_ctx, refcpu, shape):
+    # an image network's first layer (C <= 4, enough pixels): per-pixel kernels specialised with hiprtc
+    N, H, W, C, F, FH, FW = shape
+    rng = np.random.default_rng(sum(shape))
+    img = rng.random((N, H, W, C), dtype=np.float32)
+    flt = (rng.random((F, FH, FW, C), dtype=np.float32) * 2 - 1).astype(np.float32)
+    gout = (rng.random((N, H - FH + 1, W - FW + 1, F), dtype=np.float32) - 0.5).astype(np.float32)
+    dimg, dflt, dg = dev(gpu_ctx, img), dev(gpu_ctx, flt), dev(gpu_ctx, gout)
+    out = gpu_ctx.allocTensor(gout.shape)
+    base = rng.random(gout.shape, dtype=np.float32)
+    for accumulate in (False, True):
+        out.write(base)
+        ops.conv2_nhwc(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dflt, out, accumulate=accumulate)
+        want = refcpu.conv2_nhwc(img, flt, out=base.copy() if accumulate else None, threads_n=16)
+        assert rel_err(out.read(), want) <= TOL
+    gflt = gpu_ctx.allocTensor(flt.shape)
+    fbase = rng.random(flt.shape, dtype=np.float32)
+    for accumulate in (False, True):
+        gflt.write(fbase)
+        ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dg, gflt, accumulate=accumulate)
+        want = refcpu.conv2_nhwc_grad_filter(img, gout, flt.shape, out=fbase.copy() if accumulate else None)
+        assert rel_err(gflt.read(), want) <= 2e-5     # 150k-term sums: the reference's sequential f32 order drifts too
+    # run-to-run determinism of the block-partial reduction
+    again = gpu_ctx.allocTensor(flt.shape)
+    again.write(fbase)
+    ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dg, again, accumulate=True)
+    assert np.array_equal(again.read(), gflt.read())
