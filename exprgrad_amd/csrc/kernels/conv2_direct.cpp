@@ -14,6 +14,7 @@
 //   filter gradient  a thread walks pixels grid-stride with the F*FH*FW*C partial gradient in
 //                    registers; wave shuffle tree -> per-block partial row -> the library's
 //                    fixed-order column sum (deterministic, no float atomics)
+#include <cstdio>
 #include <map>
 #include <string>
 
@@ -49,7 +50,9 @@ int conv2_direct_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long F
   const long taps = FH * FW * C;
   // F * taps multiply-adds per pixel on the vector pipe: only while that stays small (beyond it the
   // matrix cores win even with their padding), and only when there are enough pixels to fill the chip
-  if (disabled() || C > 4 || F < 1 || F * taps > 512) return EG_OK;
+  long max_c = 4, max_work = 512;
+  if (const char* e = getenv("EG_CONV_DIRECT_LIMITS")) sscanf(e, "%ld,%ld", &max_c, &max_work);  // tuning aid
+  if (disabled() || C > max_c || F < 1 || F * taps > max_work) return EG_OK;
   const long Ho = H - FH + 1, Wo = W - FW + 1, P = N * Ho * Wo;
   if (P < 8192) return EG_OK;
   const bool vec_out = F % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;

@@ -356,7 +356,7 @@ extern "C" int eg_conv2_nhwc(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64
   if (rc) return rc;
   if (FH == 1 && FW == 1 && C > 0)  // a 1x1 filter bank is a plain contraction over the channels: out[P,F] = img[P,C] * flt[F,C]^T
     return eg_sgemm(ctx, 0, 1, N * H * W, F, C, img, C, flt, C, out, F, accumulate, nullptr);
-  if (C > 0 && C <= 4) {  // an image network's first layer: per-pixel kernel specialised for the filter geometry
+  if (C > 0 && C <= 16) {  // few channels (an image network's first layers): per-pixel kernel specialised for the filter geometry
     bool launched = false;
     rc = eg::conv2_direct_try(ctx, N, H, W, C, F, FH, FW, img, flt, out, accumulate, &launched);
     if (rc || launched) return rc;
