@@ -303,6 +303,44 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
 
 }  // namespace
 
+namespace {
+
+// Tiny contractions (a 32-sample batch through dense(400, 10): 320 outputs, K = 400): one matrix-core
+// block would walk K alone for ~20 us.  One WAVE per output element instead: lane l sums
+// k = l, l + 64, ... and a shuffle tree folds the 64 partial sums (fixed order: deterministic).
+__global__ __launch_bounds__(256) void gemm_small_kernel(const float* __restrict__ A, const float* __restrict__ B, float* C,
+                                                         const float* __restrict__ bias, long M, long N, long K,
+                                                         long a_sm, long a_sk, long b_sk, long b_sn, long ldc,
+                                                         int accumulate) {
+  const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // 4 waves per block, one output each
+  if (idx >= M * N) return;
+  const int lane = threadIdx.x & 63;
+  const long m = idx / N, n = idx - m * N;
+  const float* a = A + m * a_sm;
+  const float* b = B + n * b_sn;
+  float s = 0.f;
+  for (long k = lane; k < K; k += 64) s = s + a[k * a_sk] * b[k * b_sk];
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane == 0) {
+    float* c = C + m * ldc + n;
+    float v = s;
+    if (accumulate) v = *c + v;
+    if (bias) v = v + bias[n];
+    *c = v;
+  }
+}
+
+bool small_gemm_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("EG_NO_SMALL_GEMM");
+    return !(e && e[0] && e[0] != '0');
+  }();
+  return on;
+}
+
+}  // namespace
+
 extern "C" int eg_sgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A,
                         int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int accumulate,
                         const float* bias) {
@@ -316,6 +354,15 @@ extern "C" int eg_sgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_
   int rc = eg::set_device(ctx);
   if (rc) return rc;
 
+  if (M * N <= 16384 && K <= 2048 && M * N * K <= (4L << 20) && K > 0 && small_gemm_enabled()) {
+    const long a_sm = trans_a ? 1 : lda, a_sk = trans_a ? lda : 1;  // A(m, k)
+    const long b_sk = trans_b ? 1 : ldb, b_sn = trans_b ? ldb : 1;  // B(k, n)
+    const long blocks = (M * N + 3) / 4;
+    hipLaunchKernelGGL(gemm_small_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, A, B, C, bias, (long)M, (long)N,
+                       (long)K, a_sm, a_sk, b_sk, b_sn, (long)ldc, accumulate);
+    EG_HIP_CHECK(hipGetLastError());
+    return EG_OK;
+  }
   // Operand "k-contiguous" flags: A[M,K] row-major has k contiguous unless transposed;
   // B[K,N] row-major has n contiguous unless transposed.
   const bool a_kc = !trans_a, b_kc = trans_b != 0;
