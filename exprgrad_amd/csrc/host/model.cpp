@@ -774,6 +774,18 @@ int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<
     int q = p;
     while (q < n && eligible(q) && !(q != p && q == t.first_update)) ++q;
     if (q - p >= 2) {
+      // a run made of elementwise maps only (adam: m, v and parameter updates of every parameter) is
+      // better off as a map group below: many blocks instead of one
+      bool all_maps = true;
+      for (int s = p; s < q && all_maps; ++s) {
+        long count = 0;
+        all_maps = ts.lowered[s].kind == StepKind::GenericA &&
+                   is_map_kernel(m->prog, t.all[t.live[s]], infos[t.live[s]], shapes, count);
+      }
+      if (all_maps) {
+        p = q;
+        continue;
+      }
       std::unique_ptr<PlanSmallGroup> sg(new PlanSmallGroup());
       for (int s = p; s < q; ++s) sg->g.kernel_index.push_back(t.live[s]);
       char name[64];
