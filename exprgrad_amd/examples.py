@@ -112,3 +112,11 @@ def gan(seed_dim=32, h1=64, h2=128, pixels=28 * 28, rate=0.1):
     fit_discr = layers.mse(discr, dsl.input("labels")).target("loss.discr").backwards()
     fit_discr = fit_discr.optimize(discr_params, layers.gradient_descent(rate)).target("fit.discr")
     return [gen, discr, fit_gen, fit_discr]
+
+
+def matmul_graph():
+    """benchmarks/matmul/matmul_gpu.nim:61-64 / examples/matmul: c*[y, x] ++= a[y, it] * b[it, x]."""
+    y, x, it = iters("y x it")
+    c = Fun()
+    c[y, x] += dsl.input("a")[y, it] * dsl.input("b")[it, x]
+    return [c.target("c")]
