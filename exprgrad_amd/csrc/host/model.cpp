@@ -172,6 +172,7 @@ struct Lowered {
   GemmMatch gemm;
   int bias_tensor = 0;  // fused bias (0 = none)
   bool absorbed = false;  // this kernel was folded into the previous step
+  bool inlined = false;   // an elementwise producer recomputed inside its consumers: never launched, never stored
   ConvMatch conv;
   Generic mode_a;
   std::map<int, Generic> mode_b;  // by tx
@@ -322,10 +323,113 @@ int build_generic(eg_model* m, Generic& g) {
   return EG_OK;
 }
 
+// Producer inlining.  A unary elementwise kernel `T{it} ++= f(S{it})` whose result is read only by
+// generated kernels (not by a contraction / convolution the library runs) is recomputed inside
+// those consumers: every read `T[index]` becomes `f(S[index])`, the producer is never launched and T
+// never touches memory (conv2 -> leakyRelu -> maxpool2: the activation disappears into the pooling
+// kernel and into maxpool2's hand-written gradient).  Same operations in the same order per element:
+// results are bit-identical.  The reference's CPU target gets a similar effect from fuseLoops
+// (passes.nim:1929-2004); its GPU target launches every kernel.
+void inline_producers(eg_model* m, TargetState& ts) {
+  static const bool off = [] {
+    const char* e = getenv("EG_NO_INLINE");
+    return e && e[0] && e[0] != '0';
+  }();
+  if (off) return;
+  Target& t = *ts.target;
+  const Program& prog = m->prog;
+  auto is_library = [&](const Kernel& k) {
+    GemmMatch g;
+    ConvMatch c;
+    return k.is_seed || match_gemm(k, g) || match_conv(k, c);
+  };
+  for (size_t p = 0; p < t.live.size(); ++p) {
+    if (ts.lowered[p].absorbed || (int)p == t.first_update) continue;
+    const Kernel P = t.all[t.live[p]];  // copy: the consumers below are edited in place
+    // ---- a pure unary map over whole tensors?
+    if (P.loops.size() != 1 || !P.index_instrs.empty() || !P.setup.empty() || P.is_seed || P.instrs.size() > 32) continue;
+    if (P.reads.empty() || !P.write.raw || P.write.dims.size() != 1) continue;
+    const int it = P.loops[0].reg;
+    if (P.loops[0].has_bounds || P.write.dims[0].only_register() != it) continue;
+    const int T = P.write.tensor, S = P.reads[0].tensor;
+    bool pure = prog.tensors[T].kind == TK::Result && T != S && T != t.output && !ts.bucket_offset.count(T);
+    for (auto& rd : P.reads)
+      if (rd.tensor != S || !rd.raw || rd.dims.size() != 1 || rd.dims[0].only_register() != it) pure = false;
+    for (auto& ins : P.instrs) {
+      if (ins.kind == IK::Shape || ins.kind == IK::Len || ins.kind == IK::ShapeLen || ins.kind == IK::Epoch) pure = false;
+      for (int a : ins.args)
+        if (a == it) pure = false;  // the value depends on the position
+    }
+    if (P.result == it) pure = false;
+    // T must be shaped like S for an index into T to address the same element of S
+    auto sc = prog.shape_copy.find(T);
+    if (prog.shape_dims.count(T) || (sc != prog.shape_copy.end() ? sc->second != S : P.reads.size() != 1)) pure = false;
+    if (!pure) continue;
+    // ---- every other kernel: nobody else writes T, S is final, all readers of T are generated kernels
+    std::vector<size_t> consumers;
+    bool ok = true;
+    for (size_t q = 0; q < t.live.size() && ok; ++q) {
+      if (q == p) continue;
+      const Kernel& K = t.all[t.live[q]];
+      if (K.write.tensor == T) ok = false;
+      if (q > p && K.write.tensor == S) ok = false;
+      bool reads_t = false;
+      for (auto& rd : K.reads) reads_t = reads_t || rd.tensor == T;
+      if (!reads_t) continue;
+      if (q < p || ts.lowered[q].absorbed || is_library(K) || K.instrs.size() + P.instrs.size() * K.reads.size() > 96) ok = false;
+      if ((t.first_update >= 0) && ((int)p < t.first_update) != ((int)q < t.first_update)) ok = false;  // stay on one side
+      consumers.push_back(q);
+    }
+    if (!ok || consumers.empty()) continue;
+    // ---- rewrite the consumers
+    for (size_t q : consumers) {
+      Kernel& K = t.all[t.live[q]];
+      std::vector<Op> reads;
+      std::vector<Instr> prefix;
+      for (auto& rd : K.reads) {
+        if (rd.tensor != T) {
+          reads.push_back(rd);
+          continue;
+        }
+        // one load of S at the same index, then P's instructions with fresh registers
+        std::map<int, int> rename;
+        Op load = rd;
+        load.tensor = S;
+        load.reg = K.alloc();
+        for (auto& pr : P.reads) rename[pr.reg] = load.reg;
+        reads.push_back(load);
+        for (auto& ins : P.instrs) {
+          Instr c = ins;
+          c.res = K.alloc();
+          rename[ins.res] = c.res;
+          for (int& a : c.args) a = rename.count(a) ? rename[a] : a;
+          prefix.push_back(c);
+        }
+        // the old data register of the T read now names the recomputed value (0 + f, as P stored it)
+        Instr zero, sum;
+        zero.kind = IK::Scalar;
+        zero.lit = 0.0;
+        zero.res = K.alloc();
+        sum.kind = IK::Add;
+        sum.args = {zero.res, rename.count(P.result) ? rename[P.result] : P.result};
+        sum.res = rd.reg;
+        prefix.push_back(zero);
+        prefix.push_back(sum);
+      }
+      K.reads.swap(reads);
+      K.instrs.insert(K.instrs.begin(), prefix.begin(), prefix.end());
+    }
+    ts.lowered[p].absorbed = true;
+    ts.lowered[p].inlined = true;
+    ts.lowered[p].all_index = t.live[p];
+  }
+}
+
 int lower_target(eg_model* m, TargetState& ts) {
   Target& t = *ts.target;
   ts.lowered.clear();
   ts.lowered.resize(t.live.size());
+  inline_producers(m, ts);
   for (size_t p = 0; p < t.live.size(); ++p) {
     Lowered& lo = ts.lowered[p];
     lo.all_index = t.live[p];
@@ -1008,6 +1112,7 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   std::map<int, int> first_writer;  // tensor -> position in live
   std::vector<int> result_tensors;
   for (size_t p = 0; p < t.live.size(); ++p) {
+    if (ts.lowered[p].inlined) continue;  // its tensor is never materialised
     const Kernel& k = t.all[t.live[p]];
     const int wt = k.write.tensor;
     if (m->prog.tensors[wt].kind == TK::Result && !first_writer.count(wt)) {

@@ -90,6 +90,34 @@ def test_gpu_pooling_matches_the_oracle(gpu_ctx, kind, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["max", "avg"])
+def test_gpu_activation_is_inlined_into_the_pooling_kernels(gpu_ctx, kind):
+    """conv2 -> leakyRelu -> pool, as in the reference's fashion_mnist network: the activation is
+    recomputed inside the pooling kernel (and inside maxpool2's hand-written gradient) instead of
+    being stored.  Same operations per element, so the result is bit-identical to the oracle's."""
+    from exprgrad_amd import model as egm
+
+    def graphs():
+        img = dsl.input("img")
+        act = layers.tanh(layers.leaky_relu(img))                 # a chain of two maps
+        pool = {"max": layers.maxpool2, "avg": layers.avgpool2}[kind](act)
+        it = dsl.iters("it")
+        loss = dsl.Fun()
+        loss[0] += pool.raw[it] * pool.raw[it]
+        return [pool.target("out"), loss.target("loss").backwards().grad(img).target("grad")]
+
+    a = (np.random.default_rng(5).random((4, 64, 64, 16), dtype=np.float32) - 0.5).astype(np.float32)
+    ref = oracle(graphs(), threads=8)
+    gpu = egm.compile(*graphs(), gpu=gpu_ctx)
+    got, want = gpu.call("out", {"img": a}), ref.call("out", {"img": a})
+    assert rel_err(got, want) <= TOL
+    plan = [ln for ln in gpu.launch_plan("out").splitlines() if ln.startswith("[")]
+    assert len(plan) == 1 and gpu.kernel_count("out") == ref.kernel_count("out") == 3, plan
+    assert rel_err(gpu.call("grad", {"img": a}), ref.call("grad", {"img": a})) <= TOL
+    gpu.close()
+
+
+@pytest.mark.gpu
 def test_gpu_reshape_and_custom_grad(gpu_ctx):
     from exprgrad_amd import model as egm
     b = np.arange(24, dtype=np.float32)
