@@ -94,6 +94,7 @@ _SIGS = {
     "eg_model_run": (c_int, [c_void_p, c_char_p]),
     "eg_model_run_backward": (c_int, [c_void_p, c_char_p]),
     "eg_model_run_update": (c_int, [c_void_p, c_char_p]),
+    "eg_model_fit": (c_int, [c_void_p, c_char_p, c_int, P(c_char_p), P(c_void_p), P(c_int), P(c_int), P(c_i64), c_i64]),
     "eg_model_set_grad_scale": (c_int, [c_void_p, c_f32]),
     "eg_model_output_shape": (c_int, [c_void_p, c_char_p, P(c_int), P(c_i64)]),
     "eg_model_read_output": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),

@@ -94,6 +94,14 @@ int conv2_direct_grad_filter_try(eg_ctx* ctx, long N, long H, long W, long C, lo
 // LDS-halo convolution (kernels/conv2_halo.hip); *launched = false when the problem does not suit it.
 int conv2_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
                    const float* flt, float* out, int accumulate, bool* launched);
+// Several contiguous device-to-device float copies in one launch (kernels/elementwise.hip).
+struct CopySegments {
+  const float* src[8];
+  float* dst[8];
+  long count[8];
+  int n;
+};
+int copy_segments(eg_ctx* ctx, const CopySegments& seg);
 inline int set_device(eg_ctx* ctx) {
   EG_HIP_CHECK(hipSetDevice(ctx->device));
   return EG_OK;

@@ -260,6 +260,37 @@ __global__ __launch_bounds__(NT) void fill_uniform_kernel(float lo, float hi, co
 
 __global__ void rng_advance_kernel(uint64_t* state) { state[1] += 1; }
 
+// Copies up to 8 contiguous float ranges in one launch: Model.fit's mini-batch views of the
+// device-resident data set -> the inputs' fixed staging buffers (eg_model_fit, host/model.cpp).
+__global__ __launch_bounds__(NT) void copy_segments_kernel(eg::CopySegments seg) {
+  const int s = blockIdx.y;
+  const float* __restrict__ src = seg.src[s];
+  float* __restrict__ dst = seg.dst[s];
+  const long n = seg.count[s];
+  const long stride = (long)gridDim.x * NT;
+  long i = (long)blockIdx.x * NT + threadIdx.x;
+  if ((((unsigned long)src | (unsigned long)dst) & 15) == 0) {
+    const long n4 = n >> 2;
+    for (long j = i; j < n4; j += stride) reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(src)[j];
+    for (long j = (n4 << 2) + i; j < n; j += stride) dst[j] = src[j];
+  } else {
+    for (; i < n; i += stride) dst[i] = src[i];
+  }
+}
+
+namespace eg {
+int copy_segments(eg_ctx* ctx, const CopySegments& seg) {
+  if (seg.n <= 0) return EG_OK;
+  EG_REQUIRE(seg.n <= 8, EG_ERR_INVALID, "copy_segments: more than 8 ranges");
+  long most = 0;
+  for (int i = 0; i < seg.n; ++i) most = seg.count[i] > most ? seg.count[i] : most;
+  if (most == 0) return EG_OK;
+  hipLaunchKernelGGL(copy_segments_kernel, dim3(grid_for(ctx, (most + 3) / 4), seg.n), dim3(NT), 0, ctx->stream, seg);
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+}  // namespace eg
+
 extern "C" {
 
 int eg_map(eg_ctx* ctx, int op, int64_t n, const float* in, float* out, float param, int accumulate) {

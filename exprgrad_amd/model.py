@@ -156,19 +156,34 @@ class Model:
 
     def fit(self, target, args, batch_size=32, log_status=False):
         """fit (model.nim:413-454): one epoch of mini-batches; the tail that does not fill a batch is
-        dropped (batchCount = shape[0] div batchSize), Model.epoch is bumped once."""
+        dropped (batchCount = shape[0] div batchSize), Model.epoch is bumped once.  The loop itself
+        is eg_model_fit: the data set goes to the device once, every batch is two launches."""
         items = list(args.items() if isinstance(args, dict) else args)
         if not items:
             raise RuntimeErrorEG("Model.fit requires at least one input tensor. Use Model.apply instead if the "
                                  "target has zero inputs.")
-        if target not in self.program.targets:
-            raise RuntimeErrorEG(target + " is not a target of the model")
-        batch_count = int(items[0][1].shape[0]) // batch_size
-        self.epoch = self.epoch + 1
-        for b in range(batch_count):
-            lo = b * batch_size
-            # viewFirst (tensors.nim:290-297): a zero-copy slice of the leading dimension
-            self.apply(target, [(n, a[lo:lo + batch_size]) for n, a in items])
+        n = len(items)
+        names = (ctypes.c_char_p * n)(*[name.encode() for name, _ in items])
+        data = (ctypes.c_void_p * n)()
+        on_device = (ctypes.c_int * n)()
+        ranks = (ctypes.c_int * n)()
+        shapes = (ctypes.c_int64 * (8 * n))()
+        keep = []
+        for i, (_, tensor) in enumerate(items):
+            if hasattr(tensor, "data_ptr"):      # device tensor: read in place
+                if hasattr(tensor, "is_contiguous") and not tensor.is_contiguous():
+                    tensor = tensor.contiguous()
+                data[i], on_device[i], shape = tensor.data_ptr(), 1, [int(s) for s in tensor.shape]
+            else:
+                tensor = np.ascontiguousarray(tensor, dtype=np.float32)
+                data[i], on_device[i], shape = tensor.ctypes.data, 0, list(tensor.shape)
+            keep.append(tensor)
+            if len(shape) > 8:
+                raise GpuError("inputs have at most 8 dimensions")
+            ranks[i] = len(shape)
+            shapes[8 * i:8 * i + len(shape)] = shape
+        self._keep = {"fit": keep}
+        call("eg_model_fit", self.handle, target.encode(), n, names, data, on_device, ranks, shapes, int(batch_size))
 
     # ---- data-parallel hooks (SURVEY.md §8e) ---------------------------------------------------
     def grad_bucket(self, target):

@@ -248,6 +248,14 @@ int eg_model_run(eg_model* model, const char* target);
  * kernels, then the optimizer kernels.  run == run_backward + run_update. */
 int eg_model_run_backward(eg_model* model, const char* target);
 int eg_model_run_update(eg_model* model, const char* target);
+/* fit (model.nim:413-454): Model.epoch += 1, then the target once per mini-batch of `batch_size`
+ * leading rows of every input (batchCount = rows of the first input div batch_size; the tail is
+ * dropped).  data[i] is a host array (on_device[i] == 0: uploaded once, piecewise, overlapped
+ * with the batches already queued) or a device array used in place; shapes8 holds 8 extents per
+ * input.  Asynchronous with respect to the kernels; the host arrays are free on return.
+ * EG_ERR_RUNTIME with the reference's message when n_inputs == 0. */
+int eg_model_fit(eg_model* model, const char* target, int n_inputs, const char* const* names, const float* const* data,
+                 const int* on_device, const int* ranks, const int64_t* shapes8, int64_t batch_size);
 /* Scale applied to the seed gradient gradLoss (passes.nim:594-596) — B_local/B_global for
  * batch-mean losses under data parallelism.  Default 1. */
 int eg_model_set_grad_scale(eg_model* model, float scale);

@@ -1,0 +1,147 @@
+"""Model.fit (model.nim:413-454) through eg_model_fit: the data set is uploaded once (piecewise, on
+a second stream) and every mini-batch is a segment copy + the captured launch sequence.  Compared
+with the oracle stepping through the same batches (viewFirst slices, tail dropped, epoch bumped
+once per call), and with the GPU's own apply() loop bit for bit."""
+import numpy as np
+import pytest
+
+import refcases
+from conftest import TOL, rel_err
+from exprgrad_amd import examples, layers, dsl
+from exprgrad_amd import model as egm
+from exprgrad_amd._lib import RuntimeErrorEG
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle(graphs, threads=4):
+    from oracle import kd
+    return kd.Model(refcases.program_text(graphs), threads=threads)
+
+
+def dense_graphs(optim):
+    net = layers.tanh(layers.dense(dsl.input("x"), 24, 16))
+    net = layers.sigmoid(layers.dense(net, 16, 5)).target("predict")
+    net = layers.mse(net, dsl.input("y")).target("loss")
+    opt = layers.adam(0.01) if optim == "adam" else layers.gradient_descent(0.05)
+    return [net.backprop(opt).target("train")]
+
+
+def same_start(models, seed):
+    rng = np.random.default_rng(seed)
+    ids = models[0].params.ids() if hasattr(models[0].params, "ids") else sorted(models[0].params)
+    for tid in ids:
+        shape = models[0].params[tid].shape
+        v = (rng.random(shape, dtype=np.float32) - 0.5).astype(np.float32)
+        for m in models:
+            if hasattr(m.params, "ids"):
+                m.params[tid] = v
+            else:
+                m.params[tid][...] = v
+
+
+def oracle_fit(ref, target, x, y, batch):
+    ref.epoch += 1
+    for b in range(x.shape[0] // batch):
+        ref.apply(target, {"x": x[b * batch:(b + 1) * batch], "y": y[b * batch:(b + 1) * batch]})
+
+
+@pytest.mark.parametrize("optim", ["sgd", "adam"])
+@pytest.mark.parametrize("rows,batch", [(64, 8), (77, 16), (10, 16)])
+def test_fit_matches_the_oracle_batch_by_batch(gpu_ctx, optim, rows, batch):
+    gpu = egm.compile(*dense_graphs(optim), gpu=gpu_ctx)
+    looped = egm.compile(*dense_graphs(optim), gpu=gpu_ctx)
+    ref = oracle(dense_graphs(optim))
+    same_start((gpu, looped, ref), seed=rows)
+    rng = np.random.default_rng(batch)
+    x = rng.random((rows, 24), dtype=np.float32)
+    y = rng.random((rows, 5), dtype=np.float32)
+    for _ in range(3):
+        gpu.fit("train", {"x": x, "y": y}, batch_size=batch)
+        oracle_fit(ref, "train", x, y, batch)
+        looped.epoch = looped.epoch + 1
+        for b in range(rows // batch):
+            looped.apply("train", {"x": x[b * batch:(b + 1) * batch], "y": y[b * batch:(b + 1) * batch]})
+    assert gpu.epoch == ref.epoch == 3
+    for tid in gpu.params.ids():
+        assert np.array_equal(gpu.params[tid], looped.params[tid]), tid
+        assert rel_err(gpu.params[tid], ref.params[tid]) <= (2e-4 if optim == "adam" else TOL), tid
+    for m in (gpu, looped):
+        m.close()
+
+
+def test_fit_in_small_segments_and_pieces(gpu_ctx, monkeypatch):
+    """The data set does not fit the device copy at once: segments are reused, pieces overlap."""
+    rows, batch = 96, 8
+    rng = np.random.default_rng(2)
+    x = rng.random((rows, 24), dtype=np.float32)
+    y = rng.random((rows, 5), dtype=np.float32)
+    whole = egm.compile(*dense_graphs("sgd"), gpu=gpu_ctx)
+    pieces = egm.compile(*dense_graphs("sgd"), gpu=gpu_ctx)
+    same_start((whole, pieces), seed=9)
+    whole.fit("train", {"x": x, "y": y}, batch_size=batch)
+    monkeypatch.setenv("EG_FIT_SEGMENT_BYTES", str(3 * batch * 29 * 4))   # three batches per segment
+    monkeypatch.setenv("EG_FIT_PIECE_BYTES", str(2 * batch * 29 * 4))     # two batches per upload
+    pieces.fit("train", {"x": x, "y": y}, batch_size=batch)
+    for tid in whole.params.ids():
+        assert np.array_equal(whole.params[tid], pieces.params[tid]), tid
+    whole.close()
+    pieces.close()
+
+
+def test_fit_reads_device_resident_data_in_place(gpu_ctx):
+    import torch
+    rows, batch = 40, 8
+    rng = np.random.default_rng(4)
+    x = rng.random((rows, 24), dtype=np.float32)
+    y = rng.random((rows, 5), dtype=np.float32)
+    host = egm.compile(*dense_graphs("adam"), gpu=gpu_ctx)
+    dev = egm.compile(*dense_graphs("adam"), gpu=gpu_ctx)
+    same_start((host, dev), seed=1)
+    host.fit("train", {"x": x, "y": y}, batch_size=batch)
+    dev.fit("train", {"x": torch.from_numpy(x).cuda(), "y": y}, batch_size=batch)   # mixed: one device, one host
+    torch.cuda.synchronize()
+    for tid in host.params.ids():
+        assert np.array_equal(host.params[tid], dev.params[tid]), tid
+    host.close()
+    dev.close()
+
+
+def test_fit_errors_follow_the_reference(gpu_ctx):
+    gpu = egm.compile(*dense_graphs("sgd"), gpu=gpu_ctx)
+    with pytest.raises(RuntimeErrorEG, match="requires at least one input tensor"):   # model.nim:417-421
+        gpu.fit("train", {}, batch_size=4)
+    x = np.zeros((8, 24), np.float32)
+    with pytest.raises(RuntimeErrorEG, match="is not a target of the model"):
+        gpu.fit("nope", {"x": x, "y": np.zeros((8, 5), np.float32)}, batch_size=4)
+    with pytest.raises(RuntimeErrorEG, match="is not an input to the model"):
+        gpu.fit("train", {"x": x, "z": x}, batch_size=4)
+    with pytest.raises(Exception, match="fewer rows"):
+        gpu.fit("train", {"x": x, "y": np.zeros((4, 5), np.float32)}, batch_size=4)
+    assert gpu.epoch == 0
+    gpu.close()
+
+
+def test_fit_of_the_fashion_mnist_network(gpu_ctx):
+    """examples/fashion_mnist/fashion_mnist.nim:59-66 in small: fit over several batches, then the loss fell."""
+    graphs = lambda: examples.fashion_mnist_net(size=12, f1=4, f2=8, eta=0.02)
+    gpu = egm.compile(*graphs(), gpu=gpu_ctx)
+    ref = oracle(graphs(), threads=8)
+    same_start((gpu, ref), seed=0)
+    for m in (gpu, ref):
+        for tid in (m.params.ids() if hasattr(m.params, "ids") else sorted(m.params)):
+            v = np.asarray(m.params[tid]) * np.float32(0.4)
+            if hasattr(m.params, "ids"):
+                m.params[tid] = v
+            else:
+                m.params[tid][...] = v
+    rng = np.random.default_rng(0)
+    x = rng.random((40, 144), dtype=np.float32)
+    y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 40)]
+    first = float(gpu.call("loss", {"x": x, "y": y}).sum())
+    for _ in range(4):
+        gpu.fit("fit", {"x": x, "y": y}, batch_size=8)
+        oracle_fit(ref, "fit", x, y, 8)
+    assert float(gpu.call("loss", {"x": x, "y": y}).sum()) < first
+    assert rel_err(gpu.call("predict", {"x": x}), ref.call("predict", {"x": x})) <= 5e-3   # 20 adam steps apart
+    gpu.close()
