@@ -58,10 +58,13 @@ class GpuEngine:
 
 
 class DataParallel:
-    def __init__(self, engine, reduction="mean", group=None):
+    def __init__(self, engine, reduction="mean", group=None, always_reduce=False):
+        """always_reduce: issue the all-reduce on a one-rank group too (exercises the RCCL path on a
+        one-GPU box; a sum over one rank leaves the bucket unchanged)."""
         if reduction not in ("mean", "sum"):
             raise ValueError("reduction must be 'mean' (loss divides by the batch) or 'sum'")
         self.engine, self.reduction, self.group = engine, reduction, group
+        self.always_reduce = always_reduce and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
 
@@ -70,6 +73,6 @@ class DataParallel:
         e = self.engine
         e.set_grad_scale(1.0 / self.world if self.reduction == "mean" else 1.0)
         e.run_backward(local_args)
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             dist.all_reduce(e.bucket, op=dist.ReduceOp.SUM, group=self.group)
         e.run_update()

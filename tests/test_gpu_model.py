@@ -258,3 +258,50 @@ def test_data_parallel_engine_world1(gpu_ctx):
     assert float(engine.bucket.abs().sum()) > 0
     a.close()
     b.close()
+
+
+def test_data_parallel_step_over_rccl(gpu_ctx):
+    """The step as bench.py --gpus N runs it: side stream (so the launch ranges are captured into HIP
+    graphs), gradient bucket in a torch tensor, all-reduce through torch.distributed's "nccl" backend
+    (RCCL) between the backward graph and the update graph.  One rank on this one-GPU box — the sum
+    over one rank is the identity, so the result must equal plain apply() bit for bit."""
+    torch = pytest.importorskip("torch")
+    import socket
+    import torch.distributed as dist
+    from exprgrad_amd.parallel import DataParallel, GpuEngine
+    import exprgrad_amd as eg
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
+                            device_id=torch.device("cuda", 0))
+    try:
+        stream = torch.cuda.Stream()
+        with torch.cuda.stream(stream):
+            ctx = eg.newGpuContext(0, stream=stream.cuda_stream)
+            a = egm.compile(*refcases.dense_softmax_net(n_in=96, n_hidden=128, n_out=10), gpu=ctx)
+            b = egm.compile(*refcases.dense_softmax_net(n_in=96, n_hidden=128, n_out=10), gpu=ctx)
+            rng = np.random.default_rng(5)
+            for tid in a.params.ids():
+                v = (rng.random(a.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+                a.params[tid] = v
+                b.params[tid] = v
+            x = torch.rand((512, 96), device="cuda")
+            y = torch.nn.functional.one_hot(torch.randint(0, 10, (512,), device="cuda"), 10).to(torch.float32).contiguous()
+            engine = GpuEngine(b, "train")
+            dp = DataParallel(engine, reduction="mean", always_reduce=True)
+            assert dp.world == 1 and dp.always_reduce
+            for _ in range(6):     # eager, captured, then replays
+                a.apply("train", [("x", x), ("y", y)])
+                dp.step([("x", x), ("y", y)])
+            stream.synchronize()
+            probe = torch.ones(4, device="cuda")
+            dist.all_reduce(probe)
+            assert float(probe.sum()) == 4.0
+            for tid in a.params.ids():
+                assert np.array_equal(a.params[tid], b.params[tid]), tid
+            assert float(engine.bucket.abs().sum()) > 0
+            a.close()
+            b.close()
+    finally:
+        dist.destroy_process_group()
