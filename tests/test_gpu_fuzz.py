@@ -1,7 +1,9 @@
 """Differential fuzzing: random layer chains built with the Python front-end run through the product
 (GPU: pattern matcher, generated kernels, row / map / small fusion, fused epilogues, graphs) and
 through the oracle's independent restatement of generate / derive / shape inference / execution.
-Seeds are fixed: the cases are reproducible."""
+Seeds are fixed: the cases are reproducible.  EG_FUZZ_CHAINS / EG_FUZZ_CNNS = "start:stop" run other
+seed ranges (wider sweeps before a release; CNN seeds >= 16 also draw larger images and batches)."""
+import os
 import random
 
 import numpy as np
@@ -13,6 +15,11 @@ from exprgrad_amd import dsl, layers
 from exprgrad_amd.dsl import Fun, iters
 
 pytestmark = pytest.mark.gpu
+
+
+def seeds(var, default):
+    lo, hi = (int(v) for v in os.environ.get(var, default).split(":"))
+    return range(lo, hi)
 
 
 def unary(rng, x):
@@ -71,7 +78,7 @@ def build(seed):
     return [loss.backprop(opt).target("train"), loss.backwards().grad(dsl.input("x")).target("gx")], width, dims
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", seeds("EG_FUZZ_CHAINS", "0:40"))
 def test_random_chain_matches_the_oracle(gpu_ctx, monkeypatch, seed):
     from oracle import kd
     from exprgrad_amd import model as egm
@@ -108,7 +115,7 @@ def test_random_chain_matches_the_oracle(gpu_ctx, monkeypatch, seed):
 def build_cnn(seed):
     rng = random.Random(1000 + seed)
     chans = rng.choice([1, 3, 4, 16])
-    size = rng.choice([8, 12, 18])
+    size = rng.choice([8, 12, 18] if seed < 16 else [8, 12, 18, 30, 44])
     net = dsl.input("x")
     h = w = size
     for depth in range(rng.randint(1, 3)):
@@ -138,7 +145,7 @@ def chans_in(seed):
     return random.Random(1000 + seed).choice([1, 3, 4, 16])
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", seeds("EG_FUZZ_CNNS", "0:16"))
 def test_random_cnn_matches_the_oracle(gpu_ctx, seed):
     from oracle import kd
     from exprgrad_amd import model as egm
@@ -150,7 +157,7 @@ def test_random_cnn_matches_the_oracle(gpu_ctx, seed):
         v = (rng.random(ref.params[tid].shape, dtype=np.float32) * 0.6 - 0.3).astype(np.float32)
         ref.params[tid][...] = v
         gpu.params[tid] = v
-    batch = [2, 9, 40][seed % 3]
+    batch = [2, 9, 40][seed % 3] if seed < 16 else [2, 9, 40, 33, 96][seed % 5]
     x = (rng.random((batch, h, w, c), dtype=np.float32) - 0.5).astype(np.float32)
     out_r = ref.call("predict", {"x": x})
     y = rng.random(out_r.shape, dtype=np.float32)
