@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch of the train/xor workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--native-dp", action="store_true",
+                    help="N > 1: exchange the gradients with the C ABI's own RCCL group (eg_dp_*, eg_model_step_dp) "
+                         "instead of torch.distributed's all_reduce")
     return ap.parse_args()
 
 
@@ -236,8 +239,36 @@ def build_dense(env, batch):
     x = torch.rand((batch, DENSE["n_in"]), device="cuda", dtype=torch.float32, generator=gen)
     labels = torch.randint(0, DENSE["n_out"], (batch,), device="cuda", generator=gen)
     y = torch.nn.functional.one_hot(labels, DENSE["n_out"]).to(torch.float32).contiguous()
-    dp = DataParallel(GpuEngine(model, "train"), reduction="mean")
+    if env.get("native_dp") and env["world"] > 1:
+        # the library's own communicator: rank 0 draws the id, torch.distributed only carries its 128 bytes
+        import torch.distributed as dist
+        from exprgrad_amd.parallel import NativeDataParallel, RcclGroup
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if env["rank"] == 0:
+            uid.copy_(torch.frombuffer(bytearray(RcclGroup.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        group = RcclGroup(env["ctx"], bytes(uid.cpu().numpy().tobytes()), env["rank"], env["world"])
+        dp = NativeDataParallel(model, "train", group, reduction="mean")
+        dp.engine = _NativeEngine(model, "train")
+    else:
+        dp = DataParallel(GpuEngine(model, "train"), reduction="mean")
     return model, dp, x, y
+
+
+class _NativeEngine:
+    """The single-GPU reference step of run_train for the --native-dp path (library-owned bucket)."""
+
+    def __init__(self, model, target):
+        self.model, self.target = model, target
+
+    def set_grad_scale(self, s):
+        self.model.set_grad_scale(s)
+
+    def run_backward(self, args):
+        self.model.run_backward(self.target, args)
+
+    def run_update(self):
+        self.model.run_update(self.target)
 
 
 def run_train(args, env):
@@ -273,6 +304,9 @@ def run_train(args, env):
                                "backward + parameter-gradient all-reduce + update",
                    "global_batch": batch * world, "per_gpu_batch": batch,
                    "parallelism": f"dp{world}" if world > 1 else "single",
+                   "collective": "none" if world == 1 else ("RCCL all-reduce from the C ABI (eg_model_step_dp)"
+                                                            if env.get("native_dp") else
+                                                            "RCCL all-reduce through torch.distributed (nccl backend)"),
                    "grad_bucket_floats": model.grad_bucket("train")[1]},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
@@ -424,7 +458,7 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx = eg.newGpuContext(local_rank, stream=stream.cuda_stream)
-    env = {"torch": torch, "ops": ops, "ctx": ctx, "world": world, "rank": rank,
+    env = {"torch": torch, "ops": ops, "ctx": ctx, "world": world, "rank": rank, "native_dp": args.native_dp,
            "timer": Timer(torch, dist, world, stream)}
 
     workload = args.workload

@@ -95,6 +95,13 @@ _SIGS = {
     "eg_model_run_backward": (c_int, [c_void_p, c_char_p]),
     "eg_model_run_update": (c_int, [c_void_p, c_char_p]),
     "eg_model_fit": (c_int, [c_void_p, c_char_p, c_int, P(c_char_p), P(c_void_p), P(c_int), P(c_int), P(c_i64), c_i64]),
+    "eg_dp_unique_id": (c_int, [c_void_p]),
+    "eg_dp_init": (c_int, [c_void_p, c_void_p, c_int, c_int, P(c_void_p)]),
+    "eg_dp_free": (c_int, [c_void_p]),
+    "eg_dp_rank": (c_int, [c_void_p]),
+    "eg_dp_world": (c_int, [c_void_p]),
+    "eg_dp_allreduce_sum_f32": (c_int, [c_void_p, c_void_p, c_i64]),
+    "eg_model_step_dp": (c_int, [c_void_p, c_char_p, c_void_p, c_int]),
     "eg_model_set_grad_scale": (c_int, [c_void_p, c_f32]),
     "eg_model_output_shape": (c_int, [c_void_p, c_char_p, P(c_int), P(c_i64)]),
     "eg_model_read_output": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),
@@ -108,7 +115,8 @@ _SIGS = {
 }
 
 # functions whose int return value is not a status code
-_NOT_STATUS = {"eg_version", "eg_ctx_device", "eg_model_kernel_count", "eg_model_tensor_count"}
+_NOT_STATUS = {"eg_version", "eg_ctx_device", "eg_model_kernel_count", "eg_model_tensor_count", "eg_dp_rank",
+               "eg_dp_world"}
 
 
 def declared_symbols():

@@ -1,0 +1,152 @@
+// Data-parallel exchange of the C ABI: one process per GPU, one RCCL
+// communicator per context, one in-place SUM all-reduce of the flat parameter-gradient bucket on
+// the context's stream between the backward kernels and the optimizer kernels.
+//
+// The reference has no multi-device code; this is what a Nim host binds for the north-star's
+// "RCCL all-reduce of parameter gradients before the gradientDescent step" (the Python mirror
+// uses torch.distributed's "nccl" backend, which is the same RCCL).  librccl is opened lazily
+// with dlopen — a process that never calls eg_dp_* never loads it, and a process that already
+// has one (torch ships its own) reuses that copy instead of loading a second one.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "eg_internal.hpp"
+
+namespace {
+
+// The slice of rccl.h this file needs (rccl/rccl.h: ncclUniqueId is 128 opaque bytes, passed by
+// value; ncclFloat32 = 7; ncclSum = 0).
+struct UniqueId {
+  char internal[128];
+};
+using Comm = void*;
+struct Rccl {
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(Comm) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+  std::string why;
+};
+
+const Rccl& rccl() {
+  static const Rccl lib = [] {
+    Rccl r;
+    void* h = nullptr;
+    const char* names[] = {"librccl.so", "librccl.so.1"};
+    for (const char* n : names)  // a copy that is already in the process wins
+      if (!h) h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+    const char* paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* p : paths)
+      if (!h) h = dlopen(p, RTLD_NOW | RTLD_GLOBAL);
+    if (!h) {
+      r.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "");
+      return r;
+    }
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
+    if (!r.ok) r.why = "librccl.so lacks an expected symbol";
+    return r;
+  }();
+  return lib;
+}
+
+#define EG_RCCL_CHECK(expr)                                                                         \
+  do {                                                                                              \
+    int _r = (expr);                                                                                \
+    if (_r != 0) {                                                                                  \
+      ::eg::set_error("%s failed: %s (%d)", #expr, rccl().GetErrorString(_r), _r);                  \
+      return EG_ERR_HIP;                                                                            \
+    }                                                                                               \
+  } while (0)
+
+}  // namespace
+
+struct eg_dp {
+  eg_ctx* ctx = nullptr;
+  Comm comm = nullptr;
+  int rank = 0, world = 1;
+};
+
+extern "C" {
+
+int eg_dp_unique_id(void* id128) {
+  EG_REQUIRE(id128, EG_ERR_INVALID, "eg_dp_unique_id: NULL buffer");
+  EG_REQUIRE(rccl().ok, EG_ERR_RUNTIME, "%s", rccl().why.c_str());
+  UniqueId id;
+  EG_RCCL_CHECK(rccl().GetUniqueId(&id));
+  memcpy(id128, &id, sizeof(id));
+  return EG_OK;
+}
+
+int eg_dp_init(eg_ctx* ctx, const void* id128, int rank, int world, eg_dp** out) {
+  EG_REQUIRE(ctx && id128 && out, EG_ERR_INVALID, "eg_dp_init: NULL argument");
+  EG_REQUIRE(world >= 1 && rank >= 0 && rank < world, EG_ERR_INVALID, "eg_dp_init: rank %d of %d", rank, world);
+  EG_REQUIRE(rccl().ok, EG_ERR_RUNTIME, "%s", rccl().why.c_str());
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  UniqueId id;
+  memcpy(&id, id128, sizeof(id));
+  Comm comm = nullptr;
+  EG_RCCL_CHECK(rccl().CommInitRank(&comm, world, id, rank));
+  eg_dp* dp = new eg_dp();
+  dp->ctx = ctx;
+  dp->comm = comm;
+  dp->rank = rank;
+  dp->world = world;
+  *out = dp;
+  return EG_OK;
+}
+
+int eg_dp_free(eg_dp* dp) {
+  if (!dp) return EG_OK;
+  if (dp->comm) {
+    hipSetDevice(dp->ctx->device);
+    hipStreamSynchronize(dp->ctx->stream);
+    rccl().CommDestroy(dp->comm);
+  }
+  delete dp;
+  return EG_OK;
+}
+
+int eg_dp_world(const eg_dp* dp) { return dp ? dp->world : 0; }
+int eg_dp_rank(const eg_dp* dp) { return dp ? dp->rank : -1; }
+
+int eg_dp_allreduce_sum_f32(eg_dp* dp, float* device_buf, int64_t count) {
+  EG_REQUIRE(dp && dp->comm, EG_ERR_INVALID, "eg_dp_allreduce_sum_f32: NULL communicator");
+  EG_REQUIRE(count >= 0, EG_ERR_INVALID, "eg_dp_allreduce_sum_f32: negative count");
+  if (count == 0) return EG_OK;
+  EG_REQUIRE(device_buf, EG_ERR_INVALID, "eg_dp_allreduce_sum_f32: NULL buffer");
+  int rc = eg::set_device(dp->ctx);
+  if (rc) return rc;
+  EG_RCCL_CHECK(rccl().AllReduce(device_buf, device_buf, (size_t)count, /*ncclFloat32*/ 7, /*ncclSum*/ 0, dp->comm,
+                                 dp->ctx->stream));
+  return EG_OK;
+}
+
+// One data-parallel training step on this rank's shard (the inputs are bound already):
+//   [forward + backward kernels] | all-reduce of the gradient bucket | [optimizer kernels]
+// mean != 0: the loss divides by the batch (mse, crossEntropy: base.nim:57-67), so the seed
+// gradient is scaled by B_local / B_global = 1 / world; sum-type losses use 1.
+int eg_model_step_dp(eg_model* model, const char* target, eg_dp* dp, int mean) {
+  EG_REQUIRE(model && target && dp, EG_ERR_INVALID, "eg_model_step_dp: NULL argument");
+  int rc = eg_model_set_grad_scale(model, mean ? 1.0f / (float)dp->world : 1.0f);
+  if (rc) return rc;
+  rc = eg_model_run_backward(model, target);
+  if (rc) return rc;
+  float* bucket = nullptr;
+  int64_t count = 0;
+  rc = eg_model_grad_bucket(model, target, &bucket, &count);
+  if (rc) return rc;
+  rc = eg_dp_allreduce_sum_f32(dp, bucket, count);
+  if (rc) return rc;
+  return eg_model_run_update(model, target);
+}
+
+}  // extern "C"

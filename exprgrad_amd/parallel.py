@@ -76,3 +76,57 @@ class DataParallel:
         if self.world > 1 or self.always_reduce:
             dist.all_reduce(e.bucket, op=dist.ReduceOp.SUM, group=self.group)
         e.run_update()
+
+
+class RcclGroup:
+    """One rank of the C ABI's own data-parallel group (eg_dp_*, include/exprgrad_hip.h group 4):
+    RCCL called from the library on the context's stream — what a Nim host binds.  Rank 0 creates
+    the id with RcclGroup.unique_id() and the host hands its 128 bytes to the other ranks."""
+
+    def __init__(self, ctx, unique_id, rank, world):
+        import ctypes
+        from ._lib import call
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL unique id has 128 bytes")
+        self.ctx = ctx
+        self._id = (ctypes.c_char * 128).from_buffer_copy(bytes(unique_id))
+        h = ctypes.c_void_p()
+        call("eg_dp_init", ctx.handle, ctypes.cast(self._id, ctypes.c_void_p), int(rank), int(world), ctypes.byref(h))
+        self.handle = h
+        self.rank, self.world = int(rank), int(world)
+
+    @staticmethod
+    def unique_id():
+        import ctypes
+        from ._lib import call
+        buf = (ctypes.c_char * 128)()
+        call("eg_dp_unique_id", ctypes.cast(buf, ctypes.c_void_p))
+        return bytes(buf)
+
+    def all_reduce(self, tensor):
+        """In-place SUM of a float32 device tensor, asynchronous on the context's stream."""
+        import ctypes
+        from ._lib import call
+        call("eg_dp_allreduce_sum_f32", self.handle, ctypes.c_void_p(tensor.data_ptr()), int(tensor.numel()))
+
+    def close(self):
+        from ._lib import call
+        if self.handle:
+            call("eg_dp_free", self.handle)
+            self.handle = None
+
+
+class NativeDataParallel:
+    """DataParallel.step through one C-ABI call (eg_model_step_dp): backward | RCCL all-reduce of the
+    library-owned gradient bucket | update, all on the context's stream."""
+
+    def __init__(self, model, target, group, reduction="mean"):
+        if reduction not in ("mean", "sum"):
+            raise ValueError("reduction must be 'mean' (loss divides by the batch) or 'sum'")
+        self.model, self.target, self.group, self.mean = model, target, group, int(reduction == "mean")
+        self.world, self.rank = group.world, group.rank
+
+    def step(self, local_args):
+        from ._lib import call
+        self.model._bind_all(local_args)
+        call("eg_model_step_dp", self.model.handle, self.target.encode(), self.group.handle, self.mean)

@@ -50,6 +50,7 @@ extern "C" {
 typedef struct eg_ctx eg_ctx;       /* GpuContext  (cl.nim:24-27)  */
 typedef struct eg_buf eg_buf;       /* GpuBuffer   (cl.nim:29-32)  */
 typedef struct eg_kernel eg_kernel; /* GpuKernel   (cl.nim:38-40)  */
+typedef struct eg_dp eg_dp;         /* one rank of a data-parallel group (no reference counterpart) */
 typedef struct eg_model eg_model;   /* Model[T] restricted to its GpuModel (model.nim:21-43) */
 
 /* Thread-local text of the last failure on this thread ("" if none). cl.nim:41-43. */
@@ -277,6 +278,28 @@ int64_t eg_model_epoch(eg_model* model);
 /* Seed of the model's random tensors (`rand` / dropout; the reference draws them from Nim's global
  * generator, `randomize(seed)`): same seed, same call sequence -> same numbers.  Resets the draw counter. */
 int eg_model_set_seed(eg_model* model, uint64_t seed);
+
+/* ---------------------------------------------------------------------------------------------
+ * Group 4 — data-parallel exchange (BASELINE.json north_star: "training-step batches
+ * shard data-parallel across the 8 GPUs of one node with an RCCL all-reduce of parameter gradients
+ * over xGMI before the gradientDescent optim step").  The reference has no multi-device code.
+ * One process per GPU: rank 0 draws an id and hands its 128 bytes to the other ranks (file,
+ * socket, environment — the host's business), every rank joins with its own context; the
+ * collective runs on the context's stream, after the backward kernels, before the optimizer's.
+ * librccl.so is opened on first use.
+ * ------------------------------------------------------------------------------------------- */
+int eg_dp_unique_id(void* id128);                     /* ncclGetUniqueId: 128 opaque bytes */
+int eg_dp_init(eg_ctx* ctx, const void* id128, int rank, int world, eg_dp** out);
+int eg_dp_free(eg_dp* dp);
+int eg_dp_rank(const eg_dp* dp);
+int eg_dp_world(const eg_dp* dp);
+/* In-place SUM over the ranks of `count` floats at `device_buf`; asynchronous on the stream. */
+int eg_dp_allreduce_sum_f32(eg_dp* dp, float* device_buf, int64_t count);
+/* One training step on this rank's shard of the batch (inputs bound with eg_model_set_input_*):
+ * eg_model_run_backward | all-reduce of the gradient bucket | eg_model_run_update.  mean != 0 for
+ * losses that divide by the batch (mse, crossEntropy; base.nim:57-67): the seed gradient is scaled
+ * by 1 / world so the summed gradients are those of the full batch; 0 for sum-type losses. */
+int eg_model_step_dp(eg_model* model, const char* target, eg_dp* dp, int mean);
 
 #ifdef __cplusplus
 }

@@ -305,3 +305,43 @@ def test_data_parallel_step_over_rccl(gpu_ctx):
             b.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_data_parallel_step_through_the_c_abi(gpu_ctx):
+    """eg_dp_* + eg_model_step_dp (group 4 of the C ABI): the library itself calls RCCL on the
+    context's stream.  One rank here; the sum over one rank is the identity, so the step must equal
+    plain apply() bit for bit, and an all-reduce leaves a buffer unchanged."""
+    torch = pytest.importorskip("torch")
+    from exprgrad_amd.parallel import NativeDataParallel, RcclGroup
+    import exprgrad_amd as eg
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = eg.newGpuContext(0, stream=stream.cuda_stream)
+        uid = RcclGroup.unique_id()
+        assert len(uid) == 128 and any(uid)
+        group = RcclGroup(ctx, uid, rank=0, world=1)
+        probe = torch.arange(1000, device="cuda", dtype=torch.float32)
+        group.all_reduce(probe)
+        stream.synchronize()
+        assert torch.equal(probe.cpu(), torch.arange(1000, dtype=torch.float32))
+        a = egm.compile(*refcases.dense_softmax_net(n_in=96, n_hidden=128, n_out=10), gpu=ctx)
+        b = egm.compile(*refcases.dense_softmax_net(n_in=96, n_hidden=128, n_out=10), gpu=ctx)
+        rng = np.random.default_rng(8)
+        for tid in a.params.ids():
+            v = (rng.random(a.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+            a.params[tid] = v
+            b.params[tid] = v
+        x = torch.rand((512, 96), device="cuda")
+        y = torch.nn.functional.one_hot(torch.randint(0, 10, (512,), device="cuda"), 10).to(torch.float32).contiguous()
+        dp = NativeDataParallel(b, "train", group, reduction="mean")
+        for _ in range(6):     # eager, captured, then replays
+            a.apply("train", [("x", x), ("y", y)])
+            dp.step([("x", x), ("y", y)])
+        stream.synchronize()
+        for tid in a.params.ids():
+            assert np.array_equal(a.params[tid], b.params[tid]), tid
+        with pytest.raises(Exception):
+            RcclGroup(ctx, uid, rank=3, world=2)
+        a.close()
+        b.close()
+        group.close()
