@@ -306,7 +306,9 @@ def run_train(args, env):
                    "parallelism": f"dp{world}" if world > 1 else "single",
                    "collective": "none" if world == 1 else ("RCCL all-reduce from the C ABI (eg_model_step_dp)"
                                                             if env.get("native_dp") else
-                                                            "RCCL all-reduce through torch.distributed (nccl backend)"),
+                                                            ("gloo all-reduce (EG_BENCH_ONE_GPU test mode)"
+                                                             if os.environ.get("EG_BENCH_ONE_GPU") == "1" else
+                                                             "RCCL all-reduce through torch.distributed (nccl backend)")),
                    "grad_bucket_floats": model.grad_bucket("train")[1]},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
