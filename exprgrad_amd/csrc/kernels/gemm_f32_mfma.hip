@@ -446,15 +446,31 @@ extern "C" int eg_conv2_nhwc(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64
 
 namespace {
 
-// gOut [N,Ho,Wo,F] -> zero-bordered [N, Ho + 2(FH-1), Wo + 2(FW-1), F].  One thread per VEC floats
-// of one padded pixel; 32-bit index arithmetic (the host checks the sizes).
+// Operands of the image gradient in ONE launch:
+//  - blocks [0, pad_blocks): gOut [N,Ho,Wo,F] -> zero-bordered [N, Ho + 2(FH-1), Wo + 2(FW-1), F], one
+//    thread per VEC floats of one padded pixel; 32-bit index arithmetic (the host checks the sizes);
+//  - the remaining blocks: flt [F,FH,FW,C] -> [C,FH,FW,F] with both spatial axes reversed.
 template <int VEC>
-__global__ __launch_bounds__(256) void pad_gradient_kernel(const float* __restrict__ g, float* __restrict__ out,
-                                                           unsigned pixels, unsigned Hp, unsigned Wp, unsigned Ho,
-                                                           unsigned Wo, unsigned F, unsigned ph, unsigned pw) {
+__global__ __launch_bounds__(256) void grad_image_operands_kernel(const float* __restrict__ g, float* __restrict__ out,
+                                                                  unsigned pixels, unsigned Hp, unsigned Wp, unsigned Ho,
+                                                                  unsigned Wo, unsigned F, unsigned ph, unsigned pw,
+                                                                  unsigned pad_blocks, const float* __restrict__ flt,
+                                                                  float* __restrict__ flipped, unsigned FH, unsigned FW,
+                                                                  unsigned C) {
+  if (blockIdx.x >= pad_blocks) {
+    const unsigned total = F * FH * FW * C;
+    const unsigned stride = (gridDim.x - pad_blocks) * blockDim.x;
+    for (unsigned i = (blockIdx.x - pad_blocks) * blockDim.x + threadIdx.x; i < total; i += stride) {
+      const unsigned f = i % F, p = i / F;
+      const unsigned dx = p % FW, q = p / FW;
+      const unsigned dy = q % FH, c = q / FH;
+      flipped[i] = flt[((size_t)(f * FH + (FH - 1 - dy)) * FW + (FW - 1 - dx)) * C + c];
+    }
+    return;
+  }
   const unsigned per_pixel = F / VEC;
   const unsigned total = pixels * per_pixel;
-  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += pad_blocks * blockDim.x) {
     const unsigned p = i / per_pixel, f = (i - p * per_pixel) * VEC;
     const unsigned xp = p % Wp, q = p / Wp;
     const unsigned yp = q % Hp, n = q / Hp;
@@ -468,18 +484,6 @@ __global__ __launch_bounds__(256) void pad_gradient_kernel(const float* __restri
     } else {
       out[(size_t)p * F + f] = inside ? g[src] : 0.f;
     }
-  }
-}
-
-// flt [F,FH,FW,C] -> [C,FH,FW,F] with both spatial axes reversed
-__global__ __launch_bounds__(256) void flip_filter_kernel(const float* __restrict__ flt, float* __restrict__ out, long F,
-                                                          long FH, long FW, long C) {
-  const long total = F * FH * FW * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long f = i % F, p = i / F;
-    const long dx = p % FW, q = p / FW;
-    const long dy = q % FH, c = q / FH;
-    out[i] = flt[((f * FH + (FH - 1 - dy)) * FW + (FW - 1 - dx)) * C + c];
   }
 }
 
@@ -569,20 +573,21 @@ extern "C" int eg_conv2_nhwc_grad_image(eg_ctx* ctx, int64_t N, int64_t H, int64
   float* padded = static_cast<float*>(ctx->aux);
   float* flipped = padded + pad_floats;
   EG_REQUIRE(N * Hp * Wp * F < (1L << 32), EG_ERR_INVALID, "eg_conv2_nhwc_grad_image: padded gradient exceeds 2^32 elements");
+  EG_REQUIRE(flt_floats < (1UL << 32), EG_ERR_INVALID, "eg_conv2_nhwc_grad_image: filter bank exceeds 2^32 elements");
   const bool vec4 = F % 4 == 0 && aligned16(gout);
   const long work = N * Hp * Wp * (vec4 ? F / 4 : F);
   const long blocks = std::min<long>((work + 255) / 256, 16L * ctx->compute_units);
+  const long fblocks = std::min<long>(((long)flt_floats + 255) / 256, 2L * ctx->compute_units);
   if (vec4)
-    hipLaunchKernelGGL(pad_gradient_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, gout, padded,
-                       (unsigned)(N * Hp * Wp), (unsigned)Hp, (unsigned)Wp, (unsigned)Ho, (unsigned)Wo, (unsigned)F,
-                       (unsigned)(FH - 1), (unsigned)(FW - 1));
+    hipLaunchKernelGGL(grad_image_operands_kernel<4>, dim3((unsigned)(blocks + fblocks)), dim3(256), 0, ctx->stream, gout,
+                       padded, (unsigned)(N * Hp * Wp), (unsigned)Hp, (unsigned)Wp, (unsigned)Ho, (unsigned)Wo,
+                       (unsigned)F, (unsigned)(FH - 1), (unsigned)(FW - 1), (unsigned)blocks, flt, flipped, (unsigned)FH,
+                       (unsigned)FW, (unsigned)C);
   else
-    hipLaunchKernelGGL(pad_gradient_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, gout, padded,
-                       (unsigned)(N * Hp * Wp), (unsigned)Hp, (unsigned)Wp, (unsigned)Ho, (unsigned)Wo, (unsigned)F,
-                       (unsigned)(FH - 1), (unsigned)(FW - 1));
-  const long fblocks = std::min<long>(((long)flt_floats + 255) / 256, 8L * ctx->compute_units);
-  hipLaunchKernelGGL(flip_filter_kernel, dim3((unsigned)fblocks), dim3(256), 0, ctx->stream, flt, flipped, (long)F,
-                     (long)FH, (long)FW, (long)C);
+    hipLaunchKernelGGL(grad_image_operands_kernel<1>, dim3((unsigned)(blocks + fblocks)), dim3(256), 0, ctx->stream, gout,
+                       padded, (unsigned)(N * Hp * Wp), (unsigned)Hp, (unsigned)Wp, (unsigned)Ho, (unsigned)Wo,
+                       (unsigned)F, (unsigned)(FH - 1), (unsigned)(FW - 1), (unsigned)blocks, flt, flipped, (unsigned)FH,
+                       (unsigned)FW, (unsigned)C);
   EG_HIP_CHECK(hipGetLastError());
   return eg_conv2_nhwc(ctx, N, Hp, Wp, F, C, FH, FW, padded, flipped, gimg, accumulate);
 }
