@@ -53,6 +53,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch of the train/xor workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="matmul: skip the Model.call (H2D + product + D2H) figure; tools/profile.sh sets it so that "
+                         "rocprofv3's per-kernel average covers the device-resident launches only (the first "
+                         "Model.call launch touches fresh allocations and takes ~24 ms)")
     ap.add_argument("--native-dp", action="store_true",
                     help="N > 1: exchange the gradients with the C ABI's own RCCL group (eg_dp_*, eg_model_step_dp) "
                          "instead of torch.distributed's all_reduce")
@@ -192,7 +196,7 @@ def run_matmul(args, env):
     # what the reference's benchmark times (matmul_gpu.nim:35-46): model.call with host tensors — 128 MiB
     # host->device, the product, 64 MiB device->host per call.  Reported next to the kernel figure, never as `value`.
     end_to_end = None
-    if env["rank"] == 0 and n <= 8192:
+    if env["rank"] == 0 and n <= 8192 and not args.no_end_to_end:
         from exprgrad_amd import examples as refcases
         from exprgrad_amd import model as egm
         import numpy as np
