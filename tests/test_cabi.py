@@ -16,10 +16,11 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(eg_[a-z0-9_]+)\s*\(", text)))
 
 
-def test_header_declares_three_groups():
+def test_header_declares_the_four_groups():
     syms = header_symbols()
     for must in ("eg_ctx_create", "eg_buf_write", "eg_kernel_compile", "eg_kernel_launch", "eg_sgemm",
-                 "eg_conv2_nhwc", "eg_model_compile", "eg_model_run"):
+                 "eg_conv2_nhwc", "eg_model_compile", "eg_model_run", "eg_model_fit", "eg_dp_init",
+                 "eg_dp_allreduce_sum_f32", "eg_model_step_dp"):
         assert must in syms
 
 
@@ -66,3 +67,26 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"\boracle\b|refcpu|librefcpu", text):
                     offenders.append(os.path.join(dirpath, f))
     assert not offenders, offenders
+
+
+def test_null_handles_are_errors_with_a_message():
+    """Argument validation needs no device: status != 0 and eg_last_error() says why (never a crash)."""
+    import ctypes
+    from exprgrad_amd import _lib
+    lib = _lib.lib()
+    null = ctypes.c_void_p()
+    out = ctypes.c_void_p()
+    cases = [
+        lambda: lib.eg_model_run(null, b"t"),
+        lambda: lib.eg_model_fit(null, b"t", 0, None, None, None, None, None, 4),
+        lambda: lib.eg_dp_init(null, null, 0, 1, ctypes.byref(out)),
+        lambda: lib.eg_dp_allreduce_sum_f32(null, null, 4),
+        lambda: lib.eg_model_step_dp(null, b"t", null, 1),
+        lambda: lib.eg_dp_unique_id(null),
+        lambda: lib.eg_sgemm(null, 0, 0, 1, 1, 1, null, 1, null, 1, null, 1, 0, null),
+    ]
+    for i, case in enumerate(cases):
+        assert case() != 0, i
+        assert _lib.last_error(), i
+    assert lib.eg_dp_free(null) == 0 and lib.eg_model_free(null) == 0      # freeing nothing is fine
+    assert lib.eg_dp_world(null) == 0 and lib.eg_dp_rank(null) == -1
