@@ -173,6 +173,11 @@ struct Lowered {
   int bias_tensor = 0;  // fused bias (0 = none)
   bool absorbed = false;  // this kernel was folded into the previous step
   bool inlined = false;   // an elementwise producer recomputed inside its consumers: never launched, never stored
+  // Consumer inlining (inline_consumers): this kernel with the elementwise kernel at live position
+  // `consumer` applied to every value before it is stored; used by a plan when the shapes allow it.
+  int consumer = -1;
+  std::unique_ptr<Kernel> with_consumer;
+  Generic with_consumer_code;
   ConvMatch conv;
   Generic mode_a;
   std::map<int, Generic> mode_b;  // by tx
@@ -199,6 +204,7 @@ struct Launch {
   std::vector<int> epoch_slots;             // params refreshed from Model.epoch at every launch
   int row_group = -1;                       // RowFused: index into Plan::row_groups
   int epilogue = -1;                        // GemmFused: index into Plan::epilogues
+  int consumer = -1;                        // GenericA: live position of the elementwise consumer folded into it
 };
 
 // A run of per-sample kernels fused into one generated kernel (rowfuse.hpp), built per plan.
@@ -430,6 +436,108 @@ void inline_producers(eg_model* m, TargetState& ts) {
   }
 }
 
+// Consumer inlining, the mirror image of inline_producers.  A generated kernel P without a reduction
+// (every iteration writes its own element: maxpool2's hand-written gradient, upsample2, a binary
+// map) followed directly by an elementwise kernel `U{it} ++= g(T{it}, V{it}...)` that is the only
+// reader of P's result T: P stores g(value, V...) into U right away and T never exists.  The
+// combined kernel is generated here; a plan uses it only when P covers T completely and T, U and
+// the V have one shape (make_plan), otherwise both kernels run as they are.
+void inline_consumers(eg_model* m, TargetState& ts) {
+  static const bool off = [] {
+    const char* e = getenv("EG_NO_INLINE");
+    return e && e[0] && e[0] != '0';
+  }();
+  if (off) return;
+  Target& t = *ts.target;
+  const Program& prog = m->prog;
+  const int n = (int)t.live.size();
+  for (int p = 0; p < n; ++p) {
+    Lowered& lo = ts.lowered[p];
+    if (lo.absorbed || lo.kind != StepKind::GenericA) continue;
+    int q = p + 1;
+    while (q < n && ts.lowered[q].absorbed) ++q;
+    if (q >= n || ts.lowered[q].kind != StepKind::GenericA || q == t.first_update) continue;
+    if (t.first_update >= 0 && (p < t.first_update) != (q < t.first_update)) continue;
+    const Kernel& P = t.all[t.live[p]];
+    const Kernel& C = t.all[t.live[q]];
+    // ---- P: one element per iteration
+    std::vector<int> indep, red;
+    bool scatter = false;
+    split_loops(P, indep, red, scatter);
+    if (!red.empty() || scatter || P.is_seed || P.gen != Gen::None) continue;
+    const int T = P.write.tensor, U = C.write.tensor;
+    if (prog.tensors[T].kind != TK::Result || T == t.output || ts.bucket_offset.count(T) || T == U) continue;
+    // ---- C: a map over whole tensors that reads T
+    if (C.loops.size() != 1 || !C.index_instrs.empty() || !C.setup.empty() || C.is_seed || C.gen != Gen::None) continue;
+    if (C.loops[0].has_bounds || C.instrs.size() + P.instrs.size() > 96) continue;
+    const int it = C.loops[0].reg;
+    bool ok = C.write.raw && C.write.dims.size() == 1 && C.write.dims[0].only_register() == it && C.result != it;
+    bool reads_t = false;
+    for (auto& rd : C.reads) {
+      if (!rd.raw || rd.dims.size() != 1 || rd.dims[0].only_register() != it || rd.tensor == U) ok = false;
+      reads_t = reads_t || rd.tensor == T;
+    }
+    for (auto& ins : C.instrs) {
+      if (ins.kind == IK::Shape || ins.kind == IK::Len || ins.kind == IK::ShapeLen || ins.kind == IK::Epoch) ok = false;
+      for (int a : ins.args)
+        if (a == it) ok = false;
+    }
+    for (auto& rd : P.reads)
+      if (rd.tensor == U) ok = false;
+    if (!ok || !reads_t) continue;
+    // ---- nobody else writes or reads T
+    for (int s2 = 0; s2 < n && ok; ++s2) {
+      if (s2 == p || s2 == q) continue;
+      const Kernel& K = t.all[t.live[s2]];
+      if (K.write.tensor == T) ok = false;
+      for (auto& rd : K.reads)
+        if (rd.tensor == T) ok = false;
+    }
+    if (!ok) continue;
+    // ---- P + C
+    std::unique_ptr<Kernel> F(new Kernel(P));
+    std::map<int, int> rename;
+    Instr zero, value;  // what C would have loaded: 0 + P's value, as P stored it
+    zero.kind = IK::Scalar;
+    zero.lit = 0.0;
+    zero.res = F->alloc();
+    value.kind = IK::Add;
+    value.args = {zero.res, P.result};
+    value.res = F->alloc();
+    F->instrs.push_back(zero);
+    F->instrs.push_back(value);
+    for (auto& rd : C.reads) {
+      if (rd.tensor == T) {
+        rename[rd.reg] = value.res;
+        continue;
+      }
+      Op op = P.write;  // same element as the one P writes
+      op.tensor = rd.tensor;
+      op.reg = F->alloc();
+      rename[rd.reg] = op.reg;
+      F->reads.push_back(op);
+    }
+    for (auto& ins : C.instrs) {
+      Instr c = ins;
+      c.res = F->alloc();
+      rename[ins.res] = c.res;
+      for (int& a : c.args) a = rename.count(a) ? rename[a] : a;
+      F->instrs.push_back(c);
+    }
+    F->result = rename.count(C.result) ? rename[C.result] : C.result;
+    F->write.tensor = U;
+    char name[64];
+    snprintf(name, sizeof(name), "eg_k%d_ac", m->kernel_serial++);
+    if (generate_mode_a(*F, name, lo.with_consumer_code.src) != EG_OK) {
+      eg::clear_error();
+      continue;
+    }
+    lo.consumer = q;
+    lo.with_consumer = std::move(F);
+    m->pending.push_back(&lo.with_consumer_code);
+  }
+}
+
 int lower_target(eg_model* m, TargetState& ts) {
   Target& t = *ts.target;
   ts.lowered.clear();
@@ -473,6 +581,7 @@ int lower_target(eg_model* m, TargetState& ts) {
     if (rc) return rc;
     m->pending.push_back(&lo.mode_a);  // built together with the model's other generated kernels
   }
+  inline_consumers(m, ts);
   return EG_OK;
 }
 
@@ -1143,8 +1252,10 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   std::set<int> needs_zero;
   plan.launches.clear();
   plan.n_backward = -1;
+  std::set<int> folded;  // consumers that run inside the kernel before them
   for (size_t p = 0; p < t.live.size(); ++p) {
     if ((int)p == t.first_update) plan.n_backward = (int)plan.launches.size();
+    if (folded.count((int)p)) continue;
     if (group_of[p] <= -2) {
       const int wt = t.all[t.live[p]].write.tensor;  // small groups always accumulate
       if (m->prog.tensors[wt].kind == TK::Result && first_writer[wt] == (int)p) needs_zero.insert(wt);
@@ -1179,6 +1290,44 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
     if (lo.kind == StepKind::GenericA && first && copy_can_alias(m, ts, k, info, shapes, (int)p)) {
       plan.alias[wt] = k.reads[0].tensor;
       continue;
+    }
+    if (lo.consumer >= 0 && group_of[lo.consumer] == -1 && first && info.ok && full_cover(k, info, wshape)) {
+      // consumer inlining: P covers T, and T, U and the consumer's other operands have one shape
+      const int q = lo.consumer;
+      const Kernel& C = t.all[t.live[q]];
+      const KernelInfo& cinfo = infos[t.live[q]];
+      const Kernel& F = *lo.with_consumer;
+      const int U = C.write.tensor;
+      const long count = prod(wshape);
+      bool same = cinfo.ok && cinfo.bounds[0].first == 0 && cinfo.bounds[0].second == count;
+      auto matches = [&](int tensor) {
+        auto sh = shapes.find(tensor);
+        if (sh == shapes.end()) return false;
+        return k.write.raw ? prod(sh->second) == count : sh->second == wshape;
+      };
+      same = same && matches(U);
+      for (auto& rd : C.reads) same = same && matches(rd.tensor);
+      if (same) {
+        const bool u_result = m->prog.tensors[U].kind == TK::Result;
+        const bool u_first = u_result && first_writer[U] == q;
+        Launch L;
+        L.lowered = (int)p;
+        L.kind = StepKind::GenericA;
+        L.generic = &lo.with_consumer_code;
+        L.consumer = q;
+        L.blocks_x = (count + 255) / 256;
+        int rc = fill_params(m, F, info, shapes, lo.with_consumer_code.src, !u_first, count, 1, 0, L.params);
+        if (rc) return rc;
+        for (size_t si = 0; si < L.generic->src.slots.size(); ++si) {
+          const Slot& sl = L.generic->src.slots[si];
+          if (sl.kind == Slot::InstrVal && F.instrs[sl.a].kind == IK::Epoch) L.epoch_slots.push_back((int)si);
+        }
+        L.c_tensor = U;
+        L.accumulate = !u_first;
+        plan.launches.push_back(L);
+        folded.insert(q);
+        continue;
+      }
     }
     Launch L;
     L.lowered = (int)p;
@@ -1779,7 +1928,10 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
       case StepKind::Conv: os << "conv2 -> t" << L.c_tensor << (L.accumulate ? " accumulate" : ""); break;
       case StepKind::ConvGradImage: os << "conv2-grad-image -> t" << L.c_tensor << (L.accumulate ? " accumulate" : ""); break;
       case StepKind::ConvGradFilter: os << "conv2-grad-filter -> t" << L.c_tensor << (L.accumulate ? " accumulate" : ""); break;
-      case StepKind::GenericA: os << "generated(map) kernel " << L.lowered << " -> t" << L.c_tensor; break;
+      case StepKind::GenericA:
+        os << "generated(map) kernel " << L.lowered << " -> t" << L.c_tensor;
+        if (L.consumer >= 0) os << " (with its consumer, kernel " << L.consumer << ")";
+        break;
       case StepKind::GenericB: os << "generated(split-reduce) kernel " << L.lowered << " -> t" << L.c_tensor; break;
       case StepKind::RowFused: {
         const PlanRowGroup& pg = *plan.row_groups[L.row_group];

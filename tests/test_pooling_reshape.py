@@ -118,6 +118,30 @@ def test_gpu_activation_is_inlined_into_the_pooling_kernels(gpu_ctx, kind):
 
 
 @pytest.mark.gpu
+def test_gpu_activation_gradient_is_applied_inside_the_pooling_gradient(gpu_ctx):
+    """Backward pass of leakyRelu -> maxpool2 (the reference's fashion_mnist network): maxpool2's
+    hand-written gradient kernel applies the activation's gradient to every value before storing it
+    (consumer inlining), so the pooled gradient is never stored."""
+    from exprgrad_amd import model as egm
+
+    def graphs():
+        img = dsl.input("img")
+        pool = layers.maxpool2(layers.leaky_relu(img))
+        it = dsl.iters("it")
+        loss = dsl.Fun()
+        loss[0] += pool.raw[it] * pool.raw[it]
+        return [loss.target("loss").backwards().grad(img).target("grad")]
+
+    a = (np.random.default_rng(6).random((4, 64, 64, 16), dtype=np.float32) - 0.5).astype(np.float32)
+    ref = oracle(graphs(), threads=8)
+    gpu = egm.compile(*graphs(), gpu=gpu_ctx)
+    assert rel_err(gpu.call("grad", {"img": a}), ref.call("grad", {"img": a})) <= TOL
+    assert "with its consumer" in gpu.launch_plan("grad"), gpu.launch_plan("grad")
+    assert gpu.kernel_count("grad") == ref.kernel_count("grad")
+    gpu.close()
+
+
+@pytest.mark.gpu
 def test_gpu_reshape_and_custom_grad(gpu_ctx):
     from exprgrad_amd import model as egm
     b = np.arange(24, dtype=np.float32)
