@@ -1727,6 +1727,9 @@ int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool
     return EG_OK;
   }
   if (cap.exec) {
+    // the old sequence may still be running (launches are asynchronous): let it finish before its
+    // executable graph goes away
+    EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
     hipGraphExecDestroy(cap.exec);
     cap.exec = nullptr;
   }
