@@ -733,13 +733,26 @@ static long prod(const std::vector<long>& s) {
 }
 
 // Host evaluation of shape()/len()/index arithmetic (kernel setup, shape-constraint setup).
-static int eval_host_instrs(const std::vector<Instr>& instrs, const Shapes& shapes, long epoch, std::map<int, long>& vals) {
+// later_tensor / later: instructions that need the shape of `later_tensor` while it is unknown, and
+// everything computed from them, are skipped and their registers collected in `later` (a kernel
+// whose loop bounds name the shape of the tensor it writes, see infer_kernel).
+static int eval_host_instrs(const std::vector<Instr>& instrs, const Shapes& shapes, long epoch, std::map<int, long>& vals,
+                            int later_tensor = 0, std::set<int>* later = nullptr) {
   for (auto& s : instrs) {
     long v = 0;
     auto arg = [&](size_t i) -> long {
       auto it = i < s.args.size() ? vals.find(s.args[i]) : vals.end();
       return it == vals.end() ? 0 : it->second;
     };
+    if (later) {
+      bool skip = (s.kind == IK::Shape || s.kind == IK::Len || s.kind == IK::ShapeLen) && s.tensor == later_tensor &&
+                  !shapes.count(s.tensor);
+      for (int a : s.args) skip = skip || later->count(a);
+      if (skip) {
+        later->insert(s.res);
+        continue;
+      }
+    }
     switch (s.kind) {
       case IK::Shape: {
         auto it = shapes.find(s.tensor);
@@ -809,8 +822,12 @@ static bool user_shape(const Program& prog, int tid, const Shapes& shapes, long 
 int infer_kernel(const Program& prog, const Kernel& k, Shapes& shapes, long epoch, KernelInfo& out) {
   out = KernelInfo();
   std::map<int, long>& vals = out.vals;
+  // Explicit loop bounds may name the shape of the very tensor the kernel writes
+  // (`res[x] ++= ... | (x in 0..<res.shape[0])`, tests/test_model.nim:99-107): the reference's
+  // constraint solver gets that shape from the reads; the bounds are applied once it is known.
+  std::set<int> later;
   {
-    int rc = eval_host_instrs(k.setup, shapes, epoch, vals);
+    int rc = eval_host_instrs(k.setup, shapes, epoch, vals, k.write.tensor, &later);
     if (rc) return rc;
   }
   std::set<int> idx_regs;  // computed indices never bound a loop
@@ -822,9 +839,19 @@ int infer_kernel(const Program& prog, const Kernel& k, Shapes& shapes, long epoc
   };
   std::map<int, std::pair<long, long>> bounds;
   std::set<int> loop_regs;
+  auto known = [&](const Lin& l) {
+    for (auto& f : l.factors)
+      if (later.count(f.first)) return false;
+    return true;
+  };
+  std::set<int> postponed;  // loops whose explicit bounds wait for the written tensor's shape
   for (auto& lp : k.loops) {
     loop_regs.insert(lp.reg);
-    if (lp.has_bounds) bounds[lp.reg] = {lin_const(lp.start), lin_const(lp.stop)};
+    if (!lp.has_bounds) continue;
+    if (known(lp.start) && known(lp.stop))
+      bounds[lp.reg] = {lin_const(lp.start), lin_const(lp.stop)};
+    else
+      postponed.insert(lp.reg);
   }
   // user constraints (withShape / copyShape, parser.nim:683-697) fix the written tensor's shape
   // before its loops are bounded: PriorityUser outranks the inferred constraints
@@ -851,7 +878,8 @@ int infer_kernel(const Program& prog, const Kernel& k, Shapes& shapes, long epoc
     }
     for (size_t d = 0; d < op->dims.size(); ++d) {
       const int r = op->dims[d].only_register();
-      if (r && loop_regs.count(r) && !bounds.count(r)) bounds[r] = {0, op->raw ? prod(shp) : shp[d]};
+      // (loops with explicit bounds never take part: inferLoopBounds skips them, passes.nim:1030-1038)
+      if (r && loop_regs.count(r) && !bounds.count(r) && !postponed.count(r)) bounds[r] = {0, op->raw ? prod(shp) : shp[d]};
     }
   }
   // iterators that never appear bare (y in img[n, y+dy, ...]): max(index) = extent - 1
@@ -875,7 +903,16 @@ int infer_kernel(const Program& prog, const Kernel& k, Shapes& shapes, long epoc
             ++n_unknown;
           }
         if (n_unknown != 1 || lin.factor_of(unknown) <= 0 || !loop_regs.count(unknown)) continue;
+        // several reads of one tensor that differ only in the constant (image[x], image[x + 1],
+        // image[x + 2]): the largest offset decides (simplifyMaxIndex, passes.nim:1040-1057)
         long rest = lin.constant;
+        if (op != &k.write)
+          for (auto& other : k.reads)
+            if (other.tensor == op->tensor && !other.raw && other.dims.size() == op->dims.size()) {
+              Lin a = other.dims[d], b = lin;
+              a.constant = b.constant = 0;
+              if (a == b && other.dims[d].constant > rest) rest = other.dims[d].constant;
+            }
         for (auto& f : lin.factors) {
           if (f.first == unknown) continue;
           if (vals.count(f.first))
@@ -940,6 +977,12 @@ int infer_kernel(const Program& prog, const Kernel& k, Shapes& shapes, long epoc
   } else if (!k.write.raw && k.write.dims.size() != shapes[wt].size()) {
     set_error("tensor %d has rank %zu but is written with %zu dimensions", wt, shapes[wt].size(), k.write.dims.size());
     return EG_ERR_SHAPE;
+  }
+  if (!later.empty()) {  // the written tensor has its shape now: the postponed bounds
+    int rc = eval_host_instrs(k.setup, shapes, epoch, vals);
+    if (rc) return rc;
+    for (auto& lp : k.loops)
+      if (lp.has_bounds) bounds[lp.reg] = {lin_const(lp.start), lin_const(lp.stop)};
   }
   out.bounds.clear();
   for (auto& lp : k.loops) out.bounds.push_back(bounds[lp.reg]);

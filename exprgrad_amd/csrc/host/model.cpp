@@ -1198,8 +1198,8 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
         missing = r.tensor;
       }
     if (ready)
-      for (auto& s : k.setup)
-        if (s.tensor && !shapes.count(s.tensor)) {
+      for (auto& s : k.setup)  // (bounds that name the written tensor's own shape are resolved by infer_kernel)
+        if (s.tensor && s.tensor != k.write.tensor && !shapes.count(s.tensor)) {
           ready = false;
           missing = s.tensor;
         }

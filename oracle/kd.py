@@ -541,9 +541,18 @@ def _user_shape(prog, tid, shapes, epoch, kernel_vals):
         return None
 
 
-def _eval_host_instrs(instrs, shapes, epoch):
+def _eval_host_instrs(instrs, shapes, epoch, later_tensor=None, later=None):
+    """later_tensor / later: instructions that need the shape of `later_tensor` while it is unknown,
+    and everything computed from them, are skipped; their registers are collected in `later`."""
     vals = {}
     for s in instrs:
+        if later is not None:
+            needs = (s.kind in ("shape", "len", "shapelen") and
+                     (s.extra[0] if isinstance(s.extra, (tuple, list)) else s.extra) == later_tensor and
+                     shapes.get(later_tensor) is None)
+            if needs or any(r in later for r in s.args):
+                later.add(s.res)
+                continue
         if s.kind in ("add", "sub", "mul", "indexdiv", "mod", "negate"):
             a = [vals[r] for r in s.args]
             if s.kind == "add":
@@ -584,10 +593,19 @@ def _lin_const(lin, vals):
 def infer_kernel(prog, k, shapes, epoch=0):
     """Loop bounds (inferLoopBounds, passes.nim:986-1010) and the write tensor's shape
     (inferShapeConstraints, passes.nim:1059-1095 + the linear solve of 1420-1436)."""
-    vals = _eval_setup(k, shapes, epoch)
+    # explicit loop bounds may name the shape of the very tensor the kernel writes
+    # (`res[x] ++= ... | (x in 0..<res.shape[0])`, tests/test_model.nim:99-107): the reference's
+    # constraint solver gets that shape from the reads; such bounds are applied once it is known
+    later = set()
+    vals = _eval_host_instrs(k.setup, shapes, epoch, k.write.tensor, later)
     bounds = {}
+    postponed = set()
     for lp in k.loops:
-        if lp.bounds:
+        if not lp.bounds:
+            continue
+        if any(r in later for b in lp.bounds for r in b.factors):
+            postponed.add(lp.reg)
+        else:
             bounds[lp.reg] = (_lin_const(lp.bounds[0], vals), _lin_const(lp.bounds[1], vals))
     # user constraints (withShape / copyShape, parser.nim:683-697) fix the written tensor's shape
     # before its loops are bounded (PriorityUser outranks inferred constraints)
@@ -608,7 +626,8 @@ def infer_kernel(prog, k, shapes, epoch=0):
             raise ShapeError(f"tensor {op.tensor} has rank {len(shp)} but is indexed with {len(op.dims)} dims")
         for d, lin in enumerate(op.dims):
             r = lin.only_register()
-            if r and r not in bounds and any(lp.reg == r for lp in k.loops):
+            # (loops with explicit bounds never take part: inferLoopBounds skips them, passes.nim:1030-1038)
+            if r and r not in bounds and r not in postponed and any(lp.reg == r for lp in k.loops):
                 bounds[r] = (0, int(np.prod(shp, dtype=np.int64)) if op.raw else shp[d])
     # iterators that never appear bare: solve  sum f*(max iter) + c = dim - 1  (valid convolution)
     progress = True
@@ -624,6 +643,13 @@ def infer_kernel(prog, k, shapes, epoch=0):
                 unknown = [r for r in lin.factors if r not in bounds and r not in vals]
                 if len(unknown) == 1 and lin.factors[unknown[0]] > 0:
                     rest = lin.constant
+                    if op is not k.write:
+                        # reads of one tensor that differ only in the constant (image[x], image[x + 1],
+                        # image[x + 2]): the largest offset decides (simplifyMaxIndex, passes.nim:1040-1057)
+                        for other in k.reads:
+                            if (other.tensor == op.tensor and not other.raw and len(other.dims) == len(op.dims)
+                                    and other.dims[d].factors == lin.factors):
+                                rest = max(rest, other.dims[d].constant)
                     for r, f in lin.factors.items():
                         if r == unknown[0]:
                             continue
@@ -665,6 +691,11 @@ def infer_kernel(prog, k, shapes, epoch=0):
                         hi += f * ((bounds[r][1] - 1) if f > 0 else bounds[r][0])
                 shp.append(hi + 1)
             shapes[wt] = shp
+    if later:
+        vals = _eval_setup(k, shapes, epoch)
+        for lp in k.loops:
+            if lp.bounds:
+                bounds[lp.reg] = (_lin_const(lp.bounds[0], vals), _lin_const(lp.bounds[1], vals))
     return bounds, vals
 
 

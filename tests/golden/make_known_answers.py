@@ -130,6 +130,19 @@ case("customGrad", "tests/test_model.nim:196-214",
      [call("identity", {"inp": T([1, 2, 3, 4], [2, 2])}, T([1, 2, 3, 4], [2, 2])),
       call("grad", {"inp": T([1, 2, 3, 4], [2, 2])}, T([2, 4, 6, 8], [2, 2]))])
 
+img7 = [1, 2, 3, 2, 1, 0, -1]
+blurred = [2, f32(7 / 3), 2, 1, 0]
+case("blur", "tests/test_model.nim:99-107", [call("res", {"image": T(img7)}, T(blurred))])
+case("blurCenter", "tests/test_model.nim:109-117", [call("res", {"image": T(img7)}, T(blurred))])
+case("blurOffset", "tests/test_model.nim:119-128", [call("res", {"image": T(img7)}, T([0] + blurred + [0]))])
+x23 = np.array([1, 2, 3, 4, 5, 6], dtype=f32)
+for factor in range(-2, 3):
+    case(f"extern/{factor}", "tests/test_model.nim:156-167",
+         [call("y", {"x": T(x23, [2, 3])}, T(x23 * f32(factor), [2, 3]))])
+x32 = np.array([1, 2, 3, 4, 5, 6], dtype=f32)
+case("dynamicAst/0", "tests/test_model.nim:215-231", [call("y", {"x": T(x32, [3, 2])}, T(np.ones(6), [3, 2]), "sumsq", 0.001)])
+case("dynamicAst/1", "tests/test_model.nim:215-231", [call("y", {"x": T(x32, [3, 2])}, T(x32, [3, 2]), "sumsq", 0.001)])
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "known_answers.json")
 with open(out, "w") as f:
     json.dump(cases, f, indent=1)

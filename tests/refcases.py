@@ -122,6 +122,56 @@ def loop_bounds():
     return [res.target("res")]
 
 
+def blur():
+    # tests/test_model.nim:99-107: the loop bound names the shape of the tensor being written
+    res, image = Fun(), dsl.input("image")
+    x = dsl.iter_in("x", 0, res.shape[0])
+    res[x] += (image[x] + image[x + 1] + image[x + 2]) / 3.0
+    return [res.target("res")]
+
+
+def blur_center():
+    # tests/test_model.nim:109-117
+    res, image = Fun(), dsl.input("image")
+    x = dsl.iter_in("x", 1, image.shape[0] - 1)
+    res[x - 1] += (image[x - 1] + image[x] + image[x + 1]) / 3.0
+    return [res.target("res")]
+
+
+def blur_offset():
+    # tests/test_model.nim:119-128
+    res, image = Fun(), dsl.input("image")
+    x = dsl.iter_in("x", 0, image.shape[0] - 2)
+    res[x + 1] += (image[x] + image[x + 1] + image[x + 2]) / 3.0
+    res.with_shape(image.shape[0])
+    return [res.target("res")]
+
+
+def extern(factor):
+    # tests/test_model.nim:156-167: a host value captured by the kernel
+    def build():
+        it = iters("it")
+        res = Fun()
+        res.raw[it] += dsl.input("x").raw[it] * float(factor)
+        return [res.target("y")]
+    return build
+
+
+def dynamic_ast(n):
+    # tests/test_model.nim:215-231: the expression is assembled by host code (x^n as n multiplications)
+    def build():
+        it = iters("it")
+        x = dsl.input("x")
+        prod = dsl.literal(1.0)
+        for _ in range(n):
+            prod = prod * x.raw[it]
+        res = Fun()
+        res.raw[it] += prod
+        res.copy_shape(x)
+        return [res.target("y")]
+    return build
+
+
 def derive_polynomial():
     it = iters("it")
     x = dsl.input("x")
@@ -243,6 +293,9 @@ BUILDERS = {
     "increment": increment, "sumPositive": sum_positive, "multiple": linear,
     "multiplyAndSquare": multiply_and_square, "leakyReluGpu": leaky_relu_gpu, "matmulTalks": matmul,
     "matmulExample": matmul, "customGrad": custom_grad,
+    "blur": blur, "blurCenter": blur_center, "blurOffset": blur_offset,
+    **{f"extern/{f}": extern(f) for f in range(-2, 3)},
+    "dynamicAst/0": dynamic_ast(0), "dynamicAst/1": dynamic_ast(1),
 }
 
 
