@@ -176,6 +176,56 @@ def sq(x):
     return x * x  # dsl.nim:135-136: the SAME builder twice -> one register used twice
 
 
+class ArrayLiteral:
+    """`literal([1.0, 2.0, 3.0])` / nested arrays (parser.nim:104-121 with array nodes; the reference
+    keeps InstrArray / InstrArrayRead / InstrArrayLen in its IR, ir.nim:60-62).  The kernel-description
+    text has no array instructions: `arr[i]` is lowered here to the select chain
+    select(i == 0, a0, select(i == 1, a1, ...)) over the same literals, `arr.len` to an index literal —
+    identical values for every in-range index."""
+
+    def __init__(self, values):
+        self.values = [ArrayLiteral(v) if isinstance(v, (list, tuple)) else v for v in values]
+        if not self.values:
+            raise ParserError("an array literal needs at least one element")
+
+    def len(self):  # noqa: A003
+        return literal(len(self.values))
+
+    def __len__(self):
+        return len(self.values)
+
+    def __getitem__(self, index):
+        index = literal(index)
+        if index.typ != INDEX:
+            raise ParserError("array literals are indexed with Index expressions")
+        picked = self.values
+        if isinstance(picked[0], ArrayLiteral):   # arr[y] of a nested array: a view that waits for the next index
+            return _ArrayRow(self, index)
+        out = literal(float(picked[-1]))
+        for i in range(len(picked) - 2, -1, -1):
+            out = select(index.eq(i), literal(float(picked[i])), out)
+        return out
+
+
+class _ArrayRow:
+    def __init__(self, array, row_index):
+        self.array, self.row_index = array, row_index
+
+    def __getitem__(self, index):
+        rows = [row[index] for row in self.array.values]
+        out = rows[-1]
+        for i in range(len(rows) - 2, -1, -1):
+            out = select(self.row_index.eq(i), rows[i], out)
+        return out
+
+    def len(self):  # noqa: A003
+        return literal(len(self.array.values[0]))
+
+
+def array(values):
+    return ArrayLiteral(values)
+
+
 def max(x, y):  # noqa: A001 - dsl.nim:138-139
     x, y = _scalar(x), _scalar(y)
     return select(x > y, x, y)

@@ -143,6 +143,9 @@ x32 = np.array([1, 2, 3, 4, 5, 6], dtype=f32)
 case("dynamicAst/0", "tests/test_model.nim:215-231", [call("y", {"x": T(x32, [3, 2])}, T(np.ones(6), [3, 2]), "sumsq", 0.001)])
 case("dynamicAst/1", "tests/test_model.nim:215-231", [call("y", {"x": T(x32, [3, 2])}, T(x32, [3, 2]), "sumsq", 0.001)])
 
+case("array", "tests/test_model.nim:233-241", [call("y", {}, T([4, 5, 6]))])
+case("nestedArray", "tests/test_model.nim:243-255", [call("y", {}, T([1, 2, 3, 4, 5, 6, 7, 8, 9], [3, 3]))])
+
 out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "known_answers.json")
 with open(out, "w") as f:
     json.dump(cases, f, indent=1)

@@ -172,6 +172,26 @@ def dynamic_ast(n):
     return build
 
 
+def array_case():
+    # tests/test_model.nim:233-241
+    x = iters("x")
+    arr = dsl.array([1.0, 2.0, 3.0])
+    res = Fun()
+    res[x] += arr[x] + dsl.to_scalar(arr.len())
+    res.with_shape(3)
+    return [res.target("y")]
+
+
+def nested_array():
+    # tests/test_model.nim:243-255
+    y, x = iters("y x")
+    arr = dsl.array([[1.0, 2.0, 3.0], [4.0, 5.0, 6.0], [7.0, 8.0, 9.0]])
+    res = Fun()
+    res[y, x] += arr[y][x]
+    res.with_shape(3, 3)
+    return [res.target("y")]
+
+
 def derive_polynomial():
     it = iters("it")
     x = dsl.input("x")
@@ -296,6 +316,7 @@ BUILDERS = {
     "blur": blur, "blurCenter": blur_center, "blurOffset": blur_offset,
     **{f"extern/{f}": extern(f) for f in range(-2, 3)},
     "dynamicAst/0": dynamic_ast(0), "dynamicAst/1": dynamic_ast(1),
+    "array": array_case, "nestedArray": nested_array,
 }
 
 
