@@ -19,7 +19,7 @@
 
 #define EXPORT __attribute__((visibility("default")))
 #define MAX_LOOPS 12
-#define MAX_REGS 256
+#define MAX_REGS 4096
 
 typedef union {
   float f;
