@@ -29,7 +29,7 @@ struct TileCfg {
 
 template <int BM, int BN, int WM, int WN, int MINB>
 int launch_config(eg_ctx* ctx, bool a_kc, bool b_kc, const GemmArgs& args, int splits, bool vec, bool edge,
-                  int conv) {
+                  int conv, bool a_vec_only = false) {
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
   const long rows_m = args.edge_splits > 0 ? args.tiles_m - 1 : args.tiles_m;
   dim3 grid((unsigned)(rows_m * args.tiles_n * splits + (long)args.tiles_n * args.edge_splits), 1, 1);
@@ -45,7 +45,9 @@ int launch_config(eg_ctx* ctx, bool a_kc, bool b_kc, const GemmArgs& args, int s
       EG_GEMM_LAUNCH(AKC, BKC, 4, false, 0);  \
     else if (vec)                                 \
       EG_GEMM_LAUNCH(AKC, BKC, 4, true, 0);   \
-    else                                          \
+    else if (BN == 32 && a_vec_only) {            \
+      if constexpr (BN == 32) EG_GEMM_LAUNCH(AKC, BKC, 41, true, 0); \
+    } else                                        \
       EG_GEMM_LAUNCH(AKC, BKC, 1, true, 0);   \
   } while (0)
   if (conv == 2) {  // filter gradient: A = gOut [pixels][F], B = im2col gathered from the image
@@ -215,7 +217,7 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
 }
 
 // Shared host-side planning: tile shape, split-K, vector/edge variant, launch, second pass.
-int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool vec_ok) {
+int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool vec_ok, bool a_vec_only = false) {
   const long M = args.M, N = args.N, K = args.K;
   const long k_tiles = (K + BK - 1) / BK;
   int BM, BN, splits;
@@ -277,7 +279,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
 
   int rc;
   if (BN == 32)
-    rc = launch_config<128, 32, 32, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
+    rc = launch_config<128, 32, 32, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv, a_vec_only && !vec);
   else if (BN == 64 && BM == 256)
     rc = launch_config<256, 64, 64, 32, 2>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else if (BN == 64 && BM == 64)
@@ -380,9 +382,10 @@ extern "C" int eg_sgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_
   args.accumulate = accumulate;
   // 16-byte global loads need every row start and every chunk 16-byte aligned and whole.
   const long a_contig = a_kc ? K : M, b_contig = b_kc ? K : N;
-  const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (a_contig % 4 == 0) && (b_contig % 4 == 0) &&
-                   (A == nullptr || aligned16(A)) && (B == nullptr || aligned16(B));
-  return run_gemm(ctx, a_kc, b_kc, args, /*conv=*/0, vec);
+  const bool vec_a = (lda % 4 == 0) && (a_contig % 4 == 0) && (A == nullptr || aligned16(A));
+  const bool vec_b = (ldb % 4 == 0) && (b_contig % 4 == 0) && (B == nullptr || aligned16(B));
+  static const bool no_mixed = getenv("EG_GEMM_NO_MIXED_VEC") != nullptr;
+  return run_gemm(ctx, a_kc, b_kc, args, /*conv=*/0, vec_a && vec_b, vec_a && !vec_b && !no_mixed);
 }
 
 // Direct convolution as an implicit GEMM:  M = N*Ho*Wo output pixels, N = F filters,

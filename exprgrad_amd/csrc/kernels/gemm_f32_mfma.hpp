@@ -227,8 +227,11 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
                                               long n_blk, long k_begin, long k_end, int nk, int tid, int wm0, int wn0) {
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
   constexpr int MI = WM / 32, NI = WN / 32;
-  using LoadA = TileLoader<BM, BK, NT, A_KC, VEC, E, CONV == 1>;
-  using LoadB = TileLoader<BN, BK, NT, B_KC, VEC, E, CONV == 2>;
+  // VEC = 41: 16-byte loads for A, element loads for B (a bias-sized B whose rows of N = 10 floats
+  // are not 16-byte aligned must not force the big operand onto 4-byte loads)
+  constexpr int VA = VEC == 41 ? 4 : VEC, VB = VEC == 41 ? 1 : VEC;
+  using LoadA = TileLoader<BM, BK, NT, A_KC, VA, E, CONV == 1>;
+  using LoadB = TileLoader<BN, BK, NT, B_KC, VB, E, CONV == 2>;
   constexpr int SA = LoadA::STRIDE, SB = LoadB::STRIDE;
   constexpr int BUF = BK * (SA + SB);  // one stage: A tile then B tile
   const int lane = tid & 63;
