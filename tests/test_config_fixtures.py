@@ -1,6 +1,6 @@
 """Committed fixtures of downsized BASELINE configurations (tests/golden/config_fixtures.json, written
 by tests/golden/make_config_fixtures.py from the oracle): the oracle must keep reproducing them
-exactly (CPU), the HIP path must match them at 1e-5 relative (GPU)."""
+(CPU: bit for bit where only + and * are involved, 1e-6 where libm is), the HIP path must match them at 1e-5 relative (GPU)."""
 import importlib.util
 import json
 import os
@@ -67,7 +67,15 @@ def test_oracle_reproduces_the_committed_fixtures(name):
     from oracle import kd
     model = kd.Model(refcases.program_text(fx.GRAPHS[name][0]()), threads=1)
     entry, got = run(model, name, True)
-    check(entry, got, exact=True)
+    if "params_after_two_steps" in entry:
+        # exp / ln come from the host libm, whose last bit may depend on the CPU it dispatches for
+        def close(a, b):
+            assert rel_err(a, b) <= 1e-6
+        for t, want in entry["params_after_two_steps"].items():
+            close(got["params"][t], arr(want))
+        close(got["predict"], arr(entry["predict"]))
+    else:
+        check(entry, got, exact=True)      # multiplications and additions only: bit for bit
 
 
 @pytest.mark.gpu
