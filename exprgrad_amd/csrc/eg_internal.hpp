@@ -48,6 +48,15 @@ struct eg_ctx {
   // grow the workspace (padded output gradient + flipped filters of the convolution's image gradient).
   void* aux = nullptr;
   size_t aux_bytes = 0;
+  // Side lane (host/model.cpp, plan_overlap): a second stream with scratch blocks of its own for
+  // the bandwidth-bound launches that run next to a long contraction.  Swapped in around those
+  // launches, so the library calls they make need not know.
+  hipStream_t side_stream = nullptr;
+  void* side_workspace = nullptr;
+  size_t side_workspace_bytes = 0;
+  void* side_aux = nullptr;
+  size_t side_aux_bytes = 0;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int compute_units = 256;
   std::string arch;
   // kernels a library call specialises at run time (hiprtc) and keeps: by name

@@ -261,6 +261,12 @@ struct Plan {
     eg_kernel** slot;
   };
   std::vector<PendingKernel> pending;
+  // Overlap groups (plan_overlap): launches [first, big) run on the context's side lane while the
+  // long contraction `big` runs on the main stream; both are joined before launch big + 1.
+  struct Overlap {
+    int first = 0, big = 0;
+  };
+  std::vector<Overlap> overlaps;
   struct Captured {
     hipGraphExec_t exec = nullptr;
     std::string key;  // everything baked into the captured kernel arguments
@@ -1051,6 +1057,119 @@ int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<
   return EG_OK;
 }
 
+// ---- side lane --------------------------------------------------------------------------------
+int ensure_side_lane(eg_ctx* ctx) {
+  if (ctx->side_stream) return EG_OK;
+  EG_HIP_CHECK(hipSetDevice(ctx->device));
+  EG_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+  EG_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  EG_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+  return EG_OK;
+}
+
+// While alive, the context's stream and scratch blocks are the side lane's.
+struct LaneSwap {
+  eg_ctx* c;
+  explicit LaneSwap(eg_ctx* ctx) : c(ctx) { swap(); }
+  ~LaneSwap() { swap(); }
+  void swap() {
+    std::swap(c->stream, c->side_stream);
+    std::swap(c->workspace, c->side_workspace);
+    std::swap(c->workspace_bytes, c->side_workspace_bytes);
+    std::swap(c->aux, c->side_aux);
+    std::swap(c->aux_bytes, c->side_aux_bytes);
+  }
+};
+
+// Tensors a launch reads / writes (storage-sharing tensors folded onto their source); false for
+// launch kinds that do not take part in overlap groups.
+bool launch_tensors(const Plan& plan, const Launch& L, std::set<int>& reads, std::set<int>& writes) {
+  auto root = [&](int t) {
+    for (int guard = 0; guard < 64; ++guard) {
+      auto a = plan.alias.find(t);
+      if (a == plan.alias.end()) break;
+      t = a->second;
+    }
+    return t;
+  };
+  auto rd = [&](int t) {
+    if (t) reads.insert(root(t));
+  };
+  auto wr = [&](int t) {
+    if (t) {
+      writes.insert(root(t));
+      reads.insert(root(t));  // accumulate / partial overwrite: conservative
+    }
+  };
+  switch (L.kind) {
+    case StepKind::Gemm:
+      rd(L.a_tensor);
+      rd(L.b_tensor);
+      rd(L.bias_tensor);
+      wr(L.c_tensor);
+      return true;
+    case StepKind::GemmFused:
+      rd(L.a_tensor);
+      rd(L.b_tensor);
+      rd(L.bias_tensor);
+      wr(L.c_tensor);
+      for (int t : plan.epilogues[L.epilogue]->spec.operands) wr(t);
+      return true;
+    case StepKind::GenericA:
+    case StepKind::GenericB:
+      // mode A lists the written tensor first; mode B writes its partial sums and lists reads only
+      for (size_t i = 0; i < L.generic->src.tensor_args.size(); ++i) {
+        if (i == 0 && L.kind == StepKind::GenericA) wr(L.generic->src.tensor_args[i]);
+        else rd(L.generic->src.tensor_args[i]);
+      }
+      wr(L.c_tensor);
+      return true;
+    default: return false;
+  }
+}
+
+// A long contraction keeps the matrix cores busy and leaves the memory system idle; the
+// bandwidth-bound launches just before it that it does not depend on (dense backward: the bias
+// gradient's column sum and the small weight gradient before the large weight gradient) run next to
+// it on the side lane instead of in front of it (tools/overlap_probe.py: 582 -> 511 us).
+void plan_overlap(eg_model* m, TargetState& ts, Plan& plan) {
+  (void)ts;
+  static const bool off = [] {
+    const char* e = getenv("EG_NO_OVERLAP");
+    return e && e[0] && e[0] != '0';
+  }();
+  plan.overlaps.clear();
+  if (off) return;
+  const int n = (int)plan.launches.size();
+  for (int j = 1; j < n; ++j) {
+    const Launch& B = plan.launches[j];
+    if (B.kind != StepKind::Gemm && B.kind != StepKind::GemmFused) continue;
+    const double flops = 2.0 * (double)B.M * (double)B.N * (double)B.K;
+    if (flops < 8e9) continue;
+    std::set<int> br, bw;
+    if (!launch_tensors(plan, B, br, bw)) continue;
+    int first = j;
+    while (first > 0 && j - first < 4) {
+      const int i = first - 1;
+      if (i + 1 == plan.n_backward) break;  // never across the backward | update boundary
+      if (!plan.overlaps.empty() && i <= plan.overlaps.back().big) break;
+      const Launch& S = plan.launches[i];
+      if (S.kind != StepKind::Gemm && S.kind != StepKind::GenericA && S.kind != StepKind::GenericB) break;
+      if (S.kind == StepKind::Gemm && 2.0 * (double)S.M * (double)S.N * (double)S.K * 4 > flops) break;
+      std::set<int> sr, sw;
+      if (!launch_tensors(plan, S, sr, sw)) break;
+      bool clash = false;
+      for (int t : sr) clash = clash || bw.count(t);   // S reads (or writes) what the contraction writes
+      for (int t : sw) clash = clash || br.count(t);   // S writes what the contraction reads (or writes)
+      if (clash) break;
+      first = i;
+    }
+    static const bool debug = getenv("EG_DEBUG_OVERLAP") != nullptr;
+    if (debug) fprintf(stderr, "[eg] overlap: contraction %d (%.1f GFLOP) takes launches [%d, %d)\n", j, flops / 1e9, first, j);
+    if (first < j && ensure_side_lane(m->ctx) == EG_OK) plan.overlaps.push_back({first, j});
+  }
+}
+
 // Is live kernel p a whole-tensor raw copy `dst{it} ++= src{it}` whose destination can simply share
 // the source's storage?  (reshape and its gradient.)  Requires: dst is written by this kernel only,
 // src is complete by then (no later writer), same element count, dst not in the gradient bucket.
@@ -1473,6 +1592,7 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
     if (rc) return rc;
   }
 
+  plan_overlap(m, ts, plan);
   {
     int rc = build_plan_kernels(m, plan);
     if (rc) return rc;
@@ -1695,7 +1815,31 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
       if (rc) return rc;
     }
   }
+  size_t next_overlap = 0;
   for (int i = begin; i < end; ++i) {
+    while (next_overlap < plan.overlaps.size() && plan.overlaps[next_overlap].first < i) ++next_overlap;
+    if (next_overlap < plan.overlaps.size() && plan.overlaps[next_overlap].first == i &&
+        plan.overlaps[next_overlap].big < end) {
+      // fork: the side lane takes launches [i, big) after everything issued so far, the main stream
+      // goes on with the contraction; join before whatever follows
+      const int big = plan.overlaps[next_overlap].big;
+      eg_ctx* ctx = m->ctx;
+      EG_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+      EG_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+      {
+        LaneSwap lane(ctx);
+        for (int s2 = i; s2 < big; ++s2) {
+          int rc = run_launch(m, ts, plan, plan.launches[s2]);
+          if (rc) return rc;
+        }
+        EG_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->stream));  // (the side stream, while swapped)
+      }
+      int rc = run_launch(m, ts, plan, plan.launches[big]);
+      if (rc) return rc;
+      EG_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+      i = big;
+      continue;
+    }
     int rc = run_launch(m, ts, plan, plan.launches[i]);
     if (rc) return rc;
   }
@@ -1720,7 +1864,8 @@ int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool
   std::ostringstream key;
   for (auto& in : m->inputs)
     if (in.second.bound) key << in.first << "=" << (const void*)in.second.device << ";";
-  key << "w" << m->ctx->workspace << "x" << m->ctx->aux << "b" << (void*)ts.bucket << "g" << m->grad_scale << "e" << m->epoch;
+  key << "w" << m->ctx->workspace << "x" << m->ctx->aux << "s" << m->ctx->side_workspace << "y" << m->ctx->side_aux << "b"
+      << (void*)ts.bucket << "g" << m->grad_scale << "e" << m->epoch;
   const std::string k = key.str();
   if (cap.exec && cap.key == k) {
     EG_HIP_CHECK(hipGraphLaunch(cap.exec, m->ctx->stream));
@@ -1947,6 +2092,8 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
         break;
       }
     }
+    for (auto& ov : plan.overlaps)
+      if ((int)i >= ov.first && (int)i < ov.big) os << "   || side lane, next to launch " << ov.big;
     os << "\n";
   }
   m->launch_text = os.str();

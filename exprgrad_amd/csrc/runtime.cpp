@@ -252,6 +252,12 @@ int eg_ctx_destroy(eg_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   if (ctx->workspace) hipFree(ctx->workspace);
   if (ctx->aux) hipFree(ctx->aux);
+  if (ctx->side_stream) hipStreamSynchronize(ctx->side_stream);
+  if (ctx->side_workspace) hipFree(ctx->side_workspace);
+  if (ctx->side_aux) hipFree(ctx->side_aux);
+  if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+  if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
   for (auto& kv : ctx->jit) delete kv.second;  // eg_kernel: the code object goes with it
   if (ctx->owns_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -170,4 +170,18 @@ def test_cfg5_dense_train_step_batch_65536(gpu_ctx):
         # is ~1e-5 of the summed magnitude, hence 1e-4 on the update; parameters agree to 1e-5
         assert rel_err(du_gpu, du_ref) <= 1e-4, tid
         assert rel_err(gpu.params[tid], ref.params[tid]) <= TOL, tid
+    # the bias gradient and the small weight gradient run on the side lane, next to the large
+    # weight-gradient contraction; later steps (eager, captured, replayed) must agree with this one
+    plan = gpu.launch_plan("train")
+    assert plan.count("side lane") == 2, plan
+    serial = egm.compile(*refcases.dense_softmax_net(), gpu=gpu_ctx)
+    for tid in sorted(ref.params):
+        serial.params[tid] = gpu.params[tid]
+    for _ in range(3):                        # replays of the captured two-lane graph ...
+        gpu.apply("train", {"x": x, "y": y})
+    for _ in range(3):                        # ... against a fresh model's eager, captured and replayed steps
+        serial.apply("train", {"x": x, "y": y})
+    for tid in sorted(ref.params):
+        assert np.array_equal(gpu.params[tid], serial.params[tid]), tid
+    serial.close()
     gpu.close()
