@@ -185,3 +185,34 @@ def test_cfg5_dense_train_step_batch_65536(gpu_ctx):
         assert np.array_equal(gpu.params[tid], serial.params[tid]), tid
     serial.close()
     gpu.close()
+
+
+def test_cfg5_split_step_equals_whole_step(gpu_ctx):
+    """The data-parallel form of the step (run_backward | exchange | run_update, here on one rank
+    without a process group) at the full per-GPU batch, where the side lane is active inside the
+    backward range: bit-identical to apply()."""
+    torch = pytest.importorskip("torch")
+    from exprgrad_amd.parallel import DataParallel, GpuEngine
+    import exprgrad_amd as eg
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = eg.newGpuContext(0, stream=stream.cuda_stream)
+        whole = egm.compile(*refcases.dense_softmax_net(), gpu=ctx)
+        split = egm.compile(*refcases.dense_softmax_net(), gpu=ctx)
+        rng = np.random.default_rng(15)
+        for tid in whole.params.ids():
+            v = (rng.random(whole.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+            whole.params[tid] = v
+            split.params[tid] = v
+        x = torch.rand((65536, 784), device="cuda")
+        y = torch.nn.functional.one_hot(torch.randint(0, 10, (65536,), device="cuda"), 10).to(torch.float32).contiguous()
+        dp = DataParallel(GpuEngine(split, "train"), reduction="mean")
+        for _ in range(4):
+            whole.apply("train", [("x", x), ("y", y)])
+            dp.step([("x", x), ("y", y)])
+        stream.synchronize()
+        assert "side lane" in split.launch_plan("train")
+        for tid in whole.params.ids():
+            assert np.array_equal(whole.params[tid], split.params[tid]), tid
+        whole.close()
+        split.close()
