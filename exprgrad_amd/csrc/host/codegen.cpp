@@ -252,14 +252,31 @@ int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out
   code += "  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;\n";
   code += "  if (gid >= " + em.p(s_total) + ") return;\n";
   code += em.setup_decls();
-  // decode: last independent loop varies fastest
-  for (size_t i = out.indep.size(); i-- > 0;) {
-    const int l = out.indep[i];
-    const std::string ext = em.p(em.slot(Slot::LoopExtent, l)), start = em.p(em.slot(Slot::LoopStart, l));
-    if (i == 0)
+  // decode: last independent loop varies fastest.  The divisions by run-time extents dominate a
+  // bandwidth-bound kernel when done in 64 bits (pooling gradient over 19 M elements: 100 -> 60 us),
+  // so they are done in 32 bits whenever the iteration space fits (wave-uniform branch).
+  if (out.indep.size() > 1) {
+    for (int l : out.indep) code += "  long " + em.reg(k.loops[l].reg) + ";\n";
+    for (int wide = 0; wide < 2; ++wide) {
+      code += wide ? "  } else {\n" : "  if (" + em.p(s_total) + " <= 0x7fffffffL) {\n    unsigned g32 = (unsigned)gid;\n";
+      const std::string g = wide ? "gid" : "g32";
+      for (size_t i = out.indep.size(); i-- > 0;) {
+        const int l = out.indep[i];
+        const std::string ext = em.p(em.slot(Slot::LoopExtent, l)), start = em.p(em.slot(Slot::LoopStart, l));
+        const std::string e = wide ? ext : "(unsigned)" + ext;
+        if (i == 0)
+          code += "    " + em.reg(k.loops[l].reg) + " = " + start + " + (long)" + g + ";\n";
+        else
+          code += "    " + em.reg(k.loops[l].reg) + " = " + start + " + (long)(" + g + " % " + e + "); " + g + " /= " + e + ";\n";
+      }
+    }
+    code += "  }\n";
+  } else {
+    for (size_t i = out.indep.size(); i-- > 0;) {
+      const int l = out.indep[i];
+      const std::string start = em.p(em.slot(Slot::LoopStart, l));
       code += "  const long " + em.reg(k.loops[l].reg) + " = " + start + " + gid;\n";
-    else
-      code += "  const long " + em.reg(k.loops[l].reg) + " = " + start + " + gid % " + ext + "; gid /= " + ext + ";\n";
+    }
   }
   const int write_index = (int)k.reads.size();
   std::string inner;
