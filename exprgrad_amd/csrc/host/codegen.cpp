@@ -76,9 +76,33 @@ struct Emitter {
       out += "      const long " + reg(ins.res) + " = " + instr_expression(ins, "0L", "r") + ";\n";
     for (size_t i = 0; i < k.reads.size(); ++i) {
       const Op& r = k.reads[i];
-      out += "      const float " + reg(r.reg) + " = t" + std::to_string(r.tensor) + "[" + flat_index(r, (int)i) + "];\n";
+      out += index_decl("x" + std::to_string(i), r, (int)i, (int)i);
+      out += "      const float " + reg(r.reg) + " = t" + std::to_string(r.tensor) + "[x" + std::to_string(i) + "];\n";
     }
     for (size_t i = 0; i < k.instrs.size(); ++i) emit_instr(k.instrs[i], (int)i, out);
+  }
+
+  // `long <var> = element offset of op`.  Index arithmetic dominates generated kernels over several
+  // iterators (64-bit multiply-adds with run-time strides): an operand indexed exactly
+  // like an earlier read (`in[n, y, x, c]` and the gradient written at `[n, y, x, c]`) reuses that
+  // read's offset when its strides are the same — a comparison of kernel arguments, uniform for the
+  // launch — and computes its own only otherwise.
+  std::string index_decl(const std::string& var, const Op& op, int op_index, int nreads_before) {
+    int same = -1;
+    if (!op.raw && op.dims.size() >= 2)
+      for (int j = 0; j < nreads_before && same < 0; ++j) {
+        const Op& o = k.reads[j];
+        if (o.raw || o.dims.size() != op.dims.size()) continue;
+        bool eq = true;
+        for (size_t d = 0; d < op.dims.size(); ++d) eq = eq && o.dims[d] == op.dims[d];
+        if (eq) same = j;
+      }
+    if (same < 0) return "      const long " + var + " = " + flat_index(op, op_index) + ";\n";
+    std::string cond;
+    for (size_t d = 0; d < op.dims.size(); ++d)
+      cond += (d ? " && " : "") + p(slot(Slot::Stride, op_index, (int)d)) + " == " + p(slot(Slot::Stride, same, (int)d));
+    return "      long " + var + ";\n      if (" + cond + ") " + var + " = x" + std::to_string(same) + "; else " + var + " = " +
+           flat_index(op, op_index) + ";\n";
   }
 
   std::string setup_decls() {
@@ -289,9 +313,16 @@ int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out
               em.p(em.slot(Slot::LoopStart, l)) + " + " + em.p(em.slot(Slot::LoopExtent, l)) + "; ++" + r + ") {\n";
     }
     code += inner;
-    code += "      { const long w = " + em.flat_index(k.write, write_index) + "; t" + std::to_string(k.write.tensor) +
+    code += "      { " + em.index_decl("w", k.write, write_index, (int)k.reads.size()) + "        t" + std::to_string(k.write.tensor) +
             "[w] = t" + std::to_string(k.write.tensor) + "[w] + " + em.reg(k.result) + "; }\n";
     for (size_t i = 0; i < out.red.size(); ++i) code += "  }\n";
+  } else if (out.red.empty()) {
+    // one element per thread: the write offset can share a read's (index_decl)
+    const std::string wt = "t" + std::to_string(k.write.tensor);
+    code += "    {\n" + inner;
+    code += em.index_decl("w", k.write, write_index, (int)k.reads.size());
+    code += "      " + wt + "[w] = " + em.p(s_acc) + " ? " + wt + "[w] + " + em.reg(k.result) + " : " + em.reg(k.result) + ";\n";
+    code += "    }\n";
   } else {
     code += "  float acc = 0.0f;\n";
     for (int l : out.red) {
