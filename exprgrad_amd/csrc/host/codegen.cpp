@@ -97,6 +97,27 @@ struct Emitter {
         for (size_t d = 0; d < op.dims.size(); ++d) eq = eq && o.dims[d] == op.dims[d];
         if (eq) same = j;
       }
+    if (same < 0 && !op.raw && op.dims.size() >= 2) {
+      // the same tensor read again at a constant displacement (`in[n, 2y + dy, 2x + dx, c]`, the taps of a
+      // stencil): the earlier offset plus stride * displacement
+      for (int j = 0; j < nreads_before; ++j) {
+        const Op& o = k.reads[j];
+        if (o.tensor != op.tensor || o.raw || o.dims.size() != op.dims.size()) continue;
+        bool eq = true;
+        for (size_t d = 0; d < op.dims.size() && eq; ++d) {
+          Lin a = o.dims[d], b = op.dims[d];
+          a.constant = b.constant = 0;
+          eq = a == b;
+        }
+        if (!eq) continue;
+        std::string e = "x" + std::to_string(j);
+        for (size_t d = 0; d < op.dims.size(); ++d) {
+          const long delta = op.dims[d].constant - o.dims[d].constant;
+          if (delta) e += " + " + p(slot(Slot::Stride, op_index, (int)d)) + " * " + std::to_string(delta) + "L";
+        }
+        return "      const long " + var + " = " + e + ";\n";
+      }
+    }
     if (same < 0) return "      const long " + var + " = " + flat_index(op, op_index) + ";\n";
     std::string cond;
     for (size_t d = 0; d < op.dims.size(); ++d)
