@@ -1,5 +1,7 @@
 #include "codegen.hpp"
 
+#include <regex>
+
 #include <cmath>
 #include <cstdio>
 #include <set>
@@ -360,8 +362,22 @@ int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out
     code += "  " + wt + "[w] = " + em.p(s_acc) + " ? " + wt + "[w] + acc : acc;\n";
   }
   out.tensor_args = distinct_tensors(k, true);
+  // Index arithmetic is most of what these kernels execute.  When every operand has
+  // fewer than 2^31 elements (Slot::Narrow, decided per launch) it is exact in 32 bits: the body is
+  // emitted a second time with `int` indices and 32-bit copies of the arguments, and a
+  // launch-uniform branch picks one.
+  const size_t head_end = code.find("return;\n") + 8;
+  const std::string head = code.substr(0, head_end), wide = code.substr(head_end);
+  const int s_narrow = em.slot(Slot::Narrow);
+  std::string narrow = std::regex_replace(wide, std::regex("\\blong\\b"), "int");
+  narrow = std::regex_replace(narrow, std::regex("\\b(0x[0-9a-fA-F]+|[0-9]+)L\\b"), "$1");
+  narrow = std::regex_replace(narrow, std::regex("\\bp([0-9]+)\\b"), "q$1");
+  std::string qdecl;
+  for (size_t i = 0; i < em.slots.size(); ++i)
+    qdecl += "    const int q" + std::to_string(i) + " = (int)p" + std::to_string(i) + ";\n";
   out.slots = em.slots;
-  out.source = signature(name, out.tensor_args, k.write.tensor, false, out.slots.size()) + " {\n" + code + "}\n";
+  out.source = signature(name, out.tensor_args, k.write.tensor, false, out.slots.size()) + " {\n" + head + "  if (" +
+               em.p(s_narrow) + ") {\n" + qdecl + narrow + "  } else {\n" + wide + "  }\n}\n";
   return EG_OK;
 }
 

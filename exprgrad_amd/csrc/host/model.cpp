@@ -730,6 +730,19 @@ int fill_params(eg_model* m, const Kernel& k, const KernelInfo& info, const Shap
         break;
       }
       case Slot::SetupVal: v = info.vals.at(k.setup[s.a].res); break;
+      case Slot::Narrow: {
+        static const bool off = getenv("EG_NO_NARROW_INDEX") != nullptr;
+        const long lim = 1L << 31;
+        v = !off && total < lim && rtotal < lim;
+        auto small = [&](int tensor) {
+          auto sh = shapes.find(tensor);
+          return sh != shapes.end() && prod(sh->second) < lim;
+        };
+        for (auto& rd : k.reads) v = v && small(rd.tensor);
+        v = v && small(k.write.tensor);
+        for (auto& b : info.bounds) v = v && b.first > -lim && b.second < lim;
+        break;
+      }
       case Slot::InstrVal: {
         const Instr& ins = k.instrs[s.a];
         if (ins.kind == IK::Epoch) {
@@ -753,6 +766,11 @@ int fill_params(eg_model* m, const Kernel& k, const KernelInfo& info, const Shap
     }
     out.push_back(v);
   }
+  // 32-bit copies of the arguments must be exact too
+  for (size_t i = 0; i < src.slots.size(); ++i)
+    if (src.slots[i].kind == Slot::Narrow)
+      for (long v : out)
+        if (v >= (1L << 31) || v < -(1L << 31)) out[i] = 0;
   return EG_OK;
 }
 
