@@ -216,3 +216,43 @@ def test_cfg5_split_step_equals_whole_step(gpu_ctx):
             assert np.array_equal(whole.params[tid], split.params[tid]), tid
         whole.close()
         split.close()
+
+
+def test_cfg4_conv2_gradients_256x256x64(gpu_ctx, refcpu):
+    """Both gradients of configs[3] at full size.  Direct parity with the oracle on sub-problems that
+    are exact slices of the full one (a sub-bank of filters; a band of output-gradient rows), and the
+    adjoint identities <conv(img, flt), g> = <img, gradImage(flt, g)> = <flt, gradFilter(img, g)> in
+    float64 over the whole problem."""
+    N, H, W, C, F, FH, FW = 1, 256, 256, 64, 64, 3, 3
+    Ho, Wo = H - FH + 1, W - FW + 1
+    rng = np.random.default_rng(44)
+    img = rng.random((N, H, W, C), dtype=np.float32)
+    flt = (rng.random((F, FH, FW, C), dtype=np.float32) * 4 - 2).astype(np.float32)
+    gout = (rng.random((N, Ho, Wo, F), dtype=np.float32) - 0.5).astype(np.float32)
+    dimg, dflt, dg = dev(gpu_ctx, img), dev(gpu_ctx, flt), dev(gpu_ctx, gout)
+    out, gflt, gimg = gpu_ctx.allocTensor((N, Ho, Wo, F)), gpu_ctx.allocTensor(flt.shape), gpu_ctx.allocTensor(img.shape)
+    ops.conv2_nhwc(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dflt, out)
+    ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dg, gflt)
+    ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dg, gimg)
+    conv, gf, gi = out.read(), gflt.read(), gimg.read()
+
+    # (1) filter gradient of a sub-bank: gFlt[f] depends on gOut[..., f] only
+    sub = refcpu.conv2_nhwc_grad_filter(img, np.ascontiguousarray(gout[..., :3]), (3, FH, FW, C))
+    assert rel_err(gf[:3], sub) <= 2 * TOL          # 64 516 sequential f32 additions on the reference side
+    # (2) image gradient of a band: with gOut zero outside rows [y0, y1) only image rows [y0, y1 + FH - 1) are touched
+    y0, y1 = 100, 108
+    band = np.zeros_like(gout)
+    band[:, y0:y1] = gout[:, y0:y1]
+    dband = dev(gpu_ctx, band)
+    gimg_band = gpu_ctx.allocTensor(img.shape)
+    ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dband, gimg_band)
+    got_band = gimg_band.read()
+    want_band = refcpu.conv2_nhwc_grad_image(flt, np.ascontiguousarray(gout[:, y0:y1]), (N, y1 - y0 + FH - 1, W, C))
+    assert rel_err(got_band[:, y0:y1 + FH - 1], want_band) <= TOL
+    assert not got_band[:, :y0].any() and not got_band[:, y1 + FH - 1:].any()
+    # (3) adjoint identities over the whole problem, float64
+    lhs = float((conv.astype(np.float64) * gout).sum())
+    via_image = float((img.astype(np.float64) * gi).sum())
+    via_filter = float((flt.astype(np.float64) * gf).sum())
+    scale = float(np.abs(conv.astype(np.float64) * gout).sum())
+    assert abs(lhs - via_image) <= TOL * scale and abs(lhs - via_filter) <= TOL * scale
