@@ -73,15 +73,18 @@ struct Emitter {
 
   // loads + expression, at indentation of the innermost body
   void emit_body(std::string& out) {
-    // computed indices first (`y div 2`): Index instructions over iterators and host values
+    emit_indices(out);
+    for (size_t i = 0; i < k.reads.size(); ++i)
+      out += "      const float " + reg(k.reads[i].reg) + " = t" + std::to_string(k.reads[i].tensor) + "[x" + std::to_string(i) + "];\n";
+    for (size_t i = 0; i < k.instrs.size(); ++i) emit_instr(k.instrs[i], (int)i, out);
+  }
+
+  // computed indices first (`y div 2`): Index instructions over iterators and host values; then the
+  // element offset x<i> of every read
+  void emit_indices(std::string& out) {
     for (auto& ins : k.index_instrs)
       out += "      const long " + reg(ins.res) + " = " + instr_expression(ins, "0L", "r") + ";\n";
-    for (size_t i = 0; i < k.reads.size(); ++i) {
-      const Op& r = k.reads[i];
-      out += index_decl("x" + std::to_string(i), r, (int)i, (int)i);
-      out += "      const float " + reg(r.reg) + " = t" + std::to_string(r.tensor) + "[x" + std::to_string(i) + "];\n";
-    }
-    for (size_t i = 0; i < k.instrs.size(); ++i) emit_instr(k.instrs[i], (int)i, out);
+    for (size_t i = 0; i < k.reads.size(); ++i) out += index_decl("x" + std::to_string(i), k.reads[i], (int)i, (int)i);
   }
 
   // `long <var> = element offset of op`.  Index arithmetic dominates generated kernels over several
@@ -295,9 +298,35 @@ int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out
   split_loops(k, out.indep, out.red, out.scatter);
   const int s_acc = em.slot(Slot::Accumulate);
   const int s_total = em.slot(Slot::Total);
+  // Four elements per thread (Slot::Vec4, decided per launch): possible when every operand ends in
+  // the bare fastest iterator and nothing else depends on it — then the four elements are adjacent
+  // in every operand, the index arithmetic is shared and loads / stores are 16 bytes wide.
+  bool vec = out.red.empty() && !out.scatter && !out.indep.empty() && k.reads.size() <= 12;
+  int rc = 0;
+  if (vec) {
+    const Loop& fast = k.loops[out.indep.back()];
+    rc = fast.reg;
+    vec = !fast.has_bounds && k.result != rc;
+    auto ends_in_rc = [&](const Op& op) {
+      if (op.raw || op.dims.empty() || op.dims.back().only_register() != rc) return false;
+      for (size_t d = 0; d + 1 < op.dims.size(); ++d)
+        if (op.dims[d].factor_of(rc) != 0) return false;
+      return true;
+    };
+    vec = vec && ends_in_rc(k.write);
+    for (auto& rd : k.reads) vec = vec && ends_in_rc(rd);
+    for (auto& ins : k.index_instrs)
+      for (int a : ins.args) vec = vec && a != rc;
+    for (auto& ins : k.instrs)
+      for (int a : ins.args) vec = vec && a != rc;
+  }
+  const int s_vec = vec ? em.slot(Slot::Vec4) : -1;
+  const std::string PV = vec ? em.p(s_vec) : "0L";
   std::string code;
   code += "  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;\n";
-  code += "  if (gid >= " + em.p(s_total) + ") return;\n";
+  code += vec ? "  if (gid >= (" + PV + " ? " + em.p(s_total) + " / 4L : " + em.p(s_total) + ")) return;\n"
+              : "  if (gid >= " + em.p(s_total) + ") return;\n";
+  if (vec) code += "  const long VW = " + PV + " ? 4L : 1L;\n";
   code += em.setup_decls();
   // decode: last independent loop varies fastest.  The divisions by run-time extents dominate a
   // bandwidth-bound kernel when done in 64 bits (pooling gradient over 19 M elements: 100 -> 60 us),
@@ -309,12 +338,16 @@ int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out
       const std::string g = wide ? "gid" : "g32";
       for (size_t i = out.indep.size(); i-- > 0;) {
         const int l = out.indep[i];
-        const std::string ext = em.p(em.slot(Slot::LoopExtent, l)), start = em.p(em.slot(Slot::LoopStart, l));
+        const bool fastest = vec && i + 1 == out.indep.size();
+        std::string ext = em.p(em.slot(Slot::LoopExtent, l));
+        const std::string start = em.p(em.slot(Slot::LoopStart, l));
+        if (fastest) ext = "(" + ext + " / VW)";
         const std::string e = wide ? ext : "(unsigned)" + ext;
+        const std::string scale = fastest ? " * VW" : "";
         if (i == 0)
-          code += "    " + em.reg(k.loops[l].reg) + " = " + start + " + (long)" + g + ";\n";
+          code += "    " + em.reg(k.loops[l].reg) + " = " + start + " + (long)" + g + scale + ";\n";
         else
-          code += "    " + em.reg(k.loops[l].reg) + " = " + start + " + (long)(" + g + " % " + e + "); " + g + " /= " + e + ";\n";
+          code += "    " + em.reg(k.loops[l].reg) + " = " + start + " + (long)(" + g + " % " + e + ")" + scale + "; " + g + " /= " + e + ";\n";
       }
     }
     code += "  }\n";
@@ -322,7 +355,7 @@ int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out
     for (size_t i = out.indep.size(); i-- > 0;) {
       const int l = out.indep[i];
       const std::string start = em.p(em.slot(Slot::LoopStart, l));
-      code += "  const long " + em.reg(k.loops[l].reg) + " = " + start + " + gid;\n";
+      code += "  const long " + em.reg(k.loops[l].reg) + " = " + start + " + gid" + (vec ? " * VW" : "") + ";\n";
     }
   }
   const int write_index = (int)k.reads.size();
@@ -340,11 +373,30 @@ int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out
             "[w] = t" + std::to_string(k.write.tensor) + "[w] + " + em.reg(k.result) + "; }\n";
     for (size_t i = 0; i < out.red.size(); ++i) code += "  }\n";
   } else if (out.red.empty()) {
-    // one element per thread: the write offset can share a read's (index_decl)
+    // one element (or four) per thread: the write offset can share a read's (index_decl)
     const std::string wt = "t" + std::to_string(k.write.tensor);
-    code += "    {\n" + inner;
-    code += em.index_decl("w", k.write, write_index, (int)k.reads.size());
+    std::string idx, loads, instrs;
+    em.emit_indices(idx);
+    for (size_t i = 0; i < k.reads.size(); ++i)
+      loads += "      const float " + em.reg(k.reads[i].reg) + " = t" + std::to_string(k.reads[i].tensor) + "[x" + std::to_string(i) + "];\n";
+    for (size_t i = 0; i < k.instrs.size(); ++i) em.emit_instr(k.instrs[i], (int)i, instrs);
+    code += "    {\n" + idx + em.index_decl("w", k.write, write_index, (int)k.reads.size());
+    if (vec) {
+      code += "      if (" + PV + ") {\n";
+      for (size_t i = 0; i < k.reads.size(); ++i)
+        code += "      const eg_f4 v" + std::to_string(i) + " = *reinterpret_cast<const eg_f4*>(t" + std::to_string(k.reads[i].tensor) +
+                " + x" + std::to_string(i) + ");\n";
+      code += "      eg_f4 res;\n#pragma unroll\n      for (int j = 0; j < 4; ++j) {\n";
+      for (size_t i = 0; i < k.reads.size(); ++i)
+        code += "      const float " + em.reg(k.reads[i].reg) + " = v" + std::to_string(i) + "[j];\n";
+      code += instrs + "      res[j] = " + em.reg(k.result) + ";\n      }\n";
+      code += "      eg_f4* wp = reinterpret_cast<eg_f4*>(" + wt + " + w);\n";
+      code += "      if (" + em.p(s_acc) + ") { const eg_f4 old = *wp; for (int j = 0; j < 4; ++j) res[j] = old[j] + res[j]; }\n";
+      code += "      *wp = res;\n      } else {\n";
+    }
+    code += loads + instrs;
     code += "      " + wt + "[w] = " + em.p(s_acc) + " ? " + wt + "[w] + " + em.reg(k.result) + " : " + em.reg(k.result) + ";\n";
+    if (vec) code += "      }\n";
     code += "    }\n";
   } else {
     code += "  float acc = 0.0f;\n";
@@ -376,7 +428,8 @@ int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out
   for (size_t i = 0; i < em.slots.size(); ++i)
     qdecl += "    const int q" + std::to_string(i) + " = (int)p" + std::to_string(i) + ";\n";
   out.slots = em.slots;
-  out.source = signature(name, out.tensor_args, k.write.tensor, false, out.slots.size()) + " {\n" + head + "  if (" +
+  out.source = std::string("typedef float eg_f4 __attribute__((ext_vector_type(4)));\n") +
+               signature(name, out.tensor_args, k.write.tensor, false, out.slots.size()) + " {\n" + head + "  if (" +
                em.p(s_narrow) + ") {\n" + qdecl + narrow + "  } else {\n" + wide + "  }\n}\n";
   return EG_OK;
 }

@@ -23,7 +23,8 @@ namespace kd {
 
 struct Slot {
   enum Kind : int { Accumulate, Total, RTotal, Chunk, LoopStart, LoopExtent, Stride, SetupVal, InstrVal, GradScaleBits,
-                    Narrow /* 1: every operand has < 2^31 elements, 32-bit index arithmetic is exact */ };
+                    Narrow /* 1: every operand has < 2^31 elements, 32-bit index arithmetic is exact */,
+                    Vec4 /* 1: four elements of the fastest iterator per thread, 16-byte loads and stores */ };
   Kind kind;
   int a = 0, b = 0;  // LoopStart/LoopExtent: loop index; Stride: op index (reads..., write last), dim;
                      // SetupVal: index into k.setup; InstrVal: index into k.instrs

@@ -205,6 +205,9 @@ struct Launch {
   int row_group = -1;                       // RowFused: index into Plan::row_groups
   int epilogue = -1;                        // GemmFused: index into Plan::epilogues
   int consumer = -1;                        // GenericA: live position of the elementwise consumer folded into it
+  int vec_slot = -1;                        // GenericA: index of the Slot::Vec4 argument, if the kernel has one
+  bool vec_ok = false;                      //   the shapes allow four elements per thread (pointers are checked per launch)
+  long total_items = 0;                     //   independent iterations (grid = items or items / 4)
 };
 
 // A run of per-sample kernels fused into one generated kernel (rowfuse.hpp), built per plan.
@@ -709,6 +712,15 @@ bool full_cover(const Kernel& k, const KernelInfo& info, const std::vector<long>
   return true;
 }
 
+// Remember where a generated kernel takes its four-elements-per-thread flag and what fill_params decided.
+void note_vec4(Launch& L, long total) {
+  L.total_items = total;
+  L.vec_slot = -1;
+  for (size_t i = 0; i < L.generic->src.slots.size(); ++i)
+    if (L.generic->src.slots[i].kind == Slot::Vec4) L.vec_slot = (int)i;
+  L.vec_ok = L.vec_slot >= 0 && L.params[L.vec_slot] != 0;
+}
+
 int fill_params(eg_model* m, const Kernel& k, const KernelInfo& info, const Shapes& shapes, const GenericSource& src,
                 bool accumulate, long total, long rtotal, long chunk, std::vector<long>& out) {
   out.clear();
@@ -730,6 +742,18 @@ int fill_params(eg_model* m, const Kernel& k, const KernelInfo& info, const Shap
         break;
       }
       case Slot::SetupVal: v = info.vals.at(k.setup[s.a].res); break;
+      case Slot::Vec4: {
+        static const bool off = getenv("EG_NO_VEC4") != nullptr;
+        const int l = src.indep.empty() ? -1 : src.indep.back();
+        v = !off && l >= 0 && info.bounds[l].first == 0 && info.bounds[l].second % 4 == 0 && total % 4 == 0 && total > 0;
+        auto rows_of_four = [&](int tensor) {
+          auto sh = shapes.find(tensor);
+          return sh != shapes.end() && !sh->second.empty() && sh->second.back() % 4 == 0;
+        };
+        for (auto& rd : k.reads) v = v && rows_of_four(rd.tensor);
+        v = v && rows_of_four(k.write.tensor);
+        break;
+      }
       case Slot::Narrow: {
         static const bool off = getenv("EG_NO_NARROW_INDEX") != nullptr;
         const long lim = 1L << 31;
@@ -1455,6 +1479,7 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
         L.blocks_x = (count + 255) / 256;
         int rc = fill_params(m, F, info, shapes, lo.with_consumer_code.src, !u_first, count, 1, 0, L.params);
         if (rc) return rc;
+        note_vec4(L, count);
         for (size_t si = 0; si < L.generic->src.slots.size(); ++si) {
           const Slot& sl = L.generic->src.slots[si];
           if (sl.kind == Slot::InstrVal && F.instrs[sl.a].kind == IK::Epoch) L.epoch_slots.push_back((int)si);
@@ -1592,6 +1617,7 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
         L.blocks_x = (total + 255) / 256;
         int rc = fill_params(m, k, info, shapes, lo.mode_a.src, !overwrite, total, rtotal, 0, L.params);
         if (rc) return rc;
+        note_vec4(L, total);
       }
       for (size_t si = 0; si < L.generic->src.slots.size(); ++si) {
         const Slot& sl = L.generic->src.slots[si];
@@ -1776,7 +1802,15 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       for (auto& p : ptrs) args.push_back(&p);
       for (auto& v : L.params) args.push_back(&v);
       for (int slot : L.epoch_slots) L.params[slot] = m->epoch;
-      int rc = eg::kernel_launch_raw(L.generic->handle, (unsigned)L.blocks_x, (unsigned)L.blocks_y, 1, 256, args.data());
+      long blocks_x = L.blocks_x;
+      if (L.kind == StepKind::GenericA && L.vec_slot >= 0) {
+        // four elements per thread need 16-byte aligned operands (arena tensors are; caller-owned ones may not be)
+        bool aligned = L.vec_ok;
+        for (float* p : ptrs) aligned = aligned && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+        L.params[L.vec_slot] = aligned ? 1 : 0;
+        blocks_x = ((aligned ? L.total_items / 4 : L.total_items) + 255) / 256;
+      }
+      int rc = eg::kernel_launch_raw(L.generic->handle, (unsigned)blocks_x, (unsigned)L.blocks_y, 1, 256, args.data());
       if (rc) return rc;
       if (L.kind == StepKind::GenericB)
         return eg::colsum_with_scratch(ctx, L.partial_rows, L.partial_cols, partial,

@@ -207,3 +207,27 @@ def test_kernel_description_text_of_the_new_constructs():
     assert " -" in [l for l in text.splitlines() if l.startswith("write")][1]   # gradient placeholder: negative id
     text = refcases.program_text([dsl.reshape(dsl.input("a"), [-1, 3]).target("r")])
     assert "shapesetup" in text and "indexdiv" in text
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["max", "avg", "up"])
+def test_gpu_four_elements_per_thread_needs_aligned_operands(gpu_ctx, kind):
+    """Generated kernels whose operands all end in the fastest iterator handle four channels per
+    thread with 16-byte loads and stores — only when every operand is 16-byte aligned.  A
+    caller-owned input that starts 4 bytes off must take the element-wise path and give the same
+    result, bit for bit."""
+    torch = pytest.importorskip("torch")
+    from exprgrad_amd import model as egm
+    a = np.random.default_rng(11).random((3, 16, 20, 8), dtype=np.float32)
+    gpu = egm.compile(*pool_graphs(kind), gpu=gpu_ctx)
+    want_out, want_grad = gpu.call("out", {"img": a}), gpu.call("grad", {"img": a})       # arena copy: aligned
+    flat = torch.zeros(a.size + 1, device="cuda")
+    flat[1:] = torch.from_numpy(a.ravel()).cuda()
+    shifted = flat[1:].view(*a.shape)
+    assert shifted.data_ptr() % 16 == 4
+    assert np.array_equal(gpu.call("out", {"img": shifted}), want_out)
+    assert np.array_equal(gpu.call("grad", {"img": shifted}), want_grad)
+    ref = oracle(pool_graphs(kind))
+    assert np.array_equal(want_out, ref.call("out", {"img": a}))
+    assert rel_err(want_grad, ref.call("grad", {"img": a})) <= TOL
+    gpu.close()
