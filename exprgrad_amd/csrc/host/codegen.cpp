@@ -308,7 +308,8 @@ int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out
     rc = fast.reg;
     vec = !fast.has_bounds && k.result != rc;
     auto ends_in_rc = [&](const Op& op) {
-      if (op.raw || op.dims.empty() || op.dims.back().only_register() != rc) return false;
+      if (op.raw) return op.dims.size() == 1 && op.dims[0].only_register() == rc;  // `out{it} ++= f(in{it})`
+      if (op.dims.empty() || op.dims.back().only_register() != rc) return false;
       for (size_t d = 0; d + 1 < op.dims.size(); ++d)
         if (op.dims[d].factor_of(rc) != 0) return false;
       return true;
