@@ -112,6 +112,12 @@ _SIGS = {
     "eg_model_clear_inputs": (c_int, [c_void_p]),
     "eg_model_set_epoch": (c_int, [c_void_p, c_i64]),
     "eg_model_epoch": (c_i64, [c_void_p]),
+    "eg_model_state_bytes": (c_int, [c_void_p, P(c_size_t)]),
+    "eg_model_store_state": (c_int, [c_void_p, c_void_p, c_size_t, P(c_size_t)]),
+    "eg_model_load_state": (c_int, [c_void_p, c_void_p, c_size_t, P(c_size_t)]),
+    "eg_model_save": (c_int, [c_void_p, c_char_p]),
+    "eg_model_load": (c_int, [c_void_p, c_char_p, P(c_void_p)]),
+    "eg_model_source_text": (c_char_p, [c_void_p]),
 }
 
 # functions whose int return value is not a status code

@@ -76,6 +76,8 @@ namespace eg {
 // Ensure ctx->workspace holds at least `bytes`; synchronises the stream if it has to grow.
 int ensure_workspace(eg_ctx* ctx, size_t bytes);
 int ensure_aux(eg_ctx* ctx, size_t bytes);
+// EG_POISON=1: scratch and to-be-overwritten result storage is filled with NaN patterns before use.
+bool poison_enabled();
 // Build several kernels (extern "C" names) from one source text in a single hiprtc program.
 int kernels_compile_batch(eg_ctx* ctx, const char* label, const char* source, const std::vector<std::string>& names,
                           std::vector<eg_kernel*>& out);

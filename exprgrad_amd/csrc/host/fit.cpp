@@ -1,0 +1,175 @@
+// eg_model_fit: Model.fit (model.nim:413-454) as one C-ABI call.
+#include <random>
+#include "model_types.hpp"
+
+using namespace eg::kd;
+using namespace eg::model;
+using eg::set_error;
+
+
+extern "C" {
+
+// fit (model.nim:413-454): one epoch of mini-batches.  The reference slices the host tensors
+// (viewFirst) and uploads every batch with a blocking write before it enqueues the kernels
+// (model.nim:364-368); here the data set is uploaded once in pieces on a second stream, piece k+1
+// while the batches of piece k run, and every batch is one segment-copy launch (the batch's rows
+// of every input -> that input's fixed staging buffer, so the captured launch sequence replays
+// unchanged) plus one graph launch.  Nothing in the loop waits for the device.
+int eg_model_fit(eg_model* m, const char* target, int n_inputs, const char* const* names, const float* const* data,
+                 const int* on_device, const int* ranks, const int64_t* shapes8, int64_t batch_size) try {
+  EG_REQUIRE(m && target, EG_ERR_INVALID, "NULL model or target");
+  // model.nim:417-421
+  EG_REQUIRE(n_inputs > 0, EG_ERR_RUNTIME,
+             "Model.fit requires at least one input tensor. Use Model.apply instead if the target has zero inputs.");
+  EG_REQUIRE(n_inputs <= 8, EG_ERR_INVALID, "Model.fit takes at most 8 inputs here");
+  EG_REQUIRE(names && data && on_device && ranks && shapes8, EG_ERR_INVALID, "NULL argument");
+  EG_REQUIRE(m->targets.count(target), EG_ERR_RUNTIME, "%s is not a target of the model", target);
+  EG_REQUIRE(batch_size > 0, EG_ERR_INVALID, "batch size must be positive");
+  struct Column {
+    BoundInput* in;
+    const float* data;
+    bool device;
+    long rows, row_floats;
+    std::vector<long> batch_shape;
+  };
+  eg_model_clear_inputs(m);  // only the arguments of this call are bound (model.nim:438-447)
+  std::vector<Column> cols((size_t)n_inputs);
+  for (int i = 0; i < n_inputs; ++i) {
+    EG_REQUIRE(names[i], EG_ERR_INVALID, "NULL input name");
+    auto it = m->prog.inputs.find(names[i]);
+    EG_REQUIRE(it != m->prog.inputs.end(), EG_ERR_RUNTIME, "%s is not an input to the model", names[i]);
+    EG_REQUIRE(ranks[i] >= 1 && ranks[i] <= 8, EG_ERR_INVALID, "input %s needs a leading batch dimension", names[i]);
+    Column& c = cols[(size_t)i];
+    c.in = &m->inputs[it->second];
+    c.data = data[i];
+    c.device = on_device[i] != 0;
+    c.rows = shapes8[i * 8];
+    c.row_floats = 1;
+    c.batch_shape.assign(1, (long)batch_size);
+    for (int d = 1; d < ranks[i]; ++d) {
+      EG_REQUIRE(shapes8[i * 8 + d] >= 0, EG_ERR_INVALID, "negative extent");
+      c.row_floats *= shapes8[i * 8 + d];
+      c.batch_shape.push_back(shapes8[i * 8 + d]);
+    }
+    EG_REQUIRE(c.data || c.rows * c.row_floats == 0, EG_ERR_INVALID, "NULL data for input %s", names[i]);
+  }
+  const long batch_count = cols[0].rows / batch_size;  // model.nim:434: the ragged tail is dropped
+  for (auto& c : cols)
+    EG_REQUIRE(c.rows >= batch_count * batch_size, EG_ERR_SHAPE, "an input has fewer rows (%ld) than the first one uses (%ld)",
+               c.rows, batch_count * (long)batch_size);
+  m->epoch += 1;  // model.nim:436
+  if (batch_count == 0) return EG_OK;
+  int rc = eg::set_device(m->ctx);
+  if (rc) return rc;
+  hipStream_t stream = m->ctx->stream;
+
+  // ---- staging buffers of one batch (what the captured kernels read)
+  for (auto& c : cols) {
+    BoundInput& b = *c.in;
+    const long count = batch_size * c.row_floats;
+    if (b.owned_count < count || !b.owned) {
+      EG_HIP_CHECK(hipStreamSynchronize(stream));
+      if (b.owned) EG_HIP_CHECK(hipFree(b.owned));
+      b.owned = nullptr;
+      b.owned_count = 0;
+      EG_HIP_CHECK(hipMalloc((void**)&b.owned, (size_t)(count > 0 ? count : 1) * sizeof(float)));
+      b.owned_count = count;
+    }
+    b.device = b.owned;
+    b.shape = c.batch_shape;
+    b.bound = true;
+  }
+
+  // ---- device copy of the host columns: as many batches per segment as fit, uploaded piecewise
+  size_t host_row_bytes = 0;
+  for (auto& c : cols)
+    if (!c.device) host_row_bytes += (size_t)c.row_floats * sizeof(float);
+  long seg_batches = batch_count, piece_batches = batch_count;
+  if (host_row_bytes > 0) {
+    size_t free_b = 0, total_b = 0;
+    EG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    size_t have = 0;
+    for (size_t v : m->fit_bytes) have += v;
+    size_t budget = (free_b + have) / 2, piece_bytes = 8u << 20;  // ~8 MiB per upload
+    if (const char* e = getenv("EG_FIT_SEGMENT_BYTES")) budget = std::min<size_t>(budget, strtoull(e, nullptr, 10));
+    if (const char* e = getenv("EG_FIT_PIECE_BYTES")) piece_bytes = strtoull(e, nullptr, 10);
+    const size_t batch_bytes = host_row_bytes * (size_t)batch_size;
+    EG_REQUIRE(batch_bytes <= budget, EG_ERR_SIZE, "one batch (%zu bytes) does not fit the device", batch_bytes);
+    seg_batches = std::min<long>(batch_count, (long)(budget / batch_bytes));
+    piece_batches = std::max<long>(1, (long)(piece_bytes / batch_bytes));
+    if (!m->copy_stream) EG_HIP_CHECK(hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking));
+    if (!m->copy_event) EG_HIP_CHECK(hipEventCreateWithFlags(&m->copy_event, hipEventDisableTiming));
+    if (!m->main_event) EG_HIP_CHECK(hipEventCreateWithFlags(&m->main_event, hipEventDisableTiming));
+    m->fit_data.resize(8, nullptr);
+    m->fit_bytes.resize(8, 0);
+    for (int i = 0; i < n_inputs; ++i) {
+      Column& c = cols[(size_t)i];
+      if (c.device) continue;
+      const size_t need = (size_t)seg_batches * batch_size * c.row_floats * sizeof(float);
+      if (m->fit_bytes[i] < need) {
+        EG_HIP_CHECK(hipStreamSynchronize(stream));
+        if (m->fit_data[i]) EG_HIP_CHECK(hipFree(m->fit_data[i]));
+        m->fit_data[i] = nullptr;
+        m->fit_bytes[i] = 0;
+        EG_HIP_CHECK(hipMalloc((void**)&m->fit_data[i], need ? need : 4));
+        m->fit_bytes[i] = need;
+      }
+    }
+  }
+
+  TargetState* ts = nullptr;
+  Plan* plan = nullptr;
+  for (long seg = 0; seg < batch_count; seg += seg_batches) {
+    const long seg_end = std::min(batch_count, seg + seg_batches);
+    // the segment buffer is about to be overwritten: the batches that read it must be done — the ones
+    // of the previous segment, and (seg == 0) the ones a previous fit call left queued: this call
+    // returns once its uploads are complete, not its kernels, so the next call's first upload would
+    // otherwise land in rows that pending batches still read.  The copy stream waits; the host does not.
+    if (host_row_bytes > 0) {
+      EG_HIP_CHECK(hipEventRecord(m->main_event, stream));
+      EG_HIP_CHECK(hipStreamWaitEvent(m->copy_stream, m->main_event, 0));
+    }
+    for (long piece = seg; piece < seg_end; piece += piece_batches) {
+      const long piece_end = std::min(seg_end, piece + piece_batches);
+      if (host_row_bytes > 0) {
+        for (int i = 0; i < n_inputs; ++i) {
+          Column& c = cols[(size_t)i];
+          if (c.device) continue;
+          const size_t off = (size_t)(piece - seg) * batch_size * c.row_floats;
+          const size_t count = (size_t)(piece_end - piece) * batch_size * c.row_floats;
+          if (count)
+            EG_HIP_CHECK(hipMemcpyAsync(m->fit_data[i] + off, c.data + (size_t)piece * batch_size * c.row_floats,
+                                        count * sizeof(float), hipMemcpyHostToDevice, m->copy_stream));
+        }
+        EG_HIP_CHECK(hipEventRecord(m->copy_event, m->copy_stream));
+        EG_HIP_CHECK(hipStreamWaitEvent(stream, m->copy_event, 0));
+      }
+      for (long b = piece; b < piece_end; ++b) {
+        eg::CopySegments cs;
+        cs.n = n_inputs;
+        for (int i = 0; i < n_inputs; ++i) {
+          Column& c = cols[(size_t)i];
+          const float* base = c.device ? c.data + (size_t)b * batch_size * c.row_floats
+                                       : m->fit_data[i] + (size_t)(b - seg) * batch_size * c.row_floats;
+          cs.src[i] = base;
+          cs.dst[i] = c.in->owned;
+          cs.count[i] = batch_size * c.row_floats;
+        }
+        rc = eg::copy_segments(m->ctx, cs);
+        if (rc) return rc;
+        if (!plan) {
+          rc = get_plan(m, target, &ts, &plan);
+          if (rc) return rc;
+        }
+        rc = run_range(m, *ts, *plan, 0, (int)plan->launches.size(), true, 0);
+        if (rc) return rc;
+      }
+    }
+  }
+  // the caller may reuse its host arrays: the uploads (not the kernels) are complete on return
+  if (host_row_bytes > 0) EG_HIP_CHECK(hipStreamSynchronize(m->copy_stream));
+  return EG_OK;
+}
+EG_CATCH_ALL
+
+}  // extern "C"

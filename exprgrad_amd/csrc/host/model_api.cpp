@@ -1,0 +1,458 @@
+// Group 3 of the C ABI: compile a kernel-description program for the GPU and run its targets.
+//
+// What this replaces in the reference (for a CompileGpu target):
+//   newModel             model.nim:215-251   passes + parameter allocation + kernel build
+//   allocShapes (gpu)    model.nim:302-318   result tensors (re)allocated and zero-filled per call
+//   flushStateTensors    model.nim:326-345   parameters live on the device (and, unlike the
+//                                            reference, device-side updates are what readers see)
+//   writeInput/readOutput model.nim:357-376
+//   call / apply         model.nim:392-411   infer shapes, run the target's kernel list in order
+//   runGpuKernel & co.   model.nim:148-172   one launch per lowered kernel
+//
+// Every live kernel of a target is matched against the hand-written library
+// (contraction -> eg_sgemm with the following bias kernel folded into its epilogue,
+// convolution -> eg_conv2_nhwc, gradLoss seed -> eg_fill_f32); everything else gets generated
+// HIP source (codegen.hpp) built once with hiprtc.  A plan (shapes, launch arguments, result
+// arena) is cached per input-shape signature — the reference re-solves shapes on every call
+// (passes.nim:1386-1436).
+#include <random>
+#include "model_types.hpp"
+
+using namespace eg::kd;
+using namespace eg::model;
+using eg::set_error;
+
+
+extern "C" {
+
+int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out) try {
+  EG_REQUIRE(ctx && program_text && out, EG_ERR_INVALID, "eg_model_compile: NULL argument");
+  std::unique_ptr<eg_model> m(new eg_model());
+  m->ctx = ctx;
+  m->source_text = program_text;
+  int rc = parse(program_text, m->prog);
+  if (rc) return rc;
+  rc = compile_program(m->prog);
+  if (rc) return rc;
+  rc = eg::set_device(ctx);
+  if (rc) return rc;
+  // parameters: uniform in initRange (model.nim:241-247); deterministic here, tests overwrite them
+  std::mt19937 rng(10);
+  for (size_t tid = 1; tid < m->prog.tensors.size(); ++tid) {
+    const TensorDef& d = m->prog.tensors[tid];
+    // caches (model.nim:248-249: zero tensors) live next to the parameters: same lifetime, same access
+    if (d.kind != TK::Param && d.kind != TK::Cache) continue;
+    DevTensor dt;
+    dt.shape = d.shape;
+    dt.count = prod(d.shape);
+    if (dt.count > 0) {
+      EG_HIP_CHECK(hipMalloc((void**)&dt.ptr, (size_t)dt.count * sizeof(float)));
+      std::vector<float> host(dt.count);
+      std::uniform_real_distribution<float> dist((float)d.lo, (float)d.hi);
+      for (auto& v : host) v = d.kind == TK::Cache ? 0.0f : (d.hi > d.lo ? dist(rng) : (float)d.lo);
+      EG_HIP_CHECK(hipMemcpy(dt.ptr, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    m->params[(int)tid] = dt;
+  }
+  for (auto& t : m->prog.targets) {
+    TargetState& ts = m->targets[t.name];
+    ts.target = &t;
+    // gradient bucket: GenGradient destinations of parameters, in kernel-list order
+    long off = 0;
+    for (auto& k : t.source)
+      if (k.gen == Gen::Gradient && m->prog.tensors[k.gen_tensor].kind == TK::Param &&
+          !ts.bucket_offset.count(k.gen_dest)) {
+        ts.grad_tensors.push_back(k.gen_dest);
+        ts.bucket_offset[k.gen_dest] = off;
+        off += align4(prod(m->prog.tensors[k.gen_tensor].shape));
+      }
+    ts.bucket_floats = off;
+    if (off > 0) {
+      EG_HIP_CHECK(hipMalloc((void**)&ts.bucket, (size_t)off * sizeof(float)));
+      EG_HIP_CHECK(hipMemset(ts.bucket, 0, (size_t)off * sizeof(float)));
+      ts.bucket_owned = true;
+    }
+    rc = lower_target(m.get(), ts);
+    if (rc) return rc;
+  }
+  rc = build_pending(m.get());
+  if (rc) return rc;
+  describe(m.get());
+  *out = m.release();
+  return EG_OK;
+}
+EG_CATCH_ALL
+
+int eg_model_free(eg_model* m) try {
+  if (!m) return EG_OK;
+  hipSetDevice(m->ctx->device);
+  hipStreamSynchronize(m->ctx->stream);
+  for (auto& kv : m->targets) {
+    for (auto& p : kv.second.plans) {
+      for (auto& g : p.second->graphs)
+        if (g.exec) hipGraphExecDestroy(g.exec);
+      for (auto& rg : p.second->row_groups)
+        if (rg->partial) hipFree(rg->partial);
+      if (p.second->arena) hipFree(p.second->arena);
+    }
+    if (kv.second.bucket_owned && kv.second.bucket) hipFree(kv.second.bucket);
+  }
+  for (auto& p : m->params)
+    if (p.second.ptr) hipFree(p.second.ptr);
+  for (auto& in : m->inputs)
+    if (in.second.owned) hipFree(in.second.owned);
+  if (m->rng_state) hipFree(m->rng_state);
+  for (float* p : m->fit_data)
+    if (p) hipFree(p);
+  if (m->copy_event) hipEventDestroy(m->copy_event);
+  if (m->main_event) hipEventDestroy(m->main_event);
+  if (m->copy_stream) hipStreamDestroy(m->copy_stream);
+  for (eg_kernel* k : m->kernels) eg_kernel_free(k);
+  delete m;
+  return EG_OK;
+}
+EG_CATCH_ALL
+
+const char* eg_model_plan_text(eg_model* m) { return m ? m->plan_text.c_str() : ""; }
+
+const char* eg_model_launch_text(eg_model* m, const char* target) {
+  if (!m || !target) return "";
+  auto it = m->targets.find(target);
+  if (it == m->targets.end() || !it->second.last) return "";
+  TargetState& ts = it->second;
+  Plan& plan = *ts.last;
+  std::ostringstream os;
+  for (size_t i = 0; i < plan.launches.size(); ++i) {
+    const Launch& L = plan.launches[i];
+    if ((int)i == plan.n_backward) os << "-- update --\n";
+    os << "[" << i << "] ";
+    switch (L.kind) {
+      case StepKind::Seed: os << "seed-fill t" << L.c_tensor; break;
+      case StepKind::Gemm:
+      case StepKind::GemmFused:
+        os << (L.kind == StepKind::GemmFused ? "gemm+epilogue " : "gemm ") << (L.trans_a ? "T" : "N") << (L.trans_b ? "T" : "N")
+           << " " << L.M << "x" << L.N << "x" << L.K << " -> t" << L.c_tensor << (L.bias_tensor ? " +bias" : "")
+           << (L.accumulate ? " accumulate" : "");
+        if (L.kind == StepKind::GemmFused) {
+          const PlanEpilogue& pe = *plan.epilogues[L.epilogue];
+          os << " | consumer kernel " << pe.consumer.lowered << " operands";
+          for (int t : pe.spec.operands) os << " t" << t;
+        }
+        break;
+      case StepKind::Conv: os << "conv2 -> t" << L.c_tensor << (L.accumulate ? " accumulate" : ""); break;
+      case StepKind::ConvGradImage: os << "conv2-grad-image -> t" << L.c_tensor << (L.accumulate ? " accumulate" : ""); break;
+      case StepKind::ConvGradFilter: os << "conv2-grad-filter -> t" << L.c_tensor << (L.accumulate ? " accumulate" : ""); break;
+      case StepKind::GenericA:
+        os << "generated(map) kernel " << L.lowered << " -> t" << L.c_tensor;
+        if (L.consumer >= 0) os << " (with its consumer, kernel " << L.consumer << ")";
+        break;
+      case StepKind::GenericB: os << "generated(split-reduce) kernel " << L.lowered << " -> t" << L.c_tensor; break;
+      case StepKind::RowFused: {
+        const PlanRowGroup& pg = *plan.row_groups[L.row_group];
+        os << "row-fused " << pg.g.kernel_index.size() << " kernels";
+        break;
+      }
+      case StepKind::SmallFused: {
+        const PlanSmallGroup& sg = *plan.small_groups[L.row_group];
+        os << (sg.g.blocks > 1 ? "map-fused " : "small-fused ") << sg.g.kernel_index.size() << " kernels";
+        break;
+      }
+    }
+    for (auto& ov : plan.overlaps)
+      if ((int)i >= ov.first && (int)i < ov.big) os << "   || side lane, next to launch " << ov.big;
+    os << "\n";
+  }
+  m->launch_text = os.str();
+  return m->launch_text.c_str();
+}
+
+int eg_model_kernel_count(eg_model* m, const char* target) try {
+  if (!m || !target) return -1;
+  auto it = m->targets.find(target);
+  return it == m->targets.end() ? -1 : (int)it->second.target->live.size();
+}
+EG_CATCH_ALL
+
+int eg_model_tensor_count(eg_model* m) { return m ? (int)m->prog.tensors.size() - 1 : 0; }
+
+int eg_model_param_info(eg_model* m, int tensor_id, int* kind, int* rank, int64_t* shape8, char* name,
+                        size_t name_cap) try {
+  EG_REQUIRE(m && tensor_id >= 1 && tensor_id < (int)m->prog.tensors.size(), EG_ERR_INVALID, "bad tensor id %d", tensor_id);
+  const TensorDef& d = m->prog.tensors[tensor_id];
+  if (kind) *kind = (int)d.kind;
+  if (rank) *rank = d.has_shape ? (int)d.shape.size() : -1;
+  if (shape8)
+    for (size_t i = 0; i < d.shape.size() && i < 8; ++i) shape8[i] = d.shape[i];
+  if (name && name_cap) {
+    snprintf(name, name_cap, "%s", d.name.c_str());
+  }
+  return EG_OK;
+}
+EG_CATCH_ALL
+
+int eg_model_param_write(eg_model* m, int tensor_id, const float* host, int64_t count) try {
+  EG_REQUIRE(m && host, EG_ERR_INVALID, "eg_model_param_write: NULL argument");
+  auto it = m->params.find(tensor_id);
+  EG_REQUIRE(it != m->params.end(), EG_ERR_INVALID, "tensor %d is not a parameter", tensor_id);
+  EG_REQUIRE(count == it->second.count, EG_ERR_SIZE, "parameter %d has %ld elements, got %ld", tensor_id,
+             it->second.count, (long)count);
+  if (count == 0) return EG_OK;
+  EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+  EG_HIP_CHECK(hipMemcpyAsync(it->second.ptr, host, (size_t)count * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+  EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  return EG_OK;
+}
+EG_CATCH_ALL
+
+int eg_model_param_read(eg_model* m, int tensor_id, float* host, int64_t count) try {
+  EG_REQUIRE(m && host, EG_ERR_INVALID, "eg_model_param_read: NULL argument");
+  auto it = m->params.find(tensor_id);
+  EG_REQUIRE(it != m->params.end(), EG_ERR_INVALID, "tensor %d is not a parameter", tensor_id);
+  EG_REQUIRE(count == it->second.count, EG_ERR_SIZE, "parameter %d has %ld elements, got %ld", tensor_id,
+             it->second.count, (long)count);
+  if (count == 0) return EG_OK;
+  EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+  EG_HIP_CHECK(hipMemcpyAsync(host, it->second.ptr, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
+  EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  return EG_OK;
+}
+EG_CATCH_ALL
+
+int eg_model_param_ptr(eg_model* m, int tensor_id, float** device_ptr, int64_t* count) try {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  auto it = m->params.find(tensor_id);
+  EG_REQUIRE(it != m->params.end(), EG_ERR_INVALID, "tensor %d is not a parameter", tensor_id);
+  if (device_ptr) *device_ptr = it->second.ptr;
+  if (count) *count = it->second.count;
+  return EG_OK;
+}
+EG_CATCH_ALL
+
+int eg_model_grad_bucket(eg_model* m, const char* target, float** device_ptr, int64_t* count) try {
+  EG_REQUIRE(m && target, EG_ERR_INVALID, "NULL argument");
+  auto it = m->targets.find(target);
+  EG_REQUIRE(it != m->targets.end(), EG_ERR_RUNTIME, "%s is not a target of the model", target);
+  if (device_ptr) *device_ptr = it->second.bucket;
+  if (count) *count = it->second.bucket_floats;
+  return EG_OK;
+}
+EG_CATCH_ALL
+
+int eg_model_bind_grad_bucket(eg_model* m, const char* target, float* device_ptr, int64_t count) try {
+  EG_REQUIRE(m && target && device_ptr, EG_ERR_INVALID, "NULL argument");
+  auto it = m->targets.find(target);
+  EG_REQUIRE(it != m->targets.end(), EG_ERR_RUNTIME, "%s is not a target of the model", target);
+  TargetState& ts = it->second;
+  EG_REQUIRE(count >= ts.bucket_floats, EG_ERR_SIZE, "gradient bucket needs %ld floats, got %ld", ts.bucket_floats,
+             (long)count);
+  EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+  EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  if (ts.bucket_owned && ts.bucket) hipFree(ts.bucket);
+  ts.bucket = device_ptr;
+  ts.bucket_owned = false;
+  return EG_OK;
+}
+EG_CATCH_ALL
+
+static int bind_input(eg_model* m, const char* name, const float* device, const float* host, int rank,
+                      const int64_t* shape) {
+  EG_REQUIRE(m && name, EG_ERR_INVALID, "NULL argument");
+  auto it = m->prog.inputs.find(name);
+  // model.nim:358-359
+  EG_REQUIRE(it != m->prog.inputs.end(), EG_ERR_RUNTIME, "%s is not an input to the model", name);
+  EG_REQUIRE(rank >= 0 && rank <= 8 && (rank == 0 || shape), EG_ERR_INVALID, "bad input rank");
+  BoundInput& b = m->inputs[it->second];
+  b.bound = true;
+  b.shape.assign(shape, shape + rank);
+  const long count = prod(b.shape);
+  if (host) {
+    EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+    if (b.owned_count < count) {
+      EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+      if (b.owned) EG_HIP_CHECK(hipFree(b.owned));
+      b.owned = nullptr;
+      b.owned_count = 0;
+      EG_HIP_CHECK(hipMalloc((void**)&b.owned, (size_t)(count > 0 ? count : 1) * sizeof(float)));
+      b.owned_count = count;
+    }
+    if (count > 0) {
+      // blocking H2D on every call, as the reference does (model.nim:364-368 -> cl.nim:111-116)
+      EG_HIP_CHECK(hipMemcpyAsync(b.owned, host, (size_t)count * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
+      EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    }
+    b.device = b.owned;
+  } else {
+    EG_REQUIRE(device || count == 0, EG_ERR_INVALID, "NULL device pointer for input %s", name);
+    b.device = device;
+  }
+  return EG_OK;
+}
+
+int eg_model_set_input_host(eg_model* m, const char* name, const float* host, int rank, const int64_t* shape) try {
+  EG_REQUIRE(host || rank == 0, EG_ERR_INVALID, "NULL host pointer");
+  static const float dummy = 0;
+  return bind_input(m, name, nullptr, host ? host : &dummy, rank, shape);
+}
+EG_CATCH_ALL
+
+int eg_model_set_input_device(eg_model* m, const char* name, const float* device_ptr, int rank, const int64_t* shape) try {
+  return bind_input(m, name, device_ptr, nullptr, rank, shape);
+}
+EG_CATCH_ALL
+
+int eg_model_clear_inputs(eg_model* m) try {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  // Host-staged inputs keep their staging buffer (reused by the next host bind); only the
+  // bindings are forgotten.  No synchronisation: nothing is freed.
+  for (auto it = m->inputs.begin(); it != m->inputs.end();) {
+    if (it->second.owned) {
+      it->second.device = nullptr;
+      it->second.shape.clear();
+      it->second.bound = false;
+      ++it;
+    } else {
+      it = m->inputs.erase(it);
+    }
+  }
+  return EG_OK;
+}
+EG_CATCH_ALL
+
+int eg_model_run(eg_model* m, const char* target) try {
+  TargetState* ts;
+  Plan* plan;
+  int rc = get_plan(m, target, &ts, &plan);
+  if (rc) return rc;
+  return run_range(m, *ts, *plan, 0, (int)plan->launches.size(), true, 0);
+}
+EG_CATCH_ALL
+
+int eg_model_run_backward(eg_model* m, const char* target) try {
+  TargetState* ts;
+  Plan* plan;
+  int rc = get_plan(m, target, &ts, &plan);
+  if (rc) return rc;
+  return run_range(m, *ts, *plan, 0, plan->n_backward, true, 1);
+}
+EG_CATCH_ALL
+
+int eg_model_run_update(eg_model* m, const char* target) try {
+  TargetState* ts;
+  Plan* plan;
+  int rc = get_plan(m, target, &ts, &plan);
+  if (rc) return rc;
+  return run_range(m, *ts, *plan, plan->n_backward, (int)plan->launches.size(), false, 2);
+}
+EG_CATCH_ALL
+
+int eg_model_set_grad_scale(eg_model* m, float scale) try {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  m->grad_scale = scale;
+  return EG_OK;
+}
+EG_CATCH_ALL
+
+static int find_tensor(eg_model* m, const char* target, int* tid, TargetState** ts) {
+  auto it = m->targets.find(target);
+  EG_REQUIRE(it != m->targets.end(), EG_ERR_RUNTIME, "%s is not a target of the model", target);
+  *ts = &it->second;
+  *tid = it->second.target->output;
+  EG_REQUIRE(*tid != 0, EG_ERR_INVALID, "target %s has no output tensor", target);
+  EG_REQUIRE(it->second.last, EG_ERR_INVALID, "target %s has not been run", target);
+  return EG_OK;
+}
+
+static int tensor_shape(eg_model* m, TargetState& ts, int tid, int* rank, int64_t* shape8) {
+  EG_REQUIRE(ts.last, EG_ERR_INVALID, "the target has not been run");
+  auto s = ts.last->shapes.find(tid);
+  EG_REQUIRE(s != ts.last->shapes.end(), EG_ERR_INVALID, "tensor %d has no shape in the last run", tid);
+  if (rank) *rank = (int)s->second.size();
+  if (shape8)
+    for (size_t i = 0; i < s->second.size() && i < 8; ++i) shape8[i] = s->second[i];
+  return EG_OK;
+}
+
+static int read_tensor(eg_model* m, TargetState& ts, int tid, float* host, int64_t count) {
+  EG_REQUIRE(ts.last && host, EG_ERR_INVALID, "nothing to read");
+  auto s = ts.last->shapes.find(tid);
+  EG_REQUIRE(s != ts.last->shapes.end(), EG_ERR_INVALID, "tensor %d has no shape in the last run", tid);
+  const long n = prod(s->second);
+  EG_REQUIRE(count == n, EG_ERR_SIZE, "Buffer size is not equal to target size (%ld vs %ld)", n, (long)count);
+  if (n == 0) return EG_OK;
+  float* p = tensor_ptr(m, ts, *ts.last, tid);
+  EG_REQUIRE(p, EG_ERR_INVALID, "tensor %d was not materialised by the last run", tid);
+  EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+  EG_HIP_CHECK(hipMemcpyAsync(host, p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
+  EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+  return EG_OK;
+}
+
+int eg_model_output_shape(eg_model* m, const char* target, int* rank, int64_t* shape8) try {
+  EG_REQUIRE(m && target, EG_ERR_INVALID, "NULL argument");
+  int tid;
+  TargetState* ts;
+  int rc = find_tensor(m, target, &tid, &ts);
+  if (rc) return rc;
+  return tensor_shape(m, *ts, tid, rank, shape8);
+}
+EG_CATCH_ALL
+
+int eg_model_read_output(eg_model* m, const char* target, float* host, int64_t count) try {
+  EG_REQUIRE(m && target, EG_ERR_INVALID, "NULL argument");
+  int tid;
+  TargetState* ts;
+  int rc = find_tensor(m, target, &tid, &ts);
+  if (rc) return rc;
+  return read_tensor(m, *ts, tid, host, count);
+}
+EG_CATCH_ALL
+
+static TargetState* last_target(eg_model* m, const char* target) {
+  auto it = m->targets.find(target ? target : "");
+  return it == m->targets.end() ? nullptr : &it->second;
+}
+
+int eg_model_tensor_shape(eg_model* m, const char* target, int tensor_id, int* rank, int64_t* shape8) try {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  TargetState* ts = last_target(m, target);
+  EG_REQUIRE(ts, EG_ERR_RUNTIME, "%s is not a target of the model", target ? target : "(null)");
+  return tensor_shape(m, *ts, tensor_id, rank, shape8);
+}
+EG_CATCH_ALL
+
+int eg_model_read_tensor(eg_model* m, const char* target, int tensor_id, float* host, int64_t count) try {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  TargetState* ts = last_target(m, target);
+  EG_REQUIRE(ts, EG_ERR_RUNTIME, "%s is not a target of the model", target ? target : "(null)");
+  return read_tensor(m, *ts, tensor_id, host, count);
+}
+EG_CATCH_ALL
+
+int eg_model_tensor_ptr(eg_model* m, const char* target, int tensor_id, float** device_ptr, int64_t* count) try {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  TargetState* ts = last_target(m, target);
+  EG_REQUIRE(ts && ts->last, EG_ERR_RUNTIME, "target has not been run");
+  auto s = ts->last->shapes.find(tensor_id);
+  EG_REQUIRE(s != ts->last->shapes.end(), EG_ERR_INVALID, "tensor %d has no shape in the last run", tensor_id);
+  if (device_ptr) *device_ptr = tensor_ptr(m, *ts, *ts->last, tensor_id);
+  if (count) *count = prod(s->second);
+  return EG_OK;
+}
+EG_CATCH_ALL
+
+int eg_model_set_epoch(eg_model* m, int64_t epoch) try {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  m->epoch = epoch;
+  return EG_OK;
+}
+EG_CATCH_ALL
+
+int64_t eg_model_epoch(eg_model* m) { return m ? m->epoch : 0; }
+
+int eg_model_set_seed(eg_model* m, uint64_t seed) try {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  return ensure_rng(m, seed, true);
+}
+EG_CATCH_ALL
+
+}  // extern "C"

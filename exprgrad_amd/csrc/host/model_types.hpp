@@ -1,0 +1,297 @@
+// Types and internal interfaces of the model layer (group 3 of the C ABI), shared by its translation
+// units:
+//   match.cpp          library patterns (contraction, bias, convolution and its gradients)
+//   lower.cpp          static lowering of a target, inlining, generated sources
+//   plan.cpp           per-shape plans: launch list, overwrite / accumulate, arena   (+ plan_check.cpp)
+//   plan_groups.cpp    row / small / map fusion groups
+//   plan_epilogue.cpp  contraction + consumer epilogues
+//   plan_overlap.cpp   side-lane groups
+//   run.cpp            launches, HIP graphs
+//   fit.cpp            eg_model_fit
+//   serialize.cpp      eg_model_save / eg_model_load (io/serialize.nim layout)
+//   model_api.cpp      the remaining extern "C" entry points
+#pragma once
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../eg_internal.hpp"
+#include "../kernels/gemm_fused.hpp"
+#include "codegen.hpp"
+#include "epilogue.hpp"
+#include "kd.hpp"
+#include "rowfuse.hpp"
+
+namespace eg {
+namespace model {
+
+using namespace eg::kd;
+using eg::set_error;
+
+struct GemmMatch {
+  int a_read = 0, b_read = 0;  // indices into k.reads
+  bool trans_a = false, trans_b = false;
+  int li = 0, lj = 0, lk = 0;  // loop indices of m, n, k
+};
+
+struct ConvMatch {
+  // which operand plays which part: -1 = the written tensor, 0 / 1 = k.reads[i]
+  int out_op = -1, img_op = 0, flt_op = 1;
+  bool batched = true;
+  enum Role { Forward, GradImage, GradFilter } role = Forward;
+};
+
+enum class StepKind { Gemm, Conv, ConvGradImage, ConvGradFilter, Seed, GenericA, GenericB, RowFused, SmallFused, GemmFused };
+
+struct Generic {
+  GenericSource src;
+  eg_kernel* handle = nullptr;
+};
+
+// Static (shape independent) lowering decision for one live kernel.
+struct Lowered {
+  StepKind kind = StepKind::GenericA;
+  int all_index = 0;  // index into target.all
+  GemmMatch gemm;
+  int bias_tensor = 0;  // fused bias (0 = none)
+  bool absorbed = false;  // this kernel was folded into the previous step
+  bool inlined = false;   // an elementwise producer recomputed inside its consumers: never launched, never stored
+  // Consumer inlining (inline_consumers): this kernel with the elementwise kernel at live position
+  // `consumer` applied to every value before it is stored; used by a plan when the shapes allow it.
+  int consumer = -1;
+  std::unique_ptr<Kernel> with_consumer;
+  Generic with_consumer_code;
+  ConvMatch conv;
+  Generic mode_a;
+  std::map<int, Generic> mode_b;  // by tx
+  bool b_capable = false;
+};
+
+// Concrete launch for one plan.
+struct Launch {
+  int lowered = 0;
+  StepKind kind = StepKind::GenericA;
+  bool accumulate = true;
+  // Gemm / Conv
+  long M = 0, N = 0, K = 0, lda = 0, ldb = 0, ldc = 0;
+  int a_tensor = 0, b_tensor = 0, c_tensor = 0, bias_tensor = 0;
+  bool trans_a = false, trans_b = false;
+  long cN = 0, cH = 0, cW = 0, cC = 0, cF = 0, cFH = 0, cFW = 0;
+  // Seed
+  long count = 0;
+  // Generic
+  Generic* generic = nullptr;
+  std::vector<long> params;
+  long blocks_x = 1, blocks_y = 1;
+  long partial_rows = 0, partial_cols = 0;  // mode B second stage
+  std::vector<int> epoch_slots;             // params refreshed from Model.epoch at every launch
+  int row_group = -1;                       // RowFused: index into Plan::row_groups
+  int epilogue = -1;                        // GemmFused: index into Plan::epilogues
+  int consumer = -1;                        // GenericA: live position of the elementwise consumer folded into it
+  int vec_slot = -1;                        // GenericA: index of the Slot::Vec4 argument, if the kernel has one
+  bool vec_ok = false;                      //   the shapes allow four elements per thread (pointers are checked per launch)
+  long total_items = 0;                     //   independent iterations (grid = items or items / 4)
+};
+
+// A run of per-sample kernels fused into one generated kernel (rowfuse.hpp), built per plan.
+struct PlanRowGroup {
+  RowGroup g;
+  eg_kernel* handle = nullptr;
+  float* partial = nullptr;  // [nblocks][g.red_total]
+  int nblocks = 0;
+  std::vector<int> red_tensors;  // reduction destinations, in segment order
+};
+
+// A run of small-tensor kernels (optimizer updates) fused into one single-block kernel.
+struct PlanSmallGroup {
+  SmallGroup g;
+  eg_kernel* handle = nullptr;
+};
+
+// A contraction whose elementwise consumer runs as its epilogue (epilogue.hpp), built per plan.
+struct PlanEpilogue {
+  EpilogueSpec spec;
+  Launch consumer;                          // the consumer as its own launch (split-K fallback)
+  std::map<std::string, eg_kernel*> built;  // by template variant (tile shape, alignment class)
+};
+
+struct DevTensor {
+  float* ptr = nullptr;
+  long count = 0;
+  std::vector<long> shape;
+};
+
+struct Plan {
+  std::string key;
+  Shapes shapes;
+  std::vector<Launch> launches;
+  int n_backward = 0;  // launches before the first parameter update
+  // Result tensors that are a whole-tensor raw copy of another tensor (reshape, passes.nim:643-688,
+  // and the gradient of one) share its storage instead of being copied: dest -> source.
+  std::map<int, int> alias;
+  std::vector<int> random_tensors;   // TensorRandom tensors the live kernels read: refilled on every run
+  std::map<int, long> arena_offset;  // result tensor -> float offset in the arena
+  long arena_floats = 0;
+  long zero_floats = 0;  // leading part of the arena that is zeroed before every run
+  std::vector<int> bucket_zero;  // gradient-bucket tensors that need zeroing
+  float* arena = nullptr;
+  // The launch sequence of a range (whole call / backward part / update part) is captured into a
+  // HIP graph on its second execution and replayed afterwards: the small-batch targets are
+  // launch-latency bound (19 kernels for the XOR step), a replay costs one submission.
+  std::vector<std::unique_ptr<PlanRowGroup>> row_groups;
+  std::vector<std::unique_ptr<PlanSmallGroup>> small_groups;
+  std::vector<std::unique_ptr<PlanEpilogue>> epilogues;
+  // generated kernels of this plan waiting for the one hiprtc program make_plan builds at its end
+  struct PendingKernel {
+    std::string name, source;
+    eg_kernel** slot;
+  };
+  std::vector<PendingKernel> pending;
+  // Overlap groups (plan_overlap): launches [first, big) run on the context's side lane while the
+  // long contraction `big` runs on the main stream; both are joined before launch big + 1.
+  struct Overlap {
+    int first = 0, big = 0;
+  };
+  std::vector<Overlap> overlaps;
+  struct Captured {
+    hipGraphExec_t exec = nullptr;
+    std::string key;  // everything baked into the captured kernel arguments
+    int runs = 0;
+  };
+  Captured graphs[3];
+};
+
+struct TargetState {
+  Target* target = nullptr;
+  std::vector<Lowered> lowered;  // parallel to target->live
+  std::map<std::string, std::unique_ptr<Plan>> plans;
+  Plan* last = nullptr;
+  // parameter gradients of this target, laid out back to back (data-parallel exchange bucket)
+  std::vector<int> grad_tensors;       // tensor ids (GenGradient destinations of parameters)
+  std::map<int, long> bucket_offset;   // tensor id -> float offset
+  long bucket_floats = 0;
+  float* bucket = nullptr;
+  bool bucket_owned = false;
+};
+
+struct BoundInput {
+  const float* device = nullptr;
+  std::vector<long> shape;
+  float* owned = nullptr;  // staging copy of a host input
+  long owned_count = 0;
+  bool bound = false;
+};
+
+}  // namespace model
+}  // namespace eg
+
+struct eg_model {
+  eg_ctx* ctx = nullptr;
+  eg::kd::Program prog;
+  std::map<std::string, eg::model::TargetState> targets;
+  std::map<int, eg::model::DevTensor> params;  // device-resident parameters (model.params)
+  std::map<int, eg::model::BoundInput> inputs;
+  float grad_scale = 1.0f;
+  long epoch = 0;
+  int kernel_serial = 0;
+  std::string source_text;  // the kernel-description text this model was compiled from (eg_model_save)
+  std::string plan_text;
+  std::string launch_text;
+  std::vector<eg::model::Generic*> pending;  // generated kernels not built yet (eg_model_compile builds them together)
+  uint64_t* rng_state = nullptr;  // device: {seed, fills drawn so far} for the TensorRandom tensors (eg_fill_uniform)
+  std::vector<eg_kernel*> kernels;
+  // eg_model_fit: the data set's device copy (one buffer per input, grown on demand), uploaded on its own stream
+  std::vector<float*> fit_data;
+  std::vector<size_t> fit_bytes;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t copy_event = nullptr;
+  hipEvent_t main_event = nullptr;  // recorded on the context's stream: "the batches queued so far are done"
+};
+
+namespace eg {
+namespace model {
+
+inline long prod(const std::vector<long>& s) {
+  long p = 1;
+  for (long v : s) p *= v;
+  return p;
+}
+
+inline long align4(long n) { return (n + 3) & ~3L; }
+
+
+// While alive, the context's stream and scratch blocks are the side lane's.
+struct LaneSwap {
+  eg_ctx* c;
+  explicit LaneSwap(eg_ctx* ctx) : c(ctx) { swap(); }
+  ~LaneSwap() { swap(); }
+  void swap() {
+    std::swap(c->stream, c->side_stream);
+    std::swap(c->workspace, c->side_workspace);
+    std::swap(c->workspace_bytes, c->side_workspace_bytes);
+    std::swap(c->aux, c->side_aux);
+    std::swap(c->aux_bytes, c->side_aux_bytes);
+  }
+};
+
+// match.cpp
+bool bare2(const Op& op, int& r0, int& r1);
+int loop_index(const Kernel& k, int reg);
+bool match_gemm(const Kernel& k, GemmMatch& m);
+bool match_bias(const Kernel& k, int tensor);
+bool match_conv(const Kernel& k, ConvMatch& m);
+// lower.cpp
+int build_generic(eg_model* m, Generic& g);
+void inline_producers(eg_model* m, TargetState& ts);
+void inline_consumers(eg_model* m, TargetState& ts);
+int lower_target(eg_model* m, TargetState& ts);
+int build_pending(eg_model* m);
+void describe(eg_model* m);
+// plan_groups.cpp
+int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos, const std::map<int, int>& first_writer, std::vector<int>& group_of);
+// plan_overlap.cpp
+int ensure_side_lane(eg_ctx* ctx);
+bool launch_tensors(const Plan& plan, const Launch& L, std::set<int>& reads, std::set<int>& writes);
+void plan_overlap(eg_model* m, TargetState& ts, Plan& plan);
+// plan_epilogue.cpp
+int fuse_epilogues(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos);
+// plan.cpp
+int build_plan_kernels(eg_model* m, Plan& plan);
+float* tensor_ptr(eg_model* m, TargetState& ts, Plan& plan, int tid);
+bool full_cover(const Kernel& k, const KernelInfo& info, const std::vector<long>& shape);
+void note_vec4(Launch& L, long total);
+int fill_params(eg_model* m, const Kernel& k, const KernelInfo& info, const Shapes& shapes, const GenericSource& src, bool accumulate, long total, long rtotal, long chunk, std::vector<long>& out);
+std::string shape_key(eg_model* m);
+bool copy_can_alias(eg_model* m, TargetState& ts, const Kernel& k, const KernelInfo& info, const Shapes& shapes, int p);
+int make_plan(eg_model* m, TargetState& ts, Plan& plan);
+int get_plan(eg_model* m, const char* target, TargetState** ts_out, Plan** plan_out);
+// run.cpp
+int ensure_rng(eg_model* m, uint64_t seed = 0x5eed5eed5eed5eedULL, bool reseed = false);
+int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L);
+int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero);
+bool graphs_enabled();
+int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero, int slot);
+// plan_check.cpp: invariants of a finished plan (read / write sets against the kernel list, arena
+// layout, overlap groups).  Returns EG_OK or EG_ERR_RUNTIME with the violated invariant named.
+int check_plan(eg_model* m, TargetState& ts, Plan& plan);
+
+}  // namespace model
+}  // namespace eg
+
+// ---- helpers implemented next to the group-1 / group-2 code ------------------------------------
+// No C++ exception may cross the C ABI (std::bad_alloc, a failed .at() on a malformed program):
+// every entry point that touches the STL turns it into a status + eg_last_error().
+#define EG_CATCH_ALL                                           \
+  catch (const std::exception& e) {                            \
+    eg::set_error("internal error: %s", e.what());             \
+    return EG_ERR_RUNTIME;                                     \
+  }                                                            \
+  catch (...) {                                                \
+    eg::set_error("internal error");                           \
+    return EG_ERR_RUNTIME;                                     \
+  }

@@ -1,0 +1,298 @@
+// Fusion groups of a plan: row groups (rowfuse.hpp), small-kernel groups, map groups.
+#include "model_types.hpp"
+
+
+namespace eg {
+namespace model {
+
+bool row_fusion_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("EG_NO_ROWFUSE");
+    return !(e && e[0] && e[0] != '0');
+  }();
+  return on;
+}
+
+// Partition the live kernel list into row groups (rowfuse.hpp) and build their kernels.
+// group_of[p] = index into plan.row_groups, or -1 for kernels that keep their own launch.
+int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos,
+                    const std::map<int, int>& first_writer, std::vector<int>& group_of) {
+  Target& t = *ts.target;
+  const Shapes& shapes = plan.shapes;
+  if (!row_fusion_enabled()) return EG_OK;
+  long B = 0;
+  for (auto& in : m->inputs)
+    if (in.second.bound && !in.second.shape.empty()) {
+      B = in.second.shape[0];
+      break;
+    }
+  if (B <= 0) return EG_OK;
+  const int n = (int)t.live.size();
+  std::vector<RowKernelInfo> rki(n);
+  for (int p = 0; p < n; ++p) rki[p] = analyse_row_kernel(m->prog, t.all[t.live[p]], infos[t.live[p]], shapes, B);
+  // a bias folded into a library contraction is not available on its own
+  for (int p = 1; p < n; ++p)
+    if (ts.lowered[p].absorbed && !rki[p - 1].ok) rki[p].ok = false;
+
+  constexpr long LOCAL_BUDGET = 192;  // floats of per-thread state
+  constexpr long RED_MAX = 512;
+  int p = 0;
+  while (p < n) {
+    if (!rki[p].ok) {
+      ++p;
+      continue;
+    }
+    // grow a group from p
+    std::unique_ptr<PlanRowGroup> pg(new PlanRowGroup());
+    RowGroup& g = pg->g;
+    g.B = B;
+    int q = p;
+    int row_kernels = 0;
+    while (q < n && rki[q].ok && !(q != p && q == t.first_update) && !(p < t.first_update && q >= t.first_update && t.first_update >= 0)) {
+      const Kernel& k = t.all[t.live[q]];
+      const RowKernelInfo& ri = rki[q];
+      // tentative roles with this kernel added
+      std::map<int, RowGroupTensor> roles = g.tensors;
+      bool ok = true;
+      const int yreg = ri.row_loop >= 0 ? k.loops[ri.row_loop].reg : 0;
+      auto op_is_row = [&](const Op& op) {
+        if (ri.row_loop < 0) return false;
+        for (auto& d : op.dims)
+          if (d.factor_of(yreg)) return true;
+        return false;
+      };
+      auto touch = [&](const Op& op, bool write) {
+        const std::vector<long>& shp = shapes.at(op.tensor);
+        auto it = roles.find(op.tensor);
+        RowGroupTensor gt;
+        if (it != roles.end()) gt = it->second;
+        gt.tensor = op.tensor;
+        if (op_is_row(op)) {
+          const long inner = prod(shp) / B;
+          if (it != roles.end() && gt.role != RowGroupTensor::RowLocal && gt.role != RowGroupTensor::RowExternal) ok = false;
+          gt.inner = inner;
+          if (write) gt.role = RowGroupTensor::RowLocal;
+          else if (it == roles.end()) gt.role = RowGroupTensor::RowExternal;
+        } else {
+          const long count = prod(shp);
+          if (it != roles.end() && (gt.role == RowGroupTensor::RowLocal || gt.role == RowGroupTensor::RowExternal)) ok = false;
+          gt.inner = count;
+          if (write) {
+            const RowGroupTensor::Role want = ri.small_only ? RowGroupTensor::SmallLocal : RowGroupTensor::Reduction;
+            if (it != roles.end() && gt.role != want && gt.role != RowGroupTensor::SmallExternal) ok = false;
+            if (it != roles.end() && gt.role == RowGroupTensor::SmallExternal) ok = false;  // read earlier in the group
+            gt.role = want;
+          } else {
+            if (it != roles.end() && gt.role == RowGroupTensor::Reduction) ok = false;  // needs the grid-wide total
+            if (it == roles.end()) gt.role = RowGroupTensor::SmallExternal;
+          }
+        }
+        roles[op.tensor] = gt;
+      };
+      for (auto& rd : k.reads) touch(rd, false);
+      touch(k.write, true);
+      if (ok && ri.small_only) {
+        // thread-local recomputation only: the tensor must not exist outside the group
+        const int wt = k.write.tensor;
+        auto fw = first_writer.find(wt);
+        if (fw == first_writer.end() || fw->second != q || wt == t.output) ok = false;
+      }
+      long locals = 0, reds = 0;
+      int segs = 0;
+      for (auto& kv : roles) {
+        if (kv.second.role == RowGroupTensor::RowLocal || kv.second.role == RowGroupTensor::SmallLocal) locals += kv.second.inner;
+        if (kv.second.role == RowGroupTensor::Reduction) {
+          locals += kv.second.inner;
+          reds += kv.second.inner;
+          ++segs;
+        }
+      }
+      if (locals > LOCAL_BUDGET || reds > RED_MAX || segs > 16) ok = false;
+      // a contraction keeps its folded bias in the same group
+      if (ok && q + 1 < n && ts.lowered[q + 1].absorbed && !rki[q + 1].ok) ok = false;
+      if (!ok) break;
+      g.tensors = roles;
+      g.kernel_index.push_back(t.live[q]);
+      g.infos.push_back(ri);
+      if (!ri.small_only) ++row_kernels;
+      ++q;
+    }
+    // an absorbed bias must not be split from its contraction by the end of the group
+    while (q > p && q < n && ts.lowered[q].absorbed) {
+      --q;
+      g.kernel_index.pop_back();
+      g.infos.pop_back();
+    }
+    row_kernels = 0;
+    for (auto& ri : g.infos)
+      if (!ri.small_only) ++row_kernels;
+    if (q - p < 2 || row_kernels < 2) {
+      p = std::max(q, p + 1);
+      continue;
+    }
+    // roles may contain tensors of kernels popped above or of the kernel that failed: rebuild exactly
+    g.tensors.clear();
+    {
+      std::vector<int> keep = g.kernel_index;
+      std::vector<RowKernelInfo> keep_infos = g.infos;
+      g.kernel_index.clear();
+      g.infos.clear();
+      for (size_t i = 0; i < keep.size(); ++i) {
+        const Kernel& k = t.all[keep[i]];
+        const RowKernelInfo& ri = keep_infos[i];
+        const int yreg = ri.row_loop >= 0 ? k.loops[ri.row_loop].reg : 0;
+        auto touch = [&](const Op& op, bool write) {
+          bool row = false;
+          if (ri.row_loop >= 0)
+            for (auto& d : op.dims)
+              if (d.factor_of(yreg)) row = true;
+          RowGroupTensor& gt = g.tensors[op.tensor];
+          gt.tensor = op.tensor;
+          const long count = prod(shapes.at(op.tensor));
+          if (row) {
+            gt.inner = count / B;
+            if (write) gt.role = RowGroupTensor::RowLocal;
+            else if (gt.role != RowGroupTensor::RowLocal) gt.role = RowGroupTensor::RowExternal;
+          } else {
+            gt.inner = count;
+            if (write) gt.role = ri.small_only ? RowGroupTensor::SmallLocal : RowGroupTensor::Reduction;
+            else if (gt.role != RowGroupTensor::SmallLocal && gt.role != RowGroupTensor::Reduction)
+              gt.role = RowGroupTensor::SmallExternal;
+          }
+        };
+        for (auto& rd : k.reads) touch(rd, false);
+        touch(k.write, true);
+        g.kernel_index.push_back(keep[i]);
+        g.infos.push_back(ri);
+      }
+    }
+    // liveness: what must come from / go to memory
+    auto written_outside_before = [&](int tensor) {
+      for (int s = 0; s < p; ++s)
+        if (t.all[t.live[s]].write.tensor == tensor) return true;
+      return false;
+    };
+    auto used_after = [&](int tensor) {
+      if (tensor == t.output) return true;
+      for (int s = q; s < n; ++s) {
+        const Kernel& k = t.all[t.live[s]];
+        if (k.write.tensor == tensor) return true;
+        for (auto& rd : k.reads)
+          if (rd.tensor == tensor) return true;
+      }
+      return false;
+    };
+    bool leaks = false;  // a thread-local small tensor somebody outside the group wants
+    for (auto& kv : g.tensors)
+      if (kv.second.role == RowGroupTensor::SmallLocal && (used_after(kv.first) || written_outside_before(kv.first)))
+        leaks = true;
+    if (leaks) {
+      p = std::max(q, p + 1);
+      continue;
+    }
+    long red_off = 0;
+    for (auto& kv : g.tensors) {
+      RowGroupTensor& gt = kv.second;
+      if (gt.role == RowGroupTensor::RowLocal) {
+        gt.load_first = written_outside_before(kv.first);
+        gt.store = used_after(kv.first);
+      } else if (gt.role == RowGroupTensor::Reduction) {
+        const TK kind = m->prog.tensors[kv.first].kind;
+        gt.accumulate = kind != TK::Result || written_outside_before(kv.first);
+        gt.red_offset = red_off;
+        red_off += gt.inner;
+        pg->red_tensors.push_back(kv.first);
+      }
+    }
+    g.red_total = red_off;
+    char name[64];
+    snprintf(name, sizeof(name), "eg_rows%d", m->kernel_serial++);
+    g.name = name;
+    int rc = generate_row_group(m->prog, t.all, infos, shapes, g);
+    if (rc) return rc;
+    plan.pending.push_back({g.name, g.source, &pg->handle});
+    pg->nblocks = (int)((B + 255) / 256);
+    if (g.red_total > 0) {
+      EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+      EG_HIP_CHECK(hipMalloc((void**)&pg->partial, (size_t)pg->nblocks * g.red_total * sizeof(float)));
+    }
+    const int gi = (int)plan.row_groups.size();
+    for (int s = p; s < q; ++s) group_of[s] = gi;
+    plan.row_groups.push_back(std::move(pg));
+    p = q;
+  }
+  // ---- small-kernel groups among what is left (encoded as -2 - index in group_of)
+  p = 0;
+  while (p < n) {
+    auto eligible = [&](int s) {
+      if (group_of[s] != -1 || ts.lowered[s].absorbed || ts.lowered[s].bias_tensor) return false;
+      return is_small_kernel(m->prog, t.all[t.live[s]], infos[t.live[s]], shapes);
+    };
+    if (!eligible(p)) {
+      ++p;
+      continue;
+    }
+    int q = p;
+    while (q < n && eligible(q) && !(q != p && q == t.first_update)) ++q;
+    if (q - p >= 2) {
+      // a run made of elementwise maps only (adam: m, v and parameter updates of every parameter) is
+      // better off as a map group below: many blocks instead of one
+      bool all_maps = true;
+      for (int s = p; s < q && all_maps; ++s) {
+        long count = 0;
+        all_maps = ts.lowered[s].kind == StepKind::GenericA &&
+                   is_map_kernel(m->prog, t.all[t.live[s]], infos[t.live[s]], shapes, count);
+      }
+      if (all_maps) {
+        p = q;
+        continue;
+      }
+      std::unique_ptr<PlanSmallGroup> sg(new PlanSmallGroup());
+      for (int s = p; s < q; ++s) sg->g.kernel_index.push_back(t.live[s]);
+      char name[64];
+      snprintf(name, sizeof(name), "eg_small%d", m->kernel_serial++);
+      sg->g.name = name;
+      int rc = generate_small_group(m->prog, t.all, infos, shapes, sg->g);
+      if (rc) return rc;
+      plan.pending.push_back({sg->g.name, sg->g.source, &sg->handle});
+      const int gi = (int)plan.small_groups.size();
+      for (int s = p; s < q; ++s) group_of[s] = -2 - gi;
+      plan.small_groups.push_back(std::move(sg));
+    }
+    p = std::max(q, p + 1);
+  }
+  // ---- map groups: runs of raw elementwise kernels of any size among what is still separate (the
+  //      per-parameter optimizer kernels); same encoding and launch path as the small groups
+  p = 0;
+  while (p < n) {
+    auto eligible = [&](int s) {
+      if (group_of[s] != -1 || ts.lowered[s].absorbed || ts.lowered[s].kind != StepKind::GenericA) return false;
+      long count = 0;
+      return is_map_kernel(m->prog, t.all[t.live[s]], infos[t.live[s]], shapes, count);
+    };
+    if (!eligible(p)) {
+      ++p;
+      continue;
+    }
+    int q = p;
+    while (q < n && eligible(q) && !(q != p && q == t.first_update)) ++q;
+    if (q - p >= 2) {
+      std::unique_ptr<PlanSmallGroup> sg(new PlanSmallGroup());
+      for (int s = p; s < q; ++s) sg->g.kernel_index.push_back(t.live[s]);
+      char name[64];
+      snprintf(name, sizeof(name), "eg_maps%d", m->kernel_serial++);
+      sg->g.name = name;
+      int rc = generate_map_group(m->prog, t.all, infos, shapes, sg->g);
+      if (rc) return rc;
+      plan.pending.push_back({sg->g.name, sg->g.source, &sg->handle});
+      const int gi = (int)plan.small_groups.size();
+      for (int s = p; s < q; ++s) group_of[s] = -2 - gi;
+      plan.small_groups.push_back(std::move(sg));
+    }
+    p = std::max(q, p + 1);
+  }
+  return EG_OK;
+}
+
+}  // namespace model
+}  // namespace eg

@@ -1,0 +1,306 @@
+// Execution of a plan: one launch, a range of launches (with the side lane), HIP-graph capture and replay.
+#include "model_types.hpp"
+#include <random>
+
+namespace eg {
+namespace model {
+
+// Device-resident generator state of the model's TensorRandom tensors: {seed, fills drawn so far}.
+int ensure_rng(eg_model* m, uint64_t seed, bool reseed) {
+  EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+  const bool fresh = m->rng_state == nullptr;
+  if (fresh) EG_HIP_CHECK(hipMalloc((void**)&m->rng_state, 2 * sizeof(uint64_t)));
+  if (fresh || reseed) {
+    const uint64_t init[2] = {seed, 0};
+    EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    EG_HIP_CHECK(hipMemcpy(m->rng_state, init, sizeof(init), hipMemcpyHostToDevice));
+  }
+  return EG_OK;
+}
+
+int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
+  eg_ctx* ctx = m->ctx;
+  switch (L.kind) {
+    case StepKind::Seed:
+      return eg_fill_f32(ctx, L.count, m->grad_scale, tensor_ptr(m, ts, plan, L.c_tensor));
+    case StepKind::Gemm:
+      return eg_sgemm(ctx, L.trans_a, L.trans_b, L.M, L.N, L.K, tensor_ptr(m, ts, plan, L.a_tensor), L.lda,
+                      tensor_ptr(m, ts, plan, L.b_tensor), L.ldb, tensor_ptr(m, ts, plan, L.c_tensor), L.ldc,
+                      L.accumulate, L.bias_tensor ? tensor_ptr(m, ts, plan, L.bias_tensor) : nullptr);
+    case StepKind::GemmFused: {
+      PlanEpilogue& pe = *plan.epilogues[L.epilogue];
+      const float* bias = L.bias_tensor ? tensor_ptr(m, ts, plan, L.bias_tensor) : nullptr;
+      eg::gemm::FusedLaunch f;
+      int rc = eg::gemm::plan_fused(ctx, L.trans_a, L.trans_b, L.M, L.N, L.K, tensor_ptr(m, ts, plan, L.a_tensor), L.lda,
+                                    tensor_ptr(m, ts, plan, L.b_tensor), L.ldb, tensor_ptr(m, ts, plan, L.c_tensor), L.ldc,
+                                    bias, f);
+      if (rc) return rc;
+      if (f.splits > 1) {  // cannot happen for the shapes the plan was made for; stay correct anyway
+        rc = eg_sgemm(ctx, L.trans_a, L.trans_b, L.M, L.N, L.K, tensor_ptr(m, ts, plan, L.a_tensor), L.lda,
+                      tensor_ptr(m, ts, plan, L.b_tensor), L.ldb, tensor_ptr(m, ts, plan, L.c_tensor), L.ldc, 0, bias);
+        if (rc) return rc;
+        return run_launch(m, ts, plan, pe.consumer);
+      }
+      const std::string variant = eg::gemm::fused_variant(f);
+      eg_kernel*& handle = pe.built[variant];
+      if (!handle) {
+        const std::string name = "eg_gemm_epi" + std::to_string(m->kernel_serial++);
+        const std::string src = eg::gemm::fused_source(f, pe.spec.struct_code, pe.spec.struct_name, name);
+        rc = eg_kernel_compile(ctx, name.c_str(), src.c_str(), &handle);
+        if (rc) {
+          std::string msg = eg_last_error();
+          set_error("%s\n--- generated epilogue (%s) ---\n%s", msg.c_str(), variant.c_str(), pe.spec.struct_code.c_str());
+          handle = nullptr;
+          return rc;
+        }
+        m->kernels.push_back(handle);
+      }
+      void* operands[eg::gemm::MAX_EPILOGUE_OPERANDS] = {};
+      for (size_t o = 0; o < pe.spec.operands.size(); ++o) operands[o] = tensor_ptr(m, ts, plan, pe.spec.operands[o]);
+      eg::gemm::set_epilogue_operands(f, operands, (int)pe.spec.operands.size(), m->grad_scale, m->epoch);
+      void* args[] = {f.args};
+      return eg::kernel_launch_raw(handle, f.grid, 1, 1, (unsigned)f.nt, args);
+    }
+    case StepKind::ConvGradFilter:
+      return eg_conv2_nhwc_grad_filter(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, tensor_ptr(m, ts, plan, L.a_tensor),
+                                       tensor_ptr(m, ts, plan, L.b_tensor), tensor_ptr(m, ts, plan, L.c_tensor),
+                                       L.accumulate);
+    case StepKind::ConvGradImage:
+      return eg_conv2_nhwc_grad_image(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, tensor_ptr(m, ts, plan, L.a_tensor),
+                                      tensor_ptr(m, ts, plan, L.b_tensor), tensor_ptr(m, ts, plan, L.c_tensor),
+                                      L.accumulate);
+    case StepKind::Conv:
+      return eg_conv2_nhwc(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, tensor_ptr(m, ts, plan, L.a_tensor),
+                           tensor_ptr(m, ts, plan, L.b_tensor), tensor_ptr(m, ts, plan, L.c_tensor), L.accumulate);
+    case StepKind::SmallFused: {
+      PlanSmallGroup& sg = *plan.small_groups[L.row_group];
+      std::vector<float*> ptrs;
+      for (int tid : sg.g.ptr_args) ptrs.push_back(tensor_ptr(m, ts, plan, tid));
+      std::vector<void*> args;
+      for (auto& p : ptrs) args.push_back(&p);
+      float GS = m->grad_scale;
+      long EP = m->epoch;
+      args.push_back(&GS);
+      args.push_back(&EP);
+      return eg::kernel_launch_raw(sg.handle, (unsigned)sg.g.blocks, 1, 1, 256, args.data());
+    }
+    case StepKind::RowFused: {
+      PlanRowGroup& pg = *plan.row_groups[L.row_group];
+      std::vector<float*> ptrs;
+      ptrs.push_back(pg.partial);
+      for (int tid : pg.g.ptr_args) ptrs.push_back(tensor_ptr(m, ts, plan, tid));
+      std::vector<void*> args;
+      for (auto& p : ptrs) args.push_back(&p);
+      long B = pg.g.B, EP = m->epoch;
+      float GS = m->grad_scale;
+      args.push_back(&B);
+      args.push_back(&GS);
+      args.push_back(&EP);
+      int rc = eg::kernel_launch_raw(pg.handle, (unsigned)pg.nblocks, 1, 1, 256, args.data());
+      if (rc) return rc;
+      if (pg.g.red_total > 0) {
+        eg::RowFinalizeArgs fa = {};
+        fa.nseg = (int)pg.red_tensors.size();
+        for (int s = 0; s < fa.nseg; ++s) {
+          const RowGroupTensor& gt = pg.g.tensors.at(pg.red_tensors[s]);
+          fa.dst[s] = tensor_ptr(m, ts, plan, pg.red_tensors[s]);
+          fa.offset[s] = (int)gt.red_offset;
+          fa.accumulate[s] = gt.accumulate ? 1 : 0;
+        }
+        fa.offset[fa.nseg] = (int)pg.g.red_total;
+        return eg::row_finalize(ctx, pg.partial, pg.nblocks, (int)pg.g.red_total, fa);
+      }
+      return EG_OK;
+    }
+    case StepKind::GenericA:
+    case StepKind::GenericB: {
+      if (L.blocks_x <= 0 || L.blocks_y <= 0) return EG_OK;
+      const GenericSource& src = L.generic->src;
+      std::vector<void*> args;
+      std::vector<float*> ptrs;
+      ptrs.reserve(src.tensor_args.size() + 1);
+      float* partial = nullptr;
+      float* scratch = nullptr;
+      if (L.kind == StepKind::GenericB) {
+        const long pfloats = (L.partial_rows * L.partial_cols + 3) & ~3L;
+        const long sfloats = eg::colsum_scratch_floats(ctx, L.partial_rows, L.partial_cols);
+        int rc = eg::ensure_workspace(ctx, (size_t)(pfloats + sfloats) * sizeof(float));
+        if (rc) return rc;
+        partial = static_cast<float*>(ctx->workspace);
+        scratch = partial + pfloats;
+        ptrs.push_back(partial);
+      }
+      for (int tid : src.tensor_args) {
+        float* p = tensor_ptr(m, ts, plan, tid);
+        if (!p && prod(plan.shapes.at(tid)) > 0) {
+          set_error("tensor %d has no device storage", tid);
+          return EG_ERR_INVALID;
+        }
+        ptrs.push_back(p);
+      }
+      for (auto& p : ptrs) args.push_back(&p);
+      for (auto& v : L.params) args.push_back(&v);
+      for (int slot : L.epoch_slots) L.params[slot] = m->epoch;
+      long blocks_x = L.blocks_x;
+      if (L.kind == StepKind::GenericA && L.vec_slot >= 0) {
+        // four elements per thread need 16-byte aligned operands (arena tensors are; caller-owned ones may not be)
+        bool aligned = L.vec_ok;
+        for (float* p : ptrs) aligned = aligned && (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+        L.params[L.vec_slot] = aligned ? 1 : 0;
+        blocks_x = ((aligned ? L.total_items / 4 : L.total_items) + 255) / 256;
+      }
+      int rc = eg::kernel_launch_raw(L.generic->handle, (unsigned)blocks_x, (unsigned)L.blocks_y, 1, 256, args.data());
+      if (rc) return rc;
+      if (L.kind == StepKind::GenericB)
+        return eg::colsum_with_scratch(ctx, L.partial_rows, L.partial_cols, partial,
+                                       tensor_ptr(m, ts, plan, L.c_tensor), L.accumulate, scratch);
+      return EG_OK;
+    }
+  }
+  return EG_OK;
+}
+
+int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero) {
+  if (zero) {
+    // allocShapes / zeroResultTensor (model.nim:318, 383): results start from zero on every call
+    if (plan.zero_floats > 0)
+      EG_HIP_CHECK(hipMemsetAsync(plan.arena, 0, (size_t)plan.zero_floats * sizeof(float), m->ctx->stream));
+    for (int tid : plan.bucket_zero)
+      EG_HIP_CHECK(hipMemsetAsync(ts.bucket + ts.bucket_offset[tid], 0, (size_t)prod(plan.shapes.at(tid)) * sizeof(float),
+                                  m->ctx->stream));
+    if (eg::poison_enabled()) {
+      // EG_POISON: whatever is not zeroed must be overwritten completely by its first writer
+      if (plan.arena_floats > plan.zero_floats)
+        EG_HIP_CHECK(hipMemsetAsync(plan.arena + plan.zero_floats, 0xFF,
+                                    (size_t)(plan.arena_floats - plan.zero_floats) * sizeof(float), m->ctx->stream));
+      std::set<int> zeroed(plan.bucket_zero.begin(), plan.bucket_zero.end());
+      for (auto& b : ts.bucket_offset)
+        if (!zeroed.count(b.first) && plan.shapes.count(b.first))
+          EG_HIP_CHECK(hipMemsetAsync(ts.bucket + b.second, 0xFF, (size_t)prod(plan.shapes.at(b.first)) * sizeof(float),
+                                      m->ctx->stream));
+      for (auto& rg : plan.row_groups)
+        if (rg->partial)
+          EG_HIP_CHECK(hipMemsetAsync(rg->partial, 0xFF, (size_t)rg->nblocks * rg->g.red_total * sizeof(float), m->ctx->stream));
+    }
+    // fresh random tensors for this call (model.nim:310-314 does it on the host); the draw counter
+    // is bumped on the device so a captured sequence advances on every replay
+    for (size_t r = 0; r < plan.random_tensors.size(); ++r) {
+      const int tid = plan.random_tensors[r];
+      const TensorDef& d = m->prog.tensors[tid];
+      int rc = eg_fill_uniform(m->ctx, prod(plan.shapes.at(tid)), (float)d.lo, (float)d.hi, m->rng_state, (uint64_t)tid,
+                               plan.arena + plan.arena_offset[tid]);
+      if (rc) return rc;
+    }
+    if (!plan.random_tensors.empty()) {
+      int rc = eg_rng_advance(m->ctx, m->rng_state);
+      if (rc) return rc;
+    }
+  }
+  size_t next_overlap = 0;
+  for (int i = begin; i < end; ++i) {
+    while (next_overlap < plan.overlaps.size() && plan.overlaps[next_overlap].first < i) ++next_overlap;
+    if (next_overlap < plan.overlaps.size() && plan.overlaps[next_overlap].first == i &&
+        plan.overlaps[next_overlap].big < end) {
+      // fork: the side lane takes launches [i, big) after everything issued so far, the main stream
+      // goes on with the contraction; join before whatever follows
+      const int big = plan.overlaps[next_overlap].big;
+      eg_ctx* ctx = m->ctx;
+      EG_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+      EG_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+      {
+        LaneSwap lane(ctx);
+        for (int s2 = i; s2 < big; ++s2) {
+          int rc = run_launch(m, ts, plan, plan.launches[s2]);
+          if (rc) return rc;
+        }
+        EG_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->stream));  // (the side stream, while swapped)
+      }
+      int rc = run_launch(m, ts, plan, plan.launches[big]);
+      if (rc) return rc;
+      EG_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+      i = big;
+      continue;
+    }
+    int rc = run_launch(m, ts, plan, plan.launches[i]);
+    if (rc) return rc;
+  }
+  return EG_OK;
+}
+
+bool graphs_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("EG_NO_GRAPH");
+    return !(e && e[0] && e[0] != '0');
+  }();
+  return on;
+}
+
+// slot: 0 = whole call, 1 = backward part, 2 = update part
+int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero, int slot) {
+  int rc = eg::set_device(m->ctx);
+  if (rc) return rc;
+  Plan::Captured& cap = plan.graphs[slot];
+  if (!graphs_enabled() || end - begin < 2) return run_range_eager(m, ts, plan, begin, end, zero);
+  // every pointer / scalar that ends up in a kernel argument
+  std::ostringstream key;
+  for (auto& in : m->inputs)
+    if (in.second.bound) key << in.first << "=" << (const void*)in.second.device << ";";
+  key << "w" << m->ctx->workspace << "x" << m->ctx->aux << "s" << m->ctx->side_workspace << "y" << m->ctx->side_aux << "b"
+      << (void*)ts.bucket << "g" << m->grad_scale << "e" << m->epoch;
+  const std::string k = key.str();
+  if (cap.exec && cap.key == k) {
+    EG_HIP_CHECK(hipGraphLaunch(cap.exec, m->ctx->stream));
+    return EG_OK;
+  }
+  if (cap.exec) {
+    // the old sequence may still be running (launches are asynchronous): let it finish before its
+    // executable graph goes away
+    EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+    hipGraphExecDestroy(cap.exec);
+    cap.exec = nullptr;
+  }
+  // first execution with these arguments runs eagerly (lazy kernel builds, workspace growth);
+  // the second one is captured
+  if (cap.key != k || cap.runs < 1) {
+    if (cap.key != k) cap.runs = 0;
+    cap.key = k;
+    cap.runs++;
+    return run_range_eager(m, ts, plan, begin, end, zero);
+  }
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamBeginCapture(m->ctx->stream, hipStreamCaptureModeThreadLocal);
+  static const bool debug = getenv("EG_DEBUG_GRAPH") != nullptr;
+  if (e != hipSuccess) {  // capture unavailable on this stream: stay eager
+    if (debug) fprintf(stderr, "[eg] begin capture failed: %s\n", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return run_range_eager(m, ts, plan, begin, end, zero);
+  }
+  rc = run_range_eager(m, ts, plan, begin, end, zero);
+  e = hipStreamEndCapture(m->ctx->stream, &graph);
+  if (rc) {
+    if (graph) hipGraphDestroy(graph);
+    return rc;
+  }
+  if (e != hipSuccess || !graph) {
+    if (debug) fprintf(stderr, "[eg] end capture failed: %s\n", hipGetErrorString(e));
+    (void)hipGetLastError();
+    return run_range_eager(m, ts, plan, begin, end, zero);
+  }
+  if (debug) {
+    size_t n = 0;
+    hipGraphGetNodes(graph, nullptr, &n);
+    fprintf(stderr, "[eg] captured %zu nodes for slot %d of target %s\n", n, slot, ts.target->name.c_str());
+  }
+  e = hipGraphInstantiate(&cap.exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    cap.exec = nullptr;
+    return run_range_eager(m, ts, plan, begin, end, zero);
+  }
+  EG_HIP_CHECK(hipGraphLaunch(cap.exec, m->ctx->stream));
+  return EG_OK;
+}
+
+}  // namespace model
+}  // namespace eg

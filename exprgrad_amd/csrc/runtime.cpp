@@ -9,6 +9,7 @@
 //   clSetKernelArg (sticky) + clEnqueueNDRangeKernel-> stored argument block + hipModuleLaunchKernel
 #include <hip/hiprtc.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -35,8 +36,26 @@ void set_error(const char* fmt, ...) {
 }
 void clear_error() { g_error.clear(); }
 
+// EG_POISON=1 (debugging aid): every scratch block is filled with NaN bit patterns right before a
+// library call uses it, and models do the same with the parts of their result arena that the
+// kernels are supposed to overwrite completely.  A read of memory nobody wrote then shows up as NaN
+// in the result instead of as whatever an earlier launch left there.
+bool poison_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("EG_POISON");
+    return e && e[0] && e[0] != '0';
+  }();
+  return on;
+}
+
+static int poison_block(eg_ctx* ctx, void* p, size_t bytes) {
+  if (!poison_enabled() || !p || !bytes) return EG_OK;
+  EG_HIP_CHECK(hipMemsetAsync(p, 0xFF, bytes, ctx->stream));
+  return EG_OK;
+}
+
 int ensure_workspace(eg_ctx* ctx, size_t bytes) {
-  if (bytes <= ctx->workspace_bytes) return EG_OK;
+  if (bytes <= ctx->workspace_bytes) return poison_block(ctx, ctx->workspace, ctx->workspace_bytes);
   EG_HIP_CHECK(hipSetDevice(ctx->device));
   // Kernels already queued may still be using the old block.
   EG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -46,11 +65,11 @@ int ensure_workspace(eg_ctx* ctx, size_t bytes) {
   size_t want = bytes + bytes / 4;
   EG_HIP_CHECK(hipMalloc(&ctx->workspace, want));
   ctx->workspace_bytes = want;
-  return EG_OK;
+  return poison_block(ctx, ctx->workspace, ctx->workspace_bytes);
 }
 
 int ensure_aux(eg_ctx* ctx, size_t bytes) {
-  if (bytes <= ctx->aux_bytes) return EG_OK;
+  if (bytes <= ctx->aux_bytes) return poison_block(ctx, ctx->aux, ctx->aux_bytes);
   EG_HIP_CHECK(hipSetDevice(ctx->device));
   EG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   if (ctx->aux) EG_HIP_CHECK(hipFree(ctx->aux));
@@ -59,7 +78,7 @@ int ensure_aux(eg_ctx* ctx, size_t bytes) {
   size_t want = bytes + bytes / 4;
   EG_HIP_CHECK(hipMalloc(&ctx->aux, want));
   ctx->aux_bytes = want;
-  return EG_OK;
+  return poison_block(ctx, ctx->aux, ctx->aux_bytes);
 }
 }  // namespace eg
 

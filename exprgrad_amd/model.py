@@ -19,6 +19,24 @@ from ._lib import call, GpuError, RuntimeErrorEG  # noqa: F401
 from .runtime import GpuContext
 
 
+def _check_device_tensor(name, tensor, ctx):
+    """Only the address and the shape of a borrowed device tensor cross the C ABI: anything that is not
+    packed float32 on the context's device would be read as if it were (a transposed view, a float64
+    or half tensor), silently.  Refuse it instead."""
+    dtype = getattr(tensor, "dtype", None)
+    if dtype is not None and str(dtype) not in ("torch.float32", "float32"):
+        raise GpuError(f"input {name}: device tensors must be float32, got {dtype}")
+    if hasattr(tensor, "is_contiguous") and not tensor.is_contiguous():
+        raise GpuError(f"input {name}: device tensors must be contiguous (row-major, packed); call .contiguous()")
+    dev = getattr(tensor, "device", None)
+    if dev is not None and hasattr(dev, "type"):
+        if dev.type != "cuda":
+            raise GpuError(f"input {name}: tensor lives on {dev}, not on a GPU")
+        want = getattr(ctx, "device", None)
+        if want is not None and dev.index is not None and dev.index != want:
+            raise GpuError(f"input {name}: tensor lives on GPU {dev.index}, the context on GPU {want}")
+
+
 class _Params:
     """dict-like view of the device-resident parameters: get copies D2H, set copies H2D."""
 
@@ -106,6 +124,7 @@ class Model:
     # ---- inputs ------------------------------------------------------------------------------
     def _bind(self, name, tensor):
         if hasattr(tensor, "data_ptr"):  # device tensor: borrow
+            _check_device_tensor(name, tensor, self.ctx)
             shape = [int(s) for s in tensor.shape]
             arr = (ctypes.c_int64 * max(len(shape), 1))(*shape)
             self._keep[name] = tensor
@@ -173,6 +192,7 @@ class Model:
             if hasattr(tensor, "data_ptr"):      # device tensor: read in place
                 if hasattr(tensor, "is_contiguous") and not tensor.is_contiguous():
                     tensor = tensor.contiguous()
+                _check_device_tensor(items[i][0], tensor, self.ctx)
                 data[i], on_device[i], shape = tensor.data_ptr(), 1, [int(s) for s in tensor.shape]
             else:
                 tensor = np.ascontiguousarray(tensor, dtype=np.float32)

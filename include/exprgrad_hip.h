@@ -279,6 +279,26 @@ int64_t eg_model_epoch(eg_model* model);
  * generator, `randomize(seed)`): same seed, same call sequence -> same numbers.  Resets the draw counter. */
 int eg_model_set_seed(eg_model* model, uint64_t seed);
 
+/* save / loadModel (io/serialize.nim:344-379) in the reference's byte layout: integers little
+ * endian, `int` = 8 bytes, bool = 1 byte, string / seq = int64 length + items, Table = int64 count +
+ * (key, value) pairs, Tensor = bool isNil + seq[int] shape + elements (serialize.nim:21-75).
+ *
+ * state = the `params` and `caches` tables (Table[TensorId, Tensor[float32]]) exactly as
+ * serialize.nim:348-349 writes them, read from / written to the DEVICE copies (the reference's GPU
+ * path never copies trained parameters back, model.nim:326-345).  A Nim host stores isNil and its
+ * `Program` itself and appends these bytes; on load it reads its Program, compiles, and hands the
+ * rest of the stream to eg_model_load_state (*consumed = bytes used). */
+int eg_model_state_bytes(eg_model* model, size_t* bytes);
+int eg_model_store_state(eg_model* model, void* buf, size_t cap, size_t* written);
+int eg_model_load_state(eg_model* model, const void* buf, size_t bytes, size_t* consumed);
+/* Whole-file form for hosts without the Nim front-end: isNil, the program field holding the
+ * kernel-description text as a serialize.nim string, params, caches, and behind them one int64 with
+ * Model.epoch (which the reference forgets).  eg_model_load = read + eg_model_compile + load_state. */
+int eg_model_save(eg_model* model, const char* path);
+int eg_model_load(eg_ctx* ctx, const char* path, eg_model** out);
+/* The kernel-description text the model was compiled from. */
+const char* eg_model_source_text(eg_model* model);
+
 /* ---------------------------------------------------------------------------------------------
  * Group 4 — data-parallel exchange (BASELINE.json north_star: "training-step batches
  * shard data-parallel across the 8 GPUs of one node with an RCCL all-reduce of parameter gradients

@@ -89,6 +89,32 @@ def test_fit_in_small_segments_and_pieces(gpu_ctx, monkeypatch):
     pieces.close()
 
 
+def test_fit_calls_with_different_data_do_not_overtake_each_other(gpu_ctx):
+    """Every epoch gets another permutation of the rows (what a training loop does).  fit returns when
+    its uploads are complete, not its kernels: the next call's upload must wait for the batches still
+    queued, or they read rows of the following epoch.  Many small batches keep the queue
+    deep; compared with the oracle stepping through the same permutations."""
+    rows, batch = 4096, 16
+    gpu = egm.compile(*dense_graphs("sgd"), gpu=gpu_ctx)
+    ref = oracle(dense_graphs("sgd"))
+    same_start((gpu, ref), seed=3)
+    rng = np.random.default_rng(11)
+    x = rng.random((rows, 24), dtype=np.float32)
+    y = rng.random((rows, 5), dtype=np.float32)
+    for epoch in range(4):
+        perm = rng.permutation(rows)
+        xe, ye = np.ascontiguousarray(x[perm]), np.ascontiguousarray(y[perm])
+        gpu.fit("train", {"x": xe, "y": ye}, batch_size=batch)
+        xe[...] = -1e6   # the caller may reuse its arrays as soon as fit returns
+        ye[...] = 1e6
+        oracle_fit(ref, "train", x[perm], y[perm], batch)
+    for tid in gpu.params.ids():
+        got, want = gpu.params[tid], ref.params[tid]
+        # 1024 sequential steps: rounding differences of single steps (1e-7 each) accumulate linearly
+        assert rel_err(got, want) <= 1e-4, tid
+    gpu.close()
+
+
 def test_fit_reads_device_resident_data_in_place(gpu_ctx):
     import torch
     rows, batch = 40, 8
