@@ -116,6 +116,7 @@ struct PlanSmallGroup {
 // A contraction whose elementwise consumer runs as its epilogue (epilogue.hpp), built per plan.
 struct PlanEpilogue {
   EpilogueSpec spec;
+  bool store_c = false;                     // the contraction result itself is written too (something else reads it)
   Launch consumer;                          // the consumer as its own launch (split-K fallback)
   std::map<std::string, eg_kernel*> built;  // by template variant (tile shape, alignment class)
 };

@@ -74,9 +74,7 @@ void launch_io(eg_model* m, TargetState& ts, const Plan& plan, const Launch& L, 
       rd(L.b_tensor);
       rd(L.bias_tensor);
       const Kernel& ck = t.all[ts.lowered[pe.consumer.lowered].all_index];
-      bool stores_c = false;
-      for (int op : pe.spec.operands) stores_c = stores_c || op == L.c_tensor;
-      if (stores_c) wr(L.c_tensor, L.accumulate);
+      if (pe.store_c) wr(L.c_tensor, L.accumulate);
       for (auto& r : ck.reads)
         if (r.tensor != L.c_tensor) rd(r.tensor);
       wr(ck.write.tensor, pe.consumer.accumulate);

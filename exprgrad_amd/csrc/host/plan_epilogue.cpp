@@ -78,6 +78,7 @@ int fuse_epilogues(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
     int rc = generate_epilogue(ke, ie, plan.shapes, G.c_tensor, store_c, E.accumulate, pe->spec);
     if (rc) return rc;
     pe->consumer = E;
+    pe->store_c = store_c;
     G.kind = StepKind::GemmFused;
     G.epilogue = (int)plan.epilogues.size();
     plan.epilogues.push_back(std::move(pe));

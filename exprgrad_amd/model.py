@@ -71,15 +71,16 @@ class _Params:
 
 
 class Model:
-    def __init__(self, program, ctx):
+    def __init__(self, program, ctx, handle=None):
         if not isinstance(ctx, GpuContext):
             raise GpuError("compile(..., gpu=ctx) needs a GpuContext: this backend has no CPU path")
         self.ctx = ctx
         self.program = program
         self.source_text = program.to_text()
-        h = ctypes.c_void_p()
-        call("eg_model_compile", ctx.handle, self.source_text.encode(), ctypes.byref(h))
-        self.handle = h
+        if handle is None:
+            handle = ctypes.c_void_p()
+            call("eg_model_compile", ctx.handle, self.source_text.encode(), ctypes.byref(handle))
+        self.handle = handle
         self._param_shapes = {}
         self._cache_shapes = {}
         for tid, t in enumerate(program.tensors, 1):
@@ -232,17 +233,26 @@ class Model:
 
     # ---- save / load (io/serialize.nim:344-379) ------------------------------------------------
     def save(self, path):
-        """model.save(path): program + params + caches (serialize.nim:366-369) — here the
-        kernel-description text and the device-resident state flushed to the host first (the
-        reference never copies GPU-side updates back, model.nim:326-345).  Also stores Model.epoch,
-        which the reference forgets.  Own container (numpy .npz), not the reference's byte format."""
-        state = {"program": np.frombuffer(self.source_text.encode(), dtype=np.uint8), "epoch": np.int64(self.epoch)}
-        for tid in self.params.ids():
-            state[f"param_{tid}"] = self.params[tid]
-        for tid in self.caches.ids():
-            state[f"cache_{tid}"] = self.caches[tid]
-        with open(path, "wb") as f:
-            np.savez(f, **state)
+        """model.save(path) (serialize.nim:366-369): isNil, program, params, caches in the reference's
+        byte layout, written by the library (eg_model_save) from the DEVICE state — the reference never
+        copies GPU-side updates back (model.nim:326-345).  The program field holds the
+        kernel-description text; Model.epoch follows the caches (the reference forgets it)."""
+        call("eg_model_save", self.handle, str(path).encode())
+
+    def state_bytes(self):
+        """The `params` + `caches` tables as serialize.nim:348-349 writes them (what a Nim host appends
+        to its own `store(program)`)."""
+        n = ctypes.c_size_t(0)
+        call("eg_model_state_bytes", self.handle, ctypes.byref(n))
+        buf = (ctypes.c_ubyte * max(n.value, 1))()
+        call("eg_model_store_state", self.handle, buf, n.value, ctypes.byref(n))
+        return bytes(buf[:n.value])
+
+    def load_state(self, data):
+        buf = (ctypes.c_ubyte * max(len(data), 1)).from_buffer_copy(bytes(data) or b"\0")
+        used = ctypes.c_size_t(0)
+        call("eg_model_load_state", self.handle, buf, len(data), ctypes.byref(used))
+        return used.value
 
     def close(self):
         if self.handle:
@@ -273,18 +283,15 @@ class _LoadedProgram:
 
 
 def load_model(path, gpu=None):
-    """loadModel(path, gpu) (serialize.nim:351-364): rebuild the kernels from the stored program and
-    restore parameters, caches and epoch."""
-    with np.load(path) as data:
-        text = bytes(data["program"]).decode()
-        model = Model(_LoadedProgram(text), gpu)
-        for key in data.files:
-            if key.startswith("param_"):
-                model.params[int(key[6:])] = data[key]
-            elif key.startswith("cache_"):
-                model.caches[int(key[6:])] = data[key]
-        model.epoch = int(data["epoch"])
-    return model
+    """loadModel(path, gpu) (serialize.nim:351-364) through eg_model_load: read the file, rebuild the
+    kernels from the stored program, restore parameters, caches and epoch on the device."""
+    if not isinstance(gpu, GpuContext):
+        raise GpuError("load_model(path, gpu=ctx) needs a GpuContext: this backend has no CPU path")
+    from . import _lib
+    h = ctypes.c_void_p()
+    call("eg_model_load", gpu.handle, str(path).encode(), ctypes.byref(h))
+    text = (_lib.lib().eg_model_source_text(h) or b"").decode()
+    return Model(_LoadedProgram(text), gpu, handle=h)
 
 
 loadModel = load_model

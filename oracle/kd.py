@@ -767,11 +767,12 @@ def _encode_instrs(instrs, typ, shapes, epoch):
     return words, lits
 
 
-def _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch):
+def _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch, f64=False):
     """Kernels with computed (non-affine) indices: flat index of an operand = constant +
     sum(coefficient * register) over iterator AND index-instruction registers (ref_interp_kernel2)."""
     lib = refcpu.lib()
-    lib.ref_interp_kernel2.restype = ctypes.c_int
+    interp = lib.ref_interp_kernel2_f64 if f64 else lib.ref_interp_kernel2
+    interp.restype = ctypes.c_int
     typ = infer_types(k, vals)
     c_i64, c_i32 = ctypes.c_int64, ctypes.c_int32
     nl = len(k.loops)
@@ -806,7 +807,7 @@ def _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch):
     nreads = len(k.reads)
     out = tensors[k.write.tensor]
     arr = lambda t, v: (t * max(len(v), 1))(*v)
-    rc = lib.ref_interp_kernel2(
+    rc = interp(
         nl, arr(c_i64, [bounds[lp.reg][0] for lp in k.loops]), arr(c_i64, [bounds[lp.reg][1] for lp in k.loops]),
         arr(c_i32, [lp.reg for lp in k.loops]), k.nregs + 1,
         len(k.index_instrs), arr(c_i32, idx_words), arr(ctypes.c_double, idx_lits),
@@ -819,13 +820,13 @@ def _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch):
         raise RuntimeError(f"ref_interp_kernel2 failed ({rc})")
 
 
-def run_kernel(k, bounds, vals, shapes, tensors, epoch=0):
+def run_kernel(k, bounds, vals, shapes, tensors, epoch=0, f64=False):
+    """f64: the float64 shadow of the kernel (oracle/refinterp_body.h) on float64 tensors."""
     if k.index_instrs:
-        return _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch)
+        return _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch, f64)
     lib = refcpu.lib()
-    if not hasattr(lib, "_interp_ready"):
-        lib.ref_interp_kernel.restype = ctypes.c_int
-        lib._interp_ready = True
+    interp = lib.ref_interp_kernel_f64 if f64 else lib.ref_interp_kernel
+    interp.restype = ctypes.c_int
     nl = len(k.loops)
     loop_index = {lp.reg: i for i, lp in enumerate(k.loops)}
     typ = infer_types(k, vals)
@@ -890,8 +891,8 @@ def run_kernel(k, bounds, vals, shapes, tensors, epoch=0):
     lits_c = (ctypes.c_double * max(ninstr, 1))(*lits)
     waff = (c_i64 * (1 + nl))(*affine(k.write))
     out = tensors[k.write.tensor]
-    rc = lib.ref_interp_kernel(nl, starts, stops, lregs, k.nregs + 1, nreads, rptrs, rregs, raff_c, ninstr, instr_c,
-                               lits_c, k.result, ctypes.c_void_p(out.ctypes.data), waff, 0)
+    rc = interp(nl, starts, stops, lregs, k.nregs + 1, nreads, rptrs, rregs, raff_c, ninstr, instr_c,
+                lits_c, k.result, ctypes.c_void_p(out.ctypes.data), waff, 0)
     if rc != 0:
         raise RuntimeError(f"ref_interp_kernel failed ({rc})")
 
@@ -930,8 +931,13 @@ class Model:
     """CPU-path Model: params persist and are updated in place by optimizer kernels
     (model.nim:284), result tensors are zeroed before every call (model.nim:295-300)."""
 
-    def __init__(self, text, fast_contractions=True, threads=1):
+    def __init__(self, text, fast_contractions=True, threads=1, shadow=False):
+        """shadow=True: the float64 SHADOW of the program — the same kernel list (derive, dead-kernel
+        elimination, loop order) evaluated in float64 on float64 tensors, i.e. the exact value of what
+        the reference computes in float32.  Tests hold the GPU to 1e-5 of it and the float32 oracle to
+        its own sequential-summation bound, instead of widening a GPU-vs-oracle tolerance."""
         self.prog = parse(text)
+        self.dtype = np.float64 if shadow else np.float32
         self.compiled = {name: compile_target(self.prog, name) for name in list(self.prog.targets)}
         self.params = {}
         self.epoch = 0
@@ -946,9 +952,9 @@ class Model:
         self.random_override = {}
         for tid, t in self.prog.tensors.items():
             if t["kind"] == "param":
-                self.params[tid] = np.zeros(t["shape"], dtype=np.float32)
+                self.params[tid] = np.zeros(t["shape"], dtype=self.dtype)
             elif t["kind"] == "cache":      # model.nim:248-249: zero tensors that persist across calls
-                self.caches[tid] = np.zeros(t["shape"], dtype=np.float32)
+                self.caches[tid] = np.zeros(t["shape"], dtype=self.dtype)
 
     def kernel_count(self, target):
         return len(self.compiled[target][1])
@@ -977,17 +983,22 @@ class Model:
     def _run_one(self, k, infos, shapes, tensors, grad_scale):
         bounds, vals = infos[id(k)]
         wt = k.write.tensor
+        shadow = self.dtype == np.float64
         if wt not in tensors:
-            tensors[wt] = np.zeros(shapes[wt], dtype=np.float32)
+            tensors[wt] = np.zeros(shapes[wt], dtype=self.dtype)
         pat = contraction_pattern(k) if self.fast else None
         if k.is_seed:
             # gradLoss{i} = 1 (passes.nim:594-596), times B_local/B_global under data parallelism
-            tensors[wt] += np.float32(grad_scale)
+            tensors[wt] += self.dtype(np.float32(grad_scale))
+        elif pat is not None and shadow:
+            a_op, b_op, ta, tb = pat
+            a, b = tensors[a_op.tensor], tensors[b_op.tensor]
+            tensors[wt] += (a.T if ta else a) @ (b.T if tb else b)
         elif pat is not None:
             a_op, b_op, ta, tb = pat
             refcpu.sgemm(tensors[a_op.tensor], tensors[b_op.tensor], ta, tb, out=tensors[wt], threads=self.threads)
         else:
-            run_kernel(k, bounds, vals, shapes, tensors, self.epoch)
+            run_kernel(k, bounds, vals, shapes, tensors, self.epoch, f64=shadow)
 
     def _forward_backward(self, target, inputs, grad_scale, stop_at_update):
         if target not in self.compiled:
@@ -998,7 +1009,7 @@ class Model:
             if name not in self.prog.inputs:
                 raise KeyError(name + " is not an input to the model")    # model.nim:358-359
             tid = self.prog.inputs[name]
-            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            arr = np.ascontiguousarray(np.ascontiguousarray(arr, dtype=np.float32), dtype=self.dtype)
             static = self.prog.tensors[tid]["shape"]
             if static:
                 if len(static) != arr.ndim or any(s >= 0 and s != a for s, a in zip(static, arr.shape)):
@@ -1015,10 +1026,10 @@ class Model:
                 if t["kind"] == "random" and r.tensor not in shapes and src in shapes:
                     shapes[r.tensor] = list(shapes[src])
                     if r.tensor in self.random_override:
-                        tensors[r.tensor] = np.ascontiguousarray(self.random_override[r.tensor], dtype=np.float32)
+                        tensors[r.tensor] = np.ascontiguousarray(self.random_override[r.tensor], dtype=self.dtype)
                     else:
                         lo, hi = t["range"]
-                        tensors[r.tensor] = (lo + (hi - lo) * self.rng.random(shapes[r.tensor], dtype=np.float32)).astype(np.float32)
+                        tensors[r.tensor] = (lo + (hi - lo) * self.rng.random(shapes[r.tensor], dtype=np.float32)).astype(self.dtype)
             if any(r.tensor not in shapes for r in k.reads):
                 if id(k) in live:
                     missing = [r.tensor for r in k.reads if r.tensor not in shapes]
@@ -1040,7 +1051,7 @@ class Model:
         # gradient tensors of parameters must exist even if nothing wrote them
         for _, gt in self.prog.param_grads.get(target, []):
             if gt not in tensors and gt in shapes:
-                tensors[gt] = np.zeros(shapes[gt], dtype=np.float32)
+                tensors[gt] = np.zeros(shapes[gt], dtype=self.dtype)
         self._pending = list(kernels[stop:])
         self._pending_state = (infos, shapes, tensors, grad_scale)
         self.last = tensors

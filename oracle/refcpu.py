@@ -20,7 +20,7 @@ MAP_OPS = {
 
 def build(force=False):
     """Compile the oracle with gcc (seconds)."""
-    srcs = [os.path.join(_HERE, f) for f in ("refcpu.c", "refinterp.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("refcpu.c", "refinterp.c", "refinterp_body.h", "Makefile")]
     srcs = [s for s in srcs if os.path.exists(s)]
     if (not force and os.path.exists(_SO)
             and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):

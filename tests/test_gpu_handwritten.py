@@ -1,0 +1,70 @@
+"""The backend against closed-form known answers (softmax / crossEntropy and its gradient, one adam
+step, 4-D conv2, maxpool2 + customGrad) on kernel-description text written by hand — the DSL mirror
+is not involved, so the text front-end of the C ABI is pinned by itself
+(tests/golden/make_handwritten.py, tests/golden/handwritten/*.kd)."""
+import numpy as np
+import pytest
+
+import handwritten
+from conftest import TOL, rel_err
+from exprgrad_amd import model as egm
+
+pytestmark = pytest.mark.gpu
+CASES = handwritten.load()
+
+
+def build(gpu_ctx, text):
+    return egm.Model(egm._LoadedProgram(text), gpu_ctx)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_backend_reproduces_the_closed_forms(gpu_ctx, name):
+    case = CASES[name]
+    gpu = build(gpu_ctx, case["text"])
+
+    def set_param(t, v):
+        gpu.params[t] = v
+
+    def set_epoch(e):
+        gpu.epoch = e
+
+    handwritten.check(case, gpu, set_param, lambda t: gpu.params[t], lambda t: gpu.caches[t], set_epoch)
+    gpu.close()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_backend_equals_the_oracle_on_the_handwritten_programs(gpu_ctx, name):
+    """Larger seeded inputs through the same hand-written text: backend vs oracle at 1e-5."""
+    from oracle import kd
+    case = CASES[name]
+    gpu, ref = build(gpu_ctx, case["text"]), kd.Model(case["text"])
+    rng = np.random.default_rng(7)
+    f = np.float32
+    if name == "conv2_4d":
+        ins = {"images": rng.random((3, 9, 11, 5), dtype=f), "filters": (rng.random((7, 3, 2, 5), dtype=f) - 0.5).astype(f)}
+        assert rel_err(gpu.call("conv2", ins), ref.call("conv2", ins)) <= TOL
+    elif name == "maxpool2_grad":
+        ins = {"x": (rng.random((2, 6, 8, 3), dtype=f) - 0.5).astype(f), "w": rng.random((2, 3, 4, 3), dtype=f)}
+        assert np.array_equal(gpu.call("pool", {"x": ins["x"]}), ref.call("pool", {"x": ins["x"]}))
+        assert np.array_equal(gpu.call("grad", ins), ref.call("grad", ins))       # selection only: exact
+    elif name == "softmax_xent":
+        z = (rng.random((2, 3), dtype=f) * 4 - 2).astype(f)
+        gpu.params[1] = z
+        ref.params[1][...] = z
+        y = np.eye(3, dtype=f)[[2, 0]]
+        for target in ("predict", "loss", "grad"):
+            args = {} if target == "predict" else {"y": y}
+            assert rel_err(gpu.call(target, args), ref.call(target, args)) <= TOL, target
+    else:
+        p = (rng.random(3, dtype=f) * 4 - 2).astype(f)
+        gpu.params[1] = p
+        ref.params[1][...] = p
+        t = rng.random(3, dtype=f)
+        for step in range(1, 4):
+            gpu.epoch = ref.epoch = step
+            gpu.apply("train", {"t": t})
+            ref.apply("train", {"t": t})
+        assert rel_err(gpu.params[1], ref.params[1]) <= TOL
+        for c in (5, 6):
+            assert rel_err(gpu.caches[c], ref.caches[c]) <= TOL
+    gpu.close()

@@ -1,0 +1,62 @@
+"""The oracle against closed-form known answers of softmax / crossEntropy / adam / 4-D conv2 /
+maxpool2 + customGrad, on programs written by hand in the kernel-description grammar (no DSL
+mirror involved) — tests/golden/make_handwritten.py."""
+import pytest
+
+import handwritten
+
+CASES = handwritten.load()
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_reproduces_the_closed_forms(name):
+    from oracle import kd
+    case = CASES[name]
+    ref = kd.Model(case["text"])
+
+    def set_param(t, v):
+        ref.params[t][...] = v
+
+    def set_epoch(e):
+        ref.epoch = e
+
+    handwritten.check(case, ref, set_param, lambda t: ref.params[t], lambda t: ref.caches[t], set_epoch)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_handwritten_text_equals_what_the_dsl_mirror_emits_semantically(name):
+    """The DSL mirror's own text for the same layers, run on the oracle, gives the same numbers: a
+    front-end bug outside the 37 pinned reference programs would show here."""
+    import numpy as np
+    import refcases
+    from exprgrad_amd import dsl, layers
+    from oracle import kd
+    case = CASES[name]
+    arr = handwritten.arr
+    if name == "conv2_4d":
+        ref = kd.Model(refcases.program_text(refcases.conv2_bench()))
+        got = ref.call("conv2", {k: arr(v).astype(np.float32) for k, v in case["inputs"].items()})
+        assert np.array_equal(got, arr(case["calls"][0]["expect"]))
+    elif name == "maxpool2_grad":
+        net = layers.maxpool2(dsl.input("x")).target("pool")
+        ref = kd.Model(refcases.program_text([net]))
+        got = ref.call("pool", {"x": arr(case["inputs"]["x"]).astype(np.float32)})
+        assert np.array_equal(got, arr(case["calls"][0]["expect"]))
+    elif name == "softmax_xent":
+        net = layers.softmax(dsl.input("z")).target("predict")
+        net = layers.cross_entropy(net, dsl.input("y")).target("loss")
+        ref = kd.Model(refcases.program_text([net]))
+        ins = {"z": arr(case["params"]["1"]).astype(np.float32), "y": arr(case["inputs"]["y"]).astype(np.float32)}
+        assert handwritten.close(ref.call("predict", {"z": ins["z"]}), arr(case["calls"][0]["expect"]), 1e-6)
+        assert handwritten.close(ref.call("loss", ins), arr(case["calls"][1]["expect"]), 1e-6)
+    else:
+        it = dsl.iters("it")
+        p = dsl.param([3], name="p")
+        loss = dsl.Fun()
+        loss[0] += dsl.sq(p.raw[it] - dsl.input("t").raw[it])
+        ref = kd.Model(refcases.program_text([loss.target("loss").backprop(layers.adam(0.5)).target("train")]))
+        tid = sorted(ref.params)[0]
+        ref.params[tid][...] = arr(case["params"]["1"]).astype(np.float32)
+        ref.epoch = 1
+        ref.apply("train", {"t": arr(case["inputs"]["t"]).astype(np.float32)})
+        assert handwritten.close(ref.params[tid], arr(case["expect_params"]["1"]), 1e-5)
