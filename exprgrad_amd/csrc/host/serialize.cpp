@@ -118,7 +118,8 @@ int load_table(eg_model* m, TK kind, Reader& r, const char* what) {
                "model state: tensor %ld is not one of the model's %s", (long)tid, what);
     EG_REQUIRE(!is_nil, EG_ERR_INVALID, "model state: tensor %ld of the %s table is nil", (long)tid, what);
     const int64_t rank = r.i64();
-    EG_REQUIRE(r.ok && rank >= 0 && rank <= 64, EG_ERR_INVALID, "model state: bad rank for tensor %ld", (long)tid);
+    EG_REQUIRE(r.ok, EG_ERR_INVALID, "model state: truncated %s table", what);
+    EG_REQUIRE(rank >= 0 && rank <= 64, EG_ERR_INVALID, "model state: bad rank for tensor %ld", (long)tid);
     std::vector<long> shape;
     for (int64_t d = 0; d < rank; ++d) shape.push_back((long)r.i64());
     EG_REQUIRE(r.ok, EG_ERR_INVALID, "model state: truncated shape of tensor %ld", (long)tid);

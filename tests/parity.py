@@ -1,0 +1,165 @@
+"""Three-way parity for model tests: backend (GPU, float32) | oracle (reference arithmetic,
+float32) | shadow (the same kernel list in float64 = the exact value of what both compute).
+
+BASELINE.json states 1e-5 relative for float32.  A GPU-vs-oracle difference above that can be the
+oracle's own rounding (the reference sums batch-long reductions sequentially in float32: error up
+to n * 2^-24 of the summed magnitude) — round 1 widened tolerances for it.  Here every comparison
+is made against the shadow instead:
+
+    backend  within TOL = 1e-5 of the shadow, always;
+    oracle   within max(TOL, n * 2^-24) of the shadow, n = the longest reduction the caller names.
+
+Training steps are compared FROM IDENTICAL STATE, step by step: before every step the oracle and
+the shadow receive the backend's current parameters and caches, so a step's comparison never
+carries the divergence of earlier steps.  What is compared per step: every parameter gradient (the
+tensors themselves — a parameter difference would hide them behind the float32 spacing of the
+parameter), the parameters and the caches after the update.
+"""
+import json
+import os
+
+import numpy as np
+
+import refcases
+from conftest import TOL, rel_err
+from exprgrad_amd import model as egm
+
+U = 2.0 ** -24      # float32 unit roundoff
+
+
+class Trio:
+    def __init__(self, gpu_ctx, graphs_fn, threads=4, text=None):
+        from oracle import kd
+        self.text = text if text is not None else refcases.program_text(graphs_fn())
+        if text is None:
+            self.gpu = egm.compile(*graphs_fn(), gpu=gpu_ctx)
+        else:
+            self.gpu = egm.Model(egm._LoadedProgram(text), gpu_ctx)
+        self.ref = kd.Model(self.text, threads=threads)
+        self.exact = kd.Model(self.text, shadow=True)
+
+    # ---- state ------------------------------------------------------------------------------
+    def init_params(self, rng, lo=-0.3, hi=0.3):
+        for tid in sorted(self.ref.params):
+            v = (lo + (hi - lo) * rng.random(self.ref.params[tid].shape, dtype=np.float32)).astype(np.float32)
+            self.set_param(tid, v)
+
+    def set_param(self, tid, v):
+        self.gpu.params[tid] = v
+        self.ref.params[tid][...] = v
+        self.exact.params[tid][...] = v
+
+    def sync_from_gpu(self):
+        for tid in self.ref.params:
+            v = self.gpu.params[tid]
+            self.ref.params[tid][...] = v
+            self.exact.params[tid][...] = v
+        for tid in self.ref.caches:
+            v = self.gpu.caches[tid]
+            self.ref.caches[tid][...] = v
+            self.exact.caches[tid][...] = v
+
+    def set_epoch(self, e):
+        self.gpu.epoch = e
+        self.ref.epoch = e
+        self.exact.epoch = e
+
+    # ---- comparisons --------------------------------------------------------------------------
+    @staticmethod
+    def check(got, ref32, exact, n=1, what="", floor=0.0):
+        """floor: absolute allowance as a fraction of the magnitude that was SUMMED to get the value
+        (callers pass it when the value is a difference of large terms; default none)."""
+        bound_ref = max(TOL, n * U)
+        scale = max(float(np.max(np.abs(exact))) if np.size(exact) else 0.0, 1e-30)
+        e_gpu = float(np.max(np.abs(np.asarray(got, np.float64) - exact))) / scale if np.size(exact) else 0.0
+        e_ref = float(np.max(np.abs(np.asarray(ref32, np.float64) - exact))) / scale if np.size(exact) else 0.0
+        record = os.environ.get("EG_PARITY_RECORD")
+        if record:      # survey mode: log both distances instead of asserting (tools: choose bounds from data)
+            with open(record, "a") as f:
+                f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", ""), "what": what, "n": n,
+                                    "e_gpu": e_gpu, "e_ref": e_ref, "size": int(np.size(exact))}) + "\n")
+            return
+        assert np.all(np.isfinite(np.asarray(got))) == np.all(np.isfinite(exact)), (what, "finiteness differs")
+        if not np.all(np.isfinite(exact)):
+            return
+        assert e_gpu <= TOL + floor, (what, "backend vs exact", e_gpu)
+        assert e_ref <= bound_ref + floor, (what, "oracle vs exact", e_ref, bound_ref)
+
+    def call(self, target, inputs, n=1, floor=0.0):
+        g = self.gpu.call(target, inputs)
+        r = self.ref.call(target, inputs)
+        e = self.exact.call(target, inputs)
+        self.check(g, r, e, n, f"{target} output", floor)
+        return g
+
+    def step(self, target, inputs, n=1, floor=0.0, sync=True):
+        """One training step from identical state, checked in two links so that an ill-conditioned
+        optimizer (adam divides by sqrt(v) + 1e-8: an absolute gradient error of 1e-9 can move the
+        update by 10 %) does not force a loose bound on the parameters:
+          1. gradients:  backend vs shadow at TOL, oracle vs shadow at its summation bound
+             (n = the longest reduction, usually the batch);
+          2. optimizer:  the oracle's and the shadow's optimizer kernels are run ON THE BACKEND'S
+             gradients; parameters and caches after the update must then agree at TOL."""
+        if sync:
+            self.sync_from_gpu()
+        self.ref.run_backward(target, inputs)
+        self.exact.run_backward(target, inputs)
+        self.gpu.apply(target, inputs)
+        grads = {}
+        for ptid, gtid in self.ref.param_grads(target):
+            grads[gtid] = self.gpu.read_tensor(target, gtid)
+            self.check(grads[gtid], self.ref.last[gtid], self.exact.last[gtid], n, f"gradient of parameter {ptid}", floor)
+        for gtid, g in grads.items():
+            self.ref.last[gtid][...] = g
+            self.exact.last[gtid][...] = g
+        self.ref.run_update(target)
+        self.exact.run_update(target)
+        for tid in sorted(self.ref.params):
+            self.check(self.gpu.params[tid], self.ref.params[tid], self.exact.params[tid], 1, f"parameter {tid} after the step")
+        for tid in sorted(self.ref.caches):
+            self.check(self.gpu.caches[tid], self.ref.caches[tid], self.exact.caches[tid], 1, f"cache {tid} after the step")
+
+    def close(self):
+        self.gpu.close()
+
+
+# ---- float64 closed forms of the library ops (the exact value for op-level tests) ----------------
+def exact_conv2(img, flt):
+    img, flt = np.asarray(img, np.float64), np.asarray(flt, np.float64)
+    N, H, W, C = img.shape
+    F, FH, FW, _ = flt.shape
+    Ho, Wo = H - FH + 1, W - FW + 1
+    out = np.zeros((N, Ho, Wo, F))
+    for dy in range(FH):
+        for dx in range(FW):
+            out += img[:, dy:dy + Ho, dx:dx + Wo] @ flt[:, dy, dx].T
+    return out
+
+
+def exact_conv2_grad_filter(img, gout, flt_shape):
+    img, gout = np.asarray(img, np.float64), np.asarray(gout, np.float64)
+    F, FH, FW, C = flt_shape
+    _, Ho, Wo, _ = gout.shape
+    g = np.zeros(flt_shape)
+    go = gout.reshape(-1, F)
+    for dy in range(FH):
+        for dx in range(FW):
+            g[:, dy, dx] = go.T @ img[:, dy:dy + Ho, dx:dx + Wo].reshape(-1, C)
+    return g
+
+
+def exact_conv2_grad_image(flt, gout, img_shape):
+    flt, gout = np.asarray(flt, np.float64), np.asarray(gout, np.float64)
+    F, FH, FW, C = flt.shape
+    _, Ho, Wo, _ = gout.shape
+    g = np.zeros(img_shape)
+    for dy in range(FH):
+        for dx in range(FW):
+            g[:, dy:dy + Ho, dx:dx + Wo] += gout @ flt[:, dy, dx]
+    return g
+
+
+def check_op(got, ref32, exact, n, what=""):
+    """Op-level form of Trio.check: backend within TOL of the float64 value, the oracle within its
+    sequential-summation bound max(TOL, n * 2^-24)."""
+    Trio.check(got, ref32, np.asarray(exact, np.float64), n, what)

@@ -9,6 +9,7 @@ import refcases
 from conftest import TOL, rel_err
 from exprgrad_amd import dsl, layers
 from exprgrad_amd import model as egm
+from parity import Trio
 
 pytestmark = pytest.mark.gpu
 
@@ -39,28 +40,30 @@ def build(gpu_ctx, monkeypatch, min_elems, **kw):
     return gpu, ref
 
 
+def trio(gpu_ctx, monkeypatch, min_elems, graphs, prange):
+    monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", str(min_elems))
+    t = Trio(gpu_ctx, graphs)
+    t.init_params(np.random.default_rng(5), -prange, prange)
+    return t
+
+
 @pytest.mark.parametrize("act", sorted(ACTS))
 @pytest.mark.parametrize("batch", [64, 37, 300])
 def test_fused_epilogue_matches_the_oracle(gpu_ctx, monkeypatch, act, batch):
-    gpu, ref = build(gpu_ctx, monkeypatch, 0, act=act)
+    t = trio(gpu_ctx, monkeypatch, 0, lambda: mlp(act=act), 0.3)
     rng = np.random.default_rng(batch)
     x = (rng.random((batch, 96), dtype=np.float32) - 0.5).astype(np.float32)
     y = rng.random((batch, 8), dtype=np.float32)
-    assert rel_err(gpu.call("predict", {"x": x}), ref.call("predict", {"x": x})) <= TOL
-    assert gpu.launch_plan("predict").count("gemm+epilogue") == 2     # both hidden layers
-    assert rel_err(gpu.call("loss", {"x": x, "y": y}), ref.call("loss", {"x": x, "y": y})) <= TOL
-    before = {t: ref.params[t].copy() for t in ref.params}
-    for _ in range(2):  # the second step replays the captured graph
-        gpu.apply("train", {"x": x, "y": y})
-        ref.apply("train", {"x": x, "y": y})
-    plan = gpu.launch_plan("train")
+    t.call("predict", {"x": x}, n=96)
+    assert t.gpu.launch_plan("predict").count("gemm+epilogue") == 2     # both hidden layers
+    t.call("loss", {"x": x, "y": y}, n=batch * 8)
+    for _ in range(3):  # eager, captured, replayed — each compared from the backend's own state
+        t.step("train", {"x": x, "y": y}, n=batch)
+    plan = t.gpu.launch_plan("train")
     # 2 forward + the backward ones (at batch 37 the [37, 72] gradients are "small" tensors and the
     # activation gradients join a single-block small-kernel group instead)
     assert plan.count("gemm+epilogue") >= (3 if batch >= 64 else 2), plan
-    for tid in sorted(ref.params):
-        du_gpu, du_ref = gpu.params[tid] - before[tid], ref.params[tid] - before[tid]
-        assert rel_err(du_gpu, du_ref) <= 2e-5 + 1e-7 / max(np.abs(du_ref).max(), 1e-30), (tid, plan)
-    gpu.close()
+    t.close()
 
 
 def test_fused_and_unfused_paths_agree_bit_for_bit(gpu_ctx, monkeypatch):
@@ -86,24 +89,13 @@ def test_fused_and_unfused_paths_agree_bit_for_bit(gpu_ctx, monkeypatch):
 def test_large_layers_fuse_by_default(gpu_ctx, monkeypatch):
     # >= 2^20 output elements: no environment override needed (the cfg-5 shapes at a reduced batch)
     monkeypatch.delenv("EG_EPILOGUE_MIN_ELEMS", raising=False)
-    from oracle import kd
-    graphs = lambda: refcases.dense_softmax_net(n_in=64, n_hidden=512, n_out=10)
-    gpu = egm.compile(*graphs(), gpu=gpu_ctx)
-    ref = kd.Model(refcases.program_text(graphs()), threads=8)
+    t = Trio(gpu_ctx, lambda: refcases.dense_softmax_net(n_in=64, n_hidden=512, n_out=10), threads=8)
     rng = np.random.default_rng(1)
-    for tid in sorted(ref.params):
-        v = (rng.random(ref.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
-        ref.params[tid][...] = v
-        gpu.params[tid] = v
+    t.init_params(rng, -0.1, 0.1)
     batch = 2048
     x = rng.random((batch, 64), dtype=np.float32)
     y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, size=batch)]
-    before = {t: ref.params[t].copy() for t in ref.params}
-    gpu.apply("train", {"x": x, "y": y})
-    ref.apply("train", {"x": x, "y": y})
-    plan = gpu.launch_plan("train")
+    t.step("train", {"x": x, "y": y}, n=batch)
+    plan = t.gpu.launch_plan("train")
     assert plan.count("gemm+epilogue") == 2, plan     # relu forward, relu backward
-    for tid in sorted(ref.params):
-        du_gpu, du_ref = gpu.params[tid] - before[tid], ref.params[tid] - before[tid]
-        assert rel_err(du_gpu, du_ref) <= 2e-5 + 1e-7 / max(np.abs(du_ref).max(), 1e-30), tid
-    gpu.close()
+    t.close()

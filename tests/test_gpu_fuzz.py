@@ -80,36 +80,23 @@ def build(seed):
 
 @pytest.mark.parametrize("seed", seeds("EG_FUZZ_CHAINS", "0:40"))
 def test_random_chain_matches_the_oracle(gpu_ctx, monkeypatch, seed):
-    from oracle import kd
-    from exprgrad_amd import model as egm
+    from parity import Trio
     monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", "0" if seed % 2 else str(1 << 40))
     graphs, width, out_dims = build(seed)
-    gpu = egm.compile(*graphs, gpu=gpu_ctx)
-    ref = kd.Model(refcases.program_text(build(seed)[0]), threads=2)
+    t = Trio(gpu_ctx, lambda: build(seed)[0], threads=2)
     rng = np.random.default_rng(seed)
-    for tid in sorted(ref.params):
-        v = (rng.random(ref.params[tid].shape, dtype=np.float32) * 0.6 - 0.3).astype(np.float32)
-        ref.params[tid][...] = v
-        gpu.params[tid] = v
+    t.init_params(rng, -0.3, 0.3)
     batch = [5, 64, 257, 1500][seed % 4]
     x = (rng.random((batch, width), dtype=np.float32) - 0.5).astype(np.float32)
     y = rng.random((batch, out_dims), dtype=np.float32)
-    tol = 2e-5
-    assert rel_err(gpu.call("predict", {"x": x}), ref.call("predict", {"x": x})) <= tol, gpu.launch_plan("predict")
-    assert rel_err(gpu.call("loss", {"x": x, "y": y}), ref.call("loss", {"x": x, "y": y})) <= tol
-    gx_g, gx_r = gpu.call("gx", {"x": x, "y": y}), ref.call("gx", {"x": x, "y": y})
-    assert rel_err(gx_g, gx_r) <= 5e-5 + 1e-7 / max(np.abs(gx_r).max(), 1e-30), gpu.launch_plan("gx")
-    gpu.epoch = ref.epoch = 1
-    before = {t: ref.params[t].copy() for t in ref.params}
-    for _ in range(2):
-        gpu.apply("train", {"x": x, "y": y})
-        ref.apply("train", {"x": x, "y": y})
-    for tid in sorted(ref.params):
-        # adam divides by sqrt(v) + eps: where the gradient is ~0 its step amplifies rounding; compare parameters
-        assert rel_err(gpu.params[tid], ref.params[tid]) <= 2e-4, (tid, gpu.launch_plan("train"))
-        du_g, du_r = gpu.params[tid] - before[tid], ref.params[tid] - before[tid]
-        assert rel_err(du_g, du_r) <= 2e-2, (tid, gpu.launch_plan("train"))
-    gpu.close()
+    n = batch * 64      # longest reduction: the loss / a weight gradient over the batch, rows up to 64 wide
+    t.call("predict", {"x": x}, n=64)
+    t.call("loss", {"x": x, "y": y}, n=n)
+    t.call("gx", {"x": x, "y": y}, n=n)
+    t.set_epoch(1)
+    for _ in range(2):   # eager, then the captured sequence; each from the backend's own state
+        t.step("train", {"x": x, "y": y}, n=n)
+    t.close()
 
 
 def build_cnn(seed):
@@ -147,27 +134,16 @@ def chans_in(seed):
 
 @pytest.mark.parametrize("seed", seeds("EG_FUZZ_CNNS", "0:16"))
 def test_random_cnn_matches_the_oracle(gpu_ctx, seed):
-    from oracle import kd
-    from exprgrad_amd import model as egm
+    from parity import Trio
     graphs, (h, w, c), _ = build_cnn(seed)
-    gpu = egm.compile(*graphs, gpu=gpu_ctx)
-    ref = kd.Model(refcases.program_text(build_cnn(seed)[0]), threads=4)
+    t = Trio(gpu_ctx, lambda: build_cnn(seed)[0], threads=4)
     rng = np.random.default_rng(seed)
-    for tid in sorted(ref.params):
-        v = (rng.random(ref.params[tid].shape, dtype=np.float32) * 0.6 - 0.3).astype(np.float32)
-        ref.params[tid][...] = v
-        gpu.params[tid] = v
+    t.init_params(rng, -0.3, 0.3)
     batch = [2, 9, 40][seed % 3] if seed < 16 else [2, 9, 40, 33, 96][seed % 5]
     x = (rng.random((batch, h, w, c), dtype=np.float32) - 0.5).astype(np.float32)
-    out_r = ref.call("predict", {"x": x})
-    y = rng.random(out_r.shape, dtype=np.float32)
-    assert rel_err(gpu.call("predict", {"x": x}), out_r) <= 2e-5, gpu.launch_plan("predict")
-    gx_g, gx_r = gpu.call("gx", {"x": x, "y": y}), ref.call("gx", {"x": x, "y": y})
-    assert rel_err(gx_g, gx_r) <= 5e-5 + 1e-7 / max(np.abs(gx_r).max(), 1e-30), gpu.launch_plan("gx")
-    before = {t: ref.params[t].copy() for t in ref.params}
-    gpu.apply("train", {"x": x, "y": y})
-    ref.apply("train", {"x": x, "y": y})
-    for tid in sorted(ref.params):
-        du_g, du_r = gpu.params[tid] - before[tid], ref.params[tid] - before[tid]
-        assert rel_err(du_g, du_r) <= 1e-4 + 1e-7 / max(np.abs(du_r).max(), 1e-30), (tid, gpu.launch_plan("train"))
-    gpu.close()
+    n = batch * h * w    # a filter gradient sums over every output pixel of every image
+    out = t.call("predict", {"x": x}, n=h * w * 64)
+    y = rng.random(out.shape, dtype=np.float32)
+    t.call("gx", {"x": x, "y": y}, n=n)
+    t.step("train", {"x": x, "y": y}, n=n)
+    t.close()
