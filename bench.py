@@ -23,8 +23,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz
-HBM_PEAK_GBS = 8000.0         # HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s)
+# Roofline denominators live in ONE file shared with whoever checks the fractions:
+# f32 MFMA 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz), HBM3E 8.0 TB/s.
+with open(os.path.join(ROOT, "roofline_constants.json")) as _f:
+    ROOFLINE = json.load(_f)
+F32_MFMA_PEAK_TFLOPS = ROOFLINE["f32_mfma_peak_tflops"]
+HBM_PEAK_GBS = ROOFLINE["hbm_peak_gbs"]
 
 DENSE = dict(n_in=784, n_hidden=512, n_out=10, rate=0.01, batch=65536)
 # algorithmic GEMM FLOPs per sample of the dense-net train step (SURVEY.md §8d cfg 5):
@@ -33,14 +37,56 @@ DENSE_FLOPS_PER_SAMPLE = 2 * (2 * 784 * 512) + 3 * (2 * 512 * 10)
 XOR_BYTES_PER_SAMPLE = 72 * 4  # kernel-list traffic of the XOR train target
 
 
+def source_fingerprint():
+    """sha256 over the kernel and host sources of the library: what a PMC profile must have been taken on
+    for its byte counts to describe the kernels this run times."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "exprgrad_amd", "csrc")
+    for sub in ("kernels", "host", "."):
+        d = os.path.join(base, sub)
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".hip", ".hpp", ".cpp", ".h")):
+                with open(os.path.join(d, name), "rb") as f:
+                    h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+_TRAFFIC = None
+
+
 def measured_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
-    tools/summarize_profile.py: 2 x FETCH_SIZE + WRITE_SIZE); None when no profile covers the workload."""
+    tools/summarize_profile.py: 2 x FETCH_SIZE + WRITE_SIZE); None when no profile covers the workload.
+    The counters cannot be read inside this process (rocprofv3 wraps the command), so the figure is as
+    old as the profile: traffic_is_stale() tells whether the sources changed since."""
+    global _TRAFFIC
+    if _TRAFFIC is None:
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                _TRAFFIC = json.load(f)
+        except (OSError, ValueError):
+            _TRAFFIC = {}
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            return json.load(f)[key]["traffic_bytes"]
-    except (OSError, KeyError, ValueError):
+        return _TRAFFIC[key]["traffic_bytes"]
+    except KeyError:
         return None
+
+
+def traffic_is_stale(key):
+    """True when profiles/traffic.json was taken on other sources than the ones built now (or does not
+    say): a kernel change without a re-profile must not pass old byte counts off as current."""
+    measured_traffic(key)
+    entry = _TRAFFIC.get(key)
+    if not entry:
+        return None
+    return entry.get("source_fingerprint", _TRAFFIC.get("source_fingerprint")) != source_fingerprint()
+
+
+def traffic_fields(key):
+    t = measured_traffic(key)
+    return {"traffic": t, "traffic_stale": traffic_is_stale(key) if t is not None else None,
+            "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile.sh)"}
 
 
 def parse():
@@ -57,9 +103,13 @@ def parse():
                     help="matmul: skip the Model.call (H2D + product + D2H) figure; tools/profile.sh sets it so that "
                          "rocprofv3's per-kernel average covers the device-resident launches only (the first "
                          "Model.call launch touches fresh allocations and takes ~24 ms)")
-    ap.add_argument("--native-dp", action="store_true",
-                    help="N > 1: exchange the gradients with the C ABI's own RCCL group (eg_dp_*, eg_model_step_dp) "
-                         "instead of torch.distributed's all_reduce")
+    ap.add_argument("--native-dp", action="store_true", help="(default for N > 1; kept for old command lines)")
+    ap.add_argument("--torch-dp", action="store_true",
+                    help="N > 1: let torch.distributed all-reduce the gradient bucket instead of the C ABI's own RCCL "
+                         "group (eg_dp_*, eg_model_step_dp — what a Nim host binds, the default)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1 train workload: weak = 65536 samples per GPU (N = 8 is the config's 524288 global "
+                         "batch); strong = the config's global batch of 524288 divided over the N GPUs (SURVEY.md §8d)")
     return ap.parse_args()
 
 
@@ -180,6 +230,70 @@ def cpu_baseline_train(text, batch_cpu=2048):
                       f"threads, elementwise kernels single-threaded as in the reference), {dt * 1e3:.1f} ms/step"}
 
 
+def cpu_baseline_conv2(budget_s=6.0):
+    """configs[3] on the host: the reference's loop order n, y, f, dy, x, dx, c (conv2_naive,
+    benchmarks/conv2/conv2.nim:49-55).  The reference parallelises only the image loop n (SURVEY.md
+    Appendix A.4), so with N = 1 its policy is ONE core; a y-parallel all-core figure is given next to it,
+    labelled as not the reference's policy.  Sample: a band of output rows (each row is the complete
+    3 x 3 x 64 reduction), scaled by rows."""
+    import numpy as np
+    from oracle import refcpu
+    refcpu.build()
+    cores = os.cpu_count() or 1
+    H = W = 256
+    C = F = 64
+    rng = np.random.default_rng(4)
+    flt = (rng.random((F, 3, 3, C), dtype=np.float32) * 4 - 2).astype(np.float32)
+    flops_row = 2.0 * (W - 2) * F * 9 * C
+
+    def timed(rows, threads_y):
+        img = rng.random((1, rows + 2, W, C), dtype=np.float32)
+        t0 = time.perf_counter()
+        refcpu.conv2_nhwc(img, flt, threads_y=threads_y)
+        return time.perf_counter() - t0
+    dt = timed(2, 1)
+    rows = int(max(2, min(H - 2, 2 * budget_s / max(dt, 1e-6))))
+    dt = timed(rows, 1)
+    one = {"value": round(rows * flops_row / dt / 1e9, 3), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+           "sample": f"{rows} of the 254 output rows of configs[3], oracle/refcpu.c ref_conv2_nhwc (reference loop order), "
+                     f"one thread = the reference's policy for N = 1 (only the image loop is parallel), {dt:.2f} s wall"}
+    rows_all = H - 2
+    dt_all = timed(rows_all, cores)
+    one["all_cores_not_reference_policy"] = {
+        "value": round(rows_all * flops_row / dt_all / 1e9, 2), "unit": "GFLOP/s", "cores": min(cores, rows_all),
+        "sample": f"all 254 rows, the y loop split over {min(cores, rows_all)} threads (NOT what the reference does), {dt_all:.2f} s wall"}
+    return one
+
+
+def cpu_baseline_xor(batch=65536, budget_s=5.0):
+    """configs[2] on the host: the oracle's XOR train step at the full batch.  No kernel of this step
+    reaches the reference's 2^24 work-per-thread threshold (passes.nim:2415-2437), so its policy is one
+    thread throughout."""
+    import numpy as np
+    from exprgrad_amd import examples
+    from oracle import kd
+    m = kd.Model(__import__("exprgrad_amd").dsl.to_program(*examples.xor_from_scratch()).to_text(), threads=1)
+    rng = np.random.default_rng(3)
+    for tid in m.params:
+        m.params[tid][...] = (rng.random(m.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+    x = rng.integers(0, 2, size=(batch, 2)).astype(np.float32)
+    y = (x[:, :1] != x[:, 1:]).astype(np.float32)
+    m.apply("train", {"x": x, "y": y})
+    for tid in m.params:   # rate 0.1 on a 65536-sample sum: keep the parameters finite between repetitions
+        m.params[tid][...] = (rng.random(m.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < budget_s or reps < 1:
+        for tid in m.params:
+            m.params[tid][...] = 0.05
+        m.apply("train", {"x": x, "y": y})
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": round(1.0 / dt, 2), "unit": "steps/s", "samples_per_s": round(batch / dt, 1), "cores": 1, "kind": "port",
+            "sample": f"{reps} train steps at the full batch of {batch} (oracle/kd.py + refinterp.c, one thread = the "
+                      f"reference's policy: no kernel of the step reaches 2^24 work per thread), {dt * 1e3:.1f} ms/step"}
+
+
 # ------------------------------------------------------------------------------ workloads
 
 def _matmul_end_to_end(args, env, a, b, c, ctx, n, flops):
@@ -231,7 +345,7 @@ def run_matmul(args, env):
                    "parallelism": "single" if env["world"] == 1 else f"{env['world']} independent replicas"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                     "traffic": measured_traffic("matmul4096") if n == 4096 else None,
+                     **(traffic_fields("matmul4096") if n == 4096 else {"traffic": None}),
                      "kernel": "eg::gemm::gemm_f32_mfma_kernel<256,256,16,128,64,NN,DMA>", "flops_per_launch": flops,
                      "kernel_ms_avg": round(ev_avg, 4), "kernel_ms_min": round(ev_min, 4)},
     }
@@ -253,19 +367,39 @@ def build_dense(env, batch):
     x = torch.rand((batch, DENSE["n_in"]), device="cuda", dtype=torch.float32, generator=gen)
     labels = torch.randint(0, DENSE["n_out"], (batch,), device="cuda", generator=gen)
     y = torch.nn.functional.one_hot(labels, DENSE["n_out"]).to(torch.float32).contiguous()
-    if env.get("native_dp") and env["world"] > 1:
-        # the library's own communicator: rank 0 draws the id, torch.distributed only carries its 128 bytes
+    env["dp_path"] = "none"
+    dp = None
+    if env["world"] > 1 and env.get("native_dp"):
+        # the library's own communicator (what a Nim host binds): rank 0 draws the id, torch.distributed
+        # only carries its 128 bytes.  Every rank must take the same path, so a failure anywhere
+        # (librccl missing, init error) sends all of them to the torch.distributed exchange instead.
         import torch.distributed as dist
         from exprgrad_amd.parallel import NativeDataParallel, RcclGroup
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if env["rank"] == 0:
-            uid.copy_(torch.frombuffer(bytearray(RcclGroup.unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
-        group = RcclGroup(env["ctx"], bytes(uid.cpu().numpy().tobytes()), env["rank"], env["world"])
-        dp = NativeDataParallel(model, "train", group, reduction="mean")
-        dp.engine = _NativeEngine(model, "train")
-    else:
+        ok, group = 1, None
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if env["rank"] == 0:
+                uid.copy_(torch.frombuffer(bytearray(RcclGroup.unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, 0)
+            group = RcclGroup(env["ctx"], bytes(uid.cpu().numpy().tobytes()), env["rank"], env["world"])
+        except Exception as exc:  # noqa: BLE001
+            ok = 0
+            env["dp_fallback_reason"] = repr(exc)
+        flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            dp = NativeDataParallel(model, "train", group, reduction="mean")
+            dp.engine = _NativeEngine(model, "train")
+            env["dp_path"] = "native"
+            env["rccl_ranks"] = group.world
+        elif group is not None:
+            group.close()
+    if dp is None:
         dp = DataParallel(GpuEngine(model, "train"), reduction="mean")
+        if env["world"] > 1:
+            import torch.distributed as dist
+            env["dp_path"] = "torch"
+            env["rccl_ranks"] = dist.get_world_size()
     return model, dp, x, y
 
 
@@ -286,9 +420,10 @@ class _NativeEngine:
 
 
 def run_train(args, env):
-    batch = args.batch or DENSE["batch"]
-    model, dp, x, y = build_dense(env, batch)
     world = env["world"]
+    strong = getattr(args, "scaling", "weak") == "strong"
+    batch = args.batch or (DENSE["batch"] * 8 // world if strong else DENSE["batch"])
+    model, dp, x, y = build_dense(env, batch)
     inputs = [("x", x), ("y", y)]
     single = None
     if world > 1:
@@ -318,21 +453,25 @@ def run_train(args, env):
                                "backward + parameter-gradient all-reduce + update",
                    "global_batch": batch * world, "per_gpu_batch": batch,
                    "parallelism": f"dp{world}" if world > 1 else "single",
-                   "collective": "none" if world == 1 else ("RCCL all-reduce from the C ABI (eg_model_step_dp)"
-                                                            if env.get("native_dp") else
-                                                            ("gloo all-reduce (EG_BENCH_ONE_GPU test mode)"
-                                                             if os.environ.get("EG_BENCH_ONE_GPU") == "1" else
-                                                             "RCCL all-reduce through torch.distributed (nccl backend)")),
+                   "collective": {"none": "none",
+                                  "native": "RCCL all-reduce from the C ABI (eg_model_step_dp, the library's own communicator)",
+                                  "torch": ("gloo all-reduce (EG_BENCH_ONE_GPU test mode)" if os.environ.get("EG_BENCH_ONE_GPU") == "1"
+                                            else "RCCL all-reduce through torch.distributed (nccl backend)")}[env.get("dp_path", "none")],
+                   "rccl_ranks": env.get("rccl_ranks", 0),
+                   "scaling": "strong" if strong else "weak",
                    "grad_bucket_floats": model.grad_bucket("train")[1]},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                     "traffic": measured_traffic("train") if batch == DENSE["batch"] else None,
+                     **(traffic_fields("train") if batch == DENSE["batch"] else {"traffic": None}),
                      "kernel": "whole train step on one GPU (5 contractions dominate: gemm_f32_mfma_kernel)",
                      "flops_per_launch": step_flops, "kernel_ms_avg": round(ev_avg, 4),
                      "kernel_ms_min": round(ev_min, 4)},
     }
     if single:
         out["single_gpu_reference"] = single
+    if env.get("dp_fallback_reason"):
+        out["config"]["native_dp_fallback"] = env["dp_fallback_reason"]
+    out["scaling"] = "strong" if strong else "weak"
     return out, model
 
 
@@ -354,9 +493,16 @@ def run_xor(args, env):
             "unit": "steps/s", "samples_per_s": round(batch * steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic("xor") if batch == 65536 else None,
+                         **(traffic_fields("xor") if batch == 65536 else {"traffic": None}),
                          "kernel": "whole step (19 kernels fused into 4 launches replayed as HIP graphs; launch-latency bound)",
-                         "bytes_per_launch": XOR_BYTES_PER_SAMPLE * batch, "kernel_ms_avg": round(ev_avg, 4)}}
+                         "bytes_per_launch": XOR_BYTES_PER_SAMPLE * batch, "kernel_ms_avg": round(ev_avg, 4)},
+            "scaling_note": "launch-bound: the step is 3 dependent launches (~25 us) around 1 MB of real traffic, so its "
+                            "time is launch latency, not bandwidth.  Under data parallelism a step adds one 17-float "
+                            "all-reduce (tens of us) and cannot get shorter: steps/s does NOT scale with GPUs.  The only "
+                            "claim this workload supports is weak scaling in samples/s (65536 samples per GPU: N GPUs "
+                            "process N x 65536 samples in one step time + one all-reduce latency); the north-star's "
+                            ">= 6x from 1 to 8 GPUs is a statement about the dense step (configs[4]), whose 1.1 ms of "
+                            "matrix work dwarfs the exchange."}
 
 
 def run_xor_dp(args, env):
@@ -411,7 +557,7 @@ def run_conv2(args, env):
             "unit": "GFLOP/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": measured_traffic("conv2"),
+                         **traffic_fields("conv2"),
                          "kernel": "conv2_halo_kernel<9,3,3> (LDS-resident 10x34 halo, 8x32 patch x 64 filters per block)", "flops_per_launch": flops,
                          "kernel_ms_avg": round(ev_avg, 4)},
             "backward": backward}
@@ -474,7 +620,9 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx = eg.newGpuContext(local_rank, stream=stream.cuda_stream)
-    env = {"torch": torch, "ops": ops, "ctx": ctx, "world": world, "rank": rank, "native_dp": args.native_dp,
+    # N > 1: the C ABI's own RCCL group unless --torch-dp; the one-GPU test mode has no second device for RCCL
+    native = world > 1 and not args.torch_dp and not one_gpu
+    env = {"torch": torch, "ops": ops, "ctx": ctx, "world": world, "rank": rank, "native_dp": native,
            "timer": Timer(torch, dist, world, stream)}
 
     workload = args.workload
@@ -491,8 +639,8 @@ def main():
     else:
         line = run_conv2(args, env)
 
-    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+            "scaling": line.get("scaling", "weak"), "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
     line = {**{k: line[k] for k in ("metric", "value", "unit")}, **base,
             **{k: v for k, v in line.items() if k not in ("metric", "value", "unit")}}
 
@@ -527,6 +675,18 @@ def main():
             guarded("conv2", lambda: run_conv2(small, env))
             guarded("fashion_mnist_fit", lambda: run_fashion_fit(small, env))
             line["extra"] = extra
+            if not args.no_cpu_baseline:
+                # every config gets its CPU figure, bounded to a few seconds each
+                def baseline(name, fn):
+                    if "error" in extra.get(name, {"error": 1}):
+                        return
+                    try:
+                        extra[name]["cpu_baseline"] = fn()
+                    except Exception as exc:  # noqa: BLE001
+                        extra[name]["cpu_baseline"] = {"error": repr(exc)}
+                baseline("train", lambda: cpu_baseline_train(model.source_text))
+                baseline("xor", cpu_baseline_xor)
+                baseline("conv2", cpu_baseline_conv2)
             if "error" not in extra["train"]:
                 # the --gpus N > 1 invocations report the data-parallel train step; its 1-GPU point:
                 line["scaling_series_n1"] = {"metric": extra["train"]["metric"], "value": extra["train"]["value"],

@@ -102,6 +102,7 @@ _SIGS = {
     "eg_dp_world": (c_int, [c_void_p]),
     "eg_dp_allreduce_sum_f32": (c_int, [c_void_p, c_void_p, c_i64]),
     "eg_model_step_dp": (c_int, [c_void_p, c_char_p, c_void_p, c_int]),
+    "eg_dp_last_pieces": (c_int, [c_void_p]),
     "eg_model_set_grad_scale": (c_int, [c_void_p, c_f32]),
     "eg_model_output_shape": (c_int, [c_void_p, c_char_p, P(c_int), P(c_i64)]),
     "eg_model_read_output": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),
@@ -122,7 +123,7 @@ _SIGS = {
 
 # functions whose int return value is not a status code
 _NOT_STATUS = {"eg_version", "eg_ctx_device", "eg_model_kernel_count", "eg_model_tensor_count", "eg_dp_rank",
-               "eg_dp_world"}
+               "eg_dp_world", "eg_dp_last_pieces"}
 
 
 def declared_symbols():

@@ -72,6 +72,7 @@ struct eg_dp {
   eg_ctx* ctx = nullptr;
   Comm comm = nullptr;
   int rank = 0, world = 1;
+  int last_pieces = 0;  // all-reduce calls of the last eg_model_step_dp (2+: early gradients went under the contraction)
 };
 
 extern "C" {
@@ -132,21 +133,28 @@ int eg_dp_allreduce_sum_f32(eg_dp* dp, float* device_buf, int64_t count) {
 
 // One data-parallel training step on this rank's shard (the inputs are bound already):
 //   [forward + backward kernels] | all-reduce of the gradient bucket | [optimizer kernels]
+// with the bucket split where the plan allows it: the gradients that are complete before the last
+// long contraction of the backward pass (the first layer's weight gradient) are reduced on the side
+// lane while it runs, only its own gradient after it (eg::model_backward_with_exchange).
 // mean != 0: the loss divides by the batch (mse, crossEntropy: base.nim:57-67), so the seed
 // gradient is scaled by B_local / B_global = 1 / world; sum-type losses use 1.
 int eg_model_step_dp(eg_model* model, const char* target, eg_dp* dp, int mean) {
   EG_REQUIRE(model && target && dp, EG_ERR_INVALID, "eg_model_step_dp: NULL argument");
+  // the collective is ordered against the backward and update kernels by the stream they share
+  EG_REQUIRE(eg::model_context(model) == dp->ctx, EG_ERR_INVALID,
+             "eg_model_step_dp: the model and the data-parallel group belong to different contexts");
   int rc = eg_model_set_grad_scale(model, mean ? 1.0f / (float)dp->world : 1.0f);
   if (rc) return rc;
-  rc = eg_model_run_backward(model, target);
-  if (rc) return rc;
-  float* bucket = nullptr;
-  int64_t count = 0;
-  rc = eg_model_grad_bucket(model, target, &bucket, &count);
-  if (rc) return rc;
-  rc = eg_dp_allreduce_sum_f32(dp, bucket, count);
+  eg::GradExchange gx;
+  gx.user = dp;
+  gx.allreduce = [](void* user, float* buf, long count) {
+    return eg_dp_allreduce_sum_f32(static_cast<eg_dp*>(user), buf, (int64_t)count);
+  };
+  rc = eg::model_backward_with_exchange(model, target, gx, &dp->last_pieces);
   if (rc) return rc;
   return eg_model_run_update(model, target);
 }
+
+int eg_dp_last_pieces(const eg_dp* dp) { return dp ? dp->last_pieces : 0; }
 
 }  // extern "C"

@@ -113,6 +113,17 @@ struct CopySegments {
   int n;
 };
 int copy_segments(eg_ctx* ctx, const CopySegments& seg);
+// Data-parallel step (dp_rccl.cpp -> host/model_api.cpp): run the backward range of `target` and
+// exchange the gradient bucket through `allreduce(user, device pointer, float count)`, which must
+// enqueue an in-place SUM on the context's CURRENT stream.  Gradients that are complete before the
+// last long contraction of the backward pass are exchanged on the side lane, under that contraction
+// (host/run.cpp plan_exchange); the rest after it.  *pieces (optional) = all-reduce calls issued.
+struct GradExchange {
+  int (*allreduce)(void* user, float* buf, long count) = nullptr;
+  void* user = nullptr;
+};
+int model_backward_with_exchange(eg_model* model, const char* target, const GradExchange& gx, int* pieces);
+eg_ctx* model_context(eg_model* model);
 inline int set_device(eg_ctx* ctx) {
   EG_HIP_CHECK(hipSetDevice(ctx->device));
   return EG_OK;

@@ -23,6 +23,67 @@ using namespace eg::model;
 using eg::set_error;
 
 
+namespace eg {
+
+eg_ctx* model_context(eg_model* model) { return model ? model->ctx : nullptr; }
+
+int model_backward_with_exchange(eg_model* m, const char* target, const GradExchange& gx, int* pieces) try {
+  EG_REQUIRE(m && target && gx.allreduce, EG_ERR_INVALID, "model_backward_with_exchange: NULL argument");
+  TargetState* ts;
+  Plan* plan;
+  int rc = get_plan(m, target, &ts, &plan);
+  if (rc) return rc;
+  ExchangePlan ex;
+  rc = plan_exchange(m, *ts, *plan, ex);
+  if (rc) return rc;
+  int issued = 0;
+  auto reduce = [&](const std::vector<std::pair<long, long>>& segs) {
+    for (auto& seg : segs) {
+      if (seg.second <= 0) continue;
+      int r = gx.allreduce(gx.user, ts->bucket + seg.first, seg.second);
+      if (r) return r;
+      ++issued;
+    }
+    return (int)EG_OK;
+  };
+  static const bool no_split = [] {
+    const char* e = getenv("EG_DP_NO_SPLIT");
+    return e && e[0] && e[0] != '0';
+  }();
+  if (ex.big < 0 || no_split) {
+    // nothing to overlap with: the captured backward range, then one all-reduce of the whole bucket
+    rc = run_range(m, *ts, *plan, 0, plan->n_backward, true, 1);
+    if (rc) return rc;
+    std::vector<std::pair<long, long>> whole;
+    if (ts->bucket_floats > 0) whole.push_back({0, ts->bucket_floats});
+    rc = reduce(whole);
+  } else {
+    struct Early {
+      decltype(reduce)* reduce;
+      const ExchangePlan* ex;
+    } early = {&reduce, &ex};
+    SideHook hook;
+    hook.big = ex.big;
+    hook.user = &early;
+    hook.fn = [](void* u) {
+      Early* e = static_cast<Early*>(u);
+      return (*e->reduce)(e->ex->early);
+    };
+    rc = eg::set_device(m->ctx);
+    if (rc) return rc;
+    // launched one by one (a collective in the middle): the range is a dozen launches against a
+    // millisecond of matrix work, the host stays far ahead of the device
+    rc = run_range_eager(m, *ts, *plan, 0, plan->n_backward, true, &hook);
+    if (rc) return rc;
+    rc = reduce(ex.late);
+  }
+  if (pieces) *pieces = issued;
+  return rc;
+}
+EG_CATCH_ALL
+
+}  // namespace eg
+
 extern "C" {
 
 int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out) try {

@@ -274,7 +274,22 @@ int get_plan(eg_model* m, const char* target, TargetState** ts_out, Plan** plan_
 // run.cpp
 int ensure_rng(eg_model* m, uint64_t seed = 0x5eed5eed5eed5eedULL, bool reseed = false);
 int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L);
-int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero);
+// hook: called on the side lane of the overlap group whose contraction is launch `big`, after the group's
+// side launches and before the join (the data-parallel exchange of the gradients that are complete by then)
+struct SideHook {
+  int big = -1;
+  int (*fn)(void* user) = nullptr;
+  void* user = nullptr;
+};
+int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero, const SideHook* hook = nullptr);
+// Which parts of the gradient bucket are complete before the last long contraction of the backward
+// range finishes (early: exchanged on the side lane, under it) and which only after it (late).
+// big < 0: no such contraction, `late` is the whole bucket.  Segments are (float offset, float count).
+struct ExchangePlan {
+  int big = -1;
+  std::vector<std::pair<long, long>> early, late;
+};
+int plan_exchange(eg_model* m, TargetState& ts, Plan& plan, ExchangePlan& ex);
 bool graphs_enabled();
 int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero, int slot);
 // plan_check.cpp: invariants of a finished plan (read / write sets against the kernel list, arena

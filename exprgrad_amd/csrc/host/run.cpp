@@ -1,4 +1,6 @@
 // Execution of a plan: one launch, a range of launches (with the side lane), HIP-graph capture and replay.
+#include <algorithm>
+
 #include "model_types.hpp"
 #include <random>
 
@@ -160,7 +162,7 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
   return EG_OK;
 }
 
-int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero) {
+int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero, const SideHook* hook) {
   if (zero) {
     // allocShapes / zeroResultTensor (model.nim:318, 383): results start from zero on every call
     if (plan.zero_floats > 0)
@@ -211,6 +213,10 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
         LaneSwap lane(ctx);
         for (int s2 = i; s2 < big; ++s2) {
           int rc = run_launch(m, ts, plan, plan.launches[s2]);
+          if (rc) return rc;
+        }
+        if (hook && hook->big == big) {  // data-parallel step: the early gradients' exchange rides the side lane
+          int rc = hook->fn(hook->user);
           if (rc) return rc;
         }
         EG_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->stream));  // (the side stream, while swapped)
@@ -299,6 +305,75 @@ int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool
     return run_range_eager(m, ts, plan, begin, end, zero);
   }
   EG_HIP_CHECK(hipGraphLaunch(cap.exec, m->ctx->stream));
+  return EG_OK;
+}
+
+// ---- data-parallel step with the exchange overlapped (dp_rccl.cpp) -------------------
+// The gradient bucket is exchanged in two parts when the backward range ends in an overlap group whose
+// long contraction produces the LAST gradient (dense nets: the first layer's weight gradient, by far
+// the largest): every other gradient is complete before that contraction finishes, so its all-reduce
+// is issued on the side lane and runs under the contraction; only the contraction's own gradient is
+// reduced after it.  Both parts are contiguous runs of the bucket (at most a few segments).
+int plan_exchange(eg_model* m, TargetState& ts, Plan& plan, ExchangePlan& ex) {
+  (void)m;
+  ex = ExchangePlan();
+  // last launch of the backward range that writes each bucket tensor
+  std::map<int, int> last_writer;
+  auto note = [&](int tensor, int launch) {
+    if (ts.bucket_offset.count(tensor)) last_writer[tensor] = launch;
+  };
+  const Target& t = *ts.target;
+  for (int i = 0; i < plan.n_backward; ++i) {
+    const Launch& L = plan.launches[i];
+    switch (L.kind) {
+      case StepKind::RowFused:
+        for (int tid : plan.row_groups[L.row_group]->red_tensors) note(tid, i);
+        for (auto& kv : plan.row_groups[L.row_group]->g.tensors)
+          if (kv.second.role == RowGroupTensor::RowLocal && kv.second.store) note(kv.first, i);
+        break;
+      case StepKind::SmallFused:
+        for (int ki : plan.small_groups[L.row_group]->g.kernel_index) note(t.all[ki].write.tensor, i);
+        break;
+      case StepKind::GemmFused:
+        note(L.c_tensor, i);
+        note(t.all[ts.lowered[plan.epilogues[L.epilogue]->consumer.lowered].all_index].write.tensor, i);
+        break;
+      default: note(L.c_tensor, i);
+    }
+  }
+  int big = -1;
+  for (auto& ov : plan.overlaps)
+    if (ov.big < plan.n_backward) big = ov.big;
+  if (big >= 0) {
+    bool late_any = false, early_any = false;
+    for (auto& b : ts.bucket_offset) {
+      auto lw = last_writer.find(b.first);
+      const bool late = lw != last_writer.end() && lw->second >= big;
+      late_any = late_any || late;
+      early_any = early_any || !late;
+    }
+    if (!late_any || !early_any) big = -1;  // nothing to split: one all-reduce of the whole bucket
+  }
+  // bucket tensors in offset order -> maximal contiguous runs of one class
+  std::vector<std::pair<long, int>> order;  // (offset, tensor)
+  for (auto& b : ts.bucket_offset) order.push_back({b.second, b.first});
+  std::sort(order.begin(), order.end());
+  for (size_t i = 0; i < order.size(); ++i) {
+    const int tid = order[i].second;
+    const long begin = order[i].first;
+    const long end = i + 1 < order.size() ? order[i + 1].first : ts.bucket_floats;  // padding travels with its tensor
+    auto lw = last_writer.find(tid);
+    const bool late = big >= 0 && lw != last_writer.end() && lw->second >= big;
+    std::vector<std::pair<long, long>>& segs = late ? ex.late : ex.early;
+    if (!segs.empty() && segs.back().first + segs.back().second == begin) segs.back().second += end - begin;
+    else segs.push_back({begin, end - begin});
+  }
+  ex.big = big;
+  if (big < 0) {  // everything in one piece, after the backward range
+    ex.late.clear();
+    ex.early.clear();
+    if (ts.bucket_floats > 0) ex.late.push_back({0, ts.bucket_floats});
+  }
   return EG_OK;
 }
 

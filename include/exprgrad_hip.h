@@ -318,8 +318,13 @@ int eg_dp_allreduce_sum_f32(eg_dp* dp, float* device_buf, int64_t count);
 /* One training step on this rank's shard of the batch (inputs bound with eg_model_set_input_*):
  * eg_model_run_backward | all-reduce of the gradient bucket | eg_model_run_update.  mean != 0 for
  * losses that divide by the batch (mse, crossEntropy; base.nim:57-67): the seed gradient is scaled
- * by 1 / world so the summed gradients are those of the full batch; 0 for sum-type losses. */
+ * by 1 / world so the summed gradients are those of the full batch; 0 for sum-type losses.
+ * The model must have been compiled on dp's context (EG_ERR_INVALID otherwise). */
 int eg_model_step_dp(eg_model* model, const char* target, eg_dp* dp, int mean);
+/* How many all-reduce calls the last eg_model_step_dp issued: 1 = the whole bucket after the backward
+ * pass; more = the gradients that were complete early went out on the side lane, under the last long
+ * contraction (EG_DP_NO_SPLIT=1 forces 1). */
+int eg_dp_last_pieces(const eg_dp* dp);
 
 #ifdef __cplusplus
 }

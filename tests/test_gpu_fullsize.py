@@ -251,3 +251,44 @@ def test_cfg4_conv2_gradients_256x256x64(gpu_ctx, refcpu):
     via_filter = float((flt.astype(np.float64) * gf).sum())
     scale = float(np.abs(conv.astype(np.float64) * gout).sum())
     assert abs(lhs - via_image) <= TOL * scale and abs(lhs - via_filter) <= TOL * scale
+
+
+def test_cfg5_native_step_overlaps_the_early_exchange(gpu_ctx):
+    """eg_model_step_dp at the full per-GPU batch of configs[4]: the bias gradients and the small weight
+    gradient are all-reduced on the side lane WHILE the 784 x 512 weight-gradient contraction runs, only
+    that contraction's own gradient after it (two RCCL calls per step instead of one).  One rank here
+    (a sum over one rank is the identity), so the step must equal apply() bit for bit; EG_DP_NO_SPLIT=1
+    gives the single all-reduce after the backward pass."""
+    torch = pytest.importorskip("torch")
+    from exprgrad_amd.parallel import NativeDataParallel, RcclGroup
+    from exprgrad_amd._lib import call, GpuError
+    import exprgrad_amd as eg
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = eg.newGpuContext(0, stream=stream.cuda_stream)
+        group = RcclGroup(ctx, RcclGroup.unique_id(), rank=0, world=1)
+        whole = egm.compile(*refcases.dense_softmax_net(), gpu=ctx)
+        split = egm.compile(*refcases.dense_softmax_net(), gpu=ctx)
+        rng = np.random.default_rng(15)
+        for tid in whole.params.ids():
+            v = (rng.random(whole.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+            whole.params[tid] = v
+            split.params[tid] = v
+        x = torch.rand((65536, 784), device="cuda")
+        y = torch.nn.functional.one_hot(torch.randint(0, 10, (65536,), device="cuda"), 10).to(torch.float32).contiguous()
+        dp = NativeDataParallel(split, "train", group, reduction="mean")
+        for _ in range(4):
+            whole.apply("train", [("x", x), ("y", y)])
+            dp.step([("x", x), ("y", y)])
+        stream.synchronize()
+        assert call("eg_dp_last_pieces", group.handle) == 2, split.launch_plan("train")
+        for tid in whole.params.ids():
+            assert np.array_equal(whole.params[tid], split.params[tid]), tid
+        # a model of another context is refused: the stream is what orders the collective
+        other = egm.compile(*refcases.dense_softmax_net(n_in=8, n_hidden=8, n_out=2), gpu=gpu_ctx)
+        with pytest.raises(GpuError, match="different contexts"):
+            call("eg_model_step_dp", other.handle, b"train", group.handle, 1)
+        other.close()
+        whole.close()
+        split.close()
+        group.close()

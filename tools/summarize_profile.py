@@ -50,18 +50,34 @@ def main():
 
     stats = glob.glob(os.path.join(args.src, "trace", "**", "*kernel_stats.csv"), recursive=True) or \
         glob.glob(os.path.join(args.src, "**", "*kernel_stats.csv"), recursive=True)
+    # Per-dispatch records: the mean over ALL launches of a profiled bench run includes the clock-ramp
+    # spin-up launches bench.py issues before its warmup (up to 13 % slower), so it sits above the timed
+    # ms_per_step.  SteadyAverageNs is the mean over the second half of a kernel's launches in time order
+    # (the timed region is the end of the run): that is the figure that must agree with the bench line.
+    steady = {}
+    traces = glob.glob(os.path.join(args.src, "trace", "**", "*kernel_trace.csv"), recursive=True)
+    if traces:
+        per_kernel = collections.defaultdict(list)
+        for r in csv.DictReader(open(traces[0])):
+            per_kernel[short(r["Kernel_Name"])].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        for n, v in per_kernel.items():
+            v.sort()
+            tail = [d for _, d in v[len(v) // 2:]]
+            steady[n] = (sum(tail) / len(tail), len(tail))
     calls = {}
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         with open(os.path.join(args.dst, "kernel_stats.csv"), "w", newline="") as f:
             w = csv.writer(f)
-            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "SteadyAverageNs", "SteadyCalls"])
             for r in rows:
                 n = short(r["Name"])
                 if not ours(n):
                     continue
                 calls[n] = int(r["Calls"])
-                w.writerow([n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+                st = steady.get(n, ("", ""))
+                w.writerow([n, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"],
+                            f"{st[0]:.1f}" if st[0] != "" else "", st[1]])
 
     per = collections.defaultdict(lambda: collections.defaultdict(list))  # kernel -> counter -> values
     for path in sorted(glob.glob(os.path.join(args.src, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
@@ -98,6 +114,9 @@ def main():
             fetch = totals["FETCH_SIZE"] / once
             write = totals["WRITE_SIZE"] / once
             entry = {"kernel": "all backend kernels of one step", "launches": once}
+        fp_path = os.path.join(args.src, "source_fingerprint.txt")
+        if os.path.exists(fp_path):
+            entry["source_fingerprint"] = open(fp_path).read().strip()
         entry.update({"fetch_kib": round(fetch, 1), "write_kib": round(write, 1),
                       "traffic_bytes": int((2 * fetch + write) * 1024),
                       "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB", "source": os.path.relpath(args.dst)})
