@@ -310,8 +310,26 @@ def _matmul_end_to_end(args, env, a, b, c, ctx, n, flops):
         for _ in range(3):
             hc = model.call("c", {"a": ha, "b": hb})
         dt = (time.perf_counter() - t0) / 3
+        # the copies alone, for the PCIe rate they reach (same pageable arrays, same staged path)
+        buf = ctx.allocTensor((n, n))
+        buf.write(ha)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            buf.write(ha)
+        h2d = (time.perf_counter() - t1) / 3
+        out = np.empty((n, n), dtype=np.float32)
+        buf.readInto(out)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            buf.readInto(out)
+        d2h = (time.perf_counter() - t1) / 3
+        buf.buffer.dealloc()
+        mib = n * n * 4 / 2 ** 20
         end_to_end = {"ms_per_call": round(dt * 1e3, 2), "gflops": round(flops / dt / 1e9, 1),
-                      "note": "Model.call with pageable host arrays: H2D of A and B, the product, D2H of C",
+                      "bytes_moved_mib": round(3 * mib, 1), "pcie_gbs_over_the_call": round(3 * n * n * 4 / dt / 1e9, 1),
+                      "h2d_gbs": round(n * n * 4 / h2d / 1e9, 1), "d2h_gbs": round(n * n * 4 / d2h / 1e9, 1),
+                      "note": "Model.call with pageable host arrays (what benchmarks/matmul/matmul_gpu.nim:35-46 times): H2D of A "
+                              "and B, the product, D2H of C; copies staged through pinned buffers by a thread pool (csrc/host_copy.cpp)",
                       "checksum_matches_device_result": bool(np.allclose(hc[:8, :8], c[:8, :8].cpu().numpy(), rtol=1e-5))}
         model.close()
     return end_to_end

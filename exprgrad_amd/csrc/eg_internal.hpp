@@ -37,6 +37,11 @@ void clear_error();
 
 }  // namespace eg
 
+namespace eg {
+struct HostStager;  // host_copy.cpp: pinned staging buffers + copy threads for large pageable host arrays
+void host_stager_free(HostStager* s);
+}  // namespace eg
+
 struct eg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -57,6 +62,7 @@ struct eg_ctx {
   void* side_aux = nullptr;
   size_t side_aux_bytes = 0;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  eg::HostStager* stager = nullptr;  // created by the first large host copy
   int compute_units = 256;
   std::string arch;
   // kernels a library call specialises at run time (hiprtc) and keeps: by name
@@ -76,6 +82,10 @@ namespace eg {
 // Ensure ctx->workspace holds at least `bytes`; synchronises the stream if it has to grow.
 int ensure_workspace(eg_ctx* ctx, size_t bytes);
 int ensure_aux(eg_ctx* ctx, size_t bytes);
+// Blocking copies between a host array and device memory, ordered on ctx->stream (host_copy.cpp): large
+// pageable arrays go through pinned staging buffers filled by several threads, the rest is a plain copy.
+int copy_h2d(eg_ctx* ctx, void* device, const void* host, size_t bytes);
+int copy_d2h(eg_ctx* ctx, void* host, const void* device, size_t bytes);
 // EG_POISON=1: scratch and to-be-overwritten result storage is filled with NaN patterns before use.
 bool poison_enabled();
 // Build several kernels (extern "C" names) from one source text in a single hiprtc program.

@@ -194,6 +194,7 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
         os << (L.kind == StepKind::GemmFused ? "gemm+epilogue " : "gemm ") << (L.trans_a ? "T" : "N") << (L.trans_b ? "T" : "N")
            << " " << L.M << "x" << L.N << "x" << L.K << " -> t" << L.c_tensor << (L.bias_tensor ? " +bias" : "")
            << (L.accumulate ? " accumulate" : "");
+        if (L.ones_tensor) os << " +ones-row -> t" << L.ones_tensor << " (bias gradient, kernel " << L.ones_lowered << ")";
         if (L.kind == StepKind::GemmFused) {
           const PlanEpilogue& pe = *plan.epilogues[L.epilogue];
           os << " | consumer kernel " << pe.consumer.lowered << " operands";
@@ -258,10 +259,7 @@ int eg_model_param_write(eg_model* m, int tensor_id, const float* host, int64_t 
   EG_REQUIRE(count == it->second.count, EG_ERR_SIZE, "parameter %d has %ld elements, got %ld", tensor_id,
              it->second.count, (long)count);
   if (count == 0) return EG_OK;
-  EG_HIP_CHECK(hipSetDevice(m->ctx->device));
-  EG_HIP_CHECK(hipMemcpyAsync(it->second.ptr, host, (size_t)count * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
-  EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
-  return EG_OK;
+  return eg::copy_h2d(m->ctx, it->second.ptr, host, (size_t)count * sizeof(float));
 }
 EG_CATCH_ALL
 
@@ -272,10 +270,7 @@ int eg_model_param_read(eg_model* m, int tensor_id, float* host, int64_t count) 
   EG_REQUIRE(count == it->second.count, EG_ERR_SIZE, "parameter %d has %ld elements, got %ld", tensor_id,
              it->second.count, (long)count);
   if (count == 0) return EG_OK;
-  EG_HIP_CHECK(hipSetDevice(m->ctx->device));
-  EG_HIP_CHECK(hipMemcpyAsync(host, it->second.ptr, (size_t)count * sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
-  EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
-  return EG_OK;
+  return eg::copy_d2h(m->ctx, host, it->second.ptr, (size_t)count * sizeof(float));
 }
 EG_CATCH_ALL
 
@@ -338,8 +333,8 @@ static int bind_input(eg_model* m, const char* name, const float* device, const 
     }
     if (count > 0) {
       // blocking H2D on every call, as the reference does (model.nim:364-368 -> cl.nim:111-116)
-      EG_HIP_CHECK(hipMemcpyAsync(b.owned, host, (size_t)count * sizeof(float), hipMemcpyHostToDevice, m->ctx->stream));
-      EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+      int rc = eg::copy_h2d(m->ctx, b.owned, host, (size_t)count * sizeof(float));
+      if (rc) return rc;
     }
     b.device = b.owned;
   } else {
@@ -442,10 +437,7 @@ static int read_tensor(eg_model* m, TargetState& ts, int tid, float* host, int64
   if (n == 0) return EG_OK;
   float* p = tensor_ptr(m, ts, *ts.last, tid);
   EG_REQUIRE(p, EG_ERR_INVALID, "tensor %d was not materialised by the last run", tid);
-  EG_HIP_CHECK(hipSetDevice(m->ctx->device));
-  EG_HIP_CHECK(hipMemcpyAsync(host, p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, m->ctx->stream));
-  EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
-  return EG_OK;
+  return eg::copy_d2h(m->ctx, host, p, (size_t)n * sizeof(float));
 }
 
 int eg_model_output_shape(eg_model* m, const char* target, int* rank, int64_t* shape8) try {

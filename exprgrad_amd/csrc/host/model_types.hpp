@@ -92,6 +92,8 @@ struct Launch {
   std::vector<int> epoch_slots;             // params refreshed from Model.epoch at every launch
   int row_group = -1;                       // RowFused: index into Plan::row_groups
   int epilogue = -1;                        // GemmFused: index into Plan::epilogues
+  int ones_tensor = 0;                      // Gemm: the bias gradient that rides along as row M of [gW; gb] (fold_bias_gradients)
+  int ones_lowered = -1;                    //   live position of the column-sum kernel it replaces
   int consumer = -1;                        // GenericA: live position of the elementwise consumer folded into it
   int vec_slot = -1;                        // GenericA: index of the Slot::Vec4 argument, if the kernel has one
   bool vec_ok = false;                      //   the shapes allow four elements per thread (pointers are checked per launch)
@@ -292,6 +294,10 @@ struct ExchangePlan {
 int plan_exchange(eg_model* m, TargetState& ts, Plan& plan, ExchangePlan& ex);
 bool graphs_enabled();
 int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero, int slot);
+// plan_epilogue.cpp: a bias gradient `gb[x] ++= g[y,x]` next to the weight gradient `gW[it,x] ++= a[y,it] * g[y,x]`
+// of the same layer becomes the last row of that contraction (a virtual row of ones in A) when gb lies
+// directly behind gW in the gradient bucket; the column-sum launch disappears.
+int fold_bias_gradients(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos);
 // plan_check.cpp: invariants of a finished plan (read / write sets against the kernel list, arena
 // layout, overlap groups).  Returns EG_OK or EG_ERR_RUNTIME with the violated invariant named.
 int check_plan(eg_model* m, TargetState& ts, Plan& plan);

@@ -534,6 +534,10 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
     int rc = fuse_epilogues(m, ts, plan, infos);
     if (rc) return rc;
   }
+  {
+    int rc = fold_bias_gradients(m, ts, plan, infos);
+    if (rc) return rc;
+  }
 
   plan_overlap(m, ts, plan);
   {

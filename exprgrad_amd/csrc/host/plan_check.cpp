@@ -67,6 +67,7 @@ void launch_io(eg_model* m, TargetState& ts, const Plan& plan, const Launch& L, 
       rd(L.b_tensor);
       rd(L.bias_tensor);
       wr(L.c_tensor, L.accumulate);
+      wr(L.ones_tensor, false);
       break;
     case StepKind::GemmFused: {
       const PlanEpilogue& pe = *plan.epilogues[L.epilogue];
@@ -169,6 +170,7 @@ int check_plan(eg_model* m, TargetState& ts, Plan& plan) {
         default:
           mark(L.lowered);
           if (L.consumer >= 0) mark(L.consumer);
+          if (L.ones_lowered >= 0) mark(L.ones_lowered);
       }
     }
     for (size_t p = 0; p < t.live.size(); ++p) {

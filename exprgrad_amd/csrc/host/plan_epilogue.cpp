@@ -1,4 +1,6 @@
 // Contraction + elementwise consumer -> one launch (epilogue.hpp).
+#include <algorithm>
+
 #include "model_types.hpp"
 
 
@@ -85,6 +87,77 @@ int fuse_epilogues(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
     plan.launches.erase(plan.launches.begin() + j);
     if (plan.n_backward > (int)j) plan.n_backward--;
   }
+  return EG_OK;
+}
+
+// dense = `out[y,x] ++= in[y,it] * W[it,x]` + `out[y,x] ++= b[x]` (dnn.nim:19-24); derive turns the two into
+// `gW[it,x] ++= in[y,it] * g[y,x]` and `gb[x] ++= g[y,x]` (passes.nim:519-549): two reductions over the same
+// batch that both stream g.  With A = [in | 1] they are ONE contraction whose last row is gb — the
+// kernel supplies the ones (GemmArgs::ones_row), and because gW and gb are neighbours in the gradient
+// bucket the contraction's M + 1 rows of output land exactly in [gW; gb].  The separate column sum
+// (a second pass over g: 134 MB at cfg 5) disappears.
+int fold_bias_gradients(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos) {
+  static const bool off = [] {
+    const char* e = getenv("EG_NO_ONES_ROW");
+    return e && e[0] && e[0] != '0';
+  }();
+  if (off) return EG_OK;
+  const Target& t = *ts.target;
+  for (size_t gi = 0; gi < plan.launches.size(); ++gi) {
+    Launch& G = plan.launches[gi];
+    if (G.kind != StepKind::Gemm || G.accumulate || !G.trans_a || G.trans_b || G.bias_tensor || G.ldc != G.N) continue;
+    auto gw = ts.bucket_offset.find(G.c_tensor);
+    if (gw == ts.bucket_offset.end()) continue;
+    // candidate: a column sum of the same B operand whose destination follows gW in the bucket
+    for (size_t ci = 0; ci < plan.launches.size(); ++ci) {
+      if (ci == gi) continue;
+      Launch& C = plan.launches[ci];
+      if (C.kind != StepKind::GenericA && C.kind != StepKind::GenericB) continue;
+      if (C.accumulate || C.consumer >= 0) continue;
+      const Kernel& k = t.all[ts.lowered[C.lowered].all_index];
+      const KernelInfo& info = infos[ts.lowered[C.lowered].all_index];
+      // gb[x] ++= g[y,x]: no arithmetic, one read indexed (y, x), written at (x)
+      if (!k.instrs.empty() || k.reads.size() != 1 || k.result != k.reads[0].reg || !k.index_instrs.empty() || !k.setup.empty()) continue;
+      if (k.loops.size() != 2 || k.write.raw || k.write.dims.size() != 1 || k.reads[0].raw || k.reads[0].dims.size() != 2) continue;
+      const int x = k.write.dims[0].only_register();
+      const int ry = k.reads[0].dims[0].only_register(), rx = k.reads[0].dims[1].only_register();
+      if (!x || rx != x || !ry || ry == x) continue;
+      if (k.reads[0].tensor != G.b_tensor) continue;
+      bool bounds_ok = info.ok;
+      for (size_t l = 0; l < k.loops.size() && bounds_ok; ++l) {
+        const long want = k.loops[l].reg == x ? G.N : G.K;
+        bounds_ok = !k.loops[l].has_bounds && info.bounds[l].first == 0 && info.bounds[l].second == want;
+      }
+      if (!bounds_ok) continue;
+      auto gb = ts.bucket_offset.find(k.write.tensor);
+      if (gb == ts.bucket_offset.end() || gb->second != gw->second + G.M * G.N) continue;
+      auto sh = plan.shapes.find(k.write.tensor);
+      if (sh == plan.shapes.end() || prod(sh->second) != G.N) continue;
+      // both on one side of the backward | update boundary, and nobody between them touches what moves
+      const size_t lo = std::min(gi, ci), hi = std::max(gi, ci);
+      if ((int)lo < plan.n_backward && (int)hi >= plan.n_backward) continue;
+      bool legal = true;
+      for (size_t j = lo + 1; j < hi && legal; ++j) {
+        const Launch& X = plan.launches[j];
+        if (X.kind == StepKind::RowFused || X.kind == StepKind::SmallFused || X.kind == StepKind::GemmFused) {
+          legal = false;  // (their tensor sets are not worth analysing here: adjacent launches are the case that matters)
+          break;
+        }
+        const Kernel& kx = t.all[ts.lowered[X.lowered].all_index];
+        if (kx.write.tensor == k.write.tensor || kx.write.tensor == G.b_tensor || kx.write.tensor == G.c_tensor) legal = false;
+        for (auto& rd : kx.reads)
+          if (rd.tensor == k.write.tensor || rd.tensor == G.c_tensor) legal = false;
+      }
+      if (!legal) continue;
+      G.ones_tensor = k.write.tensor;
+      G.ones_lowered = C.lowered;
+      plan.launches.erase(plan.launches.begin() + (long)ci);
+      if (plan.n_backward > (int)ci) plan.n_backward--;
+      if (ci < gi) --gi;
+      break;
+    }
+  }
+  (void)m;
   return EG_OK;
 }
 

@@ -41,6 +41,7 @@ bool launch_tensors(const Plan& plan, const Launch& L, std::set<int>& reads, std
       rd(L.b_tensor);
       rd(L.bias_tensor);
       wr(L.c_tensor);
+      wr(L.ones_tensor);
       return true;
     case StepKind::GemmFused:
       rd(L.a_tensor);

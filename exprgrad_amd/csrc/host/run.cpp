@@ -26,6 +26,17 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
     case StepKind::Seed:
       return eg_fill_f32(ctx, L.count, m->grad_scale, tensor_ptr(m, ts, plan, L.c_tensor));
     case StepKind::Gemm:
+      if (L.ones_tensor) {
+        // weight gradient + bias gradient in one contraction; when the operands of this run do not
+        // qualify (alignment of a caller-owned input), the two reductions run separately
+        int rc = eg::gemm::sgemm_ones_row(ctx, L.trans_a, L.trans_b, L.M, L.N, L.K, tensor_ptr(m, ts, plan, L.a_tensor), L.lda,
+                                          tensor_ptr(m, ts, plan, L.b_tensor), L.ldb, tensor_ptr(m, ts, plan, L.c_tensor), L.ldc,
+                                          L.accumulate);
+        if (rc != EG_ERR_UNSUPPORTED) return rc;
+        eg::clear_error();
+        rc = eg_colsum(ctx, L.K, L.N, tensor_ptr(m, ts, plan, L.b_tensor), tensor_ptr(m, ts, plan, L.ones_tensor), 0);
+        if (rc) return rc;
+      }
       return eg_sgemm(ctx, L.trans_a, L.trans_b, L.M, L.N, L.K, tensor_ptr(m, ts, plan, L.a_tensor), L.lda,
                       tensor_ptr(m, ts, plan, L.b_tensor), L.ldb, tensor_ptr(m, ts, plan, L.c_tensor), L.ldc,
                       L.accumulate, L.bias_tensor ? tensor_ptr(m, ts, plan, L.bias_tensor) : nullptr);
@@ -338,7 +349,9 @@ int plan_exchange(eg_model* m, TargetState& ts, Plan& plan, ExchangePlan& ex) {
         note(L.c_tensor, i);
         note(t.all[ts.lowered[plan.epilogues[L.epilogue]->consumer.lowered].all_index].write.tensor, i);
         break;
-      default: note(L.c_tensor, i);
+      default:
+        note(L.c_tensor, i);
+        note(L.ones_tensor, i);
     }
   }
   int big = -1;

@@ -96,6 +96,7 @@ int launch_conv(eg_ctx* ctx, const GemmArgs& args, bool vec) {
 }
 
 int run_conv(eg_ctx* ctx, GemmArgs args, bool vec) {
+  args.a_rows = args.M;
   int v = 0;
   if (const char* f = getenv("EG_CONV_VARIANT")) v = atoi(f);  // tuning aid
   args.partial = nullptr;
@@ -188,8 +189,9 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
   // Candidates: 256x256 (16 waves, 1 block/CU) for large outputs, 128x128 (4 waves, 4 blocks/CU),
   // and narrow tiles for bias-sized N (the N = 1/4/10 layers of the XOR and dense nets, F = 64
   // filter banks) so the padding wasted in the matrix core stays small.
-  static const TileCfg cfgs[] = {{256, 256, 1}, {128, 128, 4}, {128, 64, 4}, {128, 32, 4}, {256, 64, 2}, {64, 64, 4}};
-  constexpr int NCFG = 6;
+  static const TileCfg cfgs[] = {{256, 256, 1}, {128, 128, 4}, {128, 64, 4}, {128, 32, 4}, {256, 64, 2}, {64, 64, 4}, {256, 128, 2}};
+  static const bool wide_ok = getenv("EG_GEMM_NO_256x128") == nullptr;
+  const int NCFG = wide_ok ? 7 : 6;
   int forced_bm = 0, forced_bn = 0;
   if (const char* f = getenv("EG_GEMM_FORCE_TILE")) sscanf(f, "%d,%d", &forced_bm, &forced_bn);  // tuning aid
   int best = 1, best_splits = 1;
@@ -216,8 +218,25 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
   splits = best_splits;
 }
 
+// Two co-resident blocks per CU (256x128 tiles) start out of phase (GemmArgs::stagger).
+void set_stagger(eg_ctx* ctx, GemmArgs& args, int bm, int bn) {
+  static const int periods = [] {
+    const char* e = getenv("EG_GEMM_STAGGER");
+    return e ? atoi(e) : 3;
+  }();
+  args.stagger = 0;
+  args.stagger_shift = 0;
+  if (bm == 256 && bn == 128 && periods > 0) {
+    args.stagger = periods;
+    int shift = 0;
+    while ((1 << (shift + 1)) <= ctx->compute_units) ++shift;  // 256 CUs -> blocks 256..511 are the second ones
+    args.stagger_shift = shift;
+  }
+}
+
 // Shared host-side planning: tile shape, split-K, vector/edge variant, launch, second pass.
 int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool vec_ok, bool a_vec_only = false) {
+  if (!args.ones_row) args.a_rows = args.M;
   const long M = args.M, N = args.N, K = args.K;
   const long k_tiles = (K + BK - 1) / BK;
   int BM, BN, splits;
@@ -264,6 +283,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     }
   }
   const int launch_splits = args.edge_splits > 0 ? args.splits : splits;
+  set_stagger(ctx, args, BM, BN);
   float* scratch = nullptr;
   if (splits > 1) {
     const size_t slab_floats = ((size_t)launch_splits * total + 3) & ~(size_t)3;
@@ -286,6 +306,8 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     rc = launch_config<64, 64, 32, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else if (BN == 64)
     rc = launch_config<128, 64, 64, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
+  else if (BN == 128 && BM == 256)
+    rc = launch_config<256, 128, 128, 64, 2>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else if (BN == 128)
     rc = launch_config<128, 128, 64, 64, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else
@@ -387,6 +409,46 @@ extern "C" int eg_sgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_
   static const bool no_mixed = getenv("EG_GEMM_NO_MIXED_VEC") != nullptr;
   return run_gemm(ctx, a_kc, b_kc, args, /*conv=*/0, vec_a && vec_b, vec_a && !vec_b && !no_mixed);
 }
+
+// C[0..M) = op(A) * op(B) and C[M] = column sums of op(B) in ONE contraction: A gets a virtual last row
+// of ones (GemmArgs::ones_row).  Used by the model layer to let a bias gradient ride along with the
+// weight gradient that reduces over the same batch; C must have room for M + 1 rows.  Returns
+// EG_ERR_UNSUPPORTED when the operands do not qualify for the LDS-DMA loop (the caller then runs the
+// two reductions separately).
+namespace eg {
+namespace gemm {
+bool ones_row_supported(int trans_a, int trans_b, long M, long N, long K, const float* A, long lda, const float* B, long ldb) {
+  const bool a_kc = !trans_a, b_kc = trans_b != 0;
+  const long a_contig = a_kc ? K : M, b_contig = b_kc ? K : N;
+  const bool vec_a = (lda % 4 == 0) && (a_contig % 4 == 0) && aligned16(A);
+  const bool vec_b = (ldb % 4 == 0) && (b_contig % 4 == 0) && aligned16(B);
+  // large enough for the matrix-core path (not the one-wave-per-output kernel) and at least one k-tile
+  return vec_a && vec_b && K >= 16 && !((M + 1) * N <= 16384 && K <= 2048) && getenv("EG_NO_ONES_ROW") == nullptr;
+}
+
+int sgemm_ones_row(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, const float* A, long lda, const float* B,
+                   long ldb, float* C, long ldc, int accumulate) {
+  EG_REQUIRE(ctx && A && B && C && M > 0 && N > 0, EG_ERR_INVALID, "sgemm_ones_row: bad argument");
+  if (!ones_row_supported(trans_a, trans_b, M, N, K, A, lda, B, ldb)) return EG_ERR_UNSUPPORTED;
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  GemmArgs args = {};
+  args.A = A;
+  args.B = B;
+  args.C = C;
+  args.M = M + 1;
+  args.a_rows = M;
+  args.ones_row = 1;
+  args.N = N;
+  args.K = K;
+  args.lda = lda;
+  args.ldb = ldb;
+  args.ldc = ldc;
+  args.accumulate = accumulate;
+  return run_gemm(ctx, !trans_a, trans_b != 0, args, /*conv=*/0, /*vec_ok=*/true);
+}
+}  // namespace gemm
+}  // namespace eg
 
 // Direct convolution as an implicit GEMM:  M = N*Ho*Wo output pixels, N = F filters,
 // K = FH*FW*C taps; A is gathered from the NHWC image inside the tile loader (no im2col
@@ -625,6 +687,7 @@ int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, co
   else if (bn == 64 && bm == 256) { out.wm = 64; out.wn = 32; out.minb = 2; }
   else if (bn == 64 && bm == 64) { out.wm = 32; out.wn = 32; out.minb = 4; }
   else if (bn == 64) { out.wm = 64; out.wn = 32; out.minb = 4; }
+  else if (bn == 128 && bm == 256) { out.wm = 128; out.wn = 64; out.minb = 2; }
   else if (bn == 128) { out.wm = 64; out.wn = 64; out.minb = 4; }
   else { out.wm = 128; out.wn = 64; out.minb = 1; }
   out.nt = (bm / out.wm) * (bn / out.wn) * 64;
@@ -648,12 +711,14 @@ int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, co
   args.ldb = ldb;
   args.ldc = ldc;
   args.accumulate = 0;
+  args.a_rows = M;
   args.tiles_m = (int)((M + bm - 1) / bm);
   args.tiles_n = (int)((N + bn - 1) / bn);
   args.partial = nullptr;
   args.k_per_split = ((K + BK - 1) / BK) * BK;
   if (args.k_per_split < BK) args.k_per_split = BK;
   out.grid = (unsigned)(args.tiles_m * args.tiles_n);
+  set_stagger(ctx, args, bm, bn);
   memcpy(out.args, &args, sizeof(args));
   out.args_size = sizeof(args);
   return EG_OK;

@@ -55,6 +55,18 @@ struct GemmArgs {
   void* epi[6];
   float epi_gs;
   long epi_ep;
+  // Two blocks per CU (256x128 tiles): blocks dispatched second to their CU start `stagger` sleep
+  // periods late, so that for the rest of the launch the store burst of one block's epilogue falls
+  // into the other's k loop instead of both idling the matrix pipe at the same moment.  0 = off.
+  int stagger;
+  int stagger_shift;  // log2 of the number of blocks dispatched before a CU receives its second one
+  // Virtual last row of ones: with ones_row != 0 the A operand has a_rows = M - 1 physical rows and
+  // A(M - 1, k) = 1 for every k, so row M - 1 of C is the column sum of B.  This is how a bias gradient
+  // `gb[x] ++= g[y,x]` rides along with the weight gradient `gW[it,x] ++= a[y,it] * g[y,x]` that
+  // reduces over the same batch (dnn.nim:19-24 differentiated, passes.nim:519-549): gb is row M - 1
+  // of [gW; gb] when the two are adjacent in memory.  LDS-DMA loop only (the host checks).
+  int ones_row;
+  long a_rows;  // physical rows of A (= M unless ones_row)
 };
 
 // Epilogue functor of the library kernels: plain store.  A generated epilogue (ACTIVE = true)
@@ -445,10 +457,13 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
 
   DmaA da;
   DmaB db;
-  da.init(a, m_blk, wave, lane, a.M);
+  da.init(a, m_blk, wave, lane, a.a_rows);
   db.init(a, n_blk, wave, lane, a.N);
+  // the virtual row of ones, if it falls into this tile (ragged loop only: such a tile is never interior)
+  const int one_r = CL && a.ones_row ? (int)(a.a_rows - m_blk) : -1;
+  const bool has_one = one_r >= 0 && one_r < BM;
   if (nk > 0) {
-    da.issue(a, a.A, a.lda, m_blk, k_begin, lds, wave, lane, a.M, k_end);
+    da.issue(a, a.A, a.lda, m_blk, k_begin, lds, wave, lane, a.a_rows, k_end);
     db.issue(a, a.B, a.ldb, n_blk, k_begin, lds + BK * BM, wave, lane, a.N, k_end);
   }
   const int k_tail = CL ? (int)((k_end - k_begin) % BK) : 0;  // valid k of a ragged last k-tile (0 = full)
@@ -459,7 +474,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
     if (kt + 1 < nk) {
       const long k0 = k_begin + (long)(kt + 1) * BK;
       float* nxt = lds + (cur ^ 1) * BUF;
-      da.issue(a, a.A, a.lda, m_blk, k0, nxt, wave, lane, a.M, k_end);
+      da.issue(a, a.A, a.lda, m_blk, k0, nxt, wave, lane, a.a_rows, k_end);
       db.issue(a, a.B, a.ldb, n_blk, k0, nxt + BK * BM, wave, lane, a.N, k_end);
     }
     if (CL && k_tail != 0 && kt == nk - 1) {
@@ -474,6 +489,18 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
         } else {
           At[k_tail * BM + e] = 0.f;
         }
+      }
+      __syncthreads();
+    }
+    if (CL && has_one) {
+      // the loaders re-read the last physical row for it; make it ones (after the k-tail zeroing: a ragged
+      // last k-tile must keep its zeros)
+      float* At = lds + cur * BUF;
+      const int valid = (k_tail != 0 && kt == nk - 1) ? k_tail : BK;
+      if (tid < valid) {
+        const int k = tid;
+        if (A_KC) At[one_r * BK + (((k >> 2) ^ DmaA::swizzle(one_r)) << 2) + (k & 3)] = 1.f;
+        else At[k * BM + one_r] = 1.f;
       }
       __syncthreads();
     }
@@ -546,6 +573,10 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   const int wm0 = (wave / WAVES_N) * WM;
   const int wn0 = (wave % WAVES_N) * WN;
 
+  if (a.stagger > 0 && ((blockIdx.x >> a.stagger_shift) & 1)) {
+    for (int s = 0; s < a.stagger; ++s) __builtin_amdgcn_s_sleep(127);  // 127 x 64 clocks ~ 3.4 us each
+  }
+
   // ---- tile coordinates: XCD-contiguous ids, then 8-row groups so co-resident tiles share
   //      A row-panels and B column-panels inside one L2.
   // Work items are (k-split, tile) pairs, split-major.  xcd_remap hands every XCD a contiguous
@@ -593,7 +624,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
 
   static_assert(!DMA || VEC == 4, "LDS-DMA loop: 16-byte aligned operands");
   const bool whole_k = (k_end - k_begin) % BK == 0;
-  const bool interior = m_blk + BM <= a.M && n_blk + BN <= a.N && whole_k;
+  const bool interior = m_blk + BM <= a.a_rows && n_blk + BN <= a.N && whole_k;
   bool done = false;
   if constexpr (DMA) {  // kernels without the DMA loop (tuning harness: BK = 8) never instantiate it
     if (!EDGE || interior) {

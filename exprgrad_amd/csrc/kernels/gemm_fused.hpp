@@ -31,6 +31,11 @@ constexpr int MAX_EPILOGUE_OPERANDS = 6;
 int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, const float* A, long lda, const float* B,
                long ldb, float* C, long ldc, const float* bias, FusedLaunch& out);
 
+// Weight gradient + bias gradient in one contraction (gemm_f32_mfma.hip): C[M + 1, N] = [op(A); 1] * op(B).
+bool ones_row_supported(int trans_a, int trans_b, long M, long N, long K, const float* A, long lda, const float* B, long ldb);
+int sgemm_ones_row(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, const float* A, long lda, const float* B,
+                   long ldb, float* C, long ldc, int accumulate);
+
 // Tensors the generated epilogue reads / writes (a.epi[i]), the seed-gradient scale and the epoch.
 void set_epilogue_operands(FusedLaunch& f, void* const* ptrs, int count, float grad_scale, long epoch);
 

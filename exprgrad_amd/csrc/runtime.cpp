@@ -277,6 +277,7 @@ int eg_ctx_destroy(eg_ctx* ctx) {
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
+  eg::host_stager_free(ctx->stager);
   for (auto& kv : ctx->jit) delete kv.second;  // eg_kernel: the code object goes with it
   if (ctx->owns_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -343,10 +344,7 @@ int eg_buf_write(eg_buf* buf, const void* host, size_t bytes) {
              "Attempted to write %zu bytes, but the size of the buffer is %zu bytes", bytes, buf->bytes);
   if (bytes == 0) return EG_OK;
   EG_REQUIRE(host, EG_ERR_INVALID, "eg_buf_write: host is NULL");
-  EG_HIP_CHECK(hipSetDevice(buf->ctx->device));
-  EG_HIP_CHECK(hipMemcpyAsync(buf->ptr, host, bytes, hipMemcpyHostToDevice, buf->ctx->stream));
-  EG_HIP_CHECK(hipStreamSynchronize(buf->ctx->stream));
-  return EG_OK;
+  return eg::copy_h2d(buf->ctx, buf->ptr, host, bytes);
 }
 
 int eg_buf_read(eg_buf* buf, void* host, size_t bytes) {
@@ -356,10 +354,7 @@ int eg_buf_read(eg_buf* buf, void* host, size_t bytes) {
              buf->bytes, bytes);
   if (bytes == 0) return EG_OK;
   EG_REQUIRE(host, EG_ERR_INVALID, "eg_buf_read: host is NULL");
-  EG_HIP_CHECK(hipSetDevice(buf->ctx->device));
-  EG_HIP_CHECK(hipMemcpyAsync(host, buf->ptr, bytes, hipMemcpyDeviceToHost, buf->ctx->stream));
-  EG_HIP_CHECK(hipStreamSynchronize(buf->ctx->stream));
-  return EG_OK;
+  return eg::copy_d2h(buf->ctx, host, buf->ptr, bytes);
 }
 
 int eg_buf_fill(eg_buf* buf, const void* pattern, size_t pattern_bytes) {

@@ -200,7 +200,6 @@ def test_empty_inputs_through_every_library_call(gpu_ctx):
                  lambda: ops.map_(gpu_ctx, "tanh", 0, z, z), lambda: ops.map_grad(gpu_ctx, "relu", 0, z, z, z),
                  lambda: ops.conv2_nhwc(gpu_ctx, 0, 8, 8, 4, 4, 3, 3, z, z, z),
                  lambda: ops.conv2_nhwc(gpu_ctx, 2, 8, 8, 4, 0, 3, 3, z, z, z),
-                 lambda: ops.conv2_nhwc_grad_filter(gpu_ctx, 0, 8, 8, 4, 4, 3, 3, z, z, z),
                  lambda: ops.conv2_nhwc_grad_image(gpu_ctx, 0, 8, 8, 4, 4, 3, 3, z, z, z)):
         call()
     gpu_ctx.sync()
