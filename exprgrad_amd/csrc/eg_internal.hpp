@@ -63,6 +63,7 @@ struct eg_ctx {
   size_t side_aux_bytes = 0;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   eg::HostStager* stager = nullptr;  // created by the first large host copy
+  float* ones = nullptr;             // {1,1,1,1, 1,0,0,0}: source of a contraction's virtual row of ones (GemmArgs::ones)
   int compute_units = 256;
   std::string arch;
   // kernels a library call specialises at run time (hiprtc) and keeps: by name

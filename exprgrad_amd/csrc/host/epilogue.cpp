@@ -126,11 +126,16 @@ int generate_epilogue(const Kernel& k, const KernelInfo& info, const Shapes& sha
   };
   const std::string nxs = std::to_string(nx);
   std::string c = "struct EgEpi {\n  static constexpr bool ACTIVE = true;\n  static constexpr int NX = " + nxs + ";\n"
+                  "  static constexpr bool STORE_C = " + std::string(store_c ? "true" : "false") + ";\n"
+                  "  static constexpr int OUT = " + std::to_string(operand_index(k.write.tensor)) + ";\n"
                   "  __device__ __forceinline__ static void prefetch(const eg::gemm::GemmArgs& a, long idx, float (&x)[" + nxs + "]) {\n";
   for (size_t i = 0; i < loads.size(); ++i)
     c += "    x[" + std::to_string(i) + "] = ((const float*)a.epi[" + std::to_string(operand_index(loads[i])) + "])[idx];\n";
-  c += "  }\n  __device__ __forceinline__ static void apply(const eg::gemm::GemmArgs& a, long idx, float v, const float (&x)[" + nxs + "]) {\n";
-  if (store_c) c += "    a.C[idx] = v;\n";
+  c += "  }\n  __device__ __forceinline__ static void prefetch4(const eg::gemm::GemmArgs& a, long idx, eg::gemm::f32x4 (&x)[" + nxs + "]) {\n";
+  for (size_t i = 0; i < loads.size(); ++i)
+    c += "    x[" + std::to_string(i) + "] = *reinterpret_cast<const eg::gemm::f32x4*>((const float*)a.epi[" +
+         std::to_string(operand_index(loads[i])) + "] + idx);\n";
+  c += "  }\n  __device__ __forceinline__ static float compute(const eg::gemm::GemmArgs& a, long idx, float v, const float (&x)[" + nxs + "]) {\n";
   // loop registers from the flat index (dead code unless the expression uses an iterator value)
   std::map<int, long> fac;
   long cst = 0;
@@ -165,8 +170,7 @@ int generate_epilogue(const Kernel& k, const KernelInfo& info, const Shapes& sha
     c += std::string("    const ") + ctype + " r" + std::to_string(ins.res) + " = " + instr_expression(ins, special, "r") + ";\n";
   }
   const std::string val = "(0.0f + r" + std::to_string(k.result) + ")";
-  c += "    ((float*)a.epi[" + std::to_string(operand_index(k.write.tensor)) + "])[idx] = " +
-       (accumulate ? "x[" + std::to_string(slot_of(k.write.tensor)) + "] + " + val : val) + ";\n  }\n};\n";
+  c += "    return " + (accumulate ? "x[" + std::to_string(slot_of(k.write.tensor)) + "] + " + val : val) + ";\n  }\n};\n";
   out.struct_code = c;
   return EG_OK;
 }

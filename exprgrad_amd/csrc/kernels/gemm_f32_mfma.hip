@@ -189,9 +189,8 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
   // Candidates: 256x256 (16 waves, 1 block/CU) for large outputs, 128x128 (4 waves, 4 blocks/CU),
   // and narrow tiles for bias-sized N (the N = 1/4/10 layers of the XOR and dense nets, F = 64
   // filter banks) so the padding wasted in the matrix core stays small.
-  static const TileCfg cfgs[] = {{256, 256, 1}, {128, 128, 4}, {128, 64, 4}, {128, 32, 4}, {256, 64, 2}, {64, 64, 4}, {256, 128, 2}};
-  static const bool wide_ok = getenv("EG_GEMM_NO_256x128") == nullptr;
-  const int NCFG = wide_ok ? 7 : 6;
+  static const TileCfg cfgs[] = {{256, 256, 1}, {128, 128, 4}, {128, 64, 4}, {128, 32, 4}, {256, 64, 2}, {64, 64, 4}};
+  constexpr int NCFG = 6;
   int forced_bm = 0, forced_bn = 0;
   if (const char* f = getenv("EG_GEMM_FORCE_TILE")) sscanf(f, "%d,%d", &forced_bm, &forced_bn);  // tuning aid
   int best = 1, best_splits = 1;
@@ -218,20 +217,14 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
   splits = best_splits;
 }
 
-// Two co-resident blocks per CU (256x128 tiles) start out of phase (GemmArgs::stagger).
-void set_stagger(eg_ctx* ctx, GemmArgs& args, int bm, int bn) {
-  static const int periods = [] {
-    const char* e = getenv("EG_GEMM_STAGGER");
-    return e ? atoi(e) : 3;
-  }();
-  args.stagger = 0;
-  args.stagger_shift = 0;
-  if (bm == 256 && bn == 128 && periods > 0) {
-    args.stagger = periods;
-    int shift = 0;
-    while ((1 << (shift + 1)) <= ctx->compute_units) ++shift;  // 256 CUs -> blocks 256..511 are the second ones
-    args.stagger_shift = shift;
-  }
+// Whole tiles leave through LDS as 16-byte stores (GemmArgs::wide_store) when every address the
+// epilogue touches is 16-byte aligned: the output (or the split-K slabs, which come from the
+// workspace), the bias, and whole rows of four.
+bool wide_store_ok(const GemmArgs& a, bool to_partial) {
+  static const bool off = getenv("EG_GEMM_NO_WIDE_STORE") != nullptr;
+  if (off || a.N % 4 != 0) return false;
+  if (to_partial) return (a.M * a.N) % 4 == 0;   // slabs are [split][M][N] in the 256-byte aligned workspace
+  return a.ldc % 4 == 0 && aligned16(a.C) && (a.bias == nullptr || aligned16(a.bias));
 }
 
 // Shared host-side planning: tile shape, split-K, vector/edge variant, launch, second pass.
@@ -283,7 +276,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     }
   }
   const int launch_splits = args.edge_splits > 0 ? args.splits : splits;
-  set_stagger(ctx, args, BM, BN);
+  args.wide_store = wide_store_ok(args, splits > 1);
   float* scratch = nullptr;
   if (splits > 1) {
     const size_t slab_floats = ((size_t)launch_splits * total + 3) & ~(size_t)3;
@@ -306,8 +299,6 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     rc = launch_config<64, 64, 32, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else if (BN == 64)
     rc = launch_config<128, 64, 64, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
-  else if (BN == 128 && BM == 256)
-    rc = launch_config<256, 128, 128, 64, 2>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else if (BN == 128)
     rc = launch_config<128, 128, 64, 64, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else
@@ -423,7 +414,8 @@ bool ones_row_supported(int trans_a, int trans_b, long M, long N, long K, const 
   const bool vec_a = (lda % 4 == 0) && (a_contig % 4 == 0) && aligned16(A);
   const bool vec_b = (ldb % 4 == 0) && (b_contig % 4 == 0) && aligned16(B);
   // large enough for the matrix-core path (not the one-wave-per-output kernel) and at least one k-tile
-  return vec_a && vec_b && K >= 16 && !((M + 1) * N <= 16384 && K <= 2048) && getenv("EG_NO_ONES_ROW") == nullptr;
+  const char* off = getenv("EG_NO_ONES_ROW");
+  return vec_a && vec_b && K >= 16 && !((M + 1) * N <= 16384 && K <= 2048) && !(off && off[0] && off[0] != '0');
 }
 
 int sgemm_ones_row(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, const float* A, long lda, const float* B,
@@ -439,6 +431,12 @@ int sgemm_ones_row(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K
   args.M = M + 1;
   args.a_rows = M;
   args.ones_row = 1;
+  if (!ctx->ones) {
+    static const float values[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 0.f, 0.f, 0.f};
+    EG_HIP_CHECK(hipMalloc((void**)&ctx->ones, sizeof(values)));
+    EG_HIP_CHECK(hipMemcpy(ctx->ones, values, sizeof(values), hipMemcpyHostToDevice));
+  }
+  args.ones = ctx->ones;
   args.N = N;
   args.K = K;
   args.lda = lda;
@@ -687,7 +685,6 @@ int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, co
   else if (bn == 64 && bm == 256) { out.wm = 64; out.wn = 32; out.minb = 2; }
   else if (bn == 64 && bm == 64) { out.wm = 32; out.wn = 32; out.minb = 4; }
   else if (bn == 64) { out.wm = 64; out.wn = 32; out.minb = 4; }
-  else if (bn == 128 && bm == 256) { out.wm = 128; out.wn = 64; out.minb = 2; }
   else if (bn == 128) { out.wm = 64; out.wn = 64; out.minb = 4; }
   else { out.wm = 128; out.wn = 64; out.minb = 1; }
   out.nt = (bm / out.wm) * (bn / out.wn) * 64;
@@ -718,7 +715,7 @@ int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, co
   args.k_per_split = ((K + BK - 1) / BK) * BK;
   if (args.k_per_split < BK) args.k_per_split = BK;
   out.grid = (unsigned)(args.tiles_m * args.tiles_n);
-  set_stagger(ctx, args, bm, bn);
+  args.wide_store = wide_store_ok(args, false);   // set_epilogue_operands withdraws it for unaligned operands
   memcpy(out.args, &args, sizeof(args));
   out.args_size = sizeof(args);
   return EG_OK;
@@ -727,6 +724,8 @@ int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, co
 void set_epilogue_operands(FusedLaunch& f, void* const* ptrs, int count, float grad_scale, long epoch) {
   GemmArgs* a = reinterpret_cast<GemmArgs*>(f.args);
   for (int i = 0; i < MAX_EPILOGUE_OPERANDS; ++i) a->epi[i] = i < count ? ptrs[i] : nullptr;
+  for (int i = 0; i < count; ++i)
+    if (!aligned16(ptrs[i])) a->wide_store = 0;
   a->epi_gs = grad_scale;
   a->epi_ep = epoch;
 }
@@ -744,10 +743,14 @@ std::string fused_source(const FusedLaunch& f, const std::string& epi_struct, co
   s += "\n" + epi_struct + "\n";
   char buf[512];
   const int waves = f.nt / 64;
+  // a ragged tile with a generated epilogue needs a few registers more than four waves per SIMD leave
+  // (48 bytes of scratch at 128 VGPRs): three there
+  int per_simd = (f.minb * waves + 3) / 4;
+  if (f.edge && per_simd >= 4) per_simd = 3;
   snprintf(buf, sizeof(buf),
            "extern \"C\" __global__ __launch_bounds__(%d, %d) void %s(eg::gemm::GemmArgs a) {\n"
            "  eg::gemm::gemm_block<%d, %d, %d, %d, %d, %s, %s, %d, %s, false, 0, %s, %s>(a);\n}\n",
-           f.nt, (f.minb * waves + 3) / 4, kernel_name.c_str(), f.bm, f.bn, f.bk, f.wm, f.wn, f.a_kc ? "true" : "false",
+           f.nt, per_simd, kernel_name.c_str(), f.bm, f.bn, f.bk, f.wm, f.wn, f.a_kc ? "true" : "false",
            f.b_kc ? "true" : "false", f.vec, f.edge ? "true" : "false", f.dma ? "true" : "false", epi_name.c_str());
   s += buf;
   return s;

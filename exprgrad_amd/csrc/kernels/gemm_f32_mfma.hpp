@@ -55,32 +55,49 @@ struct GemmArgs {
   void* epi[6];
   float epi_gs;
   long epi_ep;
-  // Two blocks per CU (256x128 tiles): blocks dispatched second to their CU start `stagger` sleep
-  // periods late, so that for the rest of the launch the store burst of one block's epilogue falls
-  // into the other's k loop instead of both idling the matrix pipe at the same moment.  0 = off.
-  int stagger;
-  int stagger_shift;  // log2 of the number of blocks dispatched before a CU receives its second one
   // Virtual last row of ones: with ones_row != 0 the A operand has a_rows = M - 1 physical rows and
   // A(M - 1, k) = 1 for every k, so row M - 1 of C is the column sum of B.  This is how a bias gradient
   // `gb[x] ++= g[y,x]` rides along with the weight gradient `gW[it,x] ++= a[y,it] * g[y,x]` that
   // reduces over the same batch (dnn.nim:19-24 differentiated, passes.nim:519-549): gb is row M - 1
-  // of [gW; gb] when the two are adjacent in memory.  LDS-DMA loop only (the host checks).
+  // of [gW; gb] when the two are adjacent in memory.  LDS-DMA loop only (the host checks): the lanes
+  // whose 16-byte chunk holds the virtual row fetch it from `ones` instead of from A — no extra LDS
+  // pass, no extra barrier (a first version wrote the ones into LDS after every k-tile landed: the
+  // barrier that needed cost the edge blocks 0.3 us per k-tile, 86 us on the cfg-5 weight gradient).
   int ones_row;
   long a_rows;  // physical rows of A (= M unless ones_row)
+  const float* ones;  // device constants {1,1,1,1, 1,0,0,0}: what the loaders fetch for the virtual row
+  // Whole tiles leave through LDS: the accumulator blocks of 32 tile rows per wave row are transposed
+  // into [row][BN] order and written (and, for a generated epilogue, its operands read) as 16-byte
+  // accesses, a full tile row per wave instruction instead of 128-byte pieces of 32 different rows.
+  // Requires N, ldc multiples of 4 and 16-byte aligned C / partial / epilogue operands (host checks).
+  int wide_store;
 };
 
 // Epilogue functor of the library kernels: plain store.  A generated epilogue (ACTIVE = true)
 // receives every finished element v = acc + bias of a non-accumulating, non-split launch together
-// with its flat index m * ldc + n and is responsible for all stores, including C if it is needed.
-// The work is split in two so the kernel can issue the loads of all 16 elements of an accumulator
-// block before the first dependent store: prefetch() reads the NX other operands of the element,
-// apply() computes and stores.
+// with its flat index m * ldc + n.  The work is split so the kernel can issue the loads of all
+// elements it holds before the first dependent store: prefetch() reads the NX other operands of the
+// element, compute() produces the consumer's value.
 struct EpiNone {
   static constexpr bool ACTIVE = false;
+  static constexpr bool STORE_C = true;
   static constexpr int NX = 1;
+  static constexpr int OUT = 0;
   __device__ __forceinline__ static void prefetch(const GemmArgs&, long, float (&)[1]) {}
-  __device__ __forceinline__ static void apply(const GemmArgs&, long, float, const float (&)[1]) {}
+  __device__ __forceinline__ static void prefetch4(const GemmArgs&, long, f32x4 (&)[1]) {}
+  __device__ __forceinline__ static float compute(const GemmArgs&, long, float v, const float (&)[1]) { return v; }
 };
+
+// A generated epilogue (host/epilogue.cpp) provides: NX operands to read per element (prefetch /
+// prefetch4 = four consecutive elements as 16-byte loads), compute() = the consumer's value for one
+// element given the contraction result v = acc + bias, STORE_C = whether v itself is stored too, OUT =
+// the index in a.epi[] of the tensor the consumer writes.  The kernel does the stores.
+template <class Epi>
+__device__ __forceinline__ void epi_apply(const GemmArgs& a, long idx, float v, const float (&x)[Epi::NX]) {
+  const float r = Epi::compute(a, idx, v, x);
+  if (Epi::STORE_C) a.C[idx] = v;
+  static_cast<float*>(a.epi[Epi::OUT])[idx] = r;
+}
 
 // Row stride (in floats) of an LDS operand tile [BK][stride].
 //  - m|n-contiguous operand: 16-byte ds_write_b128 rows, no padding needed.
@@ -390,7 +407,8 @@ struct DmaLoader {
 
   // issue this wave's share of the tile whose origin is (mn0, k0) into `tile` (LDS, lane-linear)
   __device__ __forceinline__ void issue(const GemmArgs& a, const float* __restrict__ base, long ld, long mn0, long k0,
-                                        float* tile, int wave, int lane, long limit = 0, long k_lim = 0) const {
+                                        float* tile, int wave, int lane, long limit = 0, long k_lim = 0,
+                                        const float* ones = nullptr) const {
     long tap_off = 0;
     if (CONV && KC) {  // block-uniform: scalar work
       const unsigned C = (unsigned)a.cC, FW = (unsigned)a.cFW;
@@ -410,6 +428,7 @@ struct DmaLoader {
           src = base + row_off[t] + tap_off + c * 4;
         else
           src = base + (CLAMP ? min(mn0 + r, limit - 1) : mn0 + r) * ld + (CLAMP ? min(k0 + c * 4, k_lim - 4) : k0 + c * 4);
+        if (CLAMP && !CONV && ones && mn0 + r == limit) src = ones;  // the virtual row: 1 for every k
       } else {
         constexpr int CPR = BMN / 4;
         const int k = q / CPR, col = (q % CPR) * 4;
@@ -421,6 +440,7 @@ struct DmaLoader {
           src = base + (((long)img * a.cH + y) * a.cW + x) * a.cC + row_off[t];
         } else {
           src = base + (CLAMP ? min(k0 + k, k_lim - 1) : k0 + k) * ld + (CLAMP ? min(mn0 + col, limit - 4) : mn0 + col);
+          if (CLAMP && ones && mn0 + col == limit) src = ones + 4;  // {1, 0, 0, 0}: the virtual row starts this chunk
         }
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -459,11 +479,9 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
   DmaB db;
   da.init(a, m_blk, wave, lane, a.a_rows);
   db.init(a, n_blk, wave, lane, a.N);
-  // the virtual row of ones, if it falls into this tile (ragged loop only: such a tile is never interior)
-  const int one_r = CL && a.ones_row ? (int)(a.a_rows - m_blk) : -1;
-  const bool has_one = one_r >= 0 && one_r < BM;
+  const float* ones = CL && a.ones_row ? a.ones : nullptr;  // (ragged loop only: a tile with the virtual row is never interior)
   if (nk > 0) {
-    da.issue(a, a.A, a.lda, m_blk, k_begin, lds, wave, lane, a.a_rows, k_end);
+    da.issue(a, a.A, a.lda, m_blk, k_begin, lds, wave, lane, a.a_rows, k_end, ones);
     db.issue(a, a.B, a.ldb, n_blk, k_begin, lds + BK * BM, wave, lane, a.N, k_end);
   }
   const int k_tail = CL ? (int)((k_end - k_begin) % BK) : 0;  // valid k of a ragged last k-tile (0 = full)
@@ -474,7 +492,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
     if (kt + 1 < nk) {
       const long k0 = k_begin + (long)(kt + 1) * BK;
       float* nxt = lds + (cur ^ 1) * BUF;
-      da.issue(a, a.A, a.lda, m_blk, k0, nxt, wave, lane, a.a_rows, k_end);
+      da.issue(a, a.A, a.lda, m_blk, k0, nxt, wave, lane, a.a_rows, k_end, ones);
       db.issue(a, a.B, a.ldb, n_blk, k0, nxt + BK * BM, wave, lane, a.N, k_end);
     }
     if (CL && k_tail != 0 && kt == nk - 1) {
@@ -489,18 +507,6 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
         } else {
           At[k_tail * BM + e] = 0.f;
         }
-      }
-      __syncthreads();
-    }
-    if (CL && has_one) {
-      // the loaders re-read the last physical row for it; make it ones (after the k-tail zeroing: a ragged
-      // last k-tile must keep its zeros)
-      float* At = lds + cur * BUF;
-      const int valid = (k_tail != 0 && kt == nk - 1) ? k_tail : BK;
-      if (tid < valid) {
-        const int k = tid;
-        if (A_KC) At[one_r * BK + (((k >> 2) ^ DmaA::swizzle(one_r)) << 2) + (k & 3)] = 1.f;
-        else At[k * BM + one_r] = 1.f;
       }
       __syncthreads();
     }
@@ -572,10 +578,6 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   const int wave = tid >> 6;
   const int wm0 = (wave / WAVES_N) * WM;
   const int wn0 = (wave % WAVES_N) * WN;
-
-  if (a.stagger > 0 && ((blockIdx.x >> a.stagger_shift) & 1)) {
-    for (int s = 0; s < a.stagger; ++s) __builtin_amdgcn_s_sleep(127);  // 127 x 64 clocks ~ 3.4 us each
-  }
 
   // ---- tile coordinates: XCD-contiguous ids, then 8-row groups so co-resident tiles share
   //      A row-panels and B column-panels inside one L2.
@@ -656,6 +658,66 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   const bool accumulate = !to_partial && a.accumulate;
   const bool has_bias = !to_partial && a.bias != nullptr;
   const bool whole_tile = m_blk + BM <= a.M && n_blk + BN <= a.N;
+  if (a.wide_store && (!EDGE || whole_tile)) {  // block-uniform
+    // ---- whole tile, through LDS (GemmArgs::wide_store).  Pass i: every wave parks block row i of its
+    // sub-tile (32 rows x WN columns) at [wave row * 32 + row][wn0 + col]; then all threads walk the
+    // (BM / WM) * 32 staged rows in 16-byte chunks, one full tile row per wave instruction.
+    constexpr int WAVES_M = BM / WM;
+    constexpr int RT = WAVES_M * 32;            // staged rows per pass
+    constexpr int C4 = BN / 4;                  // 16-byte chunks per staged row
+    constexpr int NT_ = WAVES_M * WAVES_N * 64;
+    static_assert(RT * BN <= 2 * BK * (SA + SB), "the staged rows fit the operand buffers");
+    const int wmi = wave / WAVES_N;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          lds[(wmi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BN + wn0 + j * 32 + (lane & 31)] = acc[i][j][r];
+      __syncthreads();
+#pragma unroll
+      for (int q0 = 0; q0 < RT * C4; q0 += NT_) {
+        const int q = q0 + tid;
+        if ((RT * C4) % NT_ != 0 && q >= RT * C4) break;
+        const int row = q / C4, c4 = q % C4;
+        const long m = m_blk + (long)(row >> 5) * WM + i * 32 + (row & 31);
+        const long n = n_blk + c4 * 4;
+        const long idx = m * ldo + n;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * BN + c4 * 4]);
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (has_bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+        if (Epi::ACTIVE) {
+          f32x4 x4[Epi::NX];
+          Epi::prefetch4(a, idx, x4);
+          f32x4 res;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x[Epi::NX];
+#pragma unroll
+            for (int o = 0; o < Epi::NX; ++o) x[o] = x4[o][e];
+            v[e] = v[e] + b4[e];
+            res[e] = Epi::compute(a, idx + e, v[e], x);
+          }
+          if (Epi::STORE_C) *reinterpret_cast<f32x4*>(a.C + idx) = v;
+          *reinterpret_cast<f32x4*>(static_cast<float*>(a.epi[Epi::OUT]) + idx) = res;
+        } else {
+          f32x4* p = reinterpret_cast<f32x4*>(out + idx);
+          if (accumulate) {
+            const f32x4 o = *p;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (o[e] + v[e]) + b4[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] + b4[e];
+          }
+          *p = v;
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -673,14 +735,14 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
           for (int r = 0; r < 16; ++r) Epi::prefetch(a, (m_base + (r & 3) + 8 * (r >> 2)) * ldo + n, x[r]);
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            Epi::apply(a, (m_base + (r & 3) + 8 * (r >> 2)) * ldo + n, acc[i][j][r] + bias, x[r]);
+            epi_apply<Epi>(a, (m_base + (r & 3) + 8 * (r >> 2)) * ldo + n, acc[i][j][r] + bias, x[r]);
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const long m = m_base + (r & 3) + 8 * (r >> 2);
             if (m >= a.M || !n_ok) continue;
             Epi::prefetch(a, m * ldo + n, x[r]);
-            Epi::apply(a, m * ldo + n, acc[i][j][r] + bias, x[r]);
+            epi_apply<Epi>(a, m * ldo + n, acc[i][j][r] + bias, x[r]);
           }
         }
       } else if (!EDGE || whole_tile) {  // branch-free: the 16 stores (and loads) of a block are issued back to back
