@@ -50,7 +50,7 @@ int model_backward_with_exchange(eg_model* m, const char* target, const GradExch
     const char* e = getenv("EG_DP_NO_SPLIT");
     return e && e[0] && e[0] != '0';
   }();
-  if (ex.big < 0 || no_split) {
+  if (ex.big == -1 || no_split) {
     // nothing to overlap with: the captured backward range, then one all-reduce of the whole bucket
     rc = run_range(m, *ts, *plan, 0, plan->n_backward, true, 1);
     if (rc) return rc;
@@ -183,6 +183,9 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
   TargetState& ts = it->second;
   Plan& plan = *ts.last;
   std::ostringstream os;
+  if (plan.pipe.active)
+    os << "-- batch pipeline: launches up to the update run as two halves of " << plan.pipe.half
+       << " rows; long contractions on the main lane, the rest on the side lane under them --\n";
   for (size_t i = 0; i < plan.launches.size(); ++i) {
     const Launch& L = plan.launches[i];
     if ((int)i == plan.n_backward) os << "-- update --\n";
@@ -222,6 +225,8 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
     }
     for (auto& ov : plan.overlaps)
       if ((int)i >= ov.first && (int)i < ov.big) os << "   || side lane, next to launch " << ov.big;
+    if (plan.pipe.active && (int)i < plan.n_backward)
+      os << (L.heavy ? "   || main lane" : "   || side lane") << (L.slice_mode == 2 ? ", halves accumulate" : ", by rows");
     os << "\n";
   }
   m->launch_text = os.str();

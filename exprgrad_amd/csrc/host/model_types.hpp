@@ -92,6 +92,12 @@ struct Launch {
   std::vector<int> epoch_slots;             // params refreshed from Model.epoch at every launch
   int row_group = -1;                       // RowFused: index into Plan::row_groups
   int epilogue = -1;                        // GemmFused: index into Plan::epilogues
+  // Batch pipeline (plan_pipeline.cpp): how this launch is cut when the batch runs in two halves.
+  //   0 = not cut (not pipelinable), 1 = rows: the batch indexes the rows of A / C and of every
+  //   [batch, ...] operand, 2 = reduction: the batch is the contraction's K (weight gradients), the
+  //   second half accumulates onto the first.  RowFused launches are always cut by rows.
+  int slice_mode = 0;
+  bool heavy = false;                       //   long contraction: stays on the main lane, the rest goes to the side lane
   int ones_tensor = 0;                      // Gemm: the bias gradient that rides along as row M of [gW; gb] (fold_bias_gradients)
   int ones_lowered = -1;                    //   live position of the column-sum kernel it replaces
   int consumer = -1;                        // GenericA: live position of the elementwise consumer folded into it
@@ -161,6 +167,13 @@ struct Plan {
     int first = 0, big = 0;
   };
   std::vector<Overlap> overlaps;
+  // Batch pipeline: the backward range [0, n_backward) runs as two half batches, the long contractions
+  // of both halves back to back on the main lane, everything between them on the side lane — the
+  // bandwidth-bound launches of one half under the matrix work of the other (plan_pipeline.cpp).
+  struct Pipeline {
+    bool active = false;
+    long batch = 0, half = 0;
+  } pipe;
   struct Captured {
     hipGraphExec_t exec = nullptr;
     std::string key;  // everything baked into the captured kernel arguments
@@ -298,6 +311,15 @@ int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool
 // of the same layer becomes the last row of that contraction (a virtual row of ones in A) when gb lies
 // directly behind gW in the gradient bucket; the column-sum launch disappears.
 int fold_bias_gradients(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos);
+// plan_pipeline.cpp
+void plan_pipeline(eg_model* m, TargetState& ts, Plan& plan);
+// One half of a sliced launch: rows [row0, row0 + rows) of the batch; second = the later half (reductions accumulate).
+struct Slice {
+  long row0 = 0, rows = 0;
+  bool second = false;
+};
+int run_launch_sliced(eg_model* m, TargetState& ts, Plan& plan, Launch& L, const Slice& sl);
+int run_pipelined(eg_model* m, TargetState& ts, Plan& plan, const SideHook* hook);
 // plan_check.cpp: invariants of a finished plan (read / write sets against the kernel list, arena
 // layout, overlap groups).  Returns EG_OK or EG_ERR_RUNTIME with the violated invariant named.
 int check_plan(eg_model* m, TargetState& ts, Plan& plan);

@@ -540,6 +540,7 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   }
 
   plan_overlap(m, ts, plan);
+  plan_pipeline(m, ts, plan);
   {
     int rc = build_plan_kernels(m, plan);
     if (rc) return rc;

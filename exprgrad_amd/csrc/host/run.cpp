@@ -209,6 +209,11 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
       if (rc) return rc;
     }
   }
+  if (plan.pipe.active && begin == 0 && end >= plan.n_backward) {
+    int rc = run_pipelined(m, ts, plan, hook);
+    if (rc) return rc;
+    begin = plan.n_backward;
+  }
   size_t next_overlap = 0;
   for (int i = begin; i < end; ++i) {
     while (next_overlap < plan.overlaps.size() && plan.overlaps[next_overlap].first < i) ++next_overlap;
@@ -319,6 +324,164 @@ int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool
   return EG_OK;
 }
 
+// ---- batch pipeline (plan_pipeline.cpp) ------------------------------------------------------------
+int run_launch_sliced(eg_model* m, TargetState& ts, Plan& plan, Launch& L, const Slice& sl) {
+  eg_ctx* ctx = m->ctx;
+  switch (L.kind) {
+    case StepKind::Gemm: {
+      const float* A = tensor_ptr(m, ts, plan, L.a_tensor);
+      const float* B = tensor_ptr(m, ts, plan, L.b_tensor);
+      float* C = tensor_ptr(m, ts, plan, L.c_tensor);
+      const float* bias = L.bias_tensor ? tensor_ptr(m, ts, plan, L.bias_tensor) : nullptr;
+      if (L.slice_mode == 1)  // rows of the batch: A(m, k) = A[m * lda + k]
+        return eg_sgemm(ctx, L.trans_a, L.trans_b, sl.rows, L.N, L.K, A + sl.row0 * L.lda, L.lda, B, L.ldb, C + sl.row0 * L.ldc,
+                        L.ldc, L.accumulate, bias);
+      // the batch is K: A(k, m) = A[k * lda + m], B(k, n) = B[k * ldb + n]; the second half adds to the first
+      const int accumulate = L.accumulate || sl.second;
+      A += sl.row0 * L.lda;
+      B += sl.row0 * L.ldb;
+      if (L.ones_tensor) {
+        int rc = eg::gemm::sgemm_ones_row(ctx, L.trans_a, L.trans_b, L.M, L.N, sl.rows, A, L.lda, B, L.ldb, C, L.ldc, accumulate);
+        if (rc != EG_ERR_UNSUPPORTED) return rc;
+        eg::clear_error();
+        rc = eg_colsum(ctx, sl.rows, L.N, B, tensor_ptr(m, ts, plan, L.ones_tensor), sl.second ? 1 : 0);
+        if (rc) return rc;
+      }
+      return eg_sgemm(ctx, L.trans_a, L.trans_b, L.M, L.N, sl.rows, A, L.lda, B, L.ldb, C, L.ldc, accumulate, bias);
+    }
+    case StepKind::GemmFused: {
+      PlanEpilogue& pe = *plan.epilogues[L.epilogue];
+      const float* bias = L.bias_tensor ? tensor_ptr(m, ts, plan, L.bias_tensor) : nullptr;
+      const float* A = tensor_ptr(m, ts, plan, L.a_tensor) + sl.row0 * L.lda;
+      float* C = tensor_ptr(m, ts, plan, L.c_tensor) + sl.row0 * L.ldc;
+      eg::gemm::FusedLaunch f;
+      int rc = eg::gemm::plan_fused(ctx, L.trans_a, L.trans_b, sl.rows, L.N, L.K, A, L.lda, tensor_ptr(m, ts, plan, L.b_tensor),
+                                    L.ldb, C, L.ldc, bias, f);
+      if (rc) return rc;
+      if (f.splits > 1) {
+        set_error("batch pipeline: a half of a fused contraction needs split-K");
+        return EG_ERR_RUNTIME;
+      }
+      const std::string variant = eg::gemm::fused_variant(f);
+      eg_kernel*& handle = pe.built[variant];
+      if (!handle) {
+        const std::string name = "eg_gemm_epi" + std::to_string(m->kernel_serial++);
+        const std::string src = eg::gemm::fused_source(f, pe.spec.struct_code, pe.spec.struct_name, name);
+        rc = eg_kernel_compile(ctx, name.c_str(), src.c_str(), &handle);
+        if (rc) {
+          handle = nullptr;
+          return rc;
+        }
+        m->kernels.push_back(handle);
+      }
+      void* operands[eg::gemm::MAX_EPILOGUE_OPERANDS] = {};
+      for (size_t o = 0; o < pe.spec.operands.size(); ++o)
+        operands[o] = tensor_ptr(m, ts, plan, pe.spec.operands[o]) + sl.row0 * L.N;  // [batch, N] tensors
+      eg::gemm::set_epilogue_operands(f, operands, (int)pe.spec.operands.size(), m->grad_scale, m->epoch);
+      void* args[] = {f.args};
+      return eg::kernel_launch_raw(handle, f.grid, 1, 1, (unsigned)f.nt, args);
+    }
+    case StepKind::RowFused: {
+      PlanRowGroup& pg = *plan.row_groups[L.row_group];
+      std::vector<float*> ptrs;
+      ptrs.push_back(pg.partial);
+      for (int tid : pg.g.ptr_args) {
+        float* p = tensor_ptr(m, ts, plan, tid);
+        const RowGroupTensor& gt = pg.g.tensors.at(tid);
+        if (gt.role == RowGroupTensor::RowLocal || gt.role == RowGroupTensor::RowExternal) p += sl.row0 * gt.inner;
+        ptrs.push_back(p);
+      }
+      std::vector<void*> args;
+      for (auto& p : ptrs) args.push_back(&p);
+      long B = sl.rows, EP = m->epoch;
+      float GS = m->grad_scale;
+      args.push_back(&B);
+      args.push_back(&GS);
+      args.push_back(&EP);
+      const int nblocks = (int)((sl.rows + 255) / 256);
+      int rc = eg::kernel_launch_raw(pg.handle, (unsigned)nblocks, 1, 1, 256, args.data());
+      if (rc) return rc;
+      if (pg.g.red_total > 0) {
+        eg::RowFinalizeArgs fa = {};
+        fa.nseg = (int)pg.red_tensors.size();
+        for (int s = 0; s < fa.nseg; ++s) {
+          const RowGroupTensor& gt = pg.g.tensors.at(pg.red_tensors[s]);
+          fa.dst[s] = tensor_ptr(m, ts, plan, pg.red_tensors[s]);
+          fa.offset[s] = (int)gt.red_offset;
+          fa.accumulate[s] = (gt.accumulate || sl.second) ? 1 : 0;
+        }
+        fa.offset[fa.nseg] = (int)pg.g.red_total;
+        return eg::row_finalize(ctx, pg.partial, nblocks, (int)pg.g.red_total, fa);
+      }
+      return EG_OK;
+    }
+    default:
+      set_error("batch pipeline: launch kind %d cannot be cut", (int)L.kind);
+      return EG_ERR_RUNTIME;
+  }
+}
+
+// Stage j = the j-th long contraction of the range and the streaming launches that follow it (stage
+// -1: what precedes the first one).  Main lane: contraction j of half A, of half B, contraction j + 1
+// of half A, ...  Side lane: the streaming launches of stage j, half A then half B.  Events carry the
+// per-half dependencies between the lanes; both lanes are in order, so nothing else needs saying.
+int run_pipelined(eg_model* m, TargetState& ts, Plan& plan, const SideHook* hook) {
+  eg_ctx* ctx = m->ctx;
+  int rc = ensure_side_lane(ctx);
+  if (rc) return rc;
+  const int nb = plan.n_backward;
+  std::vector<int> heavy;  // positions of the long contractions
+  for (int i = 0; i < nb; ++i)
+    if (plan.launches[i].heavy) heavy.push_back(i);
+  const int stages = (int)heavy.size();
+  const size_t need = (size_t)(stages + 1) * 4;
+  while (ctx->pipe_events.size() < need) {
+    hipEvent_t e;
+    EG_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ctx->pipe_events.push_back(e);
+  }
+  auto ev_main = [&](int stage, int h) { return ctx->pipe_events[(size_t)((stage + 1) * 4 + h)]; };      // contraction (stage, h) done
+  auto ev_side = [&](int stage, int h) { return ctx->pipe_events[(size_t)((stage + 1) * 4 + 2 + h)]; };  // streaming part (stage, h) done
+  const Slice halves[2] = {{0, plan.pipe.half, false}, {plan.pipe.half, plan.pipe.batch - plan.pipe.half, true}};
+  // everything queued so far on the main lane (zero fills, random tensors) precedes the side lane's work
+  EG_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+  EG_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+  for (int stage = -1; stage < stages; ++stage) {
+    const int first_light = stage < 0 ? 0 : heavy[(size_t)stage] + 1;
+    const int last_light = stage + 1 < stages ? heavy[(size_t)stage + 1] : nb;  // exclusive
+    if (stage >= 0) {
+      for (int h = 0; h < 2; ++h) {
+        if (stage > 0 || heavy[0] > 0)  // the streaming launches before it, same half
+          EG_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev_side(stage - 1, h), 0));
+        rc = run_launch_sliced(m, ts, plan, plan.launches[heavy[(size_t)stage]], halves[h]);
+        if (rc) return rc;
+        EG_HIP_CHECK(hipEventRecord(ev_main(stage, h), ctx->stream));
+      }
+    }
+    const bool any_light = first_light < last_light;
+    {
+      LaneSwap lane(ctx);  // ctx->stream is the side lane's from here
+      for (int h = 0; h < 2; ++h) {
+        if (stage >= 0) EG_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev_main(stage, h), 0));
+        for (int i = first_light; i < last_light; ++i) {
+          rc = run_launch_sliced(m, ts, plan, plan.launches[i], halves[h]);
+          if (rc) return rc;
+        }
+        if (stage == stages - 1 && h == 1 && hook && hook->big == -2) {  // data-parallel step: the early gradients go out here
+          rc = hook->fn(hook->user);
+          if (rc) return rc;
+        }
+        EG_HIP_CHECK(hipEventRecord(ev_side(stage, h), ctx->stream));
+      }
+    }
+    (void)any_light;
+  }
+  // join: the main lane continues after the side lane's last piece
+  EG_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev_side(stages - 1, 0), 0));
+  EG_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev_side(stages - 1, 1), 0));
+  return EG_OK;
+}
+
 // ---- data-parallel step with the exchange overlapped (dp_rccl.cpp) -------------------
 // The gradient bucket is exchanged in two parts when the backward range ends in an overlap group whose
 // long contraction produces the LAST gradient (dense nets: the first layer's weight gradient, by far
@@ -353,6 +516,32 @@ int plan_exchange(eg_model* m, TargetState& ts, Plan& plan, ExchangePlan& ex) {
         note(L.c_tensor, i);
         note(L.ones_tensor, i);
     }
+  }
+  if (plan.pipe.active) {
+    // batch pipeline: gradients written by the streaming launches (side lane) are complete when the side
+    // lane ends, before the last contraction of the main lane: they go out there (hook->big == -2)
+    bool late_any = false, early_any = false;
+    std::vector<std::pair<long, int>> order;
+    for (auto& b : ts.bucket_offset) order.push_back({b.second, b.first});
+    std::sort(order.begin(), order.end());
+    for (size_t i = 0; i < order.size(); ++i) {
+      const int tid = order[i].second;
+      const long begin = order[i].first, end = i + 1 < order.size() ? order[i + 1].first : ts.bucket_floats;
+      auto lw = last_writer.find(tid);
+      const bool late = lw != last_writer.end() && plan.launches[(size_t)lw->second].heavy;
+      (late ? late_any : early_any) = true;
+      std::vector<std::pair<long, long>>& segs = late ? ex.late : ex.early;
+      if (!segs.empty() && segs.back().first + segs.back().second == begin) segs.back().second += end - begin;
+      else segs.push_back({begin, end - begin});
+    }
+    ex.big = -2;
+    if (!late_any || !early_any) {
+      ex.big = -1;
+      ex.late.clear();
+      ex.early.clear();
+      if (ts.bucket_floats > 0) ex.late.push_back({0, ts.bucket_floats});
+    }
+    return EG_OK;
   }
   int big = -1;
   for (auto& ov : plan.overlaps)

@@ -276,6 +276,7 @@ int eg_ctx_destroy(eg_ctx* ctx) {
   if (ctx->side_aux) hipFree(ctx->side_aux);
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+  for (hipEvent_t e : ctx->pipe_events) hipEventDestroy(e);
   if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
   eg::host_stager_free(ctx->stager);
   if (ctx->ones) hipFree(ctx->ones);
