@@ -55,6 +55,8 @@ _SIGS = {
     "eg_buf_write": (c_int, [c_void_p, c_void_p, c_size_t]),
     "eg_buf_read": (c_int, [c_void_p, c_void_p, c_size_t]),
     "eg_buf_fill": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "eg_host_alloc": (c_int, [c_size_t, P(c_void_p)]),
+    "eg_host_free": (c_int, [c_void_p]),
     "eg_kernel_compile": (c_int, [c_void_p, c_char_p, c_char_p, P(c_void_p)]),
     "eg_kernel_free": (c_int, [c_void_p]),
     "eg_kernel_set_arg_buf": (c_int, [c_void_p, c_int, c_void_p]),

@@ -1,4 +1,4 @@
-// Blocking host <-> device copies of large PAGEABLE host arrays at PCIe speed.
+// Blocking device -> host copies into large PAGEABLE host arrays, and pinned host memory for callers.
 //
 // The reference uploads every input with a blocking write and downloads every output with a blocking
 // read on each call (model.nim:364-376 -> cl.nim:111-131); its matmul benchmark times exactly that
@@ -8,7 +8,7 @@
 //   * a few pinned staging buffers per context (hipHostMalloc, 8 MiB each), used round robin;
 //   * a small pool of worker threads copies pageable <-> pinned in parallel slices (one core moves
 //     ~12 GB/s, PCIe 5 x16 wants ~55);
-//   * the DMA of chunk i overlaps the host copy of chunk i + 1 (upload) / i - 1 (download);
+//   * the DMA of chunk i overlaps the host copy of chunk i - 1;
 //   * everything is enqueued on the context's stream, so ordering against kernels stays the
 //     in-order-queue contract of cl.nim:92, and the call returns when the data has arrived.
 // Copies below 4 MiB take the plain hipMemcpyAsync + synchronize path.
@@ -167,28 +167,14 @@ static bool is_pageable(const void* host) {
 }
 
 // Blocking upload: returns when `bytes` of `host` have arrived at `device` (ordered on ctx->stream).
+// Measured (4096^2 floats, pageable numpy arrays that have been touched): the runtime's own pageable
+// path reaches 56 GB/s, the staged path above 46 — uploads therefore go straight to hipMemcpyAsync.
+// What made the reference-style call slow was the DOWNLOAD into a freshly allocated result array
+// (page faults inside the copy): see copy_d2h and the pinned result arrays of eg_host_alloc.
 int copy_h2d(eg_ctx* ctx, void* device, const void* host, size_t bytes) {
   if (bytes == 0) return EG_OK;
   EG_HIP_CHECK(hipSetDevice(ctx->device));
-  if (bytes < THRESHOLD || !staging_enabled() || !is_pageable(host)) {
-    EG_HIP_CHECK(hipMemcpyAsync(device, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    EG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return EG_OK;
-  }
-  HostStager* s;
-  int rc = stager(ctx, &s);
-  if (rc) return rc;
-  std::lock_guard<std::mutex> lock(s->mu);
-  size_t off = 0;
-  for (int c = 0; off < bytes; ++c) {
-    const int b = c % NBUF;
-    const size_t len = std::min(CHUNK, bytes - off);
-    if (c >= NBUF) EG_HIP_CHECK(hipEventSynchronize(s->ev[b]));  // the DMA that last read this buffer is done
-    parallel_copy(*s->pool, s->buf[b], static_cast<const char*>(host) + off, len);
-    EG_HIP_CHECK(hipMemcpyAsync(static_cast<char*>(device) + off, s->buf[b], len, hipMemcpyHostToDevice, ctx->stream));
-    EG_HIP_CHECK(hipEventRecord(s->ev[b], ctx->stream));
-    off += len;
-  }
+  EG_HIP_CHECK(hipMemcpyAsync(device, host, bytes, hipMemcpyHostToDevice, ctx->stream));
   EG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
   return EG_OK;
 }
@@ -232,3 +218,19 @@ int copy_d2h(eg_ctx* ctx, void* host, const void* device, size_t bytes) {
 }
 
 }  // namespace eg
+
+// ---- pinned host memory for callers (group 1): result tensors allocated here are written by DMA at
+// PCIe speed and, recycled by the host, never page-fault again (the Python mirror keeps a pool).
+extern "C" int eg_host_alloc(size_t bytes, void** out) {
+  EG_REQUIRE(out, EG_ERR_INVALID, "eg_host_alloc: out is NULL");
+  *out = nullptr;
+  if (bytes == 0) return EG_OK;
+  EG_HIP_CHECK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return EG_OK;
+}
+
+extern "C" int eg_host_free(void* p) {
+  if (!p) return EG_OK;
+  EG_HIP_CHECK(hipHostFree(p));
+  return EG_OK;
+}

@@ -161,7 +161,8 @@ class Model:
         rank = ctypes.c_int(0)
         shape = (ctypes.c_int64 * 8)()
         call("eg_model_output_shape", self.handle, target.encode(), ctypes.byref(rank), shape)
-        out = np.empty([shape[i] for i in range(rank.value)], dtype=np.float32)
+        from .runtime import pinned_pool
+        out = pinned_pool.empty([shape[i] for i in range(rank.value)])   # fresh array, recycled pinned block when large
         call("eg_model_read_output", self.handle, target.encode(), out.ctypes.data_as(ctypes.c_void_p), out.size)
         return out
 

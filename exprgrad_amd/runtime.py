@@ -231,3 +231,50 @@ class GpuTensor:
     @property
     def ptr(self):
         return self.buffer.ptr
+
+
+
+class PinnedPool:
+    """Result arrays in pinned host memory (eg_host_alloc), recycled: `call` returns a FRESH array every
+    time (readOutput, model.nim:375-376), but a fresh 64 MiB numpy array page-faults inside the
+    device-to-host copy.  Arrays handed out here are numpy views of pinned blocks; when the last view
+    of a block is garbage collected the block goes back to the pool and the next result of that size
+    reuses it: direct DMA, no page faults."""
+
+    MIN_BYTES = 1 << 20
+    MAX_FREE_BYTES = 1 << 30
+
+    def __init__(self):
+        self._free = {}
+        self._free_bytes = 0
+
+    def empty(self, shape):
+        n = int(np.prod(shape, dtype=np.int64))
+        nbytes = n * 4
+        if nbytes < self.MIN_BYTES:
+            return np.empty(shape, dtype=np.float32)
+        import weakref
+        blocks = self._free.get(nbytes)
+        if blocks:
+            ptr = blocks.pop()
+            self._free_bytes -= nbytes
+        else:
+            p = ctypes.c_void_p()
+            call("eg_host_alloc", nbytes, ctypes.byref(p))
+            ptr = p.value
+        buf = (ctypes.c_float * n).from_address(ptr)
+        weakref.finalize(buf, self._release, ptr, nbytes)
+        return np.frombuffer(buf, dtype=np.float32).reshape(shape)
+
+    def _release(self, ptr, nbytes):
+        if self._free_bytes + nbytes > self.MAX_FREE_BYTES:
+            try:
+                call("eg_host_free", ctypes.c_void_p(ptr))
+            except Exception:  # noqa: BLE001 - interpreter shutdown
+                pass
+            return
+        self._free.setdefault(nbytes, []).append(ptr)
+        self._free_bytes += nbytes
+
+
+pinned_pool = PinnedPool()

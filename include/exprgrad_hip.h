@@ -93,6 +93,12 @@ void* eg_buf_ptr(const eg_buf* buf);
 int eg_buf_write(eg_buf* buf, const void* host, size_t bytes);
 /* readInto(buffer, data): gpu.nim:45-46, cl.nim:128-139. Blocking; bytes must equal the buffer size. */
 int eg_buf_read(eg_buf* buf, void* host, size_t bytes);
+/* Pinned (page-locked) host memory: a write / read with such an array is a direct DMA at PCIe speed,
+ * and a result tensor allocated here and recycled by the host never page-faults inside the copy (the
+ * reference allocates a fresh host tensor per call, gpu.nim:68-70; reading 64 MiB into fresh pageable
+ * memory costs more than the 4096^3 product that filled it).  No reference counterpart. */
+int eg_host_alloc(size_t bytes, void** out);
+int eg_host_free(void* p);
 /* fill(buffer, value): gpu.nim:44, cl.nim:122-126. Asynchronous; pattern_bytes in {1,2,4,8}. */
 int eg_buf_fill(eg_buf* buf, const void* pattern, size_t pattern_bytes);
 
