@@ -62,6 +62,7 @@ struct eg_ctx {
   void* side_aux = nullptr;
   size_t side_aux_bytes = 0;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool on_side_lane = false;  // true while the side lane's stream / scratch are swapped in (LaneSwap)
   std::vector<hipEvent_t> pipe_events;  // batch pipeline (host/plan_pipeline.cpp): per-stage, per-half dependencies between the lanes
   eg::HostStager* stager = nullptr;  // created by the first large host copy
   float* ones = nullptr;             // {1,1,1,1, 1,0,0,0}: source of a contraction's virtual row of ones (GemmArgs::ones)

@@ -252,6 +252,7 @@ struct LaneSwap {
     std::swap(c->workspace_bytes, c->side_workspace_bytes);
     std::swap(c->aux, c->side_aux);
     std::swap(c->aux_bytes, c->side_aux_bytes);
+    c->on_side_lane = !c->on_side_lane;
   }
 };
 

@@ -71,6 +71,11 @@ struct GemmArgs {
   // accesses, a full tile row per wave instruction instead of 128-byte pieces of 32 different rows.
   // Requires N, ldc multiples of 4 and 16-byte aligned C / partial / epilogue operands (host checks).
   int wide_store;
+  // Launched on the side lane, next to a long contraction of the main lane: the waves raise their issue
+  // priority (s_setprio 3).  The instruction arbiter otherwise serves the older waves of the long
+  // contraction first, whose MFMAs are always ready: a 128x32 product that takes 18 us alone was
+  // measured at 208 us next to a 256x256 one (rocprofv3 timeline, profiles/r02_pipeline_trace.txt).
+  int prio;
 };
 
 // Epilogue functor of the library kernels: plain store.  A generated epilogue (ACTIVE = true)
@@ -578,6 +583,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   const int wave = tid >> 6;
   const int wm0 = (wave / WAVES_N) * WM;
   const int wn0 = (wave % WAVES_N) * WN;
+  if (a.prio) __builtin_amdgcn_s_setprio(3);
 
   // ---- tile coordinates: XCD-contiguous ids, then 8-row groups so co-resident tiles share
   //      A row-panels and B column-panels inside one L2.

@@ -31,6 +31,7 @@ def mlp(dims, act):
 def test_pipelined_step_matches_the_oracle(gpu_ctx, monkeypatch, case):
     name, batch = case
     monkeypatch.setenv("EG_PIPELINE_MIN_FLOPS", "0")
+    monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", "0")      # activations ride on the contractions: nothing but cuttable launches
     if name == "softmax":
         graphs, n_in, n_out, onehot = (lambda: refcases.dense_softmax_net(n_in=200, n_hidden=136, n_out=10)), 200, 10, True
     elif name == "mlp3":
@@ -57,6 +58,7 @@ def test_pipelined_and_plain_plans_agree_and_repeat(gpu_ctx, monkeypatch):
     y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, size=batch)]
     results = []
     for mode in ("plain", "pipe", "pipe"):
+        monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", "0")
         if mode == "plain":
             monkeypatch.setenv("EG_NO_PIPELINE", "1")
         else:
