@@ -255,7 +255,15 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
                      (t.role == RowGroupTensor::RowLocal && (t.load_first || t.store));
     if (mem) g.ptr_args.push_back(kv.first);
   }
-  std::string sig = "extern \"C\" __global__ void __launch_bounds__(256) " + g.name + "(float* __restrict__ partial";
+  // Large batches with little per-thread state: cap the kernel at 96 registers (5 waves per SIMD) so its
+  // waves fit next to a long contraction's on the same SIMD (a 256x256 tile leaves 128 of 512 registers
+  // per lane): on the side lane of the batch pipeline a 7 us row group took 53 us waiting for whole CUs.
+  long state = 0;
+  for (auto& kv : g.tensors)
+    if (kv.second.role != RowGroupTensor::RowExternal && kv.second.role != RowGroupTensor::SmallExternal) state += kv.second.inner;
+  const bool slim = g.B >= 4096 && state <= 64;
+  std::string sig = std::string("extern \"C\" __global__ void __launch_bounds__(256") + (slim ? ", 5" : "") + ") " + g.name +
+                    "(float* __restrict__ partial";
   for (int t : g.ptr_args) {
     const RowGroupTensor& gt = g.tensors.at(t);
     sig += gt.role == RowGroupTensor::RowLocal ? ", float* t" : ", const float* __restrict__ t";

@@ -136,7 +136,10 @@ double tile_cost(const TileCfg& t, long M, long N, long k_tiles, int cus, int& s
   // split K when the output alone cannot fill the chip and K is long (weight gradients:
   // K = batch); every slice keeps at least 8 k-tiles
   int splits = 1;
-  if (tiles < slots && k_tiles >= 32) {
+  // bias-sized outputs (N <= 32) with at least one tile per CU stream their big operand once whatever the
+  // split: slabs and a second pass only add traffic (65536 x 10 x 512: 35 us as one pass of A)
+  const bool skinny = N <= 32 && tiles >= cus;
+  if (tiles < slots && k_tiles >= 32 && !skinny) {
     long want = slots / tiles;  // floor: one more slice would spill a few blocks into a second round
     long max_by_k = k_tiles / 8;
     splits = (int)(want < max_by_k ? want : max_by_k);

@@ -46,7 +46,9 @@ def test_pipelined_step_matches_the_oracle(gpu_ctx, monkeypatch, case):
     for _ in range(3):          # eager, captured, replayed
         t.step("train", {"x": x, "y": y}, n=batch)
     plan = t.gpu.launch_plan("train")
-    assert "batch pipeline" in plan, plan
+    # nets whose backward range holds a launch that cannot be cut (here: the map kernels of an 8-wide last
+    # layer, too small for an epilogue) keep the plain plan; the others must be pipelined
+    assert ("batch pipeline" in plan) == (name != "mlp3"), plan
     t.close()
 
 
