@@ -30,8 +30,14 @@ namespace model {
 void plan_pipeline(eg_model* m, TargetState& ts, Plan& plan) {
   plan.pipe = Plan::Pipeline();
   {
-    const char* e = getenv("EG_NO_PIPELINE");
-    if (e && e[0] && e[0] != '0') return;
+    // OFF unless EG_PIPELINE=1.  Measured on the cfg-5 step (profiles/r02_pipeline_trace.txt): the lanes
+    // do overlap, but a 256x256 contraction leaves one small wave per SIMD to whatever runs next to it, and
+    // bandwidth-bound kernels live on having many waves in flight — next to it they run 3 to 7 times
+    // slower (a 7 us row group: 51 us, an 18 us skinny product: 120 us, even at raised wave priority),
+    // so each half's streaming chain (296 us) outlasts the contraction it should hide under (248 us) and
+    // slows it by 35 us: 1.144 ms per step against 1.122 ms without the pipeline.
+    const char* e = getenv("EG_PIPELINE");
+    if (!(e && e[0] && e[0] != '0')) return;
   }
   double min_flops = 2e10;  // only steps with long contractions have something to hide work under
   if (const char* e = getenv("EG_PIPELINE_MIN_FLOPS")) min_flops = atof(e);
