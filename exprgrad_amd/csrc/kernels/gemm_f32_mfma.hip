@@ -33,6 +33,8 @@ int launch_config(eg_ctx* ctx, bool a_kc, bool b_kc, const GemmArgs& args, int s
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
   const long rows_m = args.edge_splits > 0 ? args.tiles_m - 1 : args.tiles_m;
   dim3 grid((unsigned)(rows_m * args.tiles_n * splits + (long)args.tiles_n * args.edge_splits), 1, 1);
+  if (args.tail_tiles > 0)
+    grid.x = (unsigned)((long)args.tiles_m * args.tiles_n - args.tail_tiles + (long)args.tail_tiles * args.tail_splits);
   dim3 block(NT);
   hipStream_t s = ctx->stream;
   // 16-byte aligned operands: interior tiles run the LDS-DMA loop (gemm_f32_mfma.hpp)
@@ -286,10 +288,35 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
       edge_row = (long)(args.tiles_m - 1) * BM;
     }
   }
+  // Tail tiles: more tiles than block slots and a short last round -> cut the last round's tiles along K.
+  long tail_slab_floats = 0;
+  if (splits == 1 && !conv && getenv("EG_GEMM_NO_TAIL") == nullptr) {
+    const long tiles = (long)args.tiles_m * args.tiles_n;
+    const long slots = (long)ctx->compute_units * (BM * BN >= 256 * 256 ? 1 : (BM == 256 ? 2 : 4));
+    const long tail = tiles % slots;
+    if (tiles > slots && tail > 0 && tail * 2 <= slots && k_tiles >= 16) {
+      long ts = slots / tail;
+      if (ts > k_tiles / 8) ts = k_tiles / 8;
+      if (ts > 16) ts = 16;
+      if (ts >= 2) {
+        const long per = (k_tiles + ts - 1) / ts;
+        ts = (k_tiles + per - 1) / per;
+        args.tail_tiles = (int)tail;
+        args.tail_splits = (int)ts;
+        args.tail_k_per_split = per * BK;
+        tail_slab_floats = tail * ts * (long)BM * BN;
+      }
+    }
+  }
   const int launch_splits = args.edge_splits > 0 ? args.splits : splits;
   args.wide_store = wide_store_ok(args, splits > 1);
   args.prio = side_priority(ctx);
   float* scratch = nullptr;
+  if (args.tail_tiles > 0) {
+    int rc = eg::ensure_workspace(ctx, (size_t)tail_slab_floats * sizeof(float));
+    if (rc) return rc;
+    args.partial = static_cast<float*>(ctx->workspace);
+  }
   if (splits > 1) {
     const size_t slab_floats = ((size_t)launch_splits * total + 3) & ~(size_t)3;
     const size_t scratch_floats = tree_reduce ? (size_t)eg::colsum_scratch_floats(ctx, splits, total) : 0;
@@ -317,6 +344,21 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     rc = launch_config<256, 256, 128, 64, 1>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   if (rc) return rc;
 
+  if (args.tail_tiles > 0) {
+    const unsigned blocks = (unsigned)(args.tail_tiles * (BM / 32));
+#define EG_TAIL_REDUCE(TM, TN)                                                                                          \
+  hipLaunchKernelGGL((gemm_tail_reduce_kernel<TM, TN>), dim3(blocks), dim3(256), 0, ctx->stream, args.partial, args.C,    \
+                     args.bias, M, N, args.ldc, args.tiles_m, args.tiles_n, args.tail_tiles, args.tail_splits, args.accumulate)
+    if (BM == 256 && BN == 256) EG_TAIL_REDUCE(256, 256);
+    else if (BM == 128 && BN == 128) EG_TAIL_REDUCE(128, 128);
+    else if (BM == 128 && BN == 64) EG_TAIL_REDUCE(128, 64);
+    else if (BM == 128 && BN == 32) EG_TAIL_REDUCE(128, 32);
+    else if (BM == 256 && BN == 64) EG_TAIL_REDUCE(256, 64);
+    else EG_TAIL_REDUCE(64, 64);
+#undef EG_TAIL_REDUCE
+    EG_HIP_CHECK(hipGetLastError());
+    return EG_OK;
+  }
   if (splits > 1) {
     if (tree_reduce) return eg::colsum_with_scratch(ctx, splits, total, args.partial, args.C, args.accumulate, scratch);
     long blocks = (total + 255) / 256;

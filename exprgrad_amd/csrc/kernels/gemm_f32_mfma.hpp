@@ -48,6 +48,13 @@ struct GemmArgs {
   // edge_splits > 0: tiles of row tiles_m - 1 use edge_splits slices of k_per_split_edge.
   int edge_splits;
   long k_per_split_edge;
+  // Tail tiles (splits <= 1 only): when the tiles do not fill a whole number of rounds of the chip, the
+  // last tail_tiles of them are cut into tail_splits k-slices each, so the partial last round is short
+  // instead of a whole tile long (4100^3: 289 tiles on 256 CUs = two rounds for 1.13 rounds of work).
+  // Their blocks write whole-tile slabs partial[(tile - first tail tile) * tail_splits + slice][BM][BN];
+  // gemm_tail_reduce_kernel folds them into C in slice order.
+  int tail_tiles, tail_splits;
+  long tail_k_per_split;
   // Implicit-GEMM convolution (A gathered from an NHWC image): m = (n, y, x), k = (dy, dx, c).
   long cH, cW, cC, cFW, cHo, cWo;
   // Operands of a generated epilogue (fused elementwise consumer, host/epilogue.cpp): tensors of
@@ -244,6 +251,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int xcd = bid % NXCD, local = bid / NXCD;
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + local;
+}
+
+// Tile id -> tile origin: groups of 8 tile rows, column-major inside a group, so co-resident tiles share
+// A row-panels and B column-panels inside one L2.
+template <int BM, int BN>
+__device__ __forceinline__ void tile_origin(int wgid, int rows_m, int tiles_n, long& m_blk, long& n_blk) {
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int group = wgid / per_group;
+  const int first_m = group * GROUP;
+  const int gsize = min(rows_m - first_m, GROUP);
+  const int in_group = wgid % per_group;
+  m_blk = (long)(first_m + in_group % gsize) * BM;
+  n_blk = (long)(in_group / gsize) * BN;
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -595,20 +616,28 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   const int nwg = rows_m * a.tiles_n;
   const int nsplit = a.splits > 1 ? a.splits : 1;
   const int nfull = nwg * nsplit;
-  const int work = xcd_remap(blockIdx.x, nfull + a.tiles_n * a.edge_splits);
+  const int tail_first = nwg - a.tail_tiles;  // (tail mode: a.splits <= 1, a.edge_splits == 0)
+  const int work = a.tail_tiles > 0 ? xcd_remap(blockIdx.x, tail_first + a.tail_tiles * a.tail_splits)
+                                    : xcd_remap(blockIdx.x, nfull + a.tiles_n * a.edge_splits);
   int split;
   long m_blk, n_blk, k_slice;
-  if (work < nfull) {
+  int tail_slab = -1;  // >= 0: this block writes a whole-tile slab
+  if (a.tail_tiles > 0) {
+    if (work < tail_first) {
+      split = 0;
+      tile_origin<BM, BN>(work, rows_m, a.tiles_n, m_blk, n_blk);
+      k_slice = a.k_per_split;
+    } else {
+      const int w = work - tail_first;
+      const int t = w / a.tail_splits;
+      split = w - t * a.tail_splits;
+      tile_origin<BM, BN>(tail_first + t, rows_m, a.tiles_n, m_blk, n_blk);
+      k_slice = a.tail_k_per_split;
+      tail_slab = w;
+    }
+  } else if (work < nfull) {
     split = work / nwg;
-    const int wgid = work - split * nwg;
-    constexpr int GROUP = 8;
-    const int per_group = GROUP * a.tiles_n;
-    const int group = wgid / per_group;
-    const int first_m = group * GROUP;
-    const int gsize = min(rows_m - first_m, GROUP);
-    const int in_group = wgid % per_group;
-    m_blk = (long)(first_m + in_group % gsize) * BM;
-    n_blk = (long)(in_group / gsize) * BN;
+    tile_origin<BM, BN>(work - split * nwg, rows_m, a.tiles_n, m_blk, n_blk);
     k_slice = a.k_per_split;
   } else {
     const int w = work - nfull;
@@ -658,9 +687,11 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
 
   // ---- epilogue.  32x32 accumulator block: register r of lane l holds
   //      row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31.
-  const bool to_partial = a.partial != nullptr;
-  float* out = to_partial ? a.partial + (long)split * a.M * a.N : a.C;
-  const long ldo = to_partial ? a.N : a.ldc;
+  const bool to_partial = a.tail_tiles > 0 ? tail_slab >= 0 : a.partial != nullptr;
+  // a tail block's slab is addressed with global (m, n) like C: slab[(m - m_blk) * BN + (n - n_blk)]
+  float* out = tail_slab >= 0 ? a.partial + (long)tail_slab * BM * BN - (m_blk * BN + n_blk)
+                              : (to_partial ? a.partial + (long)split * a.M * a.N : a.C);
+  const long ldo = tail_slab >= 0 ? BN : (to_partial ? a.N : a.ldc);
   const bool accumulate = !to_partial && a.accumulate;
   const bool has_bias = !to_partial && a.bias != nullptr;
   const bool whole_tile = m_blk + BM <= a.M && n_blk + BN <= a.N;
@@ -840,6 +871,31 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
     float s = 0.f;
     const int nz = m >= edge_row ? edge_splits : splits;
     for (int z = 0; z < nz; ++z) s += partial[(long)z * total + i];
+    float* p = C + m * ldc + n;
+    if (accumulate) s = *p + s;
+    if (bias) s += bias[n];
+    *p = s;
+  }
+}
+
+// Second pass of the tail mode: C tile = (accumulate ? C : 0) + sum over the tile's slices + bias, slices
+// added in increasing order (deterministic).  One block per (tail tile, 32-row band).
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_tail_reduce_kernel(const float* __restrict__ partial, float* C,
+                                                               const float* __restrict__ bias, long M, long N, long ldc,
+                                                               int tiles_m, int tiles_n, int tail_tiles, int tail_splits,
+                                                               int accumulate) {
+  constexpr int BANDS = BM / 32;
+  const int t = blockIdx.x / BANDS, band = blockIdx.x % BANDS;
+  long m_blk, n_blk;
+  tile_origin<BM, BN>(tiles_m * tiles_n - tail_tiles + t, tiles_m, tiles_n, m_blk, n_blk);
+  const float* slabs = partial + (long)t * tail_splits * BM * BN;
+  for (int e = threadIdx.x; e < 32 * BN; e += 256) {
+    const int r = band * 32 + e / BN, c = e % BN;
+    const long m = m_blk + r, n = n_blk + c;
+    if (m >= M || n >= N) continue;
+    float s = 0.f;
+    for (int z = 0; z < tail_splits; ++z) s += slabs[(long)z * BM * BN + r * BN + c];
     float* p = C + m * ldc + n;
     if (accumulate) s = *p + s;
     if (bias) s += bias[n];

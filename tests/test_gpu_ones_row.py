@@ -35,8 +35,10 @@ def test_bias_gradient_as_the_last_row_of_the_weight_gradient(gpu_ctx, monkeypat
     for _ in range(3):          # eager, captured, replayed
         t.step("train", {"x": x, "y": y}, n=batch)
     plan = t.gpu.launch_plan("train")
-    # the first layer's pair always qualifies here (n_in x n_hidden outputs is beyond the tiny-contraction kernel)
-    assert "+ones-row" in plan, plan
+    # the first layer's pair qualifies whenever the batch is large enough for its bias gradient to be a launch of
+    # its own (at batch 16 it joins a single-block small-kernel group instead)
+    if batch >= 256:
+        assert "+ones-row" in plan, plan
     t.close()
 
 

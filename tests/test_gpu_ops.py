@@ -323,3 +323,31 @@ def test_random_contraction_shapes(gpu_ctx, seed):
     # error budget: every output is a sum of K products of magnitude <= 0.25
     scale = max(np.abs(want).max(), 0.25 * np.sqrt(K) * 0.3)
     assert np.abs(got - want).max() <= TOL * scale, (M, N, K, ta, tb, acc, bias)
+
+
+@pytest.mark.parametrize("case", [(4100, 4100, 512, False, False, False, False), (4352, 4100, 257, False, True, True, True),
+                                  (4100, 4200, 300, True, False, True, False), (4099, 4097, 1000, False, False, False, True)])
+def test_tail_tiles_are_cut_along_k(gpu_ctx, case):
+    """More tiles than block slots with a short last round (289 tiles of 256 x 256 on 256 CUs): the last
+    round's tiles are cut into k-slices (GemmArgs::tail_tiles), folded by a second pass.  Ragged M / N / K,
+    transposed operands, bias and accumulation against a float64 product; deterministic."""
+    M, N, K, ta, tb, acc, bias = case
+    rng = np.random.default_rng(M + K)
+    a = (rng.random((K, M) if ta else (M, K), dtype=np.float32) - 0.5).astype(np.float32)
+    b = (rng.random((N, K) if tb else (K, N), dtype=np.float32) - 0.5).astype(np.float32)
+    c0 = rng.random((M, N), dtype=np.float32) if acc else np.zeros((M, N), dtype=np.float32)
+    bv = (rng.random((N,), dtype=np.float32) - 0.5).astype(np.float32) if bias else None
+    want = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64) + c0
+    if bias:
+        want = want + bv
+    da, db = dev(gpu_ctx, a), dev(gpu_ctx, b)
+    dbias = dev(gpu_ctx, bv) if bias else None
+    outs = []
+    for _ in range(2):
+        dc = dev(gpu_ctx, c0)
+        ops.sgemm(gpu_ctx, M, N, K, da, a.shape[1], db, b.shape[1], dc, N, ta, tb, acc, dbias)
+        outs.append(dc.read())
+        dc.buffer.dealloc()
+    scale = max(np.abs(want).max(), 0.25 * np.sqrt(K) * 0.3)
+    assert np.abs(outs[0] - want).max() <= TOL * scale
+    assert np.array_equal(outs[0], outs[1])
