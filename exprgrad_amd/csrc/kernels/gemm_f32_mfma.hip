@@ -27,7 +27,7 @@ struct TileCfg {
   int bm, bn, blocks_per_cu;
 };
 
-template <int BM, int BN, int WM, int WN, int MINB>
+template <int BM, int BN, int WM, int WN, int MINB, int KB = BK>
 int launch_config(eg_ctx* ctx, bool a_kc, bool b_kc, const GemmArgs& args, int splits, bool vec, bool edge,
                   int conv, bool a_vec_only = false) {
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
@@ -39,7 +39,7 @@ int launch_config(eg_ctx* ctx, bool a_kc, bool b_kc, const GemmArgs& args, int s
   hipStream_t s = ctx->stream;
   // 16-byte aligned operands: interior tiles run the LDS-DMA loop (gemm_f32_mfma.hpp)
 #define EG_GEMM_LAUNCH(AKC, BKC, V, E, CV)                                                                        \
-  hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, MINB, AKC, BKC, V, E, CV, 0, (V == 4 && CV != 1)>), grid, \
+  hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, KB, WM, WN, MINB, AKC, BKC, V, E, CV, 0, (V == 4 && CV != 1)>), grid, \
                      block, 0, s, args)
 #define EG_GEMM_LAYOUT(AKC, BKC)                  \
   do {                                            \
@@ -244,15 +244,19 @@ bool wide_store_ok(const GemmArgs& a, bool to_partial, bool fused = false) {
 int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool vec_ok, bool a_vec_only = false) {
   if (!args.ones_row) args.a_rows = args.M;
   const long M = args.M, N = args.N, K = args.K;
-  const long k_tiles = (K + BK - 1) / BK;
   int BM, BN, splits;
   choose_tile(ctx, M, N, K, BM, BN, splits);
+  // 32-deep k-tiles for the 256x256 tile (half the barriers per unit of matrix work; 128 KB of LDS):
+  // experiment switch EG_GEMM_BK32=1
+  static const bool bk32 = getenv("EG_GEMM_BK32") != nullptr;
+  const int KB = (bk32 && BM == 256 && BN == 256 && !conv && vec_ok && K >= 64) ? 32 : BK;
+  const long k_tiles = (K + KB - 1) / KB;
   args.tiles_m = (int)((M + BM - 1) / BM);
   args.tiles_n = (int)((N + BN - 1) / BN);
   args.partial = nullptr;
   long tiles_per_split = (k_tiles + splits - 1) / splits;
   if (tiles_per_split < 1) tiles_per_split = 1;
-  args.k_per_split = tiles_per_split * BK;
+  args.k_per_split = tiles_per_split * KB;
   args.splits = splits;
 
   // Tiny outputs split many ways (the XOR net's [2,4] and [4,1] weight gradients): a
@@ -281,10 +285,10 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
       s_full = (k_tiles + per_full - 1) / per_full;
       long per_edge = (k_tiles + s_edge - 1) / s_edge;
       s_edge = (k_tiles + per_edge - 1) / per_edge;
-      args.k_per_split = per_full * BK;
+      args.k_per_split = per_full * KB;
       args.splits = (int)s_full;
       args.edge_splits = edge_splits = (int)s_edge;
-      args.k_per_split_edge = per_edge * BK;
+      args.k_per_split_edge = per_edge * KB;
       edge_row = (long)(args.tiles_m - 1) * BM;
     }
   }
@@ -303,7 +307,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
         ts = (k_tiles + per - 1) / per;
         args.tail_tiles = (int)tail;
         args.tail_splits = (int)ts;
-        args.tail_k_per_split = per * BK;
+        args.tail_k_per_split = per * KB;
         tail_slab_floats = tail * ts * (long)BM * BN;
       }
     }
@@ -327,7 +331,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   }
 
   const bool vec = vec_ok;
-  const bool edge = conv || !(vec && M % BM == 0 && N % BN == 0 && K % BK == 0 && K > 0);
+  const bool edge = conv || !(vec && M % BM == 0 && N % BN == 0 && K % KB == 0 && K > 0);
 
   int rc;
   if (BN == 32)
@@ -340,6 +344,8 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     rc = launch_config<128, 64, 64, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else if (BN == 128)
     rc = launch_config<128, 128, 64, 64, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
+  else if (KB == 32)
+    rc = launch_config<256, 256, 128, 64, 1, 32>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else
     rc = launch_config<256, 256, 128, 64, 1>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   if (rc) return rc;
@@ -474,8 +480,9 @@ bool ones_row_supported(int trans_a, int trans_b, long M, long N, long K, const 
 
 int sgemm_ones_row(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, const float* A, long lda, const float* B,
                    long ldb, float* C, long ldc, int accumulate) {
-  EG_REQUIRE(ctx && A && B && C && M > 0 && N > 0, EG_ERR_INVALID, "sgemm_ones_row: bad argument");
-  if (!ones_row_supported(trans_a, trans_b, M, N, K, A, lda, B, ldb)) return EG_ERR_UNSUPPORTED;
+  EG_REQUIRE(ctx, EG_ERR_INVALID, "sgemm_ones_row: ctx is NULL");
+  // an empty batch (K = 0, possibly NULL operands), a tiny problem, unaligned operands: the caller's two-call form
+  if (!A || !B || !C || M <= 0 || N <= 0 || !ones_row_supported(trans_a, trans_b, M, N, K, A, lda, B, ldb)) return EG_ERR_UNSUPPORTED;
   int rc = eg::set_device(ctx);
   if (rc) return rc;
   GemmArgs args = {};

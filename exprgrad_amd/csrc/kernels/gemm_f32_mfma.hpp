@@ -617,8 +617,14 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   const int nsplit = a.splits > 1 ? a.splits : 1;
   const int nfull = nwg * nsplit;
   const int tail_first = nwg - a.tail_tiles;  // (tail mode: a.splits <= 1, a.edge_splits == 0)
-  const int work = a.tail_tiles > 0 ? xcd_remap(blockIdx.x, tail_first + a.tail_tiles * a.tail_splits)
-                                    : xcd_remap(blockIdx.x, nfull + a.tiles_n * a.edge_splits);
+  // Tail mode: block ids below tail_first are the whole tiles, the rest the short tail slices, each
+  // set spread over the XCDs on its own (one contiguous remap of both would hand some XCDs nothing but
+  // whole tiles and others nothing but slices: measured 2.3 ms instead of 1.4 for 4100^3).
+  const int work = a.tail_tiles > 0
+                       ? ((int)blockIdx.x < tail_first
+                              ? xcd_remap(blockIdx.x, tail_first)
+                              : tail_first + xcd_remap(blockIdx.x - tail_first, a.tail_tiles * a.tail_splits))
+                       : xcd_remap(blockIdx.x, nfull + a.tiles_n * a.edge_splits);
   int split;
   long m_blk, n_blk, k_slice;
   int tail_slab = -1;  // >= 0: this block writes a whole-tile slab
