@@ -246,10 +246,8 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   const long M = args.M, N = args.N, K = args.K;
   int BM, BN, splits;
   choose_tile(ctx, M, N, K, BM, BN, splits);
-  // 32-deep k-tiles for the 256x256 tile (half the barriers per unit of matrix work; 128 KB of LDS):
-  // experiment switch EG_GEMM_BK32=1
-  static const bool bk32 = getenv("EG_GEMM_BK32") != nullptr;
-  const int KB = (bk32 && BM == 256 && BN == 256 && !conv && vec_ok && K >= 64) ? 32 : BK;
+  // (32-deep k-tiles for the 256x256 tile were measured in round 2: +1 % at 4096^3, -7 % at K = 784, 0 elsewhere)
+  constexpr int KB = BK;
   const long k_tiles = (K + KB - 1) / KB;
   args.tiles_m = (int)((M + BM - 1) / BM);
   args.tiles_n = (int)((N + BN - 1) / BN);
@@ -315,6 +313,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   const int launch_splits = args.edge_splits > 0 ? args.splits : splits;
   args.wide_store = wide_store_ok(args, splits > 1);
   args.prio = side_priority(ctx);
+  args.nt_store = getenv("EG_GEMM_NT_STORE") != nullptr;
   float* scratch = nullptr;
   if (args.tail_tiles > 0) {
     int rc = eg::ensure_workspace(ctx, (size_t)tail_slab_floats * sizeof(float));
@@ -344,8 +343,6 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     rc = launch_config<128, 64, 64, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else if (BN == 128)
     rc = launch_config<128, 128, 64, 64, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
-  else if (KB == 32)
-    rc = launch_config<256, 256, 128, 64, 1, 32>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else
     rc = launch_config<256, 256, 128, 64, 1>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   if (rc) return rc;
@@ -778,6 +775,7 @@ int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, co
   out.grid = (unsigned)(args.tiles_m * args.tiles_n);
   args.wide_store = wide_store_ok(args, false, true);   // set_epilogue_operands withdraws it for unaligned operands
   args.prio = side_priority(ctx);
+  args.nt_store = getenv("EG_GEMM_NT_STORE") != nullptr;
   memcpy(out.args, &args, sizeof(args));
   out.args_size = sizeof(args);
   return EG_OK;

@@ -83,6 +83,7 @@ struct GemmArgs {
   // contraction first, whose MFMAs are always ready: a 128x32 product that takes 18 us alone was
   // measured at 208 us next to a 256x256 one (rocprofv3 timeline, profiles/r02_pipeline_trace.txt).
   int prio;
+  int nt_store;  // experiment (EG_GEMM_NT_STORE=1): wide stores as nontemporal stores
 };
 
 // Epilogue functor of the library kernels: plain store.  A generated epilogue (ACTIVE = true)
@@ -742,8 +743,13 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
             v[e] = v[e] + b4[e];
             res[e] = Epi::compute(a, idx + e, v[e], x);
           }
-          if (Epi::STORE_C) *reinterpret_cast<f32x4*>(a.C + idx) = v;
-          *reinterpret_cast<f32x4*>(static_cast<float*>(a.epi[Epi::OUT]) + idx) = res;
+          if (a.nt_store) {
+            if (Epi::STORE_C) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.C + idx));
+            __builtin_nontemporal_store(res, reinterpret_cast<f32x4*>(static_cast<float*>(a.epi[Epi::OUT]) + idx));
+          } else {
+            if (Epi::STORE_C) *reinterpret_cast<f32x4*>(a.C + idx) = v;
+            *reinterpret_cast<f32x4*>(static_cast<float*>(a.epi[Epi::OUT]) + idx) = res;
+          }
         } else {
           f32x4* p = reinterpret_cast<f32x4*>(out + idx);
           if (accumulate) {
@@ -754,7 +760,8 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] + b4[e];
           }
-          *p = v;
+          if (a.nt_store) __builtin_nontemporal_store(v, p);
+          else *p = v;
         }
       }
       __syncthreads();

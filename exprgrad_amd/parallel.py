@@ -36,11 +36,27 @@ def shard(args, rank, world):
     return out
 
 
+def _check_stream(model):
+    """The collective is ordered against the backward and update kernels by the STREAM they share: the
+    model's context must have been created on torch's current stream (newGpuContext(dev, stream=...))."""
+    want = torch.cuda.current_stream().cuda_stream
+    have = model.ctx.stream
+    if int(have or 0) != int(want or 0):
+        raise RuntimeError("data-parallel step: the model's context runs on another HIP stream than torch's current one; "
+                           "the all-reduce would race with the backward / update kernels")
+
+
 class GpuEngine:
     """Adapter: exprgrad_amd.model.Model -> the engine protocol DataParallel drives."""
 
-    def __init__(self, model, target):
+    def __init__(self, model, target, rank=None):
         self.model, self.target = model, target
+        _check_stream(model)
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        # random tensors (dropout masks) are drawn per element from (seed, draw, tensor, index): with one
+        # seed every shard would draw the SAME mask for its rows; fold the rank into the seed
+        model.set_seed(0x5EED5EED + 7919 * int(rank))
         _, count = model.grad_bucket(target)
         # gradients live in a torch tensor so torch.distributed can reduce them in place
         self.bucket = torch.zeros(max(count, 1), dtype=torch.float32, device="cuda")
@@ -125,6 +141,7 @@ class NativeDataParallel:
             raise ValueError("reduction must be 'mean' (loss divides by the batch) or 'sum'")
         self.model, self.target, self.group, self.mean = model, target, group, int(reduction == "mean")
         self.world, self.rank = group.world, group.rank
+        model.set_seed(0x5EED5EED + 7919 * int(group.rank))   # distinct dropout masks per shard (see GpuEngine)
 
     def step(self, local_args):
         from ._lib import call
