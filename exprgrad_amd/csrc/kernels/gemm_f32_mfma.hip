@@ -222,6 +222,13 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
   splits = best_splits;
 }
 
+// Wide stores of whole tiles as nontemporal stores: the output of a contraction is not read again by the
+// same launch (4096^3: 137.1 -> 139.0 TFLOP/s, 65536x512x784: 447 -> 438 us; EG_GEMM_NO_NT_STORE=1 switches it off).
+int nt_store_enabled() {
+  static const bool off = getenv("EG_GEMM_NO_NT_STORE") != nullptr;
+  return off ? 0 : 1;
+}
+
 int side_priority(const eg_ctx* ctx) {
   static const bool off = getenv("EG_NO_SIDE_PRIORITY") != nullptr;
   return ctx->on_side_lane && !off ? 1 : 0;
@@ -313,7 +320,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   const int launch_splits = args.edge_splits > 0 ? args.splits : splits;
   args.wide_store = wide_store_ok(args, splits > 1);
   args.prio = side_priority(ctx);
-  args.nt_store = getenv("EG_GEMM_NT_STORE") != nullptr;
+  args.nt_store = nt_store_enabled();
   float* scratch = nullptr;
   if (args.tail_tiles > 0) {
     int rc = eg::ensure_workspace(ctx, (size_t)tail_slab_floats * sizeof(float));
@@ -775,7 +782,7 @@ int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, co
   out.grid = (unsigned)(args.tiles_m * args.tiles_n);
   args.wide_store = wide_store_ok(args, false, true);   // set_epilogue_operands withdraws it for unaligned operands
   args.prio = side_priority(ctx);
-  args.nt_store = getenv("EG_GEMM_NT_STORE") != nullptr;
+  args.nt_store = nt_store_enabled();
   memcpy(out.args, &args, sizeof(args));
   out.args_size = sizeof(args);
   return EG_OK;

@@ -83,7 +83,7 @@ struct GemmArgs {
   // contraction first, whose MFMAs are always ready: a 128x32 product that takes 18 us alone was
   // measured at 208 us next to a 256x256 one (rocprofv3 timeline, profiles/r02_pipeline_trace.txt).
   int prio;
-  int nt_store;  // experiment (EG_GEMM_NT_STORE=1): wide stores as nontemporal stores
+  int nt_store;  // wide stores as nontemporal stores (host: nt_store_enabled)
 };
 
 // Epilogue functor of the library kernels: plain store.  A generated epilogue (ACTIVE = true)
