@@ -457,7 +457,14 @@ def run_train(args, env):
         t1, _, _ = env["timer"].run(alone, k1, 3)
         single = {"value": round(batch * k1 / t1, 1), "unit": "samples/s", "ms_per_step": round(t1 / k1 * 1e3, 4),
                   "note": "one GPU's shard, no all-reduce, slowest rank; N-GPU value / (N x this) = scaling efficiency"}
-    elapsed, ev_avg, ev_min = env["timer"].run(lambda: dp.step(inputs), args.steps, args.warmup)
+    if world == 1:
+        # one GPU: the step is Model.apply (one captured launch sequence); the split form backward | exchange |
+        # update only exists for the exchange and costs a second graph boundary (~15 us)
+        model._bind_all(inputs)
+        step = lambda: model.apply("train", inputs)
+    else:
+        step = lambda: dp.step(inputs)
+    elapsed, ev_avg, ev_min = env["timer"].run(step, args.steps, args.warmup)
     samples = batch * world * args.steps
     step_flops = DENSE_FLOPS_PER_SAMPLE * batch
     achieved = step_flops / (ev_avg * 1e-3) / 1e12

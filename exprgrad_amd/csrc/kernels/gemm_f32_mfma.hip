@@ -254,7 +254,10 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   int BM, BN, splits;
   choose_tile(ctx, M, N, K, BM, BN, splits);
   // (32-deep k-tiles for the 256x256 tile were measured in round 2: +1 % at 4096^3, -7 % at K = 784, 0 elsewhere)
-  constexpr int KB = BK;
+  // the convolution's filter gradient (M = F = 64 rows, 64 x 64 tiles, K = every output pixel): a block has
+  // little matrix work per barrier, so its k-tiles are 32 deep like the forward gather's (EG_CONVGF_BK16=1: 16)
+  static const bool gf16 = getenv("EG_CONVGF_BK16") != nullptr;
+  const int KB = (conv == 2 && BM == 64 && BN == 64 && vec_ok && !gf16) ? 32 : BK;
   const long k_tiles = (K + KB - 1) / KB;
   args.tiles_m = (int)((M + BM - 1) / BM);
   args.tiles_n = (int)((N + BN - 1) / BN);
@@ -344,6 +347,8 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     rc = launch_config<128, 32, 32, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv, a_vec_only && !vec);
   else if (BN == 64 && BM == 256)
     rc = launch_config<256, 64, 64, 32, 2>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
+  else if (BN == 64 && BM == 64 && KB == 32)
+    rc = launch_config<64, 64, 32, 32, 4, 32>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else if (BN == 64 && BM == 64)
     rc = launch_config<64, 64, 32, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv);
   else if (BN == 64)
