@@ -53,16 +53,7 @@ int launch_config(eg_ctx* ctx, bool a_kc, bool b_kc, const GemmArgs& args, int s
       EG_GEMM_LAUNCH(AKC, BKC, 1, true, 0);   \
   } while (0)
   if (conv == 2) {  // filter gradient: A = gOut [pixels][F], B = im2col gathered from the image
-    static const bool three = getenv("EG_CONVGF_STAGES2") == nullptr;
-    bool launched = false;
-    if constexpr (BM == 64 && BN == 64) {  // 64x64 tiles: three LDS stages, the gather two k-tiles ahead
-      if (vec && three) {
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, KB, WM, WN, MINB, false, false, 4, true, 2, 0, true, 3>), grid, block, 0, s, args);
-        launched = true;
-      }
-    }
-    if (launched) {
-    } else if (vec)
+    if (vec)
       EG_GEMM_LAUNCH(false, false, 4, true, 2);
     else
       EG_GEMM_LAUNCH(false, false, 1, true, 2);

@@ -585,107 +585,6 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Three-stage LDS-DMA loop (interior tiles only): the k-tile TWO ahead is in flight while the current one
-// is multiplied.  For small tiles with little matrix work per k-tile (the 64x64 tiles of the
-// convolution's filter gradient: 0.4 us of MFMAs against ~2 us of gather latency) one tile of
-// prefetch distance leaves the matrix cores waiting for memory most of the time.
-// __syncthreads() cannot be used here: its release fence drains vmcnt to zero, i.e. waits for the
-// prefetches just issued.  Instead every wave waits until all but its newest P DMA instructions have
-// landed (s_waitcnt vmcnt(P): memory operations complete in order) and then meets the others at a bare
-// s_barrier — after which every wave's share of the next tile is in LDS and every wave has finished
-// reading the stage that the next iteration's prefetch overwrites.
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  // s_waitcnt simm16 on gfx9: vmcnt = bits [3:0] and [15:14], expcnt [6:4] (7 = no wait), lgkmcnt [11:8] (15 = no wait)
-  __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
-}
-
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int CONV>
-__device__ __forceinline__ void gemm_mainloop_dma3(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32],
-                                                   long m_blk, long n_blk, long k_begin, int nk, int tid, int wm0,
-                                                   int wn0) {
-  constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
-  constexpr int MI = WM / 32, NI = WN / 32;
-  constexpr int BUF = BK * (BM + BN);
-  using DmaA = DmaLoader<BM, BK, NT, A_KC, CONV == 1, false>;
-  using DmaB = DmaLoader<BN, BK, NT, B_KC, CONV == 2, false>;
-  static_assert(DmaA::INSTRS % DmaA::WAVES == 0 && DmaB::INSTRS % DmaB::WAVES == 0, "every wave issues the same number of DMAs");
-  constexpr int P = DmaA::PER_WAVE + DmaB::PER_WAVE;  // DMA instructions per wave per k-tile
-  static_assert(P < 32, "vmcnt has six bits");
-  const int lane = tid & 63, wave = tid >> 6;
-  const int i = lane & 31, hi = lane >> 5;
-  DmaA da;
-  DmaB db;
-  da.init(a, m_blk, wave, lane, a.a_rows);
-  db.init(a, n_blk, wave, lane, a.N);
-  auto issue = [&](int kt) {
-    const long k0 = k_begin + (long)kt * BK;
-    float* stage = lds + (kt % 3) * BUF;
-    da.issue(a, a.A, a.lda, m_blk, k0, stage, wave, lane);
-    db.issue(a, a.B, a.ldb, n_blk, k0, stage + BK * BM, wave, lane);
-  };
-  if (nk > 0) issue(0);
-  if (nk > 1) {
-    issue(1);
-    wait_vmcnt<P>();  // tile 0 landed (this wave's share); tile 1 may still be in flight
-  } else {
-    wait_vmcnt<0>();
-  }
-  __builtin_amdgcn_s_barrier();
-  for (int kt = 0; kt < nk; ++kt) {
-    // stage (kt + 2) % 3 was read last in iteration kt - 1, which every wave left through the barrier
-    if (kt + 2 < nk) issue(kt + 2);
-    const float* As = lds + (kt % 3) * BUF;
-    const float* Bs = As + BK * BM;
-#pragma unroll
-    for (int pp = 0; pp < BK / 8; ++pp) {
-      float av[MI][4], bv[NI][4];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int row = wm0 + mi * 32 + i;
-        if (A_KC) {
-          const int slot = (2 * pp + hi) ^ DmaA::swizzle(row);
-          const f32x4 v = *reinterpret_cast<const f32x4*>(As + row * BK + slot * 4);
-          av[mi][0] = v[0];
-          av[mi][1] = v[1];
-          av[mi][2] = v[2];
-          av[mi][3] = v[3];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) av[mi][j] = As[(8 * pp + j + 4 * hi) * BM + row];
-        }
-      }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int col = wn0 + ni * 32 + i;
-        if (B_KC) {
-          const int slot = (2 * pp + hi) ^ DmaB::swizzle(col);
-          const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + col * BK + slot * 4);
-          bv[ni][0] = v[0];
-          bv[ni][1] = v[1];
-          bv[ni][2] = v[2];
-          bv[ni][3] = v[3];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bv[ni][j] = Bs[(8 * pp + j + 4 * hi) * BN + col];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
-    }
-    // tile kt + 1 must be complete before the next iteration reads it
-    if (kt + 2 < nk) wait_vmcnt<P>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-  }
-}
-
 // MINB: blocks per CU the register allocator must leave room for (waves/SIMD = MINB * WAVES / 4).
 // EDGE kernels still run their interior tiles on the unpredicated loop.
 // DMA: interior tiles use the LDS-DMA loop (requires VEC == 4, BK in {16, 32}; with CONV the host
@@ -693,13 +592,13 @@ __device__ __forceinline__ void gemm_mainloop_dma3(const GemmArgs& a, float* lds
 // CONV: 0 = plain operands, 1 = A is the im2col matrix of an NHWC image (forward convolution),
 // 2 = B is that matrix with k = output pixel, n = tap (filter-gradient contraction).
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int VEC, bool EDGE, int CONV, int ABL, bool DMA,
-          class Epi, int STAGES = 2>
+          class Epi>
 __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   constexpr int WAVES_N = BN / WN;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int SA = LdsStride<BM, BK, A_KC>::value, SB = LdsStride<BN, BK, B_KC>::value;
 
-  __shared__ __attribute__((aligned(16))) float lds[STAGES * BK * (SA + SB)];
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (SA + SB)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -773,10 +672,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   bool done = false;
   if constexpr (DMA) {  // kernels without the DMA loop (tuning harness: BK = 8) never instantiate it
     if (!EDGE || interior) {
-      if constexpr (STAGES == 3)
-        gemm_mainloop_dma3<BM, BN, BK, WM, WN, A_KC, B_KC, CONV>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
-      else
-        gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
+      gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
       done = true;
     } else if (CONV != 1) {
       // ragged in M, N or K: still the LDS-DMA loop, with clamped addresses and a zeroed K tail
@@ -942,10 +838,10 @@ struct WavesPerSimd {
 };
 
 template <int BM, int BN, int BK, int WM, int WN, int MINB, bool A_KC, bool B_KC, int VEC, bool EDGE, int CONV,
-          int ABL = 0, bool DMA = false, int STAGES = 2>
+          int ABL = 0, bool DMA = false>
 __global__ __launch_bounds__((Geometry<BM, BN, WM, WN>::NT), (WavesPerSimd<BM, BN, WM, WN, MINB, EDGE, VEC>::value)) void
 gemm_f32_mfma_kernel(GemmArgs a) {
-  gemm_block<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, EDGE, CONV, ABL, DMA, EpiNone, STAGES>(a);
+  gemm_block<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, EDGE, CONV, ABL, DMA, EpiNone>(a);
 }
 
 // Second pass of split-K: C[m,n] = (accumulate ? C : 0) + sum_z partial[z][m][n] + bias[n],
