@@ -34,7 +34,7 @@ def dev(ctx, a):
     return t
 
 
-def same_special(got, want, what, tol=TOL):
+def same_special(got, want, what, tol=TOL, compare=None):
     """NaN where the reference has NaN, the same infinities, zeros where it has zeros, finite
     values within tol of each other relative to the value itself."""
     got, want = np.asarray(got), np.asarray(want)
@@ -48,6 +48,9 @@ def same_special(got, want, what, tol=TOL):
     # order of their names (passes.nim:927-934).  Zeros must be zeros; either sign is the reference's.
     assert np.all(got[zero] == 0), (what, "zeros")
     nz = fin & (want != 0)
+    if compare is not None:      # points where the value is compared; everywhere else only its kind (NaN / inf / zero / finite)
+        assert np.all(np.isfinite(got[nz & ~compare])), (what, "finite where the reference is")
+        nz = nz & compare
     # denormal results (|want| < 1.18e-38) may differ in the last bits of a 23-bit-or-less significand: absolute 2^-149 steps
     err = np.abs(got[nz].astype(np.float64) - want[nz]) / np.maximum(np.abs(want[nz].astype(np.float64)), 1.2e-38)
     assert err.size == 0 or err.max() <= tol, (what, err.max(), got[nz], want[nz])
@@ -68,7 +71,11 @@ def test_library_maps_on_special_values(gpu_ctx, refcpu, op):
     ops.map_grad(gpu_ctx, op, x.size, din, dg, dgin, param=param)
     with np.errstate(all="ignore"):
         want_g = refcpu.map_grad(op, x, g, param=param)
-    same_special(dgin.read(), want_g, op + " gradient", tol=4e-5 if op in ("tanh", "sigmoid") else TOL)
+    # tanh / sigmoid gradients divide by (e^x + e^-x)^2-type terms: beyond |x| = 20 the float32 value is the
+    # quotient of an overflowing or fully cancelled pair and its last bits depend on the exp implementation's;
+    # there only the kind of the result (NaN / inf / zero / finite) is compared
+    compare = np.abs(x) <= 20 if op in ("tanh", "sigmoid") else None
+    same_special(dgin.read(), want_g, op + " gradient", compare=compare)
 
 
 def test_tanh_is_the_naive_formula_and_overflows_to_nan(gpu_ctx, refcpu):
