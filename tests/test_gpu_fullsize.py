@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import refcases
-from conftest import TOL, rel_err
+from conftest import TOL, debug_toggles_active, rel_err
 from exprgrad_amd import model as egm
 from exprgrad_amd import ops
 
@@ -165,7 +165,8 @@ def test_cfg5_dense_train_step_batch_65536(gpu_ctx):
     # the small weight gradient runs on the side lane, next to the large weight-gradient contraction, whose
     # last row is the first layer's bias gradient; later steps (eager, captured, replayed) must agree with this one
     plan = gpu.launch_plan("train")
-    assert plan.count("side lane") == 1 and "+ones-row" in plan, plan
+    if not debug_toggles_active():
+        assert plan.count("side lane") == 1 and "+ones-row" in plan, plan
     serial = egm.compile(*refcases.dense_softmax_net(), gpu=gpu_ctx)
     for tid in sorted(ref.params):
         serial.params[tid] = gpu.params[tid]
@@ -203,7 +204,7 @@ def test_cfg5_split_step_equals_whole_step(gpu_ctx):
             whole.apply("train", [("x", x), ("y", y)])
             dp.step([("x", x), ("y", y)])
         stream.synchronize()
-        assert "side lane" in split.launch_plan("train")
+        assert debug_toggles_active() or "side lane" in split.launch_plan("train")
         for tid in whole.params.ids():
             assert np.array_equal(whole.params[tid], split.params[tid]), tid
         whole.close()
@@ -281,7 +282,7 @@ def test_cfg5_native_step_overlaps_the_early_exchange(gpu_ctx):
             whole.apply("train", [("x", x), ("y", y)])
             dp.step([("x", x), ("y", y)])
         stream.synchronize()
-        assert call("eg_dp_last_pieces", group.handle) == 2, split.launch_plan("train")
+        assert debug_toggles_active() or call("eg_dp_last_pieces", group.handle) == 2, split.launch_plan("train")
         for tid in whole.params.ids():
             assert np.array_equal(whole.params[tid], split.params[tid]), tid
         # a model of another context is refused: the stream is what orders the collective
