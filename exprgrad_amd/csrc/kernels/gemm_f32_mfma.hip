@@ -253,25 +253,6 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   const long M = args.M, N = args.N, K = args.K;
   int BM, BN, splits;
   choose_tile(ctx, M, N, K, BM, BN, splits);
-  // A few rows beyond whole 256-row tiles under split-K (785 = 3 x 256 + 17: the first layer's weight gradient
-  // with the bias gradient as its last row): a ragged tile row multiplies 1/8 of a tile but stages whole B
-  // tiles, i.e. it is load-bound and as long as a full tile.  Those rows run as a contraction of their own
-  // with 64-row tiles (EG_GEMM_SPLIT_REMAINDER=1; experiment)
-  static const bool split_rem = getenv("EG_GEMM_SPLIT_REMAINDER") != nullptr;
-  if (split_rem && !conv && vec_ok && splits > 1 && BM == 256 && M > 256 && M % 256 != 0 && M % 256 <= 32 && (M - M % 256) % 4 == 0) {
-    const long m0 = M - M % 256;
-    GemmArgs main = args, rem = args;
-    main.M = m0;
-    main.ones_row = 0;
-    main.a_rows = m0;
-    rem.A = a_kc ? args.A + m0 * args.lda : args.A + m0;
-    rem.C = args.C + m0 * args.ldc;
-    rem.M = M - m0;
-    rem.a_rows = args.a_rows - m0;
-    int rc = run_gemm(ctx, a_kc, b_kc, main, conv, vec_ok, a_vec_only);
-    if (rc) return rc;
-    return run_gemm(ctx, a_kc, b_kc, rem, conv, vec_ok, a_vec_only);
-  }
   // (32-deep k-tiles for the 256x256 tile were measured in round 2: +1 % at 4096^3, -7 % at K = 784, 0 elsewhere)
   // the convolution's filter gradient (M = F = 64 rows, 64 x 64 tiles, K = every output pixel): a block has
   // little matrix work per barrier, so its k-tiles are 32 deep like the forward gather's (EG_CONVGF_BK16=1: 16)
