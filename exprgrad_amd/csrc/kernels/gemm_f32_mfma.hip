@@ -253,6 +253,50 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   const long M = args.M, N = args.N, K = args.K;
   int BM, BN, splits;
   choose_tile(ctx, M, N, K, BM, BN, splits);
+  // A few rows / columns beyond whole 256 x 256 tiles of a large output (4100 = 16 x 256 + 4): the ragged
+  // tile row and column stage whole operand tiles for 1/64 of the matrix work and push the launch into another
+  // round of blocks (4100 x 4096 x 4096: +76 us, 4096 x 4100 x 4096: +154 us over 969 us).  As contractions
+  // of their own they are one pass over the other operand (4 x 4100 x 4100: 30 us), so the output is cut into
+  // whole tiles + remainder rows + remainder columns when the ragged tiles would cost a round
+  // (EG_GEMM_NO_REMAINDER=1: one launch).  Split-K launches keep their ragged tiles: those get fewer,
+  // longer k-slices next to the whole tiles at about the same cost.
+  static const bool rem_split = getenv("EG_GEMM_NO_REMAINDER") == nullptr;
+  if (rem_split && !conv && vec_ok && !a_vec_only && splits == 1 && !args.ones_row) {
+    const long m_rem = M % 256, n_rem = N % 256;
+    const long m0 = M - (m_rem <= 32 ? m_rem : 0), n0 = N - (n_rem <= 32 ? n_rem : 0);
+    const long slots = ctx->compute_units;
+    const long tiles_all = ((M + 255) / 256) * ((N + 255) / 256), tiles_main = ((m0 + 255) / 256) * ((n0 + 255) / 256);
+    const bool saves_round = (tiles_all + slots - 1) / slots > (tiles_main + slots - 1) / slots;
+    int bm_main = 0, bn_main = 0, splits_main = 0;
+    if ((m0 < M || n0 < N) && m0 >= 256 && n0 >= 256 && n0 % 4 == 0 && m0 % 4 == 0 && saves_round)
+      choose_tile(ctx, m0, n0, K, bm_main, bn_main, splits_main);  // the whole-tile part on its own: 256 x 256 tiles, no split-K?
+    if (bm_main == 256 && bn_main == 256 && splits_main == 1) {
+      GemmArgs part = args;
+      part.M = part.a_rows = m0;
+      part.N = n0;
+      int rc = run_gemm(ctx, a_kc, b_kc, part, conv, vec_ok, a_vec_only);
+      if (rc) return rc;
+      if (m0 < M) {  // remainder rows, every column
+        part = args;
+        part.A = a_kc ? args.A + m0 * args.lda : args.A + m0;
+        part.C = args.C + m0 * args.ldc;
+        part.M = part.a_rows = M - m0;
+        rc = run_gemm(ctx, a_kc, b_kc, part, conv, vec_ok, a_vec_only);
+        if (rc) return rc;
+      }
+      if (n0 < N) {  // remainder columns of the whole-tile rows
+        part = args;
+        part.B = b_kc ? args.B + n0 * args.ldb : args.B + n0;
+        part.C = args.C + n0;
+        if (args.bias) part.bias = args.bias + n0;
+        part.M = part.a_rows = m0;
+        part.N = N - n0;
+        rc = run_gemm(ctx, a_kc, b_kc, part, conv, vec_ok, a_vec_only);
+        if (rc) return rc;
+      }
+      return EG_OK;
+    }
+  }
   // (32-deep k-tiles for the 256x256 tile were measured in round 2: +1 % at 4096^3, -7 % at K = 784, 0 elsewhere)
   // the convolution's filter gradient (M = F = 64 rows, 64 x 64 tiles, K = every output pixel): a block has
   // little matrix work per barrier, so its k-tiles are 32 deep like the forward gather's (EG_CONVGF_BK16=1: 16)

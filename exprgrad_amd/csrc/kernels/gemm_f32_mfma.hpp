@@ -268,6 +268,23 @@ __device__ __forceinline__ void tile_origin(int wgid, int rows_m, int tiles_n, l
   n_blk = (long)(in_group / gsize) * BN;
 }
 
+// Which rows (columns) of its sub-tile a wave's accumulator block mi (ni) holds.  For an operand that sits
+// in LDS as [k][m|n] rows (m|n-contiguous in memory) the blocks are INTERLEAVED: lane i of block mi owns row
+// CNT * i + mi, so the CNT values a lane needs for one k are adjacent in LDS and arrive with ONE
+// ds_read_b64 / b128 instead of CNT ds_read_b32 (the weight-gradient contractions, both operands of this
+// kind, issued 24 LDS reads per 32 MFMAs; 6 now).  k-contiguous operands ([m|n][16] rows, one b128 per
+// row already) keep whole 32-row blocks.  Only INTERIOR tiles interleave: a ragged tile keeps whole blocks so
+// that the blocks outside the problem can be skipped (an interleaved block always has some row inside).
+// The epilogue follows whichever map the main loop of its tile used.
+template <bool KC, int CNT>
+struct Interleaved {
+  static constexpr bool value = !KC && (CNT == 2 || CNT == 4);
+};
+template <int CNT>
+__device__ __forceinline__ int sub_index(bool il, int block, int lane31) {
+  return il ? CNT * lane31 + block : block * 32 + lane31;
+}
+
 template <int BM, int BN, int WM, int WN>
 struct Geometry {
   static constexpr int WAVES = (BM / WM) * (BN / WN);
@@ -304,8 +321,10 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
   }
   __syncthreads();
 
-  const int a_off = (lane >> 5) * SA + wm0 + (lane & 31);
-  const int b_off = (lane >> 5) * SB + wn0 + (lane & 31);
+  constexpr bool AIL = !E && Interleaved<A_KC, MI>::value, BIL = !E && Interleaved<B_KC, NI>::value;
+  const int a_off = (lane >> 5) * SA + wm0 + (AIL ? MI * (lane & 31) : (lane & 31));
+  const int b_off = (lane >> 5) * SB + wn0 + (BIL ? NI * (lane & 31) : (lane & 31));
+  constexpr int A_STEP = AIL ? 1 : 32, B_STEP = BIL ? 1 : 32;  // distance between a lane's blocks in an LDS row
 
   // Edge tiles: 32x32 sub-blocks of the wave tile that lie completely outside the problem are
   // skipped (wave-uniform branch), so a ragged M or N costs matrix work at 32-row granularity
@@ -319,7 +338,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NI; ++j)
-        if (i * 32 < m_w && j * 32 < n_w) live |= 1u << (i * NI + j);
+        if ((AIL ? i : i * 32) < m_w && (BIL ? j : j * 32) < n_w) live |= 1u << (i * NI + j);
   }
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -336,9 +355,9 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
     // while the MFMAs of step kk issue
     float av[2][MI], bv[2][NI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) av[0][i] = as[i * 32];
+    for (int i = 0; i < MI; ++i) av[0][i] = as[i * A_STEP];
 #pragma unroll
-    for (int j = 0; j < NI; ++j) bv[0][j] = bs[j * 32];
+    for (int j = 0; j < NI; ++j) bv[0][j] = bs[j * B_STEP];
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const int c = kk & 1, n = c ^ 1;
@@ -349,9 +368,9 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
         for (int j = 0; j < NI; ++j) bv[n][j] = bv[c][j];
       } else if (kk + 1 < BK / 2) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) av[n][i] = as[(kk + 1) * 2 * SA + i * 32];
+        for (int i = 0; i < MI; ++i) av[n][i] = as[(kk + 1) * 2 * SA + i * A_STEP];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bv[n][j] = bs[(kk + 1) * 2 * SB + j * 32];
+        for (int j = 0; j < NI; ++j) bv[n][j] = bs[(kk + 1) * 2 * SB + j * B_STEP];
       }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -476,7 +495,7 @@ struct DmaLoader {
   }
 };
 
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int CONV, bool CL = false>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int CONV, bool CL = false, bool IL = !CL>
 __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32],
                                                   long m_blk, long n_blk, long k_begin, int nk, int tid, int wm0,
                                                   int wn0, long k_end = 0) {
@@ -488,6 +507,9 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
   using DmaB = DmaLoader<BN, BK, NT, B_KC, CONV == 2, CL>;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, hi = lane >> 5;
+  // IL: interleaved accumulator rows / columns (see Interleaved).  The clamped loop runs blocked for tiles
+  // that are ragged in M or N, interleaved for the last k-tile of a tile that is ragged at the end of K only.
+  constexpr bool AIL = IL && Interleaved<A_KC, MI>::value, BIL = IL && Interleaved<B_KC, NI>::value;
 
   // ragged tile: 32x32 sub-blocks of the wave tile that lie outside the problem are skipped
   unsigned live = 0xffffffffu;
@@ -499,7 +521,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
-        if (mi * 32 < m_w && ni * 32 < n_w) live |= 1u << (mi * NI + ni);
+        if ((AIL ? mi : mi * 32) < m_w && (BIL ? ni : ni * 32) < n_w) live |= 1u << (mi * NI + ni);
   }
 
   DmaA da;
@@ -542,8 +564,27 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
 #pragma unroll
     for (int pp = 0; pp < BK / 8; ++pp) {
       float av[MI][4], bv[NI][4];
+      if constexpr (AIL) {  // one 8- or 16-byte read per k brings this lane's value for every block
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          typedef float vecA __attribute__((ext_vector_type(MI)));
+          const vecA v = *reinterpret_cast<const vecA*>(As + (8 * pp + j + 4 * hi) * BM + wm0 + MI * i);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) av[mi][j] = v[mi];
+        }
+      }
+      if constexpr (BIL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          typedef float vecB __attribute__((ext_vector_type(NI)));
+          const vecB v = *reinterpret_cast<const vecB*>(Bs + (8 * pp + j + 4 * hi) * BN + wn0 + NI * i);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) bv[ni][j] = v[ni];
+        }
+      }
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
+        if (AIL) break;
         const int row = wm0 + mi * 32 + i;
         if (A_KC) {
           const int slot = (2 * pp + hi) ^ DmaA::swizzle(row);
@@ -559,6 +600,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
+        if (BIL) break;
         const int col = wn0 + ni * 32 + i;
         if (B_KC) {
           const int slot = (2 * pp + hi) ^ DmaB::swizzle(col);
@@ -669,13 +711,24 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   static_assert(!DMA || VEC == 4, "LDS-DMA loop: 16-byte aligned operands");
   const bool whole_k = (k_end - k_begin) % BK == 0;
   const bool interior = m_blk + BM <= a.a_rows && n_blk + BN <= a.N && whole_k;
+  // A tile that is whole in M and N but ends inside a k-tile (K = 4100: every tile) runs its whole k-tiles
+  // on the interior loop and only the last one on the clamped loop (4096 x 4096 x 4100 took 1060 us with
+  // every k-tile clamped, against 973 us for K = 4112).
+  const bool k_tail_only = EDGE && DMA && CONV == 0 && !whole_k && m_blk + BM <= a.a_rows && n_blk + BN <= a.N;
   bool done = false;
   if constexpr (DMA) {  // kernels without the DMA loop (tuning harness: BK = 8) never instantiate it
-    if (!EDGE || interior) {
-      gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
+    if (!EDGE || interior || k_tail_only) {
+      const int n_main = (EDGE && k_tail_only) ? nk - 1 : nk;
+      if (n_main > 0)
+        gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV>(a, lds, acc, m_blk, n_blk, k_begin, n_main, tid, wm0, wn0);
+      if constexpr (EDGE && CONV == 0) {
+        if (k_tail_only)
+          gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, true, true>(a, lds, acc, m_blk, n_blk,
+                                                                               k_begin + (long)n_main * BK, 1, tid, wm0, wn0, k_end);
+      }
       done = true;
     } else if (CONV != 1) {
-      // ragged in M, N or K: still the LDS-DMA loop, with clamped addresses and a zeroed K tail
+      // ragged in M or N (and maybe K): still the LDS-DMA loop, with clamped addresses and a zeroed K tail
       gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, true>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0,
                                                                       k_end);
       done = true;
@@ -702,6 +755,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   const bool accumulate = !to_partial && a.accumulate;
   const bool has_bias = !to_partial && a.bias != nullptr;
   const bool whole_tile = m_blk + BM <= a.M && n_blk + BN <= a.N;
+  // rows / columns of the wave sub-tile that block (i, j) register r of this lane holds (see Interleaved)
+  const bool ail = Interleaved<A_KC, MI>::value && (!EDGE || interior || k_tail_only);  // block-uniform
+  const bool bil = Interleaved<B_KC, NI>::value && (!EDGE || interior || k_tail_only);
   if (a.wide_store && (!EDGE || whole_tile)) {  // block-uniform
     // ---- whole tile, through LDS (GemmArgs::wide_store).  Pass i: every wave parks block row i of its
     // sub-tile (32 rows x WN columns) at [wave row * 32 + row][wn0 + col]; then all threads walk the
@@ -714,18 +770,29 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
     const int wmi = wave / WAVES_N;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+      if (bil) {  // the lane's NI columns are adjacent: one 8- / 16-byte LDS write per row
 #pragma unroll
-      for (int j = 0; j < NI; ++j)
+        for (int r = 0; r < 16; ++r) {
+          typedef float vecN __attribute__((ext_vector_type(NI)));
+          vecN v;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          lds[(wmi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BN + wn0 + j * 32 + (lane & 31)] = acc[i][j][r];
+          for (int j = 0; j < NI; ++j) v[j] = acc[i][j][r];
+          *reinterpret_cast<vecN*>(&lds[(wmi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BN + wn0 + NI * (lane & 31)]) = v;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            lds[(wmi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BN + wn0 + j * 32 + (lane & 31)] = acc[i][j][r];
+      }
       __syncthreads();
 #pragma unroll
       for (int q0 = 0; q0 < RT * C4; q0 += NT_) {
         const int q = q0 + tid;
         if ((RT * C4) % NT_ != 0 && q >= RT * C4) break;
         const int row = q / C4, c4 = q % C4;
-        const long m = m_blk + (long)(row >> 5) * WM + i * 32 + (row & 31);
+        const long m = m_blk + (long)(row >> 5) * WM + sub_index<MI>(ail, i, row & 31);
         const long n = n_blk + c4 * 4;
         const long idx = m * ldo + n;
         f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * BN + c4 * 4]);
@@ -772,24 +839,26 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   for (int i = 0; i < MI; ++i) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const long n = n_blk + wn0 + j * 32 + (lane & 31);
+      const long n = n_blk + wn0 + sub_index<NI>(bil, j, lane & 31);
       const bool n_ok = !EDGE || n < a.N;
       float bias = 0.f;
       if (has_bias && n_ok) bias = a.bias[n];
-      const long m_base = m_blk + wm0 + i * 32 + 4 * (lane >> 5);
+      // row of register r: m_base + RS * ((r & 3) + 8 * (r >> 2))
+      const int RS = ail ? MI : 1;
+      const long m_base = m_blk + wm0 + (ail ? i + MI * 4 * (lane >> 5) : i * 32 + 4 * (lane >> 5));
       float* col = out + n;
       if (Epi::ACTIVE) {
         float x[16][Epi::NX];
         if (!EDGE || whole_tile) {  // whole tile inside: branch-free, loads batched
 #pragma unroll
-          for (int r = 0; r < 16; ++r) Epi::prefetch(a, (m_base + (r & 3) + 8 * (r >> 2)) * ldo + n, x[r]);
+          for (int r = 0; r < 16; ++r) Epi::prefetch(a, (m_base + RS * ((r & 3) + 8 * (r >> 2))) * ldo + n, x[r]);
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            epi_apply<Epi>(a, (m_base + (r & 3) + 8 * (r >> 2)) * ldo + n, acc[i][j][r] + bias, x[r]);
+            epi_apply<Epi>(a, (m_base + RS * ((r & 3) + 8 * (r >> 2))) * ldo + n, acc[i][j][r] + bias, x[r]);
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const long m = m_base + (r & 3) + 8 * (r >> 2);
+            const long m = m_base + RS * ((r & 3) + 8 * (r >> 2));
             if (m >= a.M || !n_ok) continue;
             Epi::prefetch(a, m * ldo + n, x[r]);
             epi_apply<Epi>(a, m * ldo + n, acc[i][j][r] + bias, x[r]);
@@ -799,24 +868,24 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
         if (accumulate) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const long m = m_base + (r & 3) + 8 * (r >> 2);
+            const long m = m_base + RS * ((r & 3) + 8 * (r >> 2));
             col[m * ldo] = (col[m * ldo] + acc[i][j][r]) + bias;
           }
         } else {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) col[(m_base + (r & 3) + 8 * (r >> 2)) * ldo] = acc[i][j][r] + bias;
+          for (int r = 0; r < 16; ++r) col[(m_base + RS * ((r & 3) + 8 * (r >> 2))) * ldo] = acc[i][j][r] + bias;
         }
       } else if (accumulate) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const long m = m_base + (r & 3) + 8 * (r >> 2);
+          const long m = m_base + RS * ((r & 3) + 8 * (r >> 2));
           if (m >= a.M || !n_ok) continue;
           col[m * ldo] = (col[m * ldo] + acc[i][j][r]) + bias;
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const long m = m_base + (r & 3) + 8 * (r >> 2);
+          const long m = m_base + RS * ((r & 3) + 8 * (r >> 2));
           if (m >= a.M || !n_ok) continue;
           col[m * ldo] = acc[i][j][r] + bias;
         }
