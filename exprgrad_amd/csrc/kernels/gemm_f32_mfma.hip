@@ -188,9 +188,126 @@ double tile_cost(const TileCfg& t, long M, long N, long k_tiles, int cus, int& s
   return cost;
 }
 
+// ---- outputs wider than one narrow tile in both directions (M, N > 64): a time estimate per (tile, split).
+//
+// Calibrated on tools/sweep_mid.py (square problems 256 .. 4096, every tile x split, round 2).  A block
+// needs `mfma` us of matrix-core time per 16-deep k-tile; alone on its CU it cannot go faster than `alone`
+// us per k-tile (one wave per SIMD: the LDS-DMA round trip of the next k-tile is not hidden by the little
+// matrix work of a small tile).  The busiest CU runs ceil(blocks / CUs) blocks, co-resident up to `blocks_per_cu`:
+//     T = k-tiles per block x max(mfma x blocks on the busiest CU, alone x rounds) + fixed x rounds + second pass
+// 1024^3: 64 x 64 tiles, one per CU, no split: 23.9 us (the old choice, 256 x 256 x 16 splits: 38.5 us);
+// 3072^3: 64 x 64: 484 us (144 tiles of 256 x 256 leave 112 CUs idle: 584 us); 4096^3 keeps 256 x 256.
+struct WideTile {
+  int bm, bn, wm, wn, blocks_per_cu;
+  double mfma, alone, alone_k32, fixed;
+};
+const WideTile kWideTiles[] = {
+    {256, 256, 128, 64, 1, 3.80, 1.30, 1.30, 8.0},
+    {128, 128, 64, 64, 4, 1.05, 0.70, 0.70, 8.0},
+    {64, 64, 32, 32, 4, 0.275, 0.44, 0.30, 4.5},
+};
+
+// Matrix time of a tile with `rows` x `cols` valid outputs relative to a whole tile.  A ragged tile skips
+// its empty 32 x 32 blocks, but the block is as slow as its busiest SIMD: wave w runs on SIMD w % 4, so
+// 128 valid columns of a 256 x 256 tile (wave columns 2 and 3 idle) leave two SIMDs with the work of a whole
+// tile (8192 x 128 x 8192 on 256 x 256 tiles: 278 us, as long as N = 256), while 128 valid ROWS halve it.
+double ragged_tile_factor(const WideTile& t, long rows, long cols) {
+  const int waves_m = t.bm / t.wm, waves_n = t.bn / t.wn, mi = t.wm / 32, ni = t.wn / 32;
+  long load[4] = {0, 0, 0, 0};
+  for (int wr = 0; wr < waves_m; ++wr)
+    for (int wc = 0; wc < waves_n; ++wc) {
+      long lm = (rows - (long)wr * t.wm + 31) / 32, ln = (cols - (long)wc * t.wn + 31) / 32;
+      lm = lm < 0 ? 0 : (lm > mi ? mi : lm);
+      ln = ln < 0 ? 0 : (ln > ni ? ni : ln);
+      load[(wr * waves_n + wc) % 4] += lm * ln;
+    }
+  long worst = 0;
+  for (long l : load) worst = l > worst ? l : worst;
+  const long whole = (long)((waves_m * waves_n + 3) / 4) * mi * ni;
+  return (double)worst / (double)whole;
+}
+
+double wide_tile_time(const WideTile& t, long M, long N, long k_tiles, int cus, bool vec, int& splits_out) {
+  const long tm = (M + t.bm - 1) / t.bm, tn = (N + t.bn - 1) / t.bn;
+  const long tiles = tm * tn;
+  const long slots = (long)cus * t.blocks_per_cu;
+  // whole tiles, the ragged last row / column / corner (clamped loop: ~10 % slower per k-tile)
+  const long m_rest = M % t.bm, n_rest = N % t.bn;
+  const long full_m = M / t.bm, full_n = N / t.bn;
+  const double f_m = m_rest ? 1.1 * ragged_tile_factor(t, m_rest, t.bn) : 0, f_n = n_rest ? 1.1 * ragged_tile_factor(t, t.bm, n_rest) : 0;
+  const double f_mn = m_rest && n_rest ? 1.1 * ragged_tile_factor(t, m_rest, n_rest) : 0;
+  const double mean = ((double)full_m * full_n + f_m * full_n + f_n * full_m + f_mn) / (double)tiles;
+  double worst = full_m && full_n ? 1.0 : 0;
+  if (full_n && f_m > worst) worst = f_m;
+  if (full_m && f_n > worst) worst = f_n;
+  if (f_mn > worst) worst = f_mn;
+  const long max_by_k = k_tiles / 8 > 1 ? k_tiles / 8 : 1;  // every slice keeps at least 8 k-tiles
+  double best = 0;
+  splits_out = 1;
+  long last = 0;
+  // candidate slice counts: a geometric ladder plus the counts that fill the CUs / the block slots exactly
+  long cand[40];
+  int ncand = 0;
+  for (long want = 1; want <= 1024 && ncand < 32; want = want < 4 ? want + 1 : want + want / 2) cand[ncand++] = want;
+  for (long fillers : {(long)cus / tiles, slots / tiles, 2 * (long)cus / tiles, (long)cus / tiles + 1})
+    if (fillers > 1) cand[ncand++] = fillers;
+  std::sort(cand, cand + ncand);
+  for (int ci = 0; ci < ncand; ++ci) {
+    const long want = cand[ci];
+    if (want > max_by_k) break;
+    const long per = (k_tiles + want - 1) / want;
+    const long s = (k_tiles + per - 1) / per;
+    if (s == last) continue;
+    last = s;
+    const long blocks = tiles * s;
+    if (s > 1 && blocks > 2 * slots) break;  // more slices than the chip can hold at once only add slabs
+    const long on_cu = (blocks + cus - 1) / cus, rounds = (blocks + slots - 1) / slots;
+    const double alone = (vec && t.bm == 64 && on_cu <= 2) ? t.alone_k32 : t.alone;
+    // the busiest CU: its blocks are a sample of the tiles, never faster than one of the slowest kind
+    double matrix = t.mfma * ((double)on_cu * mean > worst ? (double)on_cu * mean : worst);
+    if (s > 1 && rounds == 1 && m_rest != 0 && m_rest * 2 <= t.bm && tm >= 2)  // run_gemm: ragged rows get fewer slices
+      matrix = t.mfma * (double)on_cu * ((double)(tm - 1) * tn + tn * ragged_tile_share(t.bm, m_rest)) / (double)tiles;
+    const double step = matrix > alone * rounds ? matrix : alone * rounds;
+    double time = (double)per * step + t.fixed * rounds;
+    if (s > 1) {
+      const double mb = (double)M * N * 4e-6;           // one slab, MB
+      time += 3.0 + mb * (double)s / 4.0 + mb * (double)(s + 1) / 4.5;  // slabs out at ~4 TB/s, second pass at ~4.5
+    }
+    if (best == 0 || time < best) {
+      best = time;
+      splits_out = (int)s;
+    }
+  }
+  return best;
+}
+
 // Tile shape and split count for an M x N x K contraction on this device.
-void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& splits) {
+void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& splits, bool vec = true, bool plain = true) {
   const long k_tiles = (K + BK - 1) / BK;
+  static const bool old_model = getenv("EG_GEMM_OLD_TILE_MODEL") != nullptr;
+  if (plain && M > 64 && N > 64 && !old_model && getenv("EG_GEMM_FORCE_TILE") == nullptr) {  // (convolutions keep their measured choices)
+    static const bool debug_tile = getenv("EG_DEBUG_TILE") != nullptr;
+    double best = 0;
+    for (const WideTile& t : kWideTiles) {
+      int sp;
+      const double time = wide_tile_time(t, M, N, k_tiles, ctx->compute_units, vec, sp);
+      if (debug_tile) fprintf(stderr, "[eg] tile model %ld x %ld x %ld: %d x %d, %d slices: %.1f us\n", M, N, K, t.bm, t.bn, sp, time);
+      if (best == 0 || time < best * 0.97) {  // larger tiles listed first: a smaller one has to win by 3 %
+        best = time;
+        bm = t.bm;
+        bn = t.bn;
+        splits = sp;
+      }
+    }
+    if (const char* f = getenv("EG_GEMM_FORCE_SPLITS")) {  // tuning aid
+      const int want = atoi(f);
+      if (want >= 1 && want <= k_tiles) {
+        const long per = (k_tiles + want - 1) / want;
+        splits = (int)((k_tiles + per - 1) / per);
+      }
+    }
+    return;
+  }
   // Candidates: 256x256 (16 waves, 1 block/CU) for large outputs, 128x128 (4 waves, 4 blocks/CU),
   // and narrow tiles for bias-sized N (the N = 1/4/10 layers of the XOR and dense nets, F = 64
   // filter banks) so the padding wasted in the matrix core stays small.
@@ -220,6 +337,13 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
   bm = cfgs[best].bm;
   bn = cfgs[best].bn;
   splits = best_splits;
+  if (const char* f = getenv("EG_GEMM_FORCE_SPLITS")) {  // tuning aid
+    const int want = atoi(f);
+    if (want >= 1 && want <= k_tiles) {
+      const long per = (k_tiles + want - 1) / want;
+      splits = (int)((k_tiles + per - 1) / per);
+    }
+  }
 }
 
 // Wide stores of whole tiles as nontemporal stores: the output of a contraction is not read again by the
@@ -252,7 +376,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   if (!args.ones_row) args.a_rows = args.M;
   const long M = args.M, N = args.N, K = args.K;
   int BM, BN, splits;
-  choose_tile(ctx, M, N, K, BM, BN, splits);
+  choose_tile(ctx, M, N, K, BM, BN, splits, vec_ok, conv == 0);
   // A few rows / columns beyond whole 256 x 256 tiles of a large output (4100 = 16 x 256 + 4): the ragged
   // tile row and column stage whole operand tiles for 1/64 of the matrix work and push the launch into another
   // round of blocks (4100 x 4096 x 4096: +76 us, 4096 x 4100 x 4096: +154 us over 969 us).  As contractions
@@ -269,7 +393,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     const bool saves_round = (tiles_all + slots - 1) / slots > (tiles_main + slots - 1) / slots;
     int bm_main = 0, bn_main = 0, splits_main = 0;
     if ((m0 < M || n0 < N) && m0 >= 256 && n0 >= 256 && n0 % 4 == 0 && m0 % 4 == 0 && saves_round)
-      choose_tile(ctx, m0, n0, K, bm_main, bn_main, splits_main);  // the whole-tile part on its own: 256 x 256 tiles, no split-K?
+      choose_tile(ctx, m0, n0, K, bm_main, bn_main, splits_main, vec_ok);  // the whole-tile part on its own: 256 x 256 tiles, no split-K?
     if (bm_main == 256 && bn_main == 256 && splits_main == 1) {
       GemmArgs part = args;
       part.M = part.a_rows = m0;
@@ -301,7 +425,14 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   // the convolution's filter gradient (M = F = 64 rows, 64 x 64 tiles, K = every output pixel): a block has
   // little matrix work per barrier, so its k-tiles are 32 deep like the forward gather's (EG_CONVGF_BK16=1: 16)
   static const bool gf16 = getenv("EG_CONVGF_BK16") != nullptr;
-  const int KB = (conv == 2 && BM == 64 && BN == 64 && vec_ok && !gf16) ? 32 : BK;
+  int KB = (conv == 2 && BM == 64 && BN == 64 && vec_ok && !gf16) ? 32 : BK;
+  // 64 x 64 tiles with at most two blocks per CU are bound by the LDS-DMA round trip of the next k-tile, not
+  // by matrix work: 32-deep k-tiles halve the round trips (1024^3: 28.1 -> 23.9 us; four blocks per CU hide
+  // it by themselves: 2048^3 142.5 vs 146.5 us).  EG_GEMM_SMALL_BK16=1: 16.
+  if (!conv && BM == 64 && BN == 64 && vec_ok && K >= 256 && getenv("EG_GEMM_SMALL_BK16") == nullptr &&
+      (M + 63) / 64 * ((N + 63) / 64) * splits <= 2L * ctx->compute_units)
+    KB = 32;
+  if (getenv("EG_GEMM_SMALL_BK32") != nullptr && !conv && BM == 64 && BN == 64 && vec_ok && K >= 256) KB = 32;  // tuning aid
   const long k_tiles = (K + KB - 1) / KB;
   args.tiles_m = (int)((M + BM - 1) / BM);
   args.tiles_n = (int)((N + BN - 1) / BN);
@@ -309,6 +440,8 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   long tiles_per_split = (k_tiles + splits - 1) / splits;
   if (tiles_per_split < 1) tiles_per_split = 1;
   args.k_per_split = tiles_per_split * KB;
+  splits = (int)((k_tiles + tiles_per_split - 1) / tiles_per_split);  // no empty slice (the count was planned in 16-deep k-tiles)
+  if (splits < 1) splits = 1;
   args.splits = splits;
 
   // Tiny outputs split many ways (the XOR net's [2,4] and [4,1] weight gradients): a

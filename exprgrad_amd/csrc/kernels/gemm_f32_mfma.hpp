@@ -495,6 +495,122 @@ struct DmaLoader {
   }
 };
 
+// This lane's operand fragments for MFMA steps (pp, 0..3) of a k-tile staged by the LDS-DMA loaders.
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool AIL, bool BIL, class DmaA, class DmaB>
+__device__ __forceinline__ void dma_read_fragments(const float* As, const float* Bs, int pp, float (&av)[WM / 32][4],
+                                                   float (&bv)[WN / 32][4], int wm0, int wn0, int i, int hi) {
+  constexpr int MI = WM / 32, NI = WN / 32;
+  if constexpr (AIL) {  // one 8- or 16-byte read per k brings this lane's value for every block
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      typedef float vecA __attribute__((ext_vector_type(MI)));
+      const vecA v = *reinterpret_cast<const vecA*>(As + (8 * pp + j + 4 * hi) * BM + wm0 + MI * i);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) av[mi][j] = v[mi];
+    }
+  }
+  if constexpr (BIL) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      typedef float vecB __attribute__((ext_vector_type(NI)));
+      const vecB v = *reinterpret_cast<const vecB*>(Bs + (8 * pp + j + 4 * hi) * BN + wn0 + NI * i);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bv[ni][j] = v[ni];
+    }
+  }
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    if (AIL) break;
+    const int row = wm0 + mi * 32 + i;
+    if (A_KC) {
+      const int slot = (2 * pp + hi) ^ DmaA::swizzle(row);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(As + row * BK + slot * 4);
+      av[mi][0] = v[0];
+      av[mi][1] = v[1];
+      av[mi][2] = v[2];
+      av[mi][3] = v[3];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[mi][j] = As[(8 * pp + j + 4 * hi) * BM + row];
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    if (BIL) break;
+    const int col = wn0 + ni * 32 + i;
+    if (B_KC) {
+      const int slot = (2 * pp + hi) ^ DmaB::swizzle(col);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + col * BK + slot * 4);
+      bv[ni][0] = v[0];
+      bv[ni][1] = v[1];
+      bv[ni][2] = v[2];
+      bv[ni][3] = v[3];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[ni][j] = Bs[(8 * pp + j + 4 * hi) * BN + col];
+    }
+  }
+}
+
+// One k-tile of the LDS-DMA loop: fragment reads + MFMAs.
+// MASKED (the clamped loop of ragged tiles): 32 x 32 blocks outside the problem are skipped.  The tests
+// are wave-uniform branches, and the compiler neither hoists them nor moves LDS reads across them: a
+// test per MFMA (what the interior loop's j-outer order turns into) or per block left every fragment
+// read exposed (64 x 64 tiles: 1000^3 34 us against 25 us for 1024^3).  So:
+//   * a wave with ONE block (64 x 64 and 128 x 32 tiles) tests it once per k-tile around the straight-line body;
+//   * otherwise the fragments of the WHOLE k-tile are read first (16-deep k-tiles only: 48 registers),
+//     then the live blocks multiply, four MFMAs per test; the reads of the second half overlap the
+//     MFMAs of the first.
+// (Two copies of the body, masked / every block live, selected per wave spill hundreds of registers.)
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool AIL, bool BIL, bool MASKED, class DmaA, class DmaB>
+__device__ __forceinline__ void dma_k_tile(const float* As, const float* Bs, f32x16 (&acc)[WM / 32][WN / 32], unsigned live,
+                                           int wm0, int wn0, int i, int hi) {
+  constexpr int MI = WM / 32, NI = WN / 32;
+  if (MASKED && live == 0) return;  // this wave's sub-tile lies outside the problem
+  if constexpr (MASKED && MI * NI > 1 && BK == 16) {
+    float av[BK / 8][MI][4], bv[BK / 8][NI][4];
+#pragma unroll
+    for (int pp = 0; pp < BK / 8; ++pp)
+      dma_read_fragments<BM, BN, BK, WM, WN, A_KC, B_KC, AIL, BIL, DmaA, DmaB>(As, Bs, pp, av[pp], bv[pp], wm0, wn0, i, hi);
+#pragma unroll
+    for (int pp = 0; pp < BK / 8; ++pp)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          if (live >> (mi * NI + ni) & 1) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[pp][mi][j], bv[pp][ni][j], acc[mi][ni], 0, 0, 0);
+          }
+  } else {
+#pragma unroll
+    for (int pp = 0; pp < BK / 8; ++pp) {
+      float av[MI][4], bv[NI][4];
+      dma_read_fragments<BM, BN, BK, WM, WN, A_KC, B_KC, AIL, BIL, DmaA, DmaB>(As, Bs, pp, av, bv, wm0, wn0, i, hi);
+      if constexpr (MASKED && MI * NI > 1) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            if (live >> (mi * NI + ni) & 1) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+            }
+      } else {  // interior loop, or a single live block
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+      }
+    }
+  }
+}
+
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int CONV, bool CL = false, bool IL = !CL>
 __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32],
                                                   long m_blk, long n_blk, long k_begin, int nk, int tid, int wm0,
@@ -561,68 +677,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
     }
     const float* As = lds + cur * BUF;
     const float* Bs = As + BK * BM;
-#pragma unroll
-    for (int pp = 0; pp < BK / 8; ++pp) {
-      float av[MI][4], bv[NI][4];
-      if constexpr (AIL) {  // one 8- or 16-byte read per k brings this lane's value for every block
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          typedef float vecA __attribute__((ext_vector_type(MI)));
-          const vecA v = *reinterpret_cast<const vecA*>(As + (8 * pp + j + 4 * hi) * BM + wm0 + MI * i);
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) av[mi][j] = v[mi];
-        }
-      }
-      if constexpr (BIL) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          typedef float vecB __attribute__((ext_vector_type(NI)));
-          const vecB v = *reinterpret_cast<const vecB*>(Bs + (8 * pp + j + 4 * hi) * BN + wn0 + NI * i);
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) bv[ni][j] = v[ni];
-        }
-      }
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        if (AIL) break;
-        const int row = wm0 + mi * 32 + i;
-        if (A_KC) {
-          const int slot = (2 * pp + hi) ^ DmaA::swizzle(row);
-          const f32x4 v = *reinterpret_cast<const f32x4*>(As + row * BK + slot * 4);
-          av[mi][0] = v[0];
-          av[mi][1] = v[1];
-          av[mi][2] = v[2];
-          av[mi][3] = v[3];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) av[mi][j] = As[(8 * pp + j + 4 * hi) * BM + row];
-        }
-      }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        if (BIL) break;
-        const int col = wn0 + ni * 32 + i;
-        if (B_KC) {
-          const int slot = (2 * pp + hi) ^ DmaB::swizzle(col);
-          const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + col * BK + slot * 4);
-          bv[ni][0] = v[0];
-          bv[ni][1] = v[1];
-          bv[ni][2] = v[2];
-          bv[ni][3] = v[3];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bv[ni][j] = Bs[(8 * pp + j + 4 * hi) * BN + col];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            if (!CL || (live >> (mi * NI + ni) & 1))
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
-    }
+    dma_k_tile<BM, BN, BK, WM, WN, A_KC, B_KC, AIL, BIL, CL, DmaA, DmaB>(As, Bs, acc, live, wm0, wn0, i, hi);
     __syncthreads();
   }
 }
@@ -714,7 +769,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   // A tile that is whole in M and N but ends inside a k-tile (K = 4100: every tile) runs its whole k-tiles
   // on the interior loop and only the last one on the clamped loop (4096 x 4096 x 4100 took 1060 us with
   // every k-tile clamped, against 973 us for K = 4112).
-  const bool k_tail_only = EDGE && DMA && CONV == 0 && !whole_k && m_blk + BM <= a.a_rows && n_blk + BN <= a.N;
+  const bool k_tail_only = EDGE && DMA && CONV == 0 && !whole_k && k_end > k_begin && m_blk + BM <= a.a_rows && n_blk + BN <= a.N;
   bool done = false;
   if constexpr (DMA) {  // kernels without the DMA loop (tuning harness: BK = 8) never instantiate it
     if (!EDGE || interior || k_tail_only) {
