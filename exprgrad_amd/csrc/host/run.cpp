@@ -59,6 +59,12 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       if (!handle) {
         const std::string name = "eg_gemm_epi" + std::to_string(m->kernel_serial++);
         const std::string src = eg::gemm::fused_source(f, pe.spec.struct_code, pe.spec.struct_name, name);
+        if (const char* dump = getenv("EG_DUMP_FUSED")) {  // debugging aid: the generated translation unit
+          if (FILE* fp = fopen((std::string(dump) + "/" + name + "_" + variant + ".hip").c_str(), "w")) {
+            fputs(src.c_str(), fp);
+            fclose(fp);
+          }
+        }
         rc = eg_kernel_compile(ctx, name.c_str(), src.c_str(), &handle);
         if (rc) {
           std::string msg = eg_last_error();

@@ -159,6 +159,9 @@ __global__ __launch_bounds__(NT, 2) void conv2_halo_kernel(HaloArgs a) {
   sources(cur_item);
   issue(0, lds);
   int stage = 0;
+  // every wave waits for ITS OWN LDS-DMA loads before the barrier that publishes them (gemm_f32_mfma.hpp:
+  // dma_publish_barrier — the compiler is free to put that wait behind the barrier)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   while (true) {
     // four independent accumulator chains per wave (filters 0-31 / 32-63 x even / odd k-step):
@@ -218,7 +221,8 @@ __global__ __launch_bounds__(NT, 2) void conv2_halo_kernel(HaloArgs a) {
             }
         }
       }
-      __syncthreads();  // drains the DMA of the next chunk and frees this stage for the one after
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next chunk's loads have landed ...
+      __syncthreads();                                  // ... for every wave; this stage is free for the one after
       stage ^= 1;
     }
 

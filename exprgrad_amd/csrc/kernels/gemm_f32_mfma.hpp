@@ -413,6 +413,21 @@ __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32
 // its last 16-byte column chunk (m|n-contiguous) — always valid memory; what they produce lands
 // in accumulator rows / columns the epilogue never stores.  Past the end of K both operands re-read
 // their last k, and the main loop zeroes the A side of those k in LDS.
+// The barrier that publishes LDS-DMA data to the other waves of the block.  An LDS-DMA's bytes are
+// ordered for a ds_read only by the ISSUING wave's vmcnt wait followed by a barrier the reader has
+// passed: every wave waits for its own loads BEFORE the barrier.  __syncthreads() alone does not say
+// so — offline hipcc happens to emit `s_waitcnt vmcnt(0)` in front of its s_barrier while an LDS-DMA
+// is pending, the hiprtc build of the same source puts it AFTER the barrier, in front of the wave's
+// first ds_read (own loads only).  A block then reads tiles other waves' loads have not delivered yet:
+// the first k-tile of a generated-epilogue contraction came out with stale LDS bytes whenever nothing
+// delayed the first read (1500 x 96 x 20 on 64 x 64 tiles: wrong 32-column stripes in most runs; with
+// more k-tiles or larger tiles the address arithmetic of the next prefetch usually hid it — the rare
+// wrong update of round 1).  The wait is spelled out, with a memory clobber so that no load moves across.
+__device__ __forceinline__ void dma_publish_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
 template <int BMN, int BK, int NT, bool KC, bool CONV, bool CLAMP = false>
 struct DmaLoader {
   static constexpr int INSTRS = BK * BMN / 256;  // 1 KiB wave instructions per tile
@@ -495,122 +510,6 @@ struct DmaLoader {
   }
 };
 
-// This lane's operand fragments for MFMA steps (pp, 0..3) of a k-tile staged by the LDS-DMA loaders.
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool AIL, bool BIL, class DmaA, class DmaB>
-__device__ __forceinline__ void dma_read_fragments(const float* As, const float* Bs, int pp, float (&av)[WM / 32][4],
-                                                   float (&bv)[WN / 32][4], int wm0, int wn0, int i, int hi) {
-  constexpr int MI = WM / 32, NI = WN / 32;
-  if constexpr (AIL) {  // one 8- or 16-byte read per k brings this lane's value for every block
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      typedef float vecA __attribute__((ext_vector_type(MI)));
-      const vecA v = *reinterpret_cast<const vecA*>(As + (8 * pp + j + 4 * hi) * BM + wm0 + MI * i);
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) av[mi][j] = v[mi];
-    }
-  }
-  if constexpr (BIL) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      typedef float vecB __attribute__((ext_vector_type(NI)));
-      const vecB v = *reinterpret_cast<const vecB*>(Bs + (8 * pp + j + 4 * hi) * BN + wn0 + NI * i);
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bv[ni][j] = v[ni];
-    }
-  }
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    if (AIL) break;
-    const int row = wm0 + mi * 32 + i;
-    if (A_KC) {
-      const int slot = (2 * pp + hi) ^ DmaA::swizzle(row);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(As + row * BK + slot * 4);
-      av[mi][0] = v[0];
-      av[mi][1] = v[1];
-      av[mi][2] = v[2];
-      av[mi][3] = v[3];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) av[mi][j] = As[(8 * pp + j + 4 * hi) * BM + row];
-    }
-  }
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    if (BIL) break;
-    const int col = wn0 + ni * 32 + i;
-    if (B_KC) {
-      const int slot = (2 * pp + hi) ^ DmaB::swizzle(col);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + col * BK + slot * 4);
-      bv[ni][0] = v[0];
-      bv[ni][1] = v[1];
-      bv[ni][2] = v[2];
-      bv[ni][3] = v[3];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bv[ni][j] = Bs[(8 * pp + j + 4 * hi) * BN + col];
-    }
-  }
-}
-
-// One k-tile of the LDS-DMA loop: fragment reads + MFMAs.
-// MASKED (the clamped loop of ragged tiles): 32 x 32 blocks outside the problem are skipped.  The tests
-// are wave-uniform branches, and the compiler neither hoists them nor moves LDS reads across them: a
-// test per MFMA (what the interior loop's j-outer order turns into) or per block left every fragment
-// read exposed (64 x 64 tiles: 1000^3 34 us against 25 us for 1024^3).  So:
-//   * a wave with ONE block (64 x 64 and 128 x 32 tiles) tests it once per k-tile around the straight-line body;
-//   * otherwise the fragments of the WHOLE k-tile are read first (16-deep k-tiles only: 48 registers),
-//     then the live blocks multiply, four MFMAs per test; the reads of the second half overlap the
-//     MFMAs of the first.
-// (Two copies of the body, masked / every block live, selected per wave spill hundreds of registers.)
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, bool AIL, bool BIL, bool MASKED, class DmaA, class DmaB>
-__device__ __forceinline__ void dma_k_tile(const float* As, const float* Bs, f32x16 (&acc)[WM / 32][WN / 32], unsigned live,
-                                           int wm0, int wn0, int i, int hi) {
-  constexpr int MI = WM / 32, NI = WN / 32;
-  if (MASKED && live == 0) return;  // this wave's sub-tile lies outside the problem
-  if constexpr (MASKED && MI * NI > 1 && BK == 16) {
-    float av[BK / 8][MI][4], bv[BK / 8][NI][4];
-#pragma unroll
-    for (int pp = 0; pp < BK / 8; ++pp)
-      dma_read_fragments<BM, BN, BK, WM, WN, A_KC, B_KC, AIL, BIL, DmaA, DmaB>(As, Bs, pp, av[pp], bv[pp], wm0, wn0, i, hi);
-#pragma unroll
-    for (int pp = 0; pp < BK / 8; ++pp)
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-          if (live >> (mi * NI + ni) & 1) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[pp][mi][j], bv[pp][ni][j], acc[mi][ni], 0, 0, 0);
-          }
-  } else {
-#pragma unroll
-    for (int pp = 0; pp < BK / 8; ++pp) {
-      float av[MI][4], bv[NI][4];
-      dma_read_fragments<BM, BN, BK, WM, WN, A_KC, B_KC, AIL, BIL, DmaA, DmaB>(As, Bs, pp, av, bv, wm0, wn0, i, hi);
-      if constexpr (MASKED && MI * NI > 1) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            if (live >> (mi * NI + ni) & 1) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
-            }
-      } else {  // interior loop, or a single live block
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
-      }
-    }
-  }
-}
-
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int CONV, bool CL = false, bool IL = !CL>
 __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32],
                                                   long m_blk, long n_blk, long k_begin, int nk, int tid, int wm0,
@@ -650,7 +549,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
     db.issue(a, a.B, a.ldb, n_blk, k_begin, lds + BK * BM, wave, lane, a.N, k_end);
   }
   const int k_tail = CL ? (int)((k_end - k_begin) % BK) : 0;  // valid k of a ragged last k-tile (0 = full)
-  __syncthreads();  // hipcc drains vmcnt before the barrier while an LDS-DMA is in flight
+  dma_publish_barrier();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
@@ -677,8 +576,69 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
     }
     const float* As = lds + cur * BUF;
     const float* Bs = As + BK * BM;
-    dma_k_tile<BM, BN, BK, WM, WN, A_KC, B_KC, AIL, BIL, CL, DmaA, DmaB>(As, Bs, acc, live, wm0, wn0, i, hi);
-    __syncthreads();
+#pragma unroll
+    for (int pp = 0; pp < BK / 8; ++pp) {
+      float av[MI][4], bv[NI][4];
+      if constexpr (AIL) {  // one 8- or 16-byte read per k brings this lane's value for every block
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          typedef float vecA __attribute__((ext_vector_type(MI)));
+          const vecA v = *reinterpret_cast<const vecA*>(As + (8 * pp + j + 4 * hi) * BM + wm0 + MI * i);
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) av[mi][j] = v[mi];
+        }
+      }
+      if constexpr (BIL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          typedef float vecB __attribute__((ext_vector_type(NI)));
+          const vecB v = *reinterpret_cast<const vecB*>(Bs + (8 * pp + j + 4 * hi) * BN + wn0 + NI * i);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) bv[ni][j] = v[ni];
+        }
+      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        if (AIL) break;
+        const int row = wm0 + mi * 32 + i;
+        if (A_KC) {
+          const int slot = (2 * pp + hi) ^ DmaA::swizzle(row);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(As + row * BK + slot * 4);
+          av[mi][0] = v[0];
+          av[mi][1] = v[1];
+          av[mi][2] = v[2];
+          av[mi][3] = v[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) av[mi][j] = As[(8 * pp + j + 4 * hi) * BM + row];
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        if (BIL) break;
+        const int col = wn0 + ni * 32 + i;
+        if (B_KC) {
+          const int slot = (2 * pp + hi) ^ DmaB::swizzle(col);
+          const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + col * BK + slot * 4);
+          bv[ni][0] = v[0];
+          bv[ni][1] = v[1];
+          bv[ni][2] = v[2];
+          bv[ni][3] = v[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[ni][j] = Bs[(8 * pp + j + 4 * hi) * BN + col];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            if (!CL || (live >> (mi * NI + ni) & 1))
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+    }
+    dma_publish_barrier();  // the next k-tile's loads (issued above) have landed; this stage is free for the one after
   }
 }
 

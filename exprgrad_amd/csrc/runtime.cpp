@@ -155,6 +155,12 @@ int kernels_compile_batch(eg_ctx* ctx, const char* label, const char* source, co
   std::vector<char> code(code_size);
   hiprtcGetCode(prog, code.data());
   hiprtcDestroyProgram(&prog);
+  if (const char* dump = getenv("EG_DUMP_CODE")) {  // debugging aid: the code object, for llvm-objdump -d
+    if (FILE* fp = fopen((std::string(dump) + "/" + label + ".co").c_str(), "wb")) {
+      fwrite(code.data(), 1, code.size(), fp);
+      fclose(fp);
+    }
+  }
 
   std::shared_ptr<eg_module> mod(new eg_module());
   mod->device = ctx->device;

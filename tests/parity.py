@@ -93,7 +93,13 @@ class Trio:
         # The rule (module docstring): 1e-5 of the exact value; where the reference's own float32
         # arithmetic is farther than that from it, at most twice the reference's distance, capped.
         assert e_ref <= ILL_CAP, (what, "oracle vs exact", e_ref)
-        assert e_gpu <= max(TOL, min(2.0 * e_ref, ILL_CAP)) + floor, (what, "backend vs exact", e_gpu, "oracle vs exact", e_ref)
+        if not e_gpu <= max(TOL, min(2.0 * e_ref, ILL_CAP)) + floor:
+            # where: worst element, how many elements are off, their bounding box (a tile? a row? everything?)
+            err = np.abs(np.asarray(got, np.float64) - exact) / scale
+            bad = np.argwhere(err > max(TOL, min(2.0 * e_ref, ILL_CAP)) + floor)
+            where = {"worst": tuple(int(v) for v in np.unravel_index(int(np.argmax(err)), err.shape)), "bad": int(len(bad)),
+                     "of": int(err.size), "box": [(int(bad[:, d].min()), int(bad[:, d].max())) for d in range(bad.shape[1])]}
+            raise AssertionError((what, "backend vs exact", e_gpu, "oracle vs exact", e_ref, where))
 
     def call(self, target, inputs, n=1, floor=0.0):
         g = self.gpu.call(target, inputs)

@@ -102,3 +102,34 @@ def test_large_layers_fuse_by_default(gpu_ctx, monkeypatch):
     plan = t.gpu.launch_plan("train")
     assert plan.count("gemm+epilogue") == 2, plan     # relu forward, relu backward
     t.close()
+
+
+@pytest.mark.parametrize("dims", [(16, 128, 2048), (20, 96, 1500), (16, 96, 1500), (32, 160, 4096)])
+def test_first_k_tile_waits_for_every_waves_loads(gpu_ctx, monkeypatch, dims):
+    """An LDS-DMA tile is published to the block by every wave's OWN `s_waitcnt vmcnt(0)` in front of the
+    barrier (gemm_f32_mfma.hpp: dma_publish_barrier).  The hiprtc build of the generated-epilogue kernels
+    used to put that wait behind the barrier: a block that reads its first k-tile right away — one or two
+    k-tiles, 64 x 64 tiles — multiplied stale LDS bytes in most runs (whole 32-column stripes wrong), larger
+    problems only once in a while.  Forward of dense + tanh against float64, several fresh models."""
+    k, n, batch = dims
+    monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", "0")
+
+    def graphs():
+        return [layers.tanh(layers.dense(dsl.input("x"), k, n)).target("predict")]
+
+    rng = np.random.default_rng(k + n)
+    for trial in range(6):
+        m = egm.compile(*graphs(), gpu=gpu_ctx)
+        vals = {}
+        for tid in m.params.ids():
+            vals[tid] = (rng.random(m._param_shapes[tid], dtype=np.float32) - 0.5).astype(np.float32)
+            m.params[tid] = vals[tid]
+        x = (rng.random((batch, k), dtype=np.float32) - 0.5).astype(np.float32)
+        got = m.call("predict", {"x": x})
+        assert "gemm+epilogue" in m.launch_plan("predict")
+        w = [v for v in vals.values() if v.ndim == 2][0].astype(np.float64)
+        b = [v for v in vals.values() if v.ndim == 1][0].astype(np.float64)
+        want = np.tanh(x.astype(np.float64) @ w + b)
+        m.close()
+        bad = np.argwhere(np.abs(got - want) > 1e-5)
+        assert len(bad) == 0, (trial, len(bad), bad[:, 0].min(), bad[:, 0].max(), bad[:, 1].min(), bad[:, 1].max())

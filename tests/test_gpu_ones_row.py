@@ -23,7 +23,9 @@ def net(n_in, n_hidden, n_out=4):
 
 
 @pytest.mark.parametrize("dims", [(784, 512, 4096), (256, 96, 1000), (255, 128, 1024), (127, 200, 777), (128, 72, 520),
-                                  (512, 260, 2048), (100, 68, 16), (1024, 128, 4099)])
+                                  (512, 260, 2048), (100, 68, 16), (1024, 128, 4099),
+                                  # 64-row tiles: the virtual row alone in the second tile row, 32-deep k-tiles, uneven slices
+                                  (64, 512, 2048), (64, 96, 3000), (192, 512, 2050), (128, 136, 300)])
 def test_bias_gradient_as_the_last_row_of_the_weight_gradient(gpu_ctx, monkeypatch, dims):
     n_in, n_hidden, batch = dims
     monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", str(1 << 40))     # keep the contractions plain: this test is about the fold

@@ -351,3 +351,42 @@ def test_tail_tiles_are_cut_along_k(gpu_ctx, case):
     scale = max(np.abs(want).max(), 0.25 * np.sqrt(K) * 0.3)
     assert np.abs(outs[0] - want).max() <= TOL * scale
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("case", [
+    # 64 x 64 tiles with 32-deep k-tiles (one block per CU), whole and ragged in every direction
+    (1024, 1024, 1024, False, False, False, False), (1000, 1000, 1000, False, False, True, True),
+    (1000, 1000, 1000, True, False, False, False), (960, 1008, 1000, False, True, False, True),
+    (300, 700, 900, False, False, True, False), (1536, 1536, 300, True, True, False, False),
+    # slices planned in 16-deep k-tiles, run in 32-deep ones: no empty slice, no k counted twice
+    (64, 1000, 784, False, False, True, True), (128, 128, 4000, False, False, False, False),
+    # 64 x 64 tiles four per CU (16-deep k-tiles), several rounds
+    (2560, 2560, 256, False, False, False, True), (3000, 1500, 200, True, False, True, False),
+    # whole 256 x 256 tiles + remainder rows + remainder columns as contractions of their own, K ending inside a k-tile
+    (4100, 4100, 260, False, False, True, True), (4104, 4096, 100, True, False, False, False),
+    (4096, 4128, 72, False, True, True, False), (4100, 4100, 260, True, True, False, True),
+    # skinny outputs next to the wide-tile model's boundary
+    (8192, 128, 512, False, False, False, False), (100, 8192, 512, False, False, True, True), (65, 65, 5000, True, False, False, False)])
+def test_mid_size_and_remainder_contractions(gpu_ctx, case):
+    """The tile / slice choices of the calibrated time model (gemm_f32_mfma.hip: wide_tile_time) and the
+    remainder split of large ragged outputs, against a float64 product; two runs bit-identical."""
+    M, N, K, ta, tb, acc, bias = case
+    rng = np.random.default_rng(7 * M + 3 * N + K)
+    a = (rng.random((K, M) if ta else (M, K), dtype=np.float32) - 0.5).astype(np.float32)
+    b = (rng.random((N, K) if tb else (K, N), dtype=np.float32) - 0.5).astype(np.float32)
+    c0 = rng.random((M, N), dtype=np.float32) if acc else np.zeros((M, N), dtype=np.float32)
+    bv = (rng.random((N,), dtype=np.float32) - 0.5).astype(np.float32) if bias else None
+    want = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64) + c0
+    if bias:
+        want = want + bv
+    da, db = dev(gpu_ctx, a), dev(gpu_ctx, b)
+    dbias = dev(gpu_ctx, bv) if bias else None
+    outs = []
+    for _ in range(2):
+        dc = dev(gpu_ctx, c0)
+        ops.sgemm(gpu_ctx, M, N, K, da, a.shape[1], db, b.shape[1], dc, N, ta, tb, acc, dbias)
+        outs.append(dc.read())
+        dc.buffer.dealloc()
+    scale = max(np.abs(want).max(), 0.25 * np.sqrt(K) * 0.3)
+    assert np.abs(outs[0] - want).max() <= TOL * scale, case
+    assert np.array_equal(outs[0], outs[1])
