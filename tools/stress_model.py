@@ -174,7 +174,8 @@ def main():
     rng = np.random.default_rng(args.seed)
     scs = scenarios()
     t0 = time.time()
-    n_iter = n_bits = n_oracle = 0
+    n_iter = n_bits = n_oracle = n_det = 0
+    seen_det = set()
     toggles = {k: os.environ.get(k) for k in ("EG_POISON", "EG_NO_GRAPH", "EG_NO_OVERLAP", "EG_NO_ROWFUSE") if os.environ.get(k)}
     while time.time() - t0 < args.seconds:
         sc = scs[int(rng.integers(0, len(scs)))]
@@ -211,7 +212,19 @@ def main():
                         problems.append({"kind": "gpu-vs-oracle", "what": f"run {tag} update of param {t} at read {s}",
                                          "err": e, "bound": bound})
         n_bits += any(p["kind"] == "gpu-vs-gpu" for p in problems)
-        n_oracle += any(p["kind"] == "gpu-vs-oracle" for p in problems)
+        # A deviation from the oracle that both runs reproduce bit for bit is not what this harness hunts
+        # (races, stale arguments, uninitialised reads): it is either a defect the test suite's f64-shadow
+        # rule would catch in any single run, or a relu / max kink — a pre-activation within rounding
+        # distance of 0 flips sides with the summation order (softmax-2048, data seed 0: column 352 of the
+        # hidden layer, one sample in 2048).  Logged once per (scenario, seed), counted separately.
+        det_only = problems and all(p["kind"] == "gpu-vs-oracle" for p in problems)
+        if det_only:
+            n_det += 1
+            if (sc["name"], seed) in seen_det:
+                continue
+            seen_det.add((sc["name"], seed))
+        else:
+            n_oracle += any(p["kind"] == "gpu-vs-oracle" for p in problems)
         if problems:
             rec = {"iter": n_iter, "t": round(time.time() - t0, 1), "scenario": sc["name"], "seed": seed, "sync": sync,
                    "problems": problems, "plan": a["plan"], "toggles": toggles}
@@ -219,6 +232,7 @@ def main():
             log.flush()
             print("MISMATCH", json.dumps(rec)[:600], flush=True)
     summary = {"summary": True, "iterations": n_iter, "gpu_vs_gpu_mismatches": n_bits, "gpu_vs_oracle_mismatches": n_oracle,
+               "deterministic_deviations_from_oracle": n_det, "deterministic_deviation_cases": sorted(f"{a}/{b}" for a, b in seen_det),
                "seconds": round(time.time() - t0, 1), "seed": args.seed, "steps": args.steps, "toggles": toggles,
                "model_runs": 2 * n_iter}
     log.write(json.dumps(summary) + "\n")
