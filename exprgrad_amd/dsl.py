@@ -748,6 +748,10 @@ class Program:
                 for ins in (c[3] if len(c) > 3 else ()):
                     out.append(f"shapesetup {c[1]} " + _ins_text(ins))
         for name, tgt in self.targets.items():
+            # the text is whitespace-separated tokens: a tensor name loses its blanks (above), a target
+            # name is the key callers look the target up by and must survive the round trip unchanged
+            if not name or any(ch.isspace() for ch in name):
+                raise ValueError(f"target name {name!r}: empty or contains whitespace (kernel-description text is token based)")
             out.append(f"target {name} {tgt.output}")
             for k in tgt.kernels:
                 if k.generator:

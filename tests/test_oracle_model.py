@@ -128,3 +128,15 @@ def test_errors(refcpu):
         model.call("c", {"a": np.zeros((2, 2)), "b": np.zeros((2, 2)), "abc": np.zeros((2, 2))})
     with pytest.raises(kd.ShapeError):
         model.call("c", {"a": np.zeros((2, 2))})
+
+
+def test_names_survive_the_token_based_text():
+    """Kernel-description text is whitespace-separated tokens: blanks inside a tensor name are replaced, a
+    target name (the key `call` / `apply` look the target up by) with a blank is refused."""
+    import pytest
+    from exprgrad_amd import dsl, layers
+    net = layers.dense(dsl.input("my input"), 3, 2).target("predict")
+    text = refcases.program_text([net])
+    assert "my_input" in text and "my input" not in text
+    with pytest.raises(ValueError):
+        refcases.program_text([layers.dense(dsl.input("x"), 3, 2).target("pre dict")])
