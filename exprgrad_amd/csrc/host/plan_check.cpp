@@ -187,7 +187,8 @@ int check_plan(eg_model* m, TargetState& ts, Plan& plan) {
         EG_PLAN_REQUIRE(seen[p] == 0, "kernel %zu is both a storage-sharing copy and a launch", p);
         continue;
       }
-      EG_PLAN_REQUIRE(seen[p] == 1, "live kernel %zu is represented %d times in the launch list", p, seen[p]);
+      EG_PLAN_REQUIRE(seen[p] == 1, "live kernel %zu (lowered as %d, writes tensor %d, consumer %d) is represented %d times in the launch list",
+                      p, (int)lo.kind, k.write.tensor, lo.consumer, seen[p]);
     }
   }
   EG_PLAN_REQUIRE(plan.n_backward >= 0 && plan.n_backward <= n, "backward | update boundary %d outside [0, %d]", plan.n_backward, n);

@@ -38,7 +38,10 @@ int fuse_epilogues(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
       for (auto& rd : kx.reads)
         if (rd.tensor == G.c_tensor) reads_c = true;
       if (reads_c) {
-        found = X.kind == StepKind::GenericA;
+        // (a launch that already carries an inlined consumer of its own stays as it is: the epilogue is
+        // generated from ONE kernel, the second one would be lost — plan invariant 1 caught exactly that
+        // under EG_NO_ROWFUSE, tests/test_gpu_fuzz.py chain 21)
+        found = X.kind == StepKind::GenericA && X.consumer < 0;
         break;
       }
     }

@@ -133,3 +133,24 @@ def test_first_k_tile_waits_for_every_waves_loads(gpu_ctx, monkeypatch, dims):
         m.close()
         bad = np.argwhere(np.abs(got - want) > 1e-5)
         assert len(bad) == 0, (trial, len(bad), bad[:, 0].min(), bad[:, 0].max(), bad[:, 1].min(), bad[:, 1].max())
+
+
+def test_consumer_with_an_inlined_consumer_is_not_taken_as_epilogue(gpu_ctx, monkeypatch):
+    """dense -> map -> map on tensors too wide for row fusion: the first map carries the second one as an
+    inlined consumer (lower.cpp inline_consumers); fusing that launch into the contraction as its epilogue
+    used to drop the second map (seen under EG_NO_ROWFUSE as a violation of plan invariant 1)."""
+    def graphs():
+        net = layers.dense(dsl.input("x"), 130, 96)
+        net = layers.sigmoid(layers.tanh(net))
+        net = layers.dense(net, 96, 8).target("predict")
+        net = layers.mse(net, dsl.input("y")).target("loss")
+        return [net.backprop(layers.gradient_descent(0.05)).target("train")]
+
+    t = trio(gpu_ctx, monkeypatch, 0, graphs, 0.3)
+    rng = np.random.default_rng(77)
+    x = (rng.random((300, 130), dtype=np.float32) - 0.5).astype(np.float32)
+    y = rng.random((300, 8), dtype=np.float32)
+    t.call("predict", {"x": x}, n=130)
+    for _ in range(3):
+        t.step("train", {"x": x, "y": y}, n=300)
+    t.close()

@@ -7,6 +7,8 @@ the batch are formed half + half), and run-to-run determinism."""
 import numpy as np
 import pytest
 
+from conftest import debug_toggles_active
+
 import refcases
 from exprgrad_amd import dsl, layers
 from exprgrad_amd import model as egm
@@ -50,7 +52,8 @@ def test_pipelined_step_matches_the_oracle(gpu_ctx, monkeypatch, case):
     plan = t.gpu.launch_plan("train")
     # nets whose backward range holds a launch that cannot be cut (here: the map kernels of an 8-wide last
     # layer, too small for an epilogue) keep the plain plan; the others must be pipelined
-    assert ("batch pipeline" in plan) == (name != "mlp3"), plan
+    if not debug_toggles_active():      # (without row fusion the softmax chain is not pipelinable)
+        assert ("batch pipeline" in plan) == (name != "mlp3"), plan
     t.close()
 
 
@@ -74,7 +77,8 @@ def test_pipelined_and_plain_plans_agree_and_repeat(gpu_ctx, monkeypatch):
             gpu.params[tid] = (prng.random(gpu.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
         for _ in range(4):
             gpu.apply("train", {"x": x, "y": y})
-        assert ("batch pipeline" in gpu.launch_plan("train")) == (mode == "pipe")
+        if not debug_toggles_active():
+            assert ("batch pipeline" in gpu.launch_plan("train")) == (mode == "pipe")
         results.append({t: gpu.params[t] for t in gpu.params.ids()})
         gpu.close()
     for t in results[0]:
