@@ -428,8 +428,16 @@ __device__ __forceinline__ void dma_publish_barrier() {
   __syncthreads();
 }
 
-template <int BMN, int BK, int NT, bool KC, bool CONV, bool CLAMP = false>
+// KCLAMP = false (with CLAMP, plain operands): the k-tiles this loader is asked for are whole — only rows / columns
+// are clamped, and those do not change from k-tile to k-tile: the clamped element offset of every chunk is
+// computed once (init) and issue() adds k0 like the interior loader does, so the compiler turns it into the
+// same pointer bumps.  (Clamping inside issue() is ~60 VALU instructions with two 64-bit multiplies per
+// k-tile, in FRONT of the fragment reads: a ragged tile that is alone on its CU ran ~25 % slower per k-tile.)
+template <int BMN, int BK, int NT, bool KC, bool CONV, bool CLAMP = false, bool KCLAMP = CLAMP>
 struct DmaLoader {
+  static constexpr bool FIXED = CLAMP && !KCLAMP && !CONV;  // precomputed clamped offsets
+  unsigned virtual_row = 0;  // FIXED: bit t = chunk t of this lane is (the start of) the virtual row of ones
+
   static constexpr int INSTRS = BK * BMN / 256;  // 1 KiB wave instructions per tile
   static constexpr int WAVES = NT / 64;
   static constexpr int PER_WAVE = (INSTRS + WAVES - 1) / WAVES;
@@ -439,7 +447,26 @@ struct DmaLoader {
 
   __device__ __forceinline__ static int swizzle(int r) { return BK == 16 ? (r >> 2) & 3 : (r >> 1) & 7; }
 
-  __device__ __forceinline__ void init(const GemmArgs& a, long mn0, int wave, int lane, long limit = 0) {
+  __device__ __forceinline__ void init(const GemmArgs& a, long mn0, int wave, int lane, long limit = 0, long ld = 0,
+                                       bool ones = false) {
+    if (FIXED) {
+#pragma unroll
+      for (int t = 0; t < PER_WAVE; ++t) {
+        const int q = (wave + t * WAVES) * 64 + lane;
+        if (KC) {
+          const int r = q / CHUNKS, slot = q % CHUNKS;
+          const int c = slot ^ swizzle(r);
+          row_off[t] = min(mn0 + r, limit - 1) * ld + c * 4;
+          if (ones && mn0 + r == limit) virtual_row |= 1u << t;
+        } else {
+          constexpr int CPR = BMN / 4;
+          const int k = q / CPR, col = (q % CPR) * 4;
+          row_off[t] = (long)k * ld + min(mn0 + col, limit - 4);
+          if (ones && mn0 + col == limit) virtual_row |= 1u << t;
+        }
+      }
+      return;
+    }
     if (CONV && KC) {
 #pragma unroll
       for (int t = 0; t < PER_WAVE; ++t) {
@@ -482,7 +509,10 @@ struct DmaLoader {
       if (INSTRS % WAVES != 0 && instr >= INSTRS) break;
       const int q = instr * 64 + lane;  // 16-byte chunk index inside the tile
       const float* src;
-      if (KC) {
+      if (FIXED) {
+        src = base + row_off[t] + (KC ? k0 : k0 * ld);
+        if (ones && (virtual_row >> t & 1)) src = KC ? ones : ones + 4;  // {1,1,1,1} / {1,0,0,0}: 1 for every k
+      } else if (KC) {
         const int r = q / CHUNKS, slot = q % CHUNKS;
         const int c = slot ^ swizzle(r);
         if (CONV)
@@ -510,7 +540,7 @@ struct DmaLoader {
   }
 };
 
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int CONV, bool CL = false, bool IL = !CL>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int CONV, bool CL = false, bool IL = !CL, bool KCL = CL>
 __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32],
                                                   long m_blk, long n_blk, long k_begin, int nk, int tid, int wm0,
                                                   int wn0, long k_end = 0) {
@@ -518,8 +548,9 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int BUF = BK * (BM + BN);
-  using DmaA = DmaLoader<BM, BK, NT, A_KC, CONV == 1, CL>;
-  using DmaB = DmaLoader<BN, BK, NT, B_KC, CONV == 2, CL>;
+  // KCL: the k range may end inside a k-tile (clamped k, zeroed tail); CL && !KCL: whole k-tiles of a ragged tile
+  using DmaA = DmaLoader<BM, BK, NT, A_KC, CONV == 1, CL, KCL>;
+  using DmaB = DmaLoader<BN, BK, NT, B_KC, CONV == 2, CL, KCL>;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, hi = lane >> 5;
   // IL: interleaved accumulator rows / columns (see Interleaved).  The clamped loop runs blocked for tiles
@@ -541,14 +572,14 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
 
   DmaA da;
   DmaB db;
-  da.init(a, m_blk, wave, lane, a.a_rows);
-  db.init(a, n_blk, wave, lane, a.N);
+  da.init(a, m_blk, wave, lane, a.a_rows, a.lda, CL && a.ones_row);
+  db.init(a, n_blk, wave, lane, a.N, a.ldb);
   const float* ones = CL && a.ones_row ? a.ones : nullptr;  // (ragged loop only: a tile with the virtual row is never interior)
   if (nk > 0) {
     da.issue(a, a.A, a.lda, m_blk, k_begin, lds, wave, lane, a.a_rows, k_end, ones);
     db.issue(a, a.B, a.ldb, n_blk, k_begin, lds + BK * BM, wave, lane, a.N, k_end);
   }
-  const int k_tail = CL ? (int)((k_end - k_begin) % BK) : 0;  // valid k of a ragged last k-tile (0 = full)
+  const int k_tail = KCL ? (int)((k_end - k_begin) % BK) : 0;  // valid k of a ragged last k-tile (0 = full)
   dma_publish_barrier();
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -559,7 +590,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
       da.issue(a, a.A, a.lda, m_blk, k0, nxt, wave, lane, a.a_rows, k_end, ones);
       db.issue(a, a.B, a.ldb, n_blk, k0, nxt + BK * BM, wave, lane, a.N, k_end);
     }
-    if (CL && k_tail != 0 && kt == nk - 1) {
+    if (KCL && k_tail != 0 && kt == nk - 1) {
       // ragged end of K: the loaders re-read the last valid k for the missing ones; zero them on
       // the A side so they contribute nothing
       float* At = lds + cur * BUF;
@@ -743,9 +774,21 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
       }
       done = true;
     } else if (CONV != 1) {
-      // ragged in M or N (and maybe K): still the LDS-DMA loop, with clamped addresses and a zeroed K tail
-      gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, true>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0,
-                                                                      k_end);
+      // ragged in M or N (and maybe K): still the LDS-DMA loop, with clamped addresses and a zeroed K tail.
+      // Plain operands: the whole k-tiles on the loader with precomputed clamped offsets, the last, partial
+      // one (if any) on the loader that clamps k as well.
+      if constexpr (CONV == 0) {
+        const int n_whole = nk <= 0 ? 0 : (whole_k ? nk : nk - 1);
+        if (n_whole > 0)
+          gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, true, false, false>(a, lds, acc, m_blk, n_blk, k_begin, n_whole, tid,
+                                                                                       wm0, wn0, k_end);
+        if (n_whole < nk)
+          gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, true, false, true>(a, lds, acc, m_blk, n_blk,
+                                                                                      k_begin + (long)n_whole * BK, 1, tid, wm0, wn0, k_end);
+      } else {
+        gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, true>(a, lds, acc, m_blk, n_blk, k_begin, nk, tid, wm0, wn0,
+                                                                        k_end);
+      }
       done = true;
     }
   }
