@@ -666,7 +666,11 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni)
-            if (!CL || (live >> (mi * NI + ni) & 1))
+            // A wave with ONE block (64 x 64, 128 x 32 tiles) multiplies unconditionally: a test per MFMA is a scalar
+            // branch per MFMA, with the fragment reads stuck in front of it — a ragged tile's waves ran ~25 % slower
+            // per k-tile than an interior tile's, and a launch is as slow as its slowest block.  What a wave outside
+            // the problem accumulates (clamped re-reads of valid data) is never stored.
+            if (!CL || MI * NI == 1 || (live >> (mi * NI + ni) & 1))
               acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
     }
     dma_publish_barrier();  // the next k-tile's loads (issued above) have landed; this stage is free for the one after
