@@ -154,3 +154,45 @@ def test_consumer_with_an_inlined_consumer_is_not_taken_as_epilogue(gpu_ctx, mon
     for _ in range(3):
         t.step("train", {"x": x, "y": y}, n=300)
     t.close()
+
+
+def test_generated_kernels_wait_for_their_lds_dma_before_the_barrier(gpu_ctx, monkeypatch, tmp_path):
+    """The same property at the instruction level, independent of timing luck: in the code object hiprtc
+    builds for a generated-epilogue contraction, no `s_barrier` follows a `global_load_lds` without an
+    `s_waitcnt vmcnt(0)` in between (fall-through order; the K loop issues, computes, waits, then synchronises).
+    The build that multiplied stale tiles had `s_barrier` first and the wait behind it — produced by the hiprtc
+    the process resolves at run time (the one bundled with PyTorch-ROCm 7.0), not by /opt/rocm's 7.2, whose
+    output has the wait in front of the barrier with or without the explicit one: the order is a compiler's
+    choice, which is why the kernel spells it out."""
+    import os
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("no llvm-objdump")
+    monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", "0")
+    monkeypatch.setenv("EG_DUMP_CODE", str(tmp_path))
+    checked = 0
+    for k, n, batch in [(16, 128, 2048), (20, 96, 1500), (784, 512, 4096)]:   # whole tiles; ragged M, N, K; the 256 x 256 tile
+        m = egm.compile(layers.tanh(layers.dense(dsl.input("x"), k, n)).target("predict"), gpu=gpu_ctx)
+        m.call("predict", {"x": np.zeros((batch, k), dtype=np.float32)})
+        assert "gemm+epilogue" in m.launch_plan("predict")
+        m.close()
+        for name in sorted(os.listdir(tmp_path)):
+            if not name.startswith("eg_gemm_epi") or not name.endswith(".co"):
+                continue
+            text = subprocess.run([objdump, "-d", os.path.join(tmp_path, name)], capture_output=True, text=True, check=True).stdout
+            os.remove(os.path.join(tmp_path, name))
+            pending, loads = False, 0
+            for line in text.splitlines():
+                ins = line.split()[0] if line.split() else ""
+                if "global_load_lds" in line:
+                    pending, loads = True, loads + 1
+                elif ins == "s_waitcnt" and "vmcnt(0)" in line:
+                    pending = False
+                elif ins in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                    pending = False     # what follows in the layout is not reached by falling through
+                elif ins == "s_barrier":
+                    assert not pending, (name, "s_barrier with an LDS-DMA load not waited for", line.strip())
+            assert loads > 0, name      # the LDS-DMA loop is what this test is about
+            checked += 1
+    assert checked >= 3

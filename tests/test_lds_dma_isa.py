@@ -1,0 +1,101 @@
+"""Instruction-level check of the LDS-DMA publish barrier, without a GPU.
+
+The generated-epilogue contractions are compiled at run time by whatever hiprtc the process resolves — inside a
+PyTorch-ROCm process that is the one bundled with torch (ROCm 7.0 here), not /opt/rocm's (7.2).  The two differ in
+where they put the `s_waitcnt vmcnt(0)` that must precede the barrier publishing a `global_load_lds` tile: the
+bundled one used to put it BEHIND the barrier (stale tiles, the rare wrong update of round 1); the kernel header now
+spells the wait out (`dma_publish_barrier`).  This test compiles the header with the bundled hiprtc (compilation needs
+no device) and scans the disassembly: no `s_barrier` may follow a `global_load_lds` in fall-through order without an
+`s_waitcnt vmcnt(0)` in between.  Checked against the header of commit 999e7c5 by hand: 1 and 3 violations there."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+EPILOGUE = """
+struct EgEpi {
+  static constexpr bool ACTIVE = true;
+  static constexpr int NX = 1;
+  static constexpr bool STORE_C = false;
+  static constexpr int OUT = 0;
+  __device__ __forceinline__ static void prefetch(const eg::gemm::GemmArgs&, long, float (&)[1]) {}
+  __device__ __forceinline__ static void prefetch4(const eg::gemm::GemmArgs&, long, eg::gemm::f32x4 (&)[1]) {}
+  __device__ __forceinline__ static float compute(const eg::gemm::GemmArgs&, long, float v, const float (&)[1]) {
+    return v > 0.0f ? v : 0.0f;
+  }
+};
+extern "C" __global__ __launch_bounds__(%(nt)d, %(waves)d) void k(eg::gemm::GemmArgs a) {
+  eg::gemm::gemm_block<%(bm)d, %(bn)d, 16, %(wm)d, %(wn)d, %(akc)s, false, 4, %(edge)s, false, 0, true, EgEpi>(a);
+}
+"""
+
+
+def bundled_hiprtc():
+    try:
+        import torch
+    except Exception:  # noqa: BLE001
+        return None
+    lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    rtc, comgr = os.path.join(lib, "libhiprtc.so"), os.path.join(lib, "libamd_comgr.so")
+    if not (os.path.exists(rtc) and os.path.exists(comgr)):
+        return None
+    ctypes.CDLL(comgr, mode=ctypes.RTLD_GLOBAL)
+    return ctypes.CDLL(rtc)
+
+
+def compile_to_isa(rtc, source, tmp_path):
+    prog = ctypes.c_void_p()
+    assert rtc.hiprtcCreateProgram(ctypes.byref(prog), source.encode(), b"k", 0, None, None) == 0
+    opts = [b"--offload-arch=gfx950", b"-O3", b"-ffp-contract=off", b"-std=c++17"]      # runtime.cpp: kernels_compile_batch
+    status = rtc.hiprtcCompileProgram(prog, len(opts), (ctypes.c_char_p * len(opts))(*opts))
+    if status != 0:
+        n = ctypes.c_size_t()
+        rtc.hiprtcGetProgramLogSize(prog, ctypes.byref(n))
+        log = ctypes.create_string_buffer(n.value)
+        rtc.hiprtcGetProgramLog(prog, log)
+        raise AssertionError(log.value.decode()[-3000:])
+    n = ctypes.c_size_t()
+    rtc.hiprtcGetCodeSize(prog, ctypes.byref(n))
+    code = ctypes.create_string_buffer(n.value)
+    rtc.hiprtcGetCode(prog, code)
+    path = os.path.join(tmp_path, "k.co")
+    with open(path, "wb") as f:
+        f.write(code.raw)
+    return subprocess.run([OBJDUMP, "-d", path], capture_output=True, text=True, check=True).stdout
+
+
+def unpublished_barriers(isa):
+    pending, loads, bad = False, 0, []
+    for line in isa.splitlines():
+        ins = line.split()[0] if line.split() else ""
+        if "global_load_lds" in line:
+            pending, loads = True, loads + 1
+        elif ins == "s_waitcnt" and "vmcnt(0)" in line:
+            pending = False
+        elif ins in ("s_branch", "s_endpgm", "s_setpc_b64"):
+            pending = False     # what follows in the layout is not reached by falling through
+        elif ins == "s_barrier" and pending:
+            bad.append(line.strip())
+            pending = False
+    return loads, bad
+
+
+@pytest.mark.parametrize("variant", [
+    dict(bm=64, bn=64, wm=32, wn=32, nt=256, waves=4, akc="true", edge="false"),
+    dict(bm=64, bn=64, wm=32, wn=32, nt=256, waves=3, akc="true", edge="true"),
+    dict(bm=256, bn=256, wm=128, wn=64, nt=512, waves=2, akc="false", edge="true"),
+], ids=["64x64-whole", "64x64-ragged", "256x256-ragged-tn"])
+def test_every_barrier_after_an_lds_dma_load_is_preceded_by_its_wait(variant, tmp_path):
+    rtc = bundled_hiprtc()
+    if rtc is None or not os.path.exists(OBJDUMP):
+        pytest.skip("no bundled hiprtc / llvm-objdump")
+    with open(os.path.join(ROOT, "exprgrad_amd", "csrc", "kernels", "gemm_f32_mfma.hpp")) as f:
+        header = f.read()
+    isa = compile_to_isa(rtc, header + EPILOGUE % variant, str(tmp_path))
+    loads, bad = unpublished_barriers(isa)
+    assert loads >= 4, loads            # the LDS-DMA loops are in there
+    assert not bad, bad
