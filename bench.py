@@ -394,15 +394,28 @@ def build_dense(env, batch):
         import torch.distributed as dist
         from exprgrad_amd.parallel import NativeDataParallel, RcclGroup
         ok, group = 1, None
+        # ncclCommInitRank blocks until every rank has joined: a rank that cannot even load RCCL must be found
+        # BEFORE anyone enters it.  Probe on every rank (dlopen + ncclGetUniqueId, no communication), agree, then init.
         try:
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-            if env["rank"] == 0:
-                uid.copy_(torch.frombuffer(bytearray(RcclGroup.unique_id()), dtype=torch.uint8))
-            dist.broadcast(uid, 0)
-            group = RcclGroup(env["ctx"], bytes(uid.cpu().numpy().tobytes()), env["rank"], env["world"])
+            own_id = RcclGroup.unique_id()
         except Exception as exc:  # noqa: BLE001
-            ok = 0
+            ok, own_id = 0, None
             env["dp_fallback_reason"] = repr(exc)
+        probe = torch.tensor([ok], device="cuda", dtype=torch.int32)
+        dist.all_reduce(probe, op=dist.ReduceOp.MIN)
+        if int(probe.item()) == 1:
+            try:
+                uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+                if env["rank"] == 0:
+                    uid.copy_(torch.frombuffer(bytearray(own_id), dtype=torch.uint8))
+                dist.broadcast(uid, 0)
+                group = RcclGroup(env["ctx"], bytes(uid.cpu().numpy().tobytes()), env["rank"], env["world"])
+            except Exception as exc:  # noqa: BLE001
+                ok = 0
+                env["dp_fallback_reason"] = repr(exc)
+        else:
+            ok = 0
+            env.setdefault("dp_fallback_reason", "another rank could not load RCCL")
         flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
