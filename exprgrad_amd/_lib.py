@@ -41,6 +41,8 @@ _SIGS = {
     "eg_device_count": (c_int, [P(c_int)]),
     "eg_device_info": (c_int, [c_int, c_char_p, c_size_t, c_char_p, c_size_t, c_char_p, c_size_t, P(c_int)]),
     "eg_device_props": (c_int, [c_int, P(c_int), P(c_int), P(c_i64), c_char_p, c_size_t]),
+    "eg_compiler_info": (c_int, [c_char_p, c_size_t]),
+    "eg_kernel_cache_stats": (c_int, [P(c_i64), P(c_i64), P(ctypes.c_double)]),
     "eg_ctx_create": (c_int, [c_int, P(c_void_p)]),
     "eg_ctx_create_on_stream": (c_int, [c_int, c_void_p, P(c_void_p)]),
     "eg_ctx_destroy": (c_int, [c_void_p]),

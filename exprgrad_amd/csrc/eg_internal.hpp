@@ -91,6 +91,12 @@ int copy_h2d(eg_ctx* ctx, void* device, const void* host, size_t bytes);
 int copy_d2h(eg_ctx* ctx, void* host, const void* device, size_t bytes);
 // EG_POISON=1: scratch and to-be-overwritten result storage is filled with NaN patterns before use.
 bool poison_enabled();
+namespace rtc {
+// Source text -> code object through the library's own hiprtc (rtc.cpp), cached on disk.
+int compile(const char* label, const char* source, const std::string& arch, std::vector<char>& code);
+std::string compiler_info();
+}  // namespace rtc
+
 // Build several kernels (extern "C" names) from one source text in a single hiprtc program.
 int kernels_compile_batch(eg_ctx* ctx, const char* label, const char* source, const std::vector<std::string>& names,
                           std::vector<eg_kernel*>& out);

@@ -648,8 +648,9 @@ extern "C" int eg_sgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_
   args.accumulate = accumulate;
   // 16-byte global loads need every row start and every chunk 16-byte aligned and whole.
   const long a_contig = a_kc ? K : M, b_contig = b_kc ? K : N;
-  const bool vec_a = (lda % 4 == 0) && (a_contig % 4 == 0) && (A == nullptr || aligned16(A));
-  const bool vec_b = (ldb % 4 == 0) && (b_contig % 4 == 0) && (B == nullptr || aligned16(B));
+  // (the LDS-DMA loaders address a tile with 32-bit byte offsets from its origin: 256 rows x ld x 4 bytes < 2^31)
+  const bool vec_a = (lda % 4 == 0) && (a_contig % 4 == 0) && (A == nullptr || aligned16(A)) && lda < (1L << 21);
+  const bool vec_b = (ldb % 4 == 0) && (b_contig % 4 == 0) && (B == nullptr || aligned16(B)) && ldb < (1L << 21);
   static const bool no_mixed = getenv("EG_GEMM_NO_MIXED_VEC") != nullptr;
   return run_gemm(ctx, a_kc, b_kc, args, /*conv=*/0, vec_a && vec_b, vec_a && !vec_b && !no_mixed);
 }
@@ -664,8 +665,8 @@ namespace gemm {
 bool ones_row_supported(int trans_a, int trans_b, long M, long N, long K, const float* A, long lda, const float* B, long ldb) {
   const bool a_kc = !trans_a, b_kc = trans_b != 0;
   const long a_contig = a_kc ? K : M, b_contig = b_kc ? K : N;
-  const bool vec_a = (lda % 4 == 0) && (a_contig % 4 == 0) && aligned16(A);
-  const bool vec_b = (ldb % 4 == 0) && (b_contig % 4 == 0) && aligned16(B);
+  const bool vec_a = (lda % 4 == 0) && (a_contig % 4 == 0) && aligned16(A) && lda < (1L << 21);
+  const bool vec_b = (ldb % 4 == 0) && (b_contig % 4 == 0) && aligned16(B) && ldb < (1L << 21);
   // large enough for the matrix-core path (not the one-wave-per-output kernel) and at least one k-tile
   const char* off = getenv("EG_NO_ONES_ROW");
   return vec_a && vec_b && K >= 16 && !((M + 1) * N <= 16384 && K <= 2048) && !(off && off[0] && off[0] != '0');
@@ -946,7 +947,7 @@ int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, co
   out.b_kc = b_kc;
   const long a_contig = a_kc ? K : M, b_contig = b_kc ? K : N;
   const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (a_contig % 4 == 0) && (b_contig % 4 == 0) && aligned16(A) &&
-                   aligned16(B);
+                   aligned16(B) && lda < (1L << 21) && ldb < (1L << 21);
   out.edge = !(vec && M % bm == 0 && N % bn == 0 && K % BK == 0 && K > 0);
   out.vec = (!out.edge || vec) ? 4 : 1;
   out.dma = out.vec == 4;

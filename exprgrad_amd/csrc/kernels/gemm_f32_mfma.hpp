@@ -294,7 +294,7 @@ struct Geometry {
 // K loop of one block.  E = predicate every global load against the problem edges.
 // ABL (tuning harness only; the library always instantiates 0): bit 0 = no LDS fragment reads in
 // the k loop, bit 1 = no global loads / LDS stores after the first tile, bit 2 = no barriers,
-// bit 3 = no LDS stores only, bit 4 = no global loads only.
+// bit 3 = no LDS stores only, bit 4 = no global loads only, bit 6 = software-pipelined LDS-DMA loop (bits 0-2 ablate its reads / DMA / barriers).
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int VEC, bool E, int CONV, int ABL>
 __device__ __forceinline__ void gemm_mainloop(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32], long m_blk,
                                               long n_blk, long k_begin, long k_end, int nk, int tid, int wm0, int wn0) {
@@ -436,7 +436,17 @@ __device__ __forceinline__ void dma_publish_barrier() {
 template <int BMN, int BK, int NT, bool KC, bool CONV, bool CLAMP = false, bool KCLAMP = CLAMP>
 struct DmaLoader {
   static constexpr bool FIXED = CLAMP && !KCLAMP && !CONV;  // precomputed clamped offsets
+  // Plain operands whose k-tiles are whole go through `buffer_load_dwordx4 ... lds` (MUBUF) instead of
+  // `global_load_lds_dwordx4` (FLAT): the descriptor's base is the tile's origin (scalar, bumped per k-tile), the
+  // per-lane part is a 32-bit byte offset computed ONCE (no 64-bit vector adds per k-tile), and — what the
+  // software-pipelined loop needs — the compiler's wait-count pass treats a pending FLAT LDS-DMA as touching both
+  // counters and turns every `s_waitcnt lgkmcnt(n)` into lgkmcnt(0) while one is in flight, i.e. a wave could never
+  // wait for its older fragment reads only.  The host keeps leading dimensions below 2^21 floats on this path.
+  static constexpr bool BUFD = !CONV && !(CLAMP && KCLAMP);
   unsigned virtual_row = 0;  // FIXED: bit t = chunk t of this lane is (the start of) the virtual row of ones
+  unsigned voff[(BK * BMN / 256 + NT / 64 - 1) / (NT / 64)];  // BUFD: byte offset of chunk t from the tile origin
+  long mn_base = 0;  // BUFD: row / column of the tile origin: mn0, or the last valid row / chunk when the tile starts past the
+                     // end (the virtual row of ones as the first row of a tile of its own) — offsets must not be negative
 
   static constexpr int INSTRS = BK * BMN / 256;  // 1 KiB wave instructions per tile
   static constexpr int WAVES = NT / 64;
@@ -449,20 +459,23 @@ struct DmaLoader {
 
   __device__ __forceinline__ void init(const GemmArgs& a, long mn0, int wave, int lane, long limit = 0, long ld = 0,
                                        bool ones = false) {
-    if (FIXED) {
+    if (BUFD) {
+      mn_base = FIXED ? min(mn0, KC ? limit - 1 : limit - 4) : mn0;
 #pragma unroll
       for (int t = 0; t < PER_WAVE; ++t) {
         const int q = (wave + t * WAVES) * 64 + lane;
         if (KC) {
           const int r = q / CHUNKS, slot = q % CHUNKS;
           const int c = slot ^ swizzle(r);
-          row_off[t] = min(mn0 + r, limit - 1) * ld + c * 4;
-          if (ones && mn0 + r == limit) virtual_row |= 1u << t;
+          const long row = FIXED ? min(mn0 + r, limit - 1) - mn_base : (long)r;  // rows past the end re-read the last one
+          voff[t] = (unsigned)((row * ld + c * 4) * 4);
+          if (FIXED && ones && mn0 + r == limit) virtual_row |= 1u << t;
         } else {
           constexpr int CPR = BMN / 4;
           const int k = q / CPR, col = (q % CPR) * 4;
-          row_off[t] = (long)k * ld + min(mn0 + col, limit - 4);
-          if (ones && mn0 + col == limit) virtual_row |= 1u << t;
+          const long cc = FIXED ? min(mn0 + col, limit - 4) - mn_base : (long)col;  // columns past the end: the last chunk
+          voff[t] = (unsigned)(((long)k * ld + cc) * 4);
+          if (FIXED && ones && mn0 + col == limit) virtual_row |= 1u << t;
         }
       }
       return;
@@ -493,10 +506,55 @@ struct DmaLoader {
     }
   }
 
+  // BUFD: wave instruction t (0 .. PER_WAVE - 1) of this wave's share alone — the pipelined loop spreads a tile's loads
+  // over an MFMA group instead of issuing them back to back (a wave that sits in the memory pipeline's issue queue
+  // behind the other waves' loads cannot issue its MFMAs: every wave of the block did that right after the barrier).
+  __device__ __forceinline__ void issue_one(int t, const float* __restrict__ base, long ld, long mn0, long k0, float* tile,
+                                            int wave, const float* ones = nullptr) const {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)
+    const int instr = wave + t * WAVES;
+    if (INSTRS % WAVES != 0 && instr >= INSTRS) return;
+    const float* origin = base + (KC ? mn_base * ld + k0 : k0 * ld + mn_base);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(origin), (short)0, -1, 0x00020000);
+    __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(tile + instr * 256);
+    if (FIXED && ones) {
+      const __amdgpu_buffer_rsrc_t one = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ones), (short)0, 32, 0x00020000);
+      if (virtual_row >> t & 1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(one, dst, 16, KC ? 0 : 16, 0, 0, 0);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff[t], 0, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff[t], 0, 0, 0);
+    }
+#endif
+  }
+
   // issue this wave's share of the tile whose origin is (mn0, k0) into `tile` (LDS, lane-linear)
   __device__ __forceinline__ void issue(const GemmArgs& a, const float* __restrict__ base, long ld, long mn0, long k0,
                                         float* tile, int wave, int lane, long limit = 0, long k_lim = 0,
                                         const float* ones = nullptr) const {
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)  // (the host pass of an offline build knows no buffer-resource type)
+    if constexpr (BUFD) {
+      const float* origin = base + (KC ? mn_base * ld + k0 : k0 * ld + mn_base);  // block-uniform: scalar registers
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(origin), (short)0, -1, 0x00020000);
+#pragma unroll
+      for (int t = 0; t < PER_WAVE; ++t) {
+        const int instr = wave + t * WAVES;
+        if (INSTRS % WAVES != 0 && instr >= INSTRS) break;
+        __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(tile + instr * 256);
+        if (FIXED && ones) {  // (block-uniform) a tile with the virtual row of ones: those lanes fetch {1,1,1,1} / {1,0,0,0}
+          const __amdgpu_buffer_rsrc_t one = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ones), (short)0, 32, 0x00020000);
+          if (virtual_row >> t & 1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(one, dst, 16, KC ? 0 : 16, 0, 0, 0);
+          else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff[t], 0, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff[t], 0, 0, 0);
+        }
+      }
+      return;
+    }
+#endif
     long tap_off = 0;
     if (CONV && KC) {  // block-uniform: scalar work
       const unsigned C = (unsigned)a.cC, FW = (unsigned)a.cFW;
@@ -540,7 +598,8 @@ struct DmaLoader {
   }
 };
 
-template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int CONV, bool CL = false, bool IL = !CL, bool KCL = CL>
+template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int CONV, bool CL = false, bool IL = !CL, bool KCL = CL,
+          int ABL = 0>
 __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32],
                                                   long m_blk, long n_blk, long k_begin, int nk, int tid, int wm0,
                                                   int wn0, long k_end = 0) {
@@ -582,6 +641,167 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
   const int k_tail = KCL ? (int)((k_end - k_begin) % BK) : 0;  // valid k of a ragged last k-tile (0 = full)
   dma_publish_barrier();
 
+  // Fragments of k-group pp (8 k) of the tile at As: av[mi][j] / bv[ni][j] = this lane's A / B value of block mi / ni for
+  // MFMA k-step j (k = 8 pp + j in lanes 0-31, 8 pp + 4 + j in lanes 32-63).
+  auto fragments = [&](const float* As, int pp, float (&av)[MI][4], float (&bv)[NI][4]) {
+    const float* Bs = As + BK * BM;
+    if constexpr (AIL) {  // one 8- or 16-byte read per k brings this lane's value for every block
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        typedef float vecA __attribute__((ext_vector_type(MI)));
+        const vecA v = *reinterpret_cast<const vecA*>(As + (8 * pp + j + 4 * hi) * BM + wm0 + MI * i);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) av[mi][j] = v[mi];
+      }
+    }
+    if constexpr (BIL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        typedef float vecB __attribute__((ext_vector_type(NI)));
+        const vecB v = *reinterpret_cast<const vecB*>(Bs + (8 * pp + j + 4 * hi) * BN + wn0 + NI * i);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bv[ni][j] = v[ni];
+      }
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      if (AIL) break;
+      const int row = wm0 + mi * 32 + i;
+      if (A_KC) {
+        const int slot = (2 * pp + hi) ^ DmaA::swizzle(row);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(As + row * BK + slot * 4);
+        av[mi][0] = v[0];
+        av[mi][1] = v[1];
+        av[mi][2] = v[2];
+        av[mi][3] = v[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) av[mi][j] = As[(8 * pp + j + 4 * hi) * BM + row];
+      }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      if (BIL) break;
+      const int col = wn0 + ni * 32 + i;
+      if (B_KC) {
+        const int slot = (2 * pp + hi) ^ DmaB::swizzle(col);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + col * BK + slot * 4);
+        bv[ni][0] = v[0];
+        bv[ni][1] = v[1];
+        bv[ni][2] = v[2];
+        bv[ni][3] = v[3];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[ni][j] = Bs[(8 * pp + j + 4 * hi) * BN + col];
+      }
+    }
+  };
+  auto multiply_step = [&](const float (&av)[MI][4], const float (&bv)[NI][4], int j) {  // MFMA k-step j of a k-group
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+        if (!CL || MI * NI == 1 || (live >> (mi * NI + ni) & 1))
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+  };
+  auto multiply = [&](const float (&av)[MI][4], const float (&bv)[NI][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          // A wave with ONE block (64 x 64, 128 x 32 tiles) multiplies unconditionally: a test per MFMA is a scalar
+          // branch per MFMA, with the fragment reads stuck in front of it — a ragged tile's waves ran ~25 % slower
+          // per k-tile than an interior tile's, and a launch is as slow as its slowest block.  What a wave outside
+          // the problem accumulates (clamped re-reads of valid data) is never stored.
+          if (!CL || MI * NI == 1 || (live >> (mi * NI + ni) & 1))
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+  };
+
+  if constexpr (!KCL && (ABL & 64)) {
+    // ---- software-pipelined loop (round 3; tuning harness only, ABL bit 6 — measured EQUAL to the straight loop, see below).  The straight loop below reads the fragments of a k-group and then
+    // multiplies them; the compiler keeps that order, so every wave of the block asks LDS for its fragments at
+    // the same moments (right after the barrier, and once per k-group) and the matrix pipes wait while LDS
+    // serves 8 waves x 5-6 KiB: measured 0.89-0.90 MFMA-busy at 4096^3 although the loop holds nothing but
+    // MFMAs and reads.  Here the reads of k-group g + 1 are issued BEFORE the MFMAs of group g (two fragment
+    // sets, +24 registers), also across the tile boundary: after the barrier that publishes tile kt + 1 a wave
+    // issues the DMA of tile kt + 2, the reads of (kt + 1, group 0), and only then the MFMAs of tile kt's last
+    // group.  Same MFMAs on the same accumulators in the same order: results are bit-identical.
+    // One barrier per k-tile as before: when a wave passes the barrier inside iteration kt, every wave has
+    // completed its reads of tile kt (s_waitcnt lgkmcnt(0) in front of s_barrier) — its stage may be refilled —
+    // and its own DMA of tile kt + 1 has landed (dma_publish_barrier).
+    constexpr int NPP = BK / 8;
+    static_assert(NPP % 2 == 0, "fragment sets alternate per k-group");
+    float av[2][MI][4], bv[2][NI][4];
+    auto issue_tile = [&](int kt) {  // DMA of tile kt into its stage
+      const long k0 = k_begin + (long)kt * BK;
+      float* stage = lds + (kt & 1) * BUF;
+      da.issue(a, a.A, a.lda, m_blk, k0, stage, wave, lane, a.a_rows, k_end, ones);
+      db.issue(a, a.B, a.ldb, n_blk, k0, stage + BK * BM, wave, lane, a.N, k_end);
+    };
+    if (nk > 0) {
+      if (nk > 1) issue_tile(1);
+      fragments(lds, 0, av[0], bv[0]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // Every tile but the last: ... reads of the tile's later k-groups, barrier, DMA of tile kt + 2 (if any), first reads
+    // of tile kt + 1, last MFMA group.  The last tile is a second copy of the body without the barrier part — inside one
+    // body the skipped barrier is a merging path on which the older reads are the youngest, and the wait-count pass then
+    // waits for everything (lgkmcnt(0)) in front of the last MFMA group of EVERY tile.
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      const float* As = lds + (kt & 1) * BUF;
+#pragma unroll
+      for (int pp = 0; pp + 1 < NPP; ++pp) {
+        if (!(ABL & 1)) fragments(As, pp + 1, av[(pp + 1) & 1], bv[(pp + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(av[(ABL & 1) ? 0 : (pp & 1)], bv[(ABL & 1) ? 0 : (pp & 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (!(ABL & 4)) dma_publish_barrier();
+      if (!(ABL & 1)) fragments(lds + ((kt + 1) & 1) * BUF, 0, av[0], bv[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      // the last MFMA group of tile kt with the DMA of tile kt + 2 spread over it: one wave instruction behind each
+      // k-step's MFMAs (see DmaLoader::issue_one).  (The MFMAs stay outside the `more` condition: MFMA groups in two
+      // branches made the register allocator copy and spill accumulators where the branches meet.)
+      const bool more = (ABL & 2) ? false : kt + 2 < nk;
+      if constexpr (DmaA::BUFD && DmaB::BUFD && DmaA::PER_WAVE + DmaB::PER_WAVE <= 4) {
+        const long k0 = k_begin + (long)(kt + 2) * BK;
+        float* stage = lds + (kt & 1) * BUF;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          multiply_step(av[(ABL & 1) ? 0 : ((NPP - 1) & 1)], bv[(ABL & 1) ? 0 : ((NPP - 1) & 1)], j);
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) {
+            if (j < DmaA::PER_WAVE)
+              da.issue_one(j, a.A, a.lda, m_blk, k0, stage, wave, ones);
+            else if (j - DmaA::PER_WAVE < DmaB::PER_WAVE)
+              db.issue_one(j - DmaA::PER_WAVE, a.B, a.ldb, n_blk, k0, stage + BK * BM, wave);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        if (more) issue_tile(kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(av[(NPP - 1) & 1], bv[(NPP - 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (nk > 0) {
+      const float* As = lds + ((nk - 1) & 1) * BUF;
+#pragma unroll
+      for (int pp = 0; pp + 1 < NPP; ++pp) {
+        fragments(As, pp + 1, av[(pp + 1) & 1], bv[(pp + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        multiply(av[pp & 1], bv[pp & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      multiply(av[(NPP - 1) & 1], bv[(NPP - 1) & 1]);
+    }
+    __syncthreads();  // every wave is done reading: the epilogue (or a following loop) may reuse the stages
+    return;
+  }
+
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
@@ -606,72 +826,11 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
       __syncthreads();
     }
     const float* As = lds + cur * BUF;
-    const float* Bs = As + BK * BM;
 #pragma unroll
     for (int pp = 0; pp < BK / 8; ++pp) {
       float av[MI][4], bv[NI][4];
-      if constexpr (AIL) {  // one 8- or 16-byte read per k brings this lane's value for every block
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          typedef float vecA __attribute__((ext_vector_type(MI)));
-          const vecA v = *reinterpret_cast<const vecA*>(As + (8 * pp + j + 4 * hi) * BM + wm0 + MI * i);
-#pragma unroll
-          for (int mi = 0; mi < MI; ++mi) av[mi][j] = v[mi];
-        }
-      }
-      if constexpr (BIL) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          typedef float vecB __attribute__((ext_vector_type(NI)));
-          const vecB v = *reinterpret_cast<const vecB*>(Bs + (8 * pp + j + 4 * hi) * BN + wn0 + NI * i);
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni) bv[ni][j] = v[ni];
-        }
-      }
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        if (AIL) break;
-        const int row = wm0 + mi * 32 + i;
-        if (A_KC) {
-          const int slot = (2 * pp + hi) ^ DmaA::swizzle(row);
-          const f32x4 v = *reinterpret_cast<const f32x4*>(As + row * BK + slot * 4);
-          av[mi][0] = v[0];
-          av[mi][1] = v[1];
-          av[mi][2] = v[2];
-          av[mi][3] = v[3];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) av[mi][j] = As[(8 * pp + j + 4 * hi) * BM + row];
-        }
-      }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        if (BIL) break;
-        const int col = wn0 + ni * 32 + i;
-        if (B_KC) {
-          const int slot = (2 * pp + hi) ^ DmaB::swizzle(col);
-          const f32x4 v = *reinterpret_cast<const f32x4*>(Bs + col * BK + slot * 4);
-          bv[ni][0] = v[0];
-          bv[ni][1] = v[1];
-          bv[ni][2] = v[2];
-          bv[ni][3] = v[3];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bv[ni][j] = Bs[(8 * pp + j + 4 * hi) * BN + col];
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            // A wave with ONE block (64 x 64, 128 x 32 tiles) multiplies unconditionally: a test per MFMA is a scalar
-            // branch per MFMA, with the fragment reads stuck in front of it — a ragged tile's waves ran ~25 % slower
-            // per k-tile than an interior tile's, and a launch is as slow as its slowest block.  What a wave outside
-            // the problem accumulates (clamped re-reads of valid data) is never stored.
-            if (!CL || MI * NI == 1 || (live >> (mi * NI + ni) & 1))
-              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+      fragments(As, pp, av, bv);
+      multiply(av, bv);
     }
     dma_publish_barrier();  // the next k-tile's loads (issued above) have landed; this stage is free for the one after
   }
@@ -770,7 +929,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
     if (!EDGE || interior || k_tail_only) {
       const int n_main = (EDGE && k_tail_only) ? nk - 1 : nk;
       if (n_main > 0)
-        gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV>(a, lds, acc, m_blk, n_blk, k_begin, n_main, tid, wm0, wn0);
+        gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, false, true, false, ABL>(a, lds, acc, m_blk, n_blk, k_begin, n_main, tid, wm0, wn0);
       if constexpr (EDGE && CONV == 0) {
         if (k_tail_only)
           gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, true, true>(a, lds, acc, m_blk, n_blk,
@@ -784,7 +943,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
       if constexpr (CONV == 0) {
         const int n_whole = nk <= 0 ? 0 : (whole_k ? nk : nk - 1);
         if (n_whole > 0)
-          gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, true, false, false>(a, lds, acc, m_blk, n_blk, k_begin, n_whole, tid,
+          gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, true, false, false, ABL>(a, lds, acc, m_blk, n_blk, k_begin, n_whole, tid,
                                                                                        wm0, wn0, k_end);
         if (n_whole < nk)
           gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, true, false, true>(a, lds, acc, m_blk, n_blk,

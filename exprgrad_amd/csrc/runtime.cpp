@@ -7,7 +7,6 @@
 //   createBuffer / blocking write / read / fill     -> hipMalloc / hipMemcpyAsync+sync / hipMemsetD*Async
 //   clCreateProgramWithSource + clBuildProgram      -> hiprtc (source text -> code object) + hipModuleLoadData
 //   clSetKernelArg (sticky) + clEnqueueNDRangeKernel-> stored argument block + hipModuleLaunchKernel
-#include <hip/hiprtc.h>
 
 #include <cstdlib>
 #include <cstring>
@@ -126,35 +125,10 @@ int kernels_compile_batch(eg_ctx* ctx, const char* label, const char* source, co
                           std::vector<eg_kernel*>& out) {
   out.clear();
   EG_HIP_CHECK(hipSetDevice(ctx->device));
-  hiprtcProgram prog;
-  hiprtcResult r = hiprtcCreateProgram(&prog, source, label, 0, nullptr, nullptr);
-  if (r != HIPRTC_SUCCESS) {
-    set_error("hiprtcCreateProgram failed: %s", hiprtcGetErrorString(r));
-    return EG_ERR_COMPILE;
-  }
-  // Arch comes from the device (e.g. "gfx950:sramecc+:xnack-").  contract=off keeps the
-  // generated scalar code inside the reference's no-fast-math arithmetic (llvm.nim:486-491).
-  std::string arch_opt = "--offload-arch=" + ctx->arch;
-  const char* opts[] = {arch_opt.c_str(), "-O3", "-ffp-contract=off", "-std=c++17"};
-  r = hiprtcCompileProgram(prog, 4, opts);
-  if (r != HIPRTC_SUCCESS) {
-    size_t log_size = 0;
-    hiprtcGetProgramLogSize(prog, &log_size);
-    std::string log(log_size, '\0');
-    if (log_size) hiprtcGetProgramLog(prog, &log[0]);
-    hiprtcDestroyProgram(&prog);
-    // cl.nim:163-171
-    if (log_size > 1)
-      set_error("Failed to build program: %s", log.c_str());
-    else
-      set_error("Failed to build program");
-    return EG_ERR_COMPILE;
-  }
-  size_t code_size = 0;
-  hiprtcGetCodeSize(prog, &code_size);
-  std::vector<char> code(code_size);
-  hiprtcGetCode(prog, code.data());
-  hiprtcDestroyProgram(&prog);
+  // which hiprtc compiles it and the on-disk cache of code objects: rtc.cpp
+  std::vector<char> code;
+  int rc = rtc::compile(label, source, ctx->arch, code);
+  if (rc) return rc;
   if (const char* dump = getenv("EG_DUMP_CODE")) {  // debugging aid: the code object, for llvm-objdump -d
     if (FILE* fp = fopen((std::string(dump) + "/" + label + ".co").c_str(), "wb")) {
       fwrite(code.data(), 1, code.size(), fp);

@@ -68,6 +68,13 @@ int eg_device_info(int device, char* name, size_t name_cap, char* vendor, size_t
 /* Static facts used for roofline reporting (not in the reference). */
 int eg_device_props(int device, int* compute_units, int* clock_khz, int64_t* hbm_bytes,
                     char* arch, size_t arch_cap);
+/* Which compiler builds kernel text at run time (compile(ctx, name, source): gpu.nim:48, cl.nim:149-179, and every
+ * generated kernel of a model, model.nim:209-213): "hiprtc <major>.<minor> <path of the library>; cache <dir>|off".
+ * The library opens hiprtc itself, preferring the ROCm release it was built with over whatever the process has
+ * loaded (EG_HIPRTC_LIB overrides); code objects are cached on disk (EG_KERNEL_CACHE, EG_NO_KERNEL_CACHE). */
+int eg_compiler_info(char* text, size_t cap);
+/* Run-time compilations of this process: served from the on-disk cache / compiled, and the seconds spent compiling. */
+int eg_kernel_cache_stats(int64_t* hits, int64_t* misses, double* compile_seconds);
 
 /* newGpuContext(device): gpu.nim:39, cl.nim:83-93. Creates one non-blocking in-order stream. */
 int eg_ctx_create(int device, eg_ctx** out);

@@ -158,7 +158,7 @@ def test_consumer_with_an_inlined_consumer_is_not_taken_as_epilogue(gpu_ctx, mon
 
 def test_generated_kernels_wait_for_their_lds_dma_before_the_barrier(gpu_ctx, monkeypatch, tmp_path):
     """The same property at the instruction level, independent of timing luck: in the code object hiprtc
-    builds for a generated-epilogue contraction, no `s_barrier` follows a `global_load_lds` without an
+    builds for a generated-epilogue contraction, no `s_barrier` follows an LDS-DMA load (`global_load_lds` / `buffer_load ... lds`) without an
     `s_waitcnt vmcnt(0)` in between (fall-through order; the K loop issues, computes, waits, then synchronises).
     The build that multiplied stale tiles had `s_barrier` first and the wait behind it — produced by the hiprtc
     the process resolves at run time (the one bundled with PyTorch-ROCm 7.0), not by /opt/rocm's 7.2, whose
@@ -185,7 +185,7 @@ def test_generated_kernels_wait_for_their_lds_dma_before_the_barrier(gpu_ctx, mo
             pending, loads = False, 0
             for line in text.splitlines():
                 ins = line.split()[0] if line.split() else ""
-                if "global_load_lds" in line:
+                if "global_load_lds" in line or ("buffer_load_" in line and " lds" in line):   # either LDS-DMA form
                     pending, loads = True, loads + 1
                 elif ins == "s_waitcnt" and "vmcnt(0)" in line:
                     pending = False

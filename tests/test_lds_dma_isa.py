@@ -2,7 +2,8 @@
 
 The generated-epilogue contractions are compiled at run time by whatever hiprtc the process resolves — inside a
 PyTorch-ROCm process that is the one bundled with torch (ROCm 7.0 here), not /opt/rocm's (7.2).  The two differ in
-where they put the `s_waitcnt vmcnt(0)` that must precede the barrier publishing a `global_load_lds` tile: the
+where they put the `s_waitcnt vmcnt(0)` that must precede the barrier publishing an LDS-DMA tile (`global_load_lds`, or
+`buffer_load ... lds` for plain operands since round 3): the
 bundled one used to put it BEHIND the barrier (stale tiles, the rare wrong update of round 1); the kernel header now
 spells the wait out (`dma_publish_barrier`).  This test compiles the header with the bundled hiprtc (compilation needs
 no device) and scans the disassembly: no `s_barrier` may follow a `global_load_lds` in fall-through order without an
@@ -72,7 +73,7 @@ def unpublished_barriers(isa):
     pending, loads, bad = False, 0, []
     for line in isa.splitlines():
         ins = line.split()[0] if line.split() else ""
-        if "global_load_lds" in line:
+        if "global_load_lds" in line or ("buffer_load_" in line and " lds" in line):   # either LDS-DMA form
             pending, loads = True, loads + 1
         elif ins == "s_waitcnt" and "vmcnt(0)" in line:
             pending = False

@@ -1,0 +1,126 @@
+// A/B harness for the LDS-DMA K loop of the f32 MFMA contraction kernel (exprgrad_amd/csrc/kernels/gemm_f32_mfma.hpp):
+// the software-pipelined loop (ABL bit 6) against the straight one the library ships (ABL = 0), same tiles, interior problems only.
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_pipe.hip -o tools/bin/gemm_pipe
+// Run:    tools/bin/gemm_pipe M N K layout(0 NN, 1 NT, 2 TN) [launches per timing = 10] [rounds = 5]
+// Prints microseconds / TFLOP/s per variant and whether the two variants agree bit for bit.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../exprgrad_amd/csrc/kernels/gemm_f32_mfma.hpp"
+
+using namespace eg::gemm;
+
+#define CHECK(x)                                                                    \
+  do {                                                                              \
+    hipError_t e = (x);                                                             \
+    if (e != hipSuccess) {                                                          \
+      fprintf(stderr, "%s failed: %s\n", #x, hipGetErrorString(e));                 \
+      exit(1);                                                                      \
+    }                                                                               \
+  } while (0)
+
+struct Variant {
+  const char* name;
+  int bm, bn, bk;
+  void (*launch)(const GemmArgs&, dim3, hipStream_t);
+};
+
+template <int BM, int BN, int BK, int WM, int WN, int MINB, bool AKC, bool BKC, int ABL>
+void launch(const GemmArgs& a, dim3 grid, hipStream_t s) {
+  constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
+  hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, MINB, AKC, BKC, 4, false, 0, ABL, true>), grid, dim3(NT), 0, s, a);
+}
+
+template <bool AKC, bool BKC>
+std::vector<Variant> variants() {
+  return {
+      {"256x256x16 pipelined", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 64>},
+      {"256x256x16 straight ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 0>},
+      {"256x256x16 p no-reads", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 65>},
+      {"256x256x16 p no-dma  ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 66>},
+      {"256x256x16 p no-barr ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 68>},
+      {"256x256x16 p none    ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 71>},
+      {"128x128x16 pipelined", 128, 128, 16, launch<128, 128, 16, 64, 64, 4, AKC, BKC, 64>},
+      {"128x128x16 straight ", 128, 128, 16, launch<128, 128, 16, 64, 64, 4, AKC, BKC, 0>},
+      {"64x64x32   pipelined", 64, 64, 32, launch<64, 64, 32, 32, 32, 4, AKC, BKC, 64>},
+      {"64x64x32   straight ", 64, 64, 32, launch<64, 64, 32, 32, 32, 4, AKC, BKC, 0>},
+  };
+}
+
+int main(int argc, char** argv) {
+  const long M = argc > 1 ? atol(argv[1]) : 4096, N = argc > 2 ? atol(argv[2]) : 4096, K = argc > 3 ? atol(argv[3]) : 4096;
+  const int layout = argc > 4 ? atoi(argv[4]) : 0;
+  const int per = argc > 5 ? atoi(argv[5]) : 10, rounds = argc > 6 ? atoi(argv[6]) : 5;
+  const bool akc = layout != 2, bkc = layout == 1;
+  std::vector<float> ha((size_t)M * K), hb((size_t)K * N);
+  srand(1);
+  for (auto& v : ha) v = (float)rand() / RAND_MAX;
+  for (auto& v : hb) v = (float)rand() / RAND_MAX * 2.f - 1.f;
+  float *A, *B, *C;
+  CHECK(hipMalloc(&A, ha.size() * 4));
+  CHECK(hipMalloc(&B, hb.size() * 4));
+  CHECK(hipMalloc(&C, (size_t)M * N * 4));
+  CHECK(hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+  hipStream_t s;
+  CHECK(hipStreamCreate(&s));
+  auto vs = layout == 0 ? variants<true, false>() : layout == 1 ? variants<true, true>() : variants<false, false>();
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  std::vector<std::vector<float>> out(vs.size());
+  std::vector<float> best(vs.size(), 1e30f);
+  auto args_for = [&](const Variant& v) {
+    GemmArgs a = {};
+    a.A = A; a.B = B; a.C = C;
+    a.M = a.a_rows = M; a.N = N; a.K = K;
+    a.lda = akc ? K : M; a.ldb = bkc ? K : N; a.ldc = N;
+    a.tiles_m = (int)(M / v.bm); a.tiles_n = (int)(N / v.bn);
+    a.k_per_split = K; a.splits = 1;
+    a.wide_store = 1; a.nt_store = 1;
+    return a;
+  };
+  for (int round = -1; round < rounds; ++round)
+    for (size_t vi = 0; vi < vs.size(); ++vi) {
+      const Variant& v = vs[vi];
+      if (M % v.bm || N % v.bn || K % v.bk) continue;
+      const GemmArgs a = args_for(v);
+      const dim3 grid((unsigned)(a.tiles_m * a.tiles_n));
+      if (round < 0) {  // correctness pass: keep the output
+        CHECK(hipMemsetAsync(C, 0xff, (size_t)M * N * 4, s));
+        v.launch(a, grid, s);
+        out[vi].resize((size_t)M * N);
+        CHECK(hipMemcpyAsync(out[vi].data(), C, (size_t)M * N * 4, hipMemcpyDeviceToHost, s));
+        CHECK(hipStreamSynchronize(s));
+        continue;
+      }
+      for (int i = 0; i < 3; ++i) v.launch(a, grid, s);
+      CHECK(hipEventRecord(e0, s));
+      for (int i = 0; i < per; ++i) v.launch(a, grid, s);
+      CHECK(hipEventRecord(e1, s));
+      CHECK(hipEventSynchronize(e1));
+      float ms;
+      CHECK(hipEventElapsedTime(&ms, e0, e1));
+      best[vi] = std::min(best[vi], ms / per);
+    }
+  // spot check against a float64 product on a sample of outputs
+  double worst = 0;
+  for (int t = 0; t < 64 && !out[0].empty(); ++t) {
+    const long m = (long)rand() % M, n = (long)rand() % N;
+    double ref = 0;
+    for (long k = 0; k < K; ++k) ref += (double)(akc ? ha[m * K + k] : ha[k * M + m]) * (double)(bkc ? hb[n * K + k] : hb[k * N + n]);
+    worst = std::max(worst, std::abs(ref - out[0][m * N + n]) / (std::abs(ref) + 1e-30));
+  }
+  printf("%ld x %ld x %ld layout %d: sampled rel err of variant 0 vs float64 %.2e\n", M, N, K, layout, worst);
+  for (size_t vi = 0; vi < vs.size(); ++vi) {
+    if (out[vi].empty()) continue;
+    const size_t other = vi ^ 1;
+    const bool same = !out[other].empty() && memcmp(out[vi].data(), out[other].data(), out[vi].size() * 4) == 0;
+    printf("  %s  %9.1f us  %7.2f TFLOP/s   %s\n", vs[vi].name, best[vi] * 1e3, 2.0 * M * N * K / best[vi] / 1e9,
+           same ? "bit-identical to its twin" : "DIFFERS from its twin");
+  }
+  return 0;
+}
