@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libexprgrad_hip.so")
+# EG_LIB_PATH: another build of the library (A/B timing of two builds on one GPU box); the default is the in-tree one
+LIB_PATH = os.environ.get("EG_LIB_PATH") or os.path.join(_HERE, "lib", "libexprgrad_hip.so")
 
 
 class GpuError(RuntimeError):

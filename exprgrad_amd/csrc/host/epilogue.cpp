@@ -98,8 +98,47 @@ bool epilogue_capable(const Kernel& k, const KernelInfo& info, const Shapes& sha
   return expect == M * N;
 }
 
+bool only_predicate_uses(const Kernel& k, int tensor, PredicateSpec& out) {
+  std::set<int> regs;
+  for (auto& rd : k.reads)
+    if (rd.tensor == tensor) regs.insert(rd.reg);
+  if (regs.empty() || regs.count(k.result) || k.write.tensor == tensor) return false;
+  std::map<int, const Instr*> def;
+  for (auto& ins : k.instrs) def[ins.res] = &ins;
+  bool any = false;
+  for (auto& ins : k.instrs) {
+    int uses = 0;
+    for (int a : ins.args) uses += regs.count(a) ? 1 : 0;
+    if (!uses) continue;
+    if (uses != 1 || ins.args.size() != 2 || (ins.kind != IK::Le && ins.kind != IK::Lt && ins.kind != IK::Eq)) return false;
+    const bool literal_first = regs.count(ins.args[1]) != 0;
+    auto d = def.find(ins.args[literal_first ? 0 : 1]);
+    if (d == def.end() || d->second->kind != IK::Scalar) return false;
+    PredicateSpec spec;
+    spec.kind = ins.kind;
+    spec.literal = (double)(float)d->second->lit;
+    spec.literal_first = literal_first;
+    if (any && !(spec == out)) return false;
+    out = spec;
+    any = true;
+  }
+  for (auto& ins : k.index_instrs)
+    for (int a : ins.args)
+      if (regs.count(a)) return false;
+  return any;
+}
+
+namespace {
+std::string predicate_expression(const PredicateSpec& p, const std::string& x) {
+  const std::string lit = f32_literal(p.literal);
+  const char* op = p.kind == IK::Le ? " <= " : (p.kind == IK::Lt ? " < " : " == ");
+  return p.literal_first ? lit + op + x : x + op + lit;
+}
+}  // namespace
+
 int generate_epilogue(const Kernel& k, const KernelInfo& info, const Shapes& shapes, int c_tensor, bool store_c,
-                      bool accumulate, EpilogueSpec& out) {
+                      bool accumulate, EpilogueSpec& out, const std::map<int, PredicateSpec>* pred_reads,
+                      const PredicateSpec* pred_write) {
   out = EpilogueSpec();
   out.struct_name = "EgEpi";
   std::set<int> tensors;
@@ -107,11 +146,13 @@ int generate_epilogue(const Kernel& k, const KernelInfo& info, const Shapes& sha
     if (rd.tensor != c_tensor) tensors.insert(rd.tensor);
   tensors.insert(k.write.tensor);
   out.operands.assign(tensors.begin(), tensors.end());
+  if (pred_write) out.operands.push_back(c_tensor);  // the bits of the contraction result: a.epi[PRED]
+  auto is_bits = [&](int t) { return pred_reads && pred_reads->count(t) != 0; };
 
   // operands other than the contraction result, in load order: x[i]
   std::vector<int> loads;
   for (int t : out.operands)
-    if (t != k.write.tensor) loads.push_back(t);
+    if (t != k.write.tensor && !(pred_write && t == c_tensor)) loads.push_back(t);
   if (accumulate) loads.push_back(k.write.tensor);
   const int nx = loads.empty() ? 1 : (int)loads.size();
   auto slot_of = [&](int t) {
@@ -128,13 +169,29 @@ int generate_epilogue(const Kernel& k, const KernelInfo& info, const Shapes& sha
   std::string c = "struct EgEpi {\n  static constexpr bool ACTIVE = true;\n  static constexpr int NX = " + nxs + ";\n"
                   "  static constexpr bool STORE_C = " + std::string(store_c ? "true" : "false") + ";\n"
                   "  static constexpr int OUT = " + std::to_string(operand_index(k.write.tensor)) + ";\n"
+                  "  static constexpr int PRED = " + std::to_string(pred_write ? operand_index(c_tensor) : -1) + ";\n"
+                  "  __device__ __forceinline__ static bool predicate(float v) { return " +
+                  (pred_write ? predicate_expression(*pred_write, "v") : std::string("false")) + "; }\n"
                   "  __device__ __forceinline__ static void prefetch(const eg::gemm::GemmArgs& a, long idx, float (&x)[" + nxs + "]) {\n";
-  for (size_t i = 0; i < loads.size(); ++i)
-    c += "    x[" + std::to_string(i) + "] = ((const float*)a.epi[" + std::to_string(operand_index(loads[i])) + "])[idx];\n";
+  for (size_t i = 0; i < loads.size(); ++i) {
+    const std::string ep = "a.epi[" + std::to_string(operand_index(loads[i])) + "]";
+    if (is_bits(loads[i]))  // one bit per element: 1.0f / 0.0f, turned back into the comparison's result in compute()
+      c += "    x[" + std::to_string(i) + "] = (float)((((const unsigned*)" + ep + ")[idx >> 5] >> (idx & 31)) & 1u);\n";
+    else
+      c += "    x[" + std::to_string(i) + "] = ((const float*)" + ep + ")[idx];\n";
+  }
   c += "  }\n  __device__ __forceinline__ static void prefetch4(const eg::gemm::GemmArgs& a, long idx, eg::gemm::f32x4 (&x)[" + nxs + "]) {\n";
-  for (size_t i = 0; i < loads.size(); ++i)
-    c += "    x[" + std::to_string(i) + "] = *reinterpret_cast<const eg::gemm::f32x4*>((const float*)a.epi[" +
-         std::to_string(operand_index(loads[i])) + "] + idx);\n";
+  for (size_t i = 0; i < loads.size(); ++i) {
+    const std::string ep = "a.epi[" + std::to_string(operand_index(loads[i])) + "]";
+    if (is_bits(loads[i])) {  // idx is a multiple of 4: the four bits sit in one word
+      c += "    { const unsigned w = ((const unsigned*)" + ep + ")[idx >> 5] >> (idx & 31);\n";
+      for (int e = 0; e < 4; ++e)
+        c += "      x[" + std::to_string(i) + "][" + std::to_string(e) + "] = (float)((w >> " + std::to_string(e) + ") & 1u);\n";
+      c += "    }\n";
+    } else {
+      c += "    x[" + std::to_string(i) + "] = *reinterpret_cast<const eg::gemm::f32x4*>((const float*)" + ep + " + idx);\n";
+    }
+  }
   c += "  }\n  __device__ __forceinline__ static float compute(const eg::gemm::GemmArgs& a, long idx, float v, const float (&x)[" + nxs + "]) {\n";
   // loop registers from the flat index (dead code unless the expression uses an iterator value)
   std::map<int, long> fac;
@@ -150,9 +207,20 @@ int generate_epilogue(const Kernel& k, const KernelInfo& info, const Shapes& sha
     c += "    const float r" + std::to_string(rd.reg) + " = " +
          (rd.tensor == c_tensor ? std::string("v") : "x[" + std::to_string(slot_of(rd.tensor)) + "]") + ";\n";
   const std::vector<Ty> ty = infer_types(k);
+  std::set<int> bit_regs;  // registers that hold a predicate bit (1.0f / 0.0f) instead of the tensor's value
+  for (auto& rd : k.reads)
+    if (is_bits(rd.tensor)) bit_regs.insert(rd.reg);
   for (auto& ins : k.instrs) {
     const Ty t = ty[ins.res];
     const char* ctype = t == Ty::Scalar ? "float" : (t == Ty::Index ? "long" : "bool");
+    bool on_bit = false;
+    for (int a_ : ins.args)
+      if (bit_regs.count(a_)) {  // the comparison only_predicate_uses() found: its answer is the stored bit
+        c += "    const bool r" + std::to_string(ins.res) + " = r" + std::to_string(a_) + " != 0.0f;\n";
+        on_bit = true;
+        break;
+      }
+    if (on_bit) continue;
     std::string special;
     if (ins.kind == IK::Epoch) {
       special = "a.epi_ep";

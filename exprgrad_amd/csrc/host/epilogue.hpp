@@ -8,6 +8,7 @@
 // `ga = gz * W2^T; gh{it} ++= select(..h{it}.., ga{it}, ..)` ga never exists in memory.
 // The generated functor is spliced into gemm_block<..., Epi> (kernels/gemm_fused.hpp).
 #pragma once
+#include <map>
 #include <string>
 #include <vector>
 
@@ -15,6 +16,19 @@
 
 namespace eg {
 namespace kd {
+
+// A yes / no question about a tensor element: cmp(literal, x) or cmp(x, literal) with cmp in {le, lt, eq} — the only
+// way some tensors are ever read after the launch that produces them (relu's `inp >= 0`, dnn.nim:26-27, in its derived
+// gradient).  Such a tensor is stored as one bit per element (plan_epilogue.cpp: predicate tensors).
+struct PredicateSpec {
+  IK kind = IK::Le;
+  double literal = 0;
+  bool literal_first = true;
+  bool operator==(const PredicateSpec& o) const { return kind == o.kind && literal == o.literal && literal_first == o.literal_first; }
+};
+
+// Is every use of `tensor` in `k` the same comparison against a literal?  (The value itself may not flow anywhere else.)
+bool only_predicate_uses(const Kernel& k, int tensor, PredicateSpec& out);
 
 struct EpilogueSpec {
   std::string struct_name;     // "EgEpi"
@@ -30,8 +44,11 @@ bool epilogue_capable(const Kernel& k, const KernelInfo& info, const Shapes& sha
 
 // store_c: also write the contraction result itself (it is read again later).
 // accumulate: the consumer adds to its destination instead of overwriting it.
+// pred_reads: operands of `k` that exist as predicate bits only (tensor -> the question they answer).
+// pred_write: the contraction result itself is stored as predicate bits answering *pred_write (then store_c is false).
 int generate_epilogue(const Kernel& k, const KernelInfo& info, const Shapes& shapes, int c_tensor, bool store_c,
-                      bool accumulate, EpilogueSpec& out);
+                      bool accumulate, EpilogueSpec& out, const std::map<int, PredicateSpec>* pred_reads = nullptr,
+                      const PredicateSpec* pred_write = nullptr);
 
 }  // namespace kd
 }  // namespace eg

@@ -201,7 +201,8 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
         if (L.kind == StepKind::GemmFused) {
           const PlanEpilogue& pe = *plan.epilogues[L.epilogue];
           os << " | consumer kernel " << pe.consumer.lowered << " operands";
-          for (int t : pe.spec.operands) os << " t" << t;
+          for (int t : pe.spec.operands) os << " t" << t << (pe.pred_reads.count(t) || (pe.pred_write && t == L.c_tensor) ? "(bits)" : "");
+          if (pe.pred_write) os << " | t" << L.c_tensor << " stored as predicate bits";
         }
         break;
       case StepKind::Conv: os << "conv2 -> t" << L.c_tensor << (L.accumulate ? " accumulate" : ""); break;
@@ -440,6 +441,8 @@ static int read_tensor(eg_model* m, TargetState& ts, int tid, float* host, int64
   const long n = prod(s->second);
   EG_REQUIRE(count == n, EG_ERR_SIZE, "Buffer size is not equal to target size (%ld vs %ld)", n, (long)count);
   if (n == 0) return EG_OK;
+  EG_REQUIRE(!ts.last->predicated.count(tid), EG_ERR_INVALID,
+             "tensor %d exists only as predicate bits in the last run's plan (EG_NO_PREDICATE=1 keeps its values)", tid);
   float* p = tensor_ptr(m, ts, *ts.last, tid);
   EG_REQUIRE(p, EG_ERR_INVALID, "tensor %d was not materialised by the last run", tid);
   return eg::copy_d2h(m->ctx, host, p, (size_t)n * sizeof(float));

@@ -125,6 +125,8 @@ struct PlanSmallGroup {
 struct PlanEpilogue {
   EpilogueSpec spec;
   bool store_c = false;                     // the contraction result itself is written too (something else reads it)
+  bool pred_write = false;                  // ... as one predicate bit per element (Plan::predicated), not as values
+  std::map<int, PredicateSpec> pred_reads;  // operands of the consumer that exist as predicate bits only
   Launch consumer;                          // the consumer as its own launch (split-K fallback)
   std::map<std::string, eg_kernel*> built;  // by template variant (tile shape, alignment class)
 };
@@ -143,6 +145,10 @@ struct Plan {
   // Result tensors that are a whole-tensor raw copy of another tensor (reshape, passes.nim:643-688,
   // and the gradient of one) share its storage instead of being copied: dest -> source.
   std::map<int, int> alias;
+  // Predicate tensors (plan_epilogue.cpp): result tensors every reader of which only asks one yes / no question of
+  // each element; stored as one bit per element (bit idx & 31 of 32-bit word idx >> 5, flat element index), in the
+  // zeroed part of the arena.
+  std::map<int, PredicateSpec> predicated;
   std::vector<int> random_tensors;   // TensorRandom tensors the live kernels read: refilled on every run
   std::map<int, long> arena_offset;  // result tensor -> float offset in the arena
   long arena_floats = 0;
@@ -239,6 +245,12 @@ inline long prod(const std::vector<long>& s) {
 }
 
 inline long align4(long n) { return (n + 3) & ~3L; }
+
+// floats of arena storage a result tensor occupies in this plan
+inline long storage_floats(const Plan& plan, int tid) {
+  const long n = prod(plan.shapes.at(tid));
+  return plan.predicated.count(tid) ? (n + 31) / 32 : n;
+}
 
 
 // While alive, the context's stream and scratch blocks are the side lane's.

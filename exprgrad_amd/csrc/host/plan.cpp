@@ -556,10 +556,10 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
         if (pass == 0 && needs_zero.count(tid)) plan.bucket_zero.push_back(tid);
         continue;
       }
-      const bool z = needs_zero.count(tid) != 0;
+      const bool z = needs_zero.count(tid) != 0 || plan.predicated.count(tid) != 0;  // (predicate bits may be OR-ed in)
       if ((pass == 0) != z) continue;
       plan.arena_offset[tid] = off;
-      off += align4(prod(shapes.at(tid)));
+      off += align4(storage_floats(plan, tid));
     }
     if (pass == 0) plan.zero_floats = off;
   }

@@ -12,6 +12,7 @@
 //                   inside the arena, pairwise disjoint; to-be-zeroed tensors lie in the zero prefix
 //   3. order        no launch reads (or accumulates into) a result tensor that is neither zeroed
 //                   nor written by an earlier launch
+//   (3b) predicate tensors are read and written as bits by every launch that touches them;
 //   4. side lane    the launches of an overlap group touch nothing the contraction they run next to
 //                   writes, and write nothing it reads; groups are disjoint, ordered, and stay on one
 //                   side of the backward | update boundary
@@ -75,7 +76,7 @@ void launch_io(eg_model* m, TargetState& ts, const Plan& plan, const Launch& L, 
       rd(L.b_tensor);
       rd(L.bias_tensor);
       const Kernel& ck = t.all[ts.lowered[pe.consumer.lowered].all_index];
-      if (pe.store_c) wr(L.c_tensor, L.accumulate);
+      if (pe.store_c || pe.pred_write) wr(L.c_tensor, L.accumulate);
       for (auto& r : ck.reads)
         if (r.tensor != L.c_tensor) rd(r.tensor);
       wr(ck.write.tensor, pe.consumer.accumulate);
@@ -199,7 +200,7 @@ int check_plan(eg_model* m, TargetState& ts, Plan& plan) {
     for (auto& kv : plan.arena_offset) {
       auto sh = plan.shapes.find(kv.first);
       EG_PLAN_REQUIRE(sh != plan.shapes.end(), "arena tensor %d has no shape", kv.first);
-      const long count = prod(sh->second);
+      const long count = storage_floats(plan, kv.first);
       EG_PLAN_REQUIRE(kv.second % 4 == 0, "arena slot of tensor %d is not 16-byte aligned", kv.first);
       EG_PLAN_REQUIRE(kv.second >= 0 && kv.second + count <= plan.arena_floats, "tensor %d leaves the arena", kv.first);
       slots.push_back({kv.second, kv.second + count});
@@ -226,7 +227,7 @@ int check_plan(eg_model* m, TargetState& ts, Plan& plan) {
   }
   for (auto& kv : plan.arena_offset) {
     auto sh = plan.shapes.find(kv.first);
-    const long count = sh == plan.shapes.end() ? 0 : prod(sh->second);
+    const long count = sh == plan.shapes.end() ? 0 : storage_floats(plan, kv.first);
     if (kv.second + count <= plan.zero_floats) present.insert(kv.first);
   }
   for (int tid : plan.bucket_zero) present.insert(tid);
@@ -258,6 +259,15 @@ int check_plan(eg_model* m, TargetState& ts, Plan& plan) {
         EG_PLAN_REQUIRE(tensor_ptr(m, ts, plan, x) != nullptr, "tensor %d (written by launch %d) has no storage", x, i);
       present.insert(x);
     }
+    // predicate tensors: one bit per element — only launches that know may touch them
+    for (int x : io.reads)
+      if (plan.predicated.count(x))
+        EG_PLAN_REQUIRE(L.kind == StepKind::GemmFused && plan.epilogues[L.epilogue]->pred_reads.count(x),
+                        "launch %d reads tensor %d, which exists as predicate bits only, as values", i, x);
+    for (int x : io.writes)
+      if (plan.predicated.count(x))
+        EG_PLAN_REQUIRE(L.kind == StepKind::GemmFused && plan.epilogues[L.epilogue]->pred_write && L.c_tensor == x,
+                        "launch %d writes values into tensor %d, which exists as predicate bits only", i, x);
   }
 
   // ---- 4. side lane

@@ -7,6 +7,85 @@
 namespace eg {
 namespace model {
 
+// Predicate tensors.  `h = x * W + b` feeds relu in the forward pass (fused above: relu(h) is written from the
+// accumulators) and is read once more, by relu's derived gradient `gIn{it} ++= select(0 <= h{it}, g{it}, 0)`
+// (dnn.nim:26-27 through passes.nim:475-483) — which asks ONE yes / no question of every element and never uses the value.
+// When every remaining reader of a fused contraction's result is itself a fused consumer that only asks the same question,
+// the result is not stored at all: the producer writes the answer, one bit per element, and the readers fetch the bit.
+// cfg 5 at 65 536 samples: 134 MB less written by the forward product, 130 MB less read by the activation-gradient
+// product (both are bound by exactly that traffic).  Same comparison on the same float32 value, evaluated where the value
+// is produced instead of where it is consumed: results are bit-identical (tests/test_gpu_epilogue.py).
+// EG_NO_PREDICATE=1 switches it off.
+static int predicate_tensors(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos) {
+  plan.predicated.clear();
+  {
+    const char* e = getenv("EG_NO_PREDICATE");
+    if (e && e[0] && e[0] != '0') return EG_OK;
+    // the batch pipeline (an experiment, off unless EG_PIPELINE=1) addresses half batches of [batch, N] tensors by rows;
+    // bit-packed tensors are not addressed that way: the experiment keeps the values
+    const char* p = getenv("EG_PIPELINE");
+    if (p && p[0] && p[0] != '0') return EG_OK;
+  }
+  Target& t = *ts.target;
+  auto fused_launch_of_consumer = [&](int live_pos) -> Launch* {
+    for (auto& L : plan.launches)
+      if (L.kind == StepKind::GemmFused && plan.epilogues[L.epilogue]->consumer.lowered == live_pos) return &L;
+    return nullptr;
+  };
+  auto regenerate = [&](Launch& G, const PredicateSpec* write_spec) {
+    PlanEpilogue& pe = *plan.epilogues[G.epilogue];
+    const Lowered& le = ts.lowered[pe.consumer.lowered];
+    return generate_epilogue(t.all[le.all_index], infos[le.all_index], plan.shapes, G.c_tensor, pe.store_c, pe.consumer.accumulate,
+                             pe.spec, &pe.pred_reads, write_spec);
+  };
+  for (auto& G : plan.launches) {
+    if (G.kind != StepKind::GemmFused) continue;
+    PlanEpilogue& pe = *plan.epilogues[G.epilogue];
+    const int T = G.c_tensor;
+    if (!pe.store_c || T == t.output || ts.bucket_offset.count(T) || m->prog.tensors[T].kind != TK::Result) continue;
+    if (G.N % 32 != 0 || G.ldc != G.N) continue;  // rows start on word boundaries
+    bool shares = plan.alias.count(T) != 0;
+    for (auto& kv : plan.alias) shares = shares || kv.second == T;
+    if (shares || (int)pe.spec.operands.size() + 1 > eg::gemm::MAX_EPILOGUE_OPERANDS) continue;
+    // every other live kernel that touches T: no writer, and every reader a fused consumer asking the same question
+    bool ok = true;
+    PredicateSpec spec;
+    std::vector<Launch*> readers;
+    for (size_t p = 0; p < t.live.size() && ok; ++p) {
+      if ((int)p == G.lowered || (int)p == pe.consumer.lowered || ts.lowered[p].absorbed || ts.lowered[p].inlined) continue;
+      const Kernel& k = t.all[t.live[p]];
+      if (k.write.tensor == T) ok = false;
+      bool reads = false;
+      for (auto& rd : k.reads) reads = reads || rd.tensor == T;
+      if (!reads || !ok) continue;
+      Launch* R = fused_launch_of_consumer((int)p);
+      PredicateSpec s;
+      if (!R || R->M * R->N != G.M * G.N || !only_predicate_uses(k, T, s) || (!readers.empty() && !(s == spec))) {
+        ok = false;
+        break;
+      }
+      spec = s;
+      readers.push_back(R);
+    }
+    if (!ok || readers.empty()) continue;
+    pe.store_c = false;
+    pe.pred_write = true;
+    int rc = regenerate(G, &spec);
+    if (rc) return rc;
+    for (Launch* R : readers) {
+      PlanEpilogue& pr = *plan.epilogues[R->epilogue];
+      pr.pred_reads[T] = spec;
+      PredicateSpec own;  // a reader may itself produce predicate bits (decided earlier in this loop)
+      const bool writes_bits = pr.pred_write;
+      if (writes_bits) own = plan.predicated.at(R->c_tensor);
+      rc = regenerate(*R, writes_bits ? &own : nullptr);
+      if (rc) return rc;
+    }
+    plan.predicated[T] = spec;
+  }
+  return EG_OK;
+}
+
 // Contraction + elementwise consumer -> one launch (epilogue.hpp).  Only large outputs: the
 // fused kernel is built at run time from the matrix kernel's source (seconds), which pays when
 // the saved round trip through HBM is megabytes; small chains are launch bound and handled by
@@ -90,7 +169,7 @@ int fuse_epilogues(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
     plan.launches.erase(plan.launches.begin() + j);
     if (plan.n_backward > (int)j) plan.n_backward--;
   }
-  return EG_OK;
+  return predicate_tensors(m, ts, plan, infos);
 }
 
 // dense = `out[y,x] ++= in[y,it] * W[it,x]` + `out[y,x] ++= b[x]` (dnn.nim:19-24); derive turns the two into

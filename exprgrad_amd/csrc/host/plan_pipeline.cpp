@@ -39,6 +39,7 @@ void plan_pipeline(eg_model* m, TargetState& ts, Plan& plan) {
     const char* e = getenv("EG_PIPELINE");
     if (!(e && e[0] && e[0] != '0')) return;
   }
+  if (!plan.predicated.empty()) return;  // (half-batch slices of predicate-bit tensors are not addressed by run_launch_sliced)
   double min_flops = 2e10;  // only steps with long contractions have something to hide work under
   if (const char* e = getenv("EG_PIPELINE_MIN_FLOPS")) min_flops = atof(e);
   const Target& t = *ts.target;

@@ -96,6 +96,8 @@ struct EpiNone {
   static constexpr bool STORE_C = true;
   static constexpr int NX = 1;
   static constexpr int OUT = 0;
+  static constexpr int PRED = -1;
+  __device__ __forceinline__ static bool predicate(float) { return false; }
   __device__ __forceinline__ static void prefetch(const GemmArgs&, long, float (&)[1]) {}
   __device__ __forceinline__ static void prefetch4(const GemmArgs&, long, f32x4 (&)[1]) {}
   __device__ __forceinline__ static float compute(const GemmArgs&, long, float v, const float (&)[1]) { return v; }
@@ -105,11 +107,18 @@ struct EpiNone {
 // prefetch4 = four consecutive elements as 16-byte loads), compute() = the consumer's value for one
 // element given the contraction result v = acc + bias, STORE_C = whether v itself is stored too, OUT =
 // the index in a.epi[] of the tensor the consumer writes.  The kernel does the stores.
+// PRED >= 0 (a "predicate tensor", host/plan_epilogue.cpp): every later reader of the contraction result v only asks
+// one yes / no question of it (the relu gradient's `0 <= h`, dnn.nim:26-27 differentiated), so instead of v the kernel
+// stores predicate(v), one bit per element — bit (idx & 31) of word idx >> 5 of a.epi[PRED], zeroed before the run —
+// and the readers fetch the bit: 1/32 of the bytes in both directions.
 template <class Epi>
 __device__ __forceinline__ void epi_apply(const GemmArgs& a, long idx, float v, const float (&x)[Epi::NX]) {
   const float r = Epi::compute(a, idx, v, x);
   if (Epi::STORE_C) a.C[idx] = v;
   static_cast<float*>(a.epi[Epi::OUT])[idx] = r;
+  if constexpr (Epi::PRED >= 0) {  // element-wise path (ragged tiles, unaligned operands): one atomic OR per set bit
+    if (Epi::predicate(v)) atomicOr(static_cast<unsigned*>(a.epi[Epi::PRED]) + (idx >> 5), 1u << (idx & 31));
+  }
 }
 
 // Row stride (in floats) of an LDS operand tile [BK][stride].
@@ -433,6 +442,16 @@ __device__ __forceinline__ void dma_publish_barrier() {
 // computed once (init) and issue() adds k0 like the interior loader does, so the compiler turns it into the
 // same pointer bumps.  (Clamping inside issue() is ~60 VALU instructions with two 64-bit multiplies per
 // k-tile, in FRONT of the fragment reads: a ragged tile that is alone on its CU ran ~25 % slower per k-tile.)
+// A block-uniform pointer, in scalar registers for certain.  A buffer-resource operand that the compiler finds in vector
+// registers — a uniform value that went through a 64-bit VALU compare, such as min(mn0, limit - 4) — is made scalar with
+// a "waterfall" loop around EVERY load (v_readfirstlane x 4, two 64-bit compares, exec juggling: 14 instructions per 1 KiB
+// piece; the ragged tiles of the cfg-5 weight gradient, which live on their loads, ran 10 % slower).
+__device__ __forceinline__ const float* uniform_pointer(const float* p) {
+  const unsigned long v = reinterpret_cast<unsigned long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const float*>(((unsigned long)hi << 32) | lo);
+}
+
 template <int BMN, int BK, int NT, bool KC, bool CONV, bool CLAMP = false, bool KCLAMP = CLAMP>
 struct DmaLoader {
   static constexpr bool FIXED = CLAMP && !KCLAMP && !CONV;  // precomputed clamped offsets
@@ -514,15 +533,13 @@ struct DmaLoader {
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)
     const int instr = wave + t * WAVES;
     if (INSTRS % WAVES != 0 && instr >= INSTRS) return;
-    const float* origin = base + (KC ? mn_base * ld + k0 : k0 * ld + mn_base);
+    const float* origin = uniform_pointer(base + (KC ? mn_base * ld + k0 : k0 * ld + mn_base));
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(origin), (short)0, -1, 0x00020000);
     __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(tile + instr * 256);
     if (FIXED && ones) {
-      const __amdgpu_buffer_rsrc_t one = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ones), (short)0, 32, 0x00020000);
-      if (virtual_row >> t & 1)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(one, dst, 16, KC ? 0 : 16, 0, 0, 0);
-      else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff[t], 0, 0, 0);
+      const float* src = reinterpret_cast<const float*>(reinterpret_cast<const char*>(origin) + voff[t]);
+      if (virtual_row >> t & 1) src = KC ? ones : ones + 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, dst, 16, 0, 0);
     } else {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff[t], 0, 0, 0);
     }
@@ -535,19 +552,20 @@ struct DmaLoader {
                                         const float* ones = nullptr) const {
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC_RTC__)  // (the host pass of an offline build knows no buffer-resource type)
     if constexpr (BUFD) {
-      const float* origin = base + (KC ? mn_base * ld + k0 : k0 * ld + mn_base);  // block-uniform: scalar registers
+      const float* origin = uniform_pointer(base + (KC ? mn_base * ld + k0 : k0 * ld + mn_base));  // block-uniform: scalar registers
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(origin), (short)0, -1, 0x00020000);
 #pragma unroll
       for (int t = 0; t < PER_WAVE; ++t) {
         const int instr = wave + t * WAVES;
         if (INSTRS % WAVES != 0 && instr >= INSTRS) break;
         __attribute__((address_space(3))) void* dst = (__attribute__((address_space(3))) void*)(tile + instr * 256);
-        if (FIXED && ones) {  // (block-uniform) a tile with the virtual row of ones: those lanes fetch {1,1,1,1} / {1,0,0,0}
-          const __amdgpu_buffer_rsrc_t one = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ones), (short)0, 32, 0x00020000);
-          if (virtual_row >> t & 1)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(one, dst, 16, KC ? 0 : 16, 0, 0, 0);
-          else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff[t], 0, 0, 0);
+        if (FIXED && ones) {
+          // (block-uniform) a tile with the virtual row of ones: those lanes fetch {1,1,1,1} / {1,0,0,0} — another base
+          // address, i.e. a per-lane pointer: the FLAT form of the load (two exec-masked buffer loads per piece, one per
+          // descriptor, cost the load-bound ragged tiles of the cfg-5 weight gradient 8 %)
+          const float* src = reinterpret_cast<const float*>(reinterpret_cast<const char*>(origin) + voff[t]);
+          if (virtual_row >> t & 1) src = KC ? ones : ones + 4;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, dst, 16, 0, 0);
         } else {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, dst, 16, voff[t], 0, 0, 0);
         }
@@ -989,6 +1007,12 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
     constexpr int NT_ = WAVES_M * WAVES_N * 64;
     static_assert(RT * BN <= 2 * BK * (SA + SB), "the staged rows fit the operand buffers");
     const int wmi = wave / WAVES_N;
+    static_assert(NT_ % C4 == 0, "a thread keeps its column chunk");
+    constexpr int NQ = (RT * C4 + NT_ - 1) / NT_;  // chunks per thread and pass
+    const int c4 = tid % C4;
+    const long n = n_blk + c4 * 4;
+    f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+    if (has_bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
       if (bil) {  // the lane's NI columns are adjacent: one 8- / 16-byte LDS write per row
@@ -1008,28 +1032,57 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
             lds[(wmi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BN + wn0 + j * 32 + (lane & 31)] = acc[i][j][r];
       }
       __syncthreads();
+      // A thread's chunks of one pass: q = q0 + tid, q0 a multiple of the block size — the same 16-byte column chunk c4 of
+      // NQ different rows (C4 divides the block size), so the bias chunk is loaded once.  The loads of all NQ chunks (a
+      // generated epilogue's operands, an accumulating launch's old values) are issued BEFORE the first store: loads and
+      // stores share vmcnt on gfx9, so a load issued behind a store makes its consumer wait for that store as well —
+      // chunk by chunk (load, wait, store, load, ...) a tile's stores went out one store latency apart.
+      long idxs[NQ];
 #pragma unroll
-      for (int q0 = 0; q0 < RT * C4; q0 += NT_) {
-        const int q = q0 + tid;
-        if ((RT * C4) % NT_ != 0 && q >= RT * C4) break;
-        const int row = q / C4, c4 = q % C4;
-        const long m = m_blk + (long)(row >> 5) * WM + sub_index<MI>(ail, i, row & 31);
-        const long n = n_blk + c4 * 4;
-        const long idx = m * ldo + n;
+      for (int c = 0; c < NQ; ++c) {
+        const int row = (c * NT_ + tid) / C4;
+        idxs[c] = (m_blk + (long)(row >> 5) * WM + sub_index<MI>(ail, i, row & 31)) * ldo + n;
+      }
+      f32x4 x4[NQ][Epi::NX];
+      f32x4 old[NQ];
+#pragma unroll
+      for (int c = 0; c < NQ; ++c) {
+        if ((RT * C4) % NT_ != 0 && c * NT_ + tid >= RT * C4) break;
+        if (Epi::ACTIVE) Epi::prefetch4(a, idxs[c], x4[c]);
+        else if (accumulate) old[c] = *reinterpret_cast<const f32x4*>(out + idxs[c]);
+      }
+      const bool packed = C4 % 8 == 0 && (ldo & 31) == 0;  // predicate bits: eight neighbouring lanes hold one 32-bit word
+#pragma unroll
+      for (int c = 0; c < NQ; ++c) {
+        if ((RT * C4) % NT_ != 0 && c * NT_ + tid >= RT * C4) break;
+        const int row = (c * NT_ + tid) / C4;
+        const long idx = idxs[c];
         f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * BN + c4 * 4]);
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (has_bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + n);
         if (Epi::ACTIVE) {
-          f32x4 x4[Epi::NX];
-          Epi::prefetch4(a, idx, x4);
           f32x4 res;
+          unsigned nibble = 0;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float x[Epi::NX];
 #pragma unroll
-            for (int o = 0; o < Epi::NX; ++o) x[o] = x4[o][e];
+            for (int o = 0; o < Epi::NX; ++o) x[o] = x4[c][o][e];
             v[e] = v[e] + b4[e];
             res[e] = Epi::compute(a, idx + e, v[e], x);
+            if constexpr (Epi::PRED >= 0) nibble |= (Epi::predicate(v[e]) ? 1u : 0u) << e;
+          }
+          if constexpr (Epi::PRED >= 0) {
+            unsigned* bits = static_cast<unsigned*>(a.epi[Epi::PRED]);
+            if (packed) {
+              // (whole tiles: n_blk and the rows' starts are multiples of 32) fold the eight nibbles with three butterfly
+              // steps; one lane stores the word
+              unsigned w = nibble << (4 * (tid & 7));
+              w |= __shfl_xor(w, 1, 64);
+              w |= __shfl_xor(w, 2, 64);
+              w |= __shfl_xor(w, 4, 64);
+              if ((tid & 7) == 0) bits[idx >> 5] = w;
+            } else if (nibble) {
+              atomicOr(bits + (idx >> 5), nibble << (idx & 31));  // (idx is a multiple of 4: a nibble never straddles words)
+            }
           }
           if (a.nt_store) {
             if (Epi::STORE_C) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.C + idx));
@@ -1041,9 +1094,8 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
         } else {
           f32x4* p = reinterpret_cast<f32x4*>(out + idx);
           if (accumulate) {
-            const f32x4 o = *p;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (o[e] + v[e]) + b4[e];
+            for (int e = 0; e < 4; ++e) v[e] = (old[c][e] + v[e]) + b4[e];
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] + b4[e];

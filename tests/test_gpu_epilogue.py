@@ -196,3 +196,75 @@ def test_generated_kernels_wait_for_their_lds_dma_before_the_barrier(gpu_ctx, mo
             assert loads > 0, name      # the LDS-DMA loop is what this test is about
             checked += 1
     assert checked >= 3
+
+
+# ---- predicate tensors (plan_epilogue.cpp): the pre-activation of a relu layer is stored as one bit per element ----
+
+def _train_state(gpu_ctx, monkeypatch, act, dims, x, y, steps, no_predicate):
+    monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", "0")
+    if no_predicate:
+        monkeypatch.setenv("EG_NO_PREDICATE", "1")
+    else:
+        monkeypatch.delenv("EG_NO_PREDICATE", raising=False)
+    gpu = egm.compile(*mlp(act=act, dims=dims), gpu=gpu_ctx)
+    rng = np.random.default_rng(5)
+    for tid in sorted(gpu.params.ids()):
+        gpu.params[tid] = (rng.random(gpu.params[tid].shape, dtype=np.float32) * 0.6 - 0.3).astype(np.float32)
+    for _ in range(steps):       # eager, captured, replayed
+        gpu.apply("train", {"x": x, "y": y})
+    plan = gpu.launch_plan("train")
+    params = {t: gpu.params[t].copy() for t in sorted(gpu.params.ids())}
+    gpu.close()
+    return plan, params
+
+
+@pytest.mark.parametrize("act", ["relu", "leaky_relu"])
+@pytest.mark.parametrize("batch", [256, 300, 37, 1024])
+def test_predicate_bits_agree_bit_for_bit_with_stored_values(gpu_ctx, monkeypatch, act, batch):
+    """Hidden widths that are multiples of 32: the pre-activations of both hidden layers exist as predicate bits only
+    (whole tiles pack eight lanes' nibbles into a word, ragged tiles OR their bits in).  Same comparison on the same
+    float32 value, evaluated by the producer instead of the reader: not one bit of any parameter may differ."""
+    dims = (96, 128, 96, 8)
+    rng = np.random.default_rng(batch)
+    x = (rng.random((batch, dims[0]), dtype=np.float32) - 0.5).astype(np.float32)
+    x[3] = 0.0                                  # a sample whose pre-activations are exactly the bias
+    y = rng.random((batch, dims[-1]), dtype=np.float32)
+    plan_bits, with_bits = _train_state(gpu_ctx, monkeypatch, act, dims, x, y, 3, no_predicate=False)
+    plan_vals, with_vals = _train_state(gpu_ctx, monkeypatch, act, dims, x, y, 3, no_predicate=True)
+    assert "predicate bits" not in plan_vals
+    if batch >= 64:                             # (at batch 37 the activation gradients join a small-kernel group: no fused reader)
+        assert plan_bits.count("stored as predicate bits") == 2, plan_bits
+    for t in with_bits:
+        assert np.array_equal(with_bits[t], with_vals[t]), (t, np.max(np.abs(with_bits[t] - with_vals[t])))
+
+
+@pytest.mark.parametrize("act", ["tanh", "sigmoid"])
+def test_activations_that_use_the_value_keep_it(gpu_ctx, monkeypatch, act):
+    dims = (96, 128, 96, 8)
+    rng = np.random.default_rng(1)
+    x = (rng.random((256, dims[0]), dtype=np.float32) - 0.5).astype(np.float32)
+    y = rng.random((256, dims[-1]), dtype=np.float32)
+    plan, _ = _train_state(gpu_ctx, monkeypatch, act, dims, x, y, 1, no_predicate=False)
+    assert "predicate bits" not in plan, plan
+
+
+def test_predicate_bits_on_zero_and_denormal_preactivations(gpu_ctx, monkeypatch):
+    """`0 <= h` at h = +0.0 (true: the gradient passes) and at a negative denormal (false) — the bit must be the
+    comparison's answer; checked against the oracle's step."""
+    monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", "0")
+    monkeypatch.delenv("EG_NO_PREDICATE", raising=False)
+    dims = (32, 128, 8)                         # (a hidden width of 64 or less would be row-fused instead)
+    t = Trio(gpu_ctx, lambda: mlp(act="relu", dims=dims), threads=4)
+    rng = np.random.default_rng(11)
+    t.init_params(rng, -0.3, 0.3)
+    bias = sorted(tid for tid in t.ref.params if t.ref.params[tid].shape == (128,))[0]
+    b = np.zeros(128, dtype=np.float32)
+    b[1::2] = -1e-42                            # negative denormal: 0 <= h is false, relu(h) is 0
+    t.set_param(bias, b)
+    batch = 128
+    x = (rng.random((batch, 32), dtype=np.float32) - 0.5).astype(np.float32)
+    x[:16] = 0.0                                # h = bias exactly: +0.0 in the even columns
+    y = rng.random((batch, 8), dtype=np.float32)
+    t.step("train", {"x": x, "y": y}, n=batch)
+    assert "stored as predicate bits" in t.gpu.launch_plan("train")
+    t.close()

@@ -23,6 +23,8 @@ struct EgEpi {
   static constexpr int NX = 1;
   static constexpr bool STORE_C = false;
   static constexpr int OUT = 0;
+  static constexpr int PRED = -1;
+  __device__ __forceinline__ static bool predicate(float) { return false; }
   __device__ __forceinline__ static void prefetch(const eg::gemm::GemmArgs&, long, float (&)[1]) {}
   __device__ __forceinline__ static void prefetch4(const eg::gemm::GemmArgs&, long, eg::gemm::f32x4 (&)[1]) {}
   __device__ __forceinline__ static float compute(const eg::gemm::GemmArgs&, long, float v, const float (&)[1]) {
