@@ -1037,26 +1037,28 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
       // generated epilogue's operands, an accumulating launch's old values) are issued BEFORE the first store: loads and
       // stores share vmcnt on gfx9, so a load issued behind a store makes its consumer wait for that store as well —
       // chunk by chunk (load, wait, store, load, ...) a tile's stores went out one store latency apart.
-      long idxs[NQ];
-#pragma unroll
-      for (int c = 0; c < NQ; ++c) {
+      auto index_of = [&](int c) {  // flat output index of this thread's chunk c of pass i
         const int row = (c * NT_ + tid) / C4;
-        idxs[c] = (m_blk + (long)(row >> 5) * WM + sub_index<MI>(ail, i, row & 31)) * ldo + n;
-      }
-      f32x4 x4[NQ][Epi::NX];
-      f32x4 old[NQ];
-#pragma unroll
-      for (int c = 0; c < NQ; ++c) {
-        if ((RT * C4) % NT_ != 0 && c * NT_ + tid >= RT * C4) break;
-        if (Epi::ACTIVE) Epi::prefetch4(a, idxs[c], x4[c]);
-        else if (accumulate) old[c] = *reinterpret_cast<const f32x4*>(out + idxs[c]);
-      }
+        return (m_blk + (long)(row >> 5) * WM + sub_index<MI>(ail, i, row & 31)) * ldo + n;
+      };
+      // (the 256 x 256 tile has the registers to hold a whole pass; tiles that run four waves per SIMD batch four chunks)
+      constexpr int GROUP = BM * BN >= 256 * 256 ? NQ : (NQ < 4 ? NQ : 4);
       const bool packed = C4 % 8 == 0 && (ldo & 31) == 0;  // predicate bits: eight neighbouring lanes hold one 32-bit word
 #pragma unroll
-      for (int c = 0; c < NQ; ++c) {
+      for (int g0 = 0; g0 < NQ; g0 += GROUP) {
+      f32x4 x4[GROUP][Epi::NX];
+      f32x4 old[GROUP];
+#pragma unroll
+      for (int c = g0; c < g0 + GROUP && c < NQ; ++c) {
+        if ((RT * C4) % NT_ != 0 && c * NT_ + tid >= RT * C4) break;
+        if (Epi::ACTIVE) Epi::prefetch4(a, index_of(c), x4[c - g0]);
+        else if (accumulate) old[c - g0] = *reinterpret_cast<const f32x4*>(out + index_of(c));
+      }
+#pragma unroll
+      for (int c = g0; c < g0 + GROUP && c < NQ; ++c) {
         if ((RT * C4) % NT_ != 0 && c * NT_ + tid >= RT * C4) break;
         const int row = (c * NT_ + tid) / C4;
-        const long idx = idxs[c];
+        const long idx = index_of(c);
         f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * BN + c4 * 4]);
         if (Epi::ACTIVE) {
           f32x4 res;
@@ -1065,7 +1067,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
           for (int e = 0; e < 4; ++e) {
             float x[Epi::NX];
 #pragma unroll
-            for (int o = 0; o < Epi::NX; ++o) x[o] = x4[c][o][e];
+            for (int o = 0; o < Epi::NX; ++o) x[o] = x4[c - g0][o][e];
             v[e] = v[e] + b4[e];
             res[e] = Epi::compute(a, idx + e, v[e], x);
             if constexpr (Epi::PRED >= 0) nibble |= (Epi::predicate(v[e]) ? 1u : 0u) << e;
@@ -1095,7 +1097,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
           f32x4* p = reinterpret_cast<f32x4*>(out + idx);
           if (accumulate) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = (old[c][e] + v[e]) + b4[e];
+            for (int e = 0; e < 4; ++e) v[e] = (old[c - g0][e] + v[e]) + b4[e];
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] + b4[e];
@@ -1103,6 +1105,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
           if (a.nt_store) __builtin_nontemporal_store(v, p);
           else *p = v;
         }
+      }
       }
       __syncthreads();
     }

@@ -1,0 +1,276 @@
+/* A host that is neither Python nor C++: plain C (what Nim compiles to) driving libexprgrad_hip.so through
+ * include/exprgrad_hip.h only — the calls nim/exprgrad/runtimes/hip.nim and hipmodel.nim make, in their order.
+ *
+ *   cabi_harness runtime                      group 1: devices, context, buffers (write / read / fill with the size
+ *                                             checks of cl.nim:111-146), compile(name, source) + sticky arguments +
+ *                                             launch (cl.nim:149-207), build log on a broken source (cl.nim:163-171)
+ *   cabi_harness model <program.kd> <case>    group 3: eg_model_compile -> param_write -> set_input_host -> run ->
+ *                                             output_shape / read_output (Model.call, model.nim:392-406), run again
+ *                                             for `apply`, param_read; values compared with the case file
+ *
+ * Case file (written by tests/test_gpu_cabi_harness.py from tests/golden/handwritten.json), one record per line:
+ *   tol <t> | epoch <n> | param <id> <count> v... | input <name> <rank> d... v...
+ *   call <target> <n names> name... <count> expected... | apply <target> | expect <id> <count> v...
+ * Build: gcc -std=c99 -Iinclude tests/cabi_harness.c -Lexprgrad_amd/lib -lexprgrad_hip -Wl,-rpath,$PWD/exprgrad_amd/lib -lm
+ * Exit status 0 = every comparison held.  No GPU: every entry point fails with an error text, the harness exits 2. */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "exprgrad_hip.h"
+
+#define CHECK(call)                                                                         \
+  do {                                                                                      \
+    int status_ = (call);                                                                   \
+    if (status_ != 0) {                                                                     \
+      fprintf(stderr, "%s:%d: %s -> %d: %s\n", __FILE__, __LINE__, #call, status_, eg_last_error()); \
+      exit(2);                                                                              \
+    }                                                                                       \
+  } while (0)
+
+static int failures = 0;
+
+static void expect(int ok, const char* what) {
+  if (!ok) {
+    fprintf(stderr, "FAILED: %s\n", what);
+    ++failures;
+  }
+}
+
+static int close_enough(const float* got, const double* want, long n, double tol, const char* what) {
+  double scale = 1e-30, worst = 0;
+  for (long i = 0; i < n; ++i)
+    if (fabs(want[i]) > scale) scale = fabs(want[i]);
+  for (long i = 0; i < n; ++i) {
+    const double d = fabs((double)got[i] - want[i]);
+    if (!(d <= worst)) worst = d; /* (NaN-proof) */
+  }
+  const int ok = tol == 0.0 ? worst == 0.0 : worst <= tol * scale;
+  if (!ok) fprintf(stderr, "FAILED: %s: max |got - want| = %.3e, allowed %.3e\n", what, worst, tol * scale);
+  return ok;
+}
+
+/* ---------------------------------------------------------------------------------------- group 1 */
+static const char* kSource =
+    "extern \"C\" __global__ void scale_shift(float* x, long n, float a, float b) {\n"
+    "  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;\n"
+    "  if (i < n) x[i] = a * x[i] + b;\n"
+    "}\n";
+
+static int run_runtime(void) {
+  int n_dev = 0;
+  CHECK(eg_device_count(&n_dev));
+  expect(n_dev >= 1, "at least one device");
+  char name[256], vendor[256], version[256], compiler[512];
+  int is_gpu = 0;
+  CHECK(eg_device_info(0, name, sizeof name, vendor, sizeof vendor, version, sizeof version, &is_gpu));
+  expect(is_gpu == 1, "device 0 is a GPU");
+  CHECK(eg_compiler_info(compiler, sizeof compiler));
+  printf("device 0: %s (%s, %s); run-time compiler: %s\n", name, vendor, version, compiler);
+
+  eg_ctx* ctx = NULL;
+  CHECK(eg_ctx_create(0, &ctx));
+  enum { N = 1000 };
+  float host[N], back[N];
+  for (int i = 0; i < N; ++i) host[i] = (float)i * 0.5f;
+  eg_buf* buf = NULL;
+  CHECK(eg_buf_alloc(ctx, sizeof host, &buf));
+  CHECK(eg_buf_write(buf, host, sizeof host));
+  expect(eg_buf_write(buf, host, sizeof host - 4) != 0, "a write of another size than the buffer is refused (cl.nim:112-113)");
+  expect(strlen(eg_last_error()) > 0, "... with an error text");
+
+  eg_kernel* kernel = NULL;
+  CHECK(eg_kernel_compile(ctx, "scale_shift", kSource, &kernel));
+  CHECK(eg_kernel_set_arg_buf(kernel, 0, buf));
+  CHECK(eg_kernel_set_arg_i64(kernel, 1, (int64_t)N));
+  CHECK(eg_kernel_set_arg_f32(kernel, 2, 2.0f));
+  CHECK(eg_kernel_set_arg_f32(kernel, 3, 1.0f));
+  int64_t groups[1] = {(N + 63) / 64}, local[1] = {64};
+  CHECK(eg_kernel_launch(kernel, 1, groups, local));
+  CHECK(eg_kernel_set_arg_f32(kernel, 3, -1.0f)); /* arguments are sticky: only the changed one is set again */
+  CHECK(eg_kernel_launch(kernel, 1, groups, local));
+  CHECK(eg_buf_read(buf, back, sizeof back));
+  int same = 1;
+  for (int i = 0; i < N; ++i) same = same && back[i] == 2.0f * (2.0f * host[i] + 1.0f) - 1.0f;
+  expect(same, "two launches with sticky arguments");
+
+  const float seven = 7.0f;
+  CHECK(eg_buf_fill(buf, &seven, sizeof seven));
+  CHECK(eg_buf_read(buf, back, sizeof back));
+  same = 1;
+  for (int i = 0; i < N; ++i) same = same && back[i] == 7.0f;
+  expect(same, "fill with a 4-byte pattern (cl.nim:122-126)");
+
+  eg_kernel* broken = NULL;
+  expect(eg_kernel_compile(ctx, "nope", "extern \"C\" __global__ void nope() { this is not HIP }", &broken) != 0,
+         "a broken source does not compile");
+  expect(strstr(eg_last_error(), "error") != NULL, "... and the error text carries the build log (cl.nim:163-171)");
+
+  CHECK(eg_kernel_free(kernel));
+  CHECK(eg_buf_free(buf));
+  CHECK(eg_ctx_destroy(ctx));
+  return failures;
+}
+
+/* ---------------------------------------------------------------------------------------- group 3 */
+static char* read_file(const char* path) {
+  FILE* fp = fopen(path, "rb");
+  if (!fp) {
+    fprintf(stderr, "cannot open %s\n", path);
+    exit(2);
+  }
+  fseek(fp, 0, SEEK_END);
+  long n = ftell(fp);
+  fseek(fp, 0, SEEK_SET);
+  char* text = (char*)malloc((size_t)n + 1);
+  if (fread(text, 1, (size_t)n, fp) != (size_t)n) exit(2);
+  text[n] = 0;
+  fclose(fp);
+  return text;
+}
+
+#define MAX_INPUTS 8
+struct input {
+  char name[64];
+  int rank;
+  int64_t shape[8];
+  float* data;
+  long count;
+};
+
+static double* read_doubles(FILE* fp, long n) {
+  double* v = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+  for (long i = 0; i < n; ++i)
+    if (fscanf(fp, "%lf", &v[i]) != 1) {
+      fprintf(stderr, "case file: number expected\n");
+      exit(2);
+    }
+  return v;
+}
+
+static int run_model(const char* kd_path, const char* case_path) {
+  char* text = read_file(kd_path);
+  eg_ctx* ctx = NULL;
+  eg_model* model = NULL;
+  CHECK(eg_ctx_create(0, &ctx));
+  CHECK(eg_model_compile(ctx, text, &model));
+  FILE* fp = fopen(case_path, "r");
+  if (!fp) {
+    fprintf(stderr, "cannot open %s\n", case_path);
+    return 2;
+  }
+  struct input inputs[MAX_INPUTS];
+  int n_inputs = 0;
+  double tol = 1e-6;
+  char word[64];
+  while (fscanf(fp, "%63s", word) == 1) {
+    if (!strcmp(word, "tol")) {
+      if (fscanf(fp, "%lf", &tol) != 1) return 2;
+    } else if (!strcmp(word, "epoch")) {
+      long e;
+      if (fscanf(fp, "%ld", &e) != 1) return 2;
+      CHECK(eg_model_set_epoch(model, e));
+    } else if (!strcmp(word, "param") || !strcmp(word, "expect")) {
+      const int is_param = word[0] == 'p';
+      int id;
+      long count;
+      if (fscanf(fp, "%d %ld", &id, &count) != 2) return 2;
+      double* v = read_doubles(fp, count);
+      float* f = (float*)malloc(sizeof(float) * (size_t)(count > 0 ? count : 1));
+      if (is_param) {
+        for (long i = 0; i < count; ++i) f[i] = (float)v[i];
+        CHECK(eg_model_param_write(model, id, f, count));
+      } else {
+        char what[96];
+        CHECK(eg_model_param_read(model, id, f, count));
+        snprintf(what, sizeof what, "tensor %d after the step", id);
+        if (!close_enough(f, v, count, tol, what)) ++failures;
+      }
+      free(f);
+      free(v);
+    } else if (!strcmp(word, "input")) {
+      if (n_inputs == MAX_INPUTS) return 2;
+      struct input* in = &inputs[n_inputs++];
+      if (fscanf(fp, "%63s %d", in->name, &in->rank) != 2) return 2;
+      in->count = 1;
+      for (int d = 0; d < in->rank; ++d) {
+        long s;
+        if (fscanf(fp, "%ld", &s) != 1) return 2;
+        in->shape[d] = s;
+        in->count *= s;
+      }
+      double* v = read_doubles(fp, in->count);
+      in->data = (float*)malloc(sizeof(float) * (size_t)(in->count > 0 ? in->count : 1));
+      for (long i = 0; i < in->count; ++i) in->data[i] = (float)v[i];
+      free(v);
+    } else if (!strcmp(word, "call") || !strcmp(word, "apply")) {
+      const int is_call = word[0] == 'c';
+      char target[64];
+      if (fscanf(fp, "%63s", target) != 1) return 2;
+      /* Model.call binds its arguments, nothing else (model.nim:400-402): an input that is not named is not bound */
+      CHECK(eg_model_clear_inputs(model));
+      int n_names = n_inputs;
+      char names[MAX_INPUTS][64];
+      if (is_call) {
+        if (fscanf(fp, "%d", &n_names) != 1) return 2;
+        for (int i = 0; i < n_names; ++i)
+          if (fscanf(fp, "%63s", names[i]) != 1) return 2;
+      } else {
+        for (int i = 0; i < n_inputs; ++i) strcpy(names[i], inputs[i].name);
+      }
+      for (int i = 0; i < n_names; ++i)
+        for (int j = 0; j < n_inputs; ++j)
+          if (!strcmp(names[i], inputs[j].name))
+            CHECK(eg_model_set_input_host(model, inputs[j].name, inputs[j].data, inputs[j].rank, inputs[j].shape));
+      CHECK(eg_model_run(model, target));
+      if (is_call) {
+        long count;
+        if (fscanf(fp, "%ld", &count) != 1) return 2;
+        double* want = read_doubles(fp, count);
+        int rank = 0;
+        int64_t shape8[8] = {0};
+        CHECK(eg_model_output_shape(model, target, &rank, shape8));
+        long have = 1;
+        for (int d = 0; d < rank; ++d) have *= shape8[d];
+        char what[96];
+        snprintf(what, sizeof what, "output of target %s", target);
+        if (have != count) {
+          fprintf(stderr, "FAILED: %s has %ld elements, %ld expected\n", what, have, count);
+          ++failures;
+        } else {
+          float* got = (float*)malloc(sizeof(float) * (size_t)(count > 0 ? count : 1));
+          CHECK(eg_model_read_output(model, target, got, count));
+          if (!close_enough(got, want, count, tol, what)) ++failures;
+          free(got);
+        }
+        free(want);
+      } else {
+        CHECK(eg_ctx_sync(ctx));
+      }
+    } else {
+      fprintf(stderr, "case file: unknown record '%s'\n", word);
+      return 2;
+    }
+  }
+  fclose(fp);
+  expect(eg_model_run(model, "no-such-target") == EG_ERR_RUNTIME, "an unknown target is a RuntimeError (model.nim:395-396)");
+  CHECK(eg_model_free(model));
+  CHECK(eg_ctx_destroy(ctx));
+  free(text);
+  return failures;
+}
+
+int main(int argc, char** argv) {
+  int rc;
+  if (argc >= 2 && !strcmp(argv[1], "runtime")) {
+    rc = run_runtime();
+  } else if (argc >= 4 && !strcmp(argv[1], "model")) {
+    rc = run_model(argv[2], argv[3]);
+  } else {
+    fprintf(stderr, "usage: %s runtime | model <program.kd> <case file>\n", argv[0]);
+    return 2;
+  }
+  printf(rc == 0 ? "ok\n" : "%d comparison(s) failed\n", rc);
+  return rc == 0 ? 0 : 1;
+}

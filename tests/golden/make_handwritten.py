@@ -100,6 +100,36 @@ cases["maxpool2_grad"] = {
               {"target": "grad", "expect": spec(gx)}],
 }
 
+# ---- examples/xor_from_scratch (xor_from_scratch.nim:19-31): forward, loss and one training step ------------------------
+# The text (handwritten/xor_from_scratch.kd) is what the Nim emitter of nim/exprgrad/runtimes/hipmodel.nim must produce
+# for the example: tensor ids, kernel order and register numbers derived by hand from parser.nim (see its header).
+X = np.array([[0, 0], [0, 1], [1, 0], [1, 1]], dtype=np.float64)
+Y = np.array([[0], [1], [1], [0]], dtype=np.float64)
+W1 = np.array([[0.5, -0.25, 0.75, -1.0], [-0.5, 0.5, 0.25, 1.0]])
+B1 = np.array([0.125, -0.125, -0.5, 0.25])
+W2 = np.array([[0.5], [-0.75], [1.0], [0.25]])
+B2 = np.array([-0.125])
+hid = X @ W1 + B1                                        # hidden[y,x] ++= x[y,it] * W1[it,x]; ++= b1[x]
+act = np.where(hid <= 0.0, 0.1 * hid, hid)               # select(hidden <= 0.0, 0.1 * hidden, hidden)
+out = act @ W2 + B2
+sig = 1.0 / (1.0 + np.exp(-out))                         # 1.0 / (1.0 + exp(-output))
+xor_loss = np.sum((sig - Y) ** 2)                        # loss[0] ++= sq(pred - y): a plain sum
+d_out = 2.0 * (sig - Y) * sig * (1.0 - sig)              # derive of the quotient (passes.nim:392-505) in closed form
+d_act = d_out @ W2.T
+d_hid = np.where(hid <= 0.0, 0.1, 1.0) * d_act
+rate = 0.1                                               # param{it} ++= -0.1 * grad{it}
+cases["xor_from_scratch"] = {
+    "source": "examples/xor_from_scratch/xor_from_scratch.nim:19-31; float32 literals 0.1 / -0.1 are 1.5e-9 off the decimal",
+    "params": {"1": spec(W1), "9": spec(B1), "10": spec(W2), "11": spec(B2)},
+    "inputs": {"x": spec(X), "y": spec(Y)}, "tol": 1e-6,
+    "calls": [{"target": "predict", "inputs": ["x"], "expect": spec(sig)},
+              {"target": "loss", "expect": spec([xor_loss])}],
+    "apply": "train",
+    "expect_params": {"1": spec(W1 - rate * (X.T @ d_hid)), "9": spec(B1 - rate * d_hid.sum(axis=0)),
+                      "10": spec(W2 - rate * (act.T @ d_out)), "11": spec(B2 - rate * d_out.sum(axis=0))},
+    "expect_caches": {},
+}
+
 with open(os.path.join(HERE, "handwritten.json"), "w") as f:
     json.dump(cases, f, indent=1)
 print("wrote", len(cases), "cases")

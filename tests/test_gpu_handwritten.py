@@ -47,6 +47,21 @@ def test_backend_equals_the_oracle_on_the_handwritten_programs(gpu_ctx, name):
         ins = {"x": (rng.random((2, 6, 8, 3), dtype=f) - 0.5).astype(f), "w": rng.random((2, 3, 4, 3), dtype=f)}
         assert np.array_equal(gpu.call("pool", {"x": ins["x"]}), ref.call("pool", {"x": ins["x"]}))
         assert np.array_equal(gpu.call("grad", ins), ref.call("grad", ins))       # selection only: exact
+    elif name == "xor_from_scratch":
+        for tid in sorted(ref.params):
+            v = (rng.random(ref.params[tid].shape, dtype=f) * 2 - 1).astype(f)
+            gpu.params[tid] = v
+            ref.params[tid][...] = v
+        x = rng.integers(0, 2, size=(256, 2)).astype(f)
+        ins = {"x": x, "y": (x[:, :1] != x[:, 1:]).astype(f)}
+        assert rel_err(gpu.call("predict", {"x": x}), ref.call("predict", {"x": x})) <= TOL
+        # (the reference sums the 256 squares one after the other in float32, the backend as a tree: n * u / 2 apart at most)
+        assert rel_err(gpu.call("loss", ins), ref.call("loss", ins)) <= 256 * 6e-8
+        for _ in range(3):
+            gpu.apply("train", ins)
+            ref.apply("train", ins)
+        for tid in sorted(ref.params):
+            assert rel_err(gpu.params[tid], ref.params[tid]) <= 3 * 256 * 6e-8, tid      # three steps of 256-term sums
     elif name == "softmax_xent":
         z = (rng.random((2, 3), dtype=f) * 4 - 2).astype(f)
         gpu.params[1] = z
