@@ -422,7 +422,8 @@ def build_dense(env, batch):
             dp = NativeDataParallel(model, "train", group, reduction="mean")
             dp.engine = _NativeEngine(model, "train")
             env["dp_path"] = "native"
-            env["rccl_ranks"] = group.world
+            env["rccl_ranks"] = group.rccl_count()      # what RCCL says (ncclCommCount), not the argument echoed back
+            env["rccl_group"] = group
         elif group is not None:
             group.close()
     if dp is None:
@@ -430,7 +431,8 @@ def build_dense(env, batch):
         if env["world"] > 1:
             import torch.distributed as dist
             env["dp_path"] = "torch"
-            env["rccl_ranks"] = dist.get_world_size()
+            # ranks an RCCL communicator spans: torch's nccl backend is RCCL; under gloo (one-GPU test mode) no RCCL ran
+            env["rccl_ranks"] = dist.get_world_size() if dist.get_backend() == "nccl" else 0
     return model, dp, x, y
 
 
@@ -478,6 +480,29 @@ def run_train(args, env):
     else:
         step = lambda: dp.step(inputs)
     elapsed, ev_avg, ev_min = env["timer"].run(step, args.steps, args.warmup)
+    exchange = None
+    if world > 1:
+        # One run decides whether exchanging the early gradients under the last long contraction pays: the same step
+        # with the split allowed and forbidden, and the bare all-reduce of the bucket, each over min(steps, 20) steps
+        # AFTER the timed region (value / ms_per_step above are the default configuration's).
+        import torch.distributed as dist
+        torch = env["torch"]
+        k2 = min(args.steps, 20)
+        exchange = {}
+        group = env.get("rccl_group")
+        if group is not None:
+            for name, allowed in (("step_ms_unsplit", False), ("step_ms_split", True)):
+                group.set_split(allowed)
+                t2, _, _ = env["timer"].run(step, k2, 3)
+                exchange[name] = round(t2 / k2 * 1e3, 4)
+                exchange["pieces_" + name[8:]] = group.last_pieces()
+            bucket = torch.zeros(max(model.grad_bucket("train")[1], 1), device="cuda")
+            t3, _, _ = env["timer"].run(lambda: group.all_reduce(bucket), k2, 3)
+        else:
+            bucket = dp.engine.bucket
+            t3, _, _ = env["timer"].run(lambda: dist.all_reduce(bucket, op=dist.ReduceOp.SUM), k2, 3)
+        exchange["allreduce_us"] = round(t3 / k2 * 1e6, 2)
+        exchange["allreduce_floats"] = int(bucket.numel())
     samples = batch * world * args.steps
     step_flops = DENSE_FLOPS_PER_SAMPLE * batch
     achieved = step_flops / (ev_avg * 1e-3) / 1e12
@@ -507,6 +532,8 @@ def run_train(args, env):
     }
     if single:
         out["single_gpu_reference"] = single
+    if exchange:
+        out["exchange"] = exchange
     if env.get("dp_fallback_reason"):
         out["config"]["native_dp_fallback"] = env["dp_fallback_reason"]
     out["scaling"] = "strong" if strong else "weak"

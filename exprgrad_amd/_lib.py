@@ -104,6 +104,9 @@ _SIGS = {
     "eg_dp_init": (c_int, [c_void_p, c_void_p, c_int, c_int, P(c_void_p)]),
     "eg_dp_free": (c_int, [c_void_p]),
     "eg_dp_rank": (c_int, [c_void_p]),
+    "eg_dp_rccl_count": (c_int, [c_void_p]),
+    "eg_dp_rccl_rank": (c_int, [c_void_p]),
+    "eg_dp_set_split": (c_int, [c_void_p, c_int]),
     "eg_dp_world": (c_int, [c_void_p]),
     "eg_dp_allreduce_sum_f32": (c_int, [c_void_p, c_void_p, c_i64]),
     "eg_model_step_dp": (c_int, [c_void_p, c_char_p, c_void_p, c_int]),
@@ -128,7 +131,7 @@ _SIGS = {
 
 # functions whose int return value is not a status code
 _NOT_STATUS = {"eg_version", "eg_ctx_device", "eg_model_kernel_count", "eg_model_tensor_count", "eg_dp_rank",
-               "eg_dp_world", "eg_dp_last_pieces"}
+               "eg_dp_world", "eg_dp_last_pieces", "eg_dp_rccl_count", "eg_dp_rccl_rank"}
 
 
 def declared_symbols():

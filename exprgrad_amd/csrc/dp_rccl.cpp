@@ -9,7 +9,12 @@
 // has one (torch ships its own) reuses that copy instead of loading a second one.
 #include <dlfcn.h>
 
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
 
 #include "eg_internal.hpp"
 
@@ -27,6 +32,8 @@ struct Rccl {
   int (*CommDestroy)(Comm) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommCount)(Comm, int*) = nullptr;     // optional: what RCCL itself says the group is
+  int (*CommUserRank)(Comm, int*) = nullptr;
   bool ok = false;
   std::string why;
 };
@@ -50,6 +57,8 @@ const Rccl& rccl() {
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(h, "ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.GetErrorString;
     if (!r.ok) r.why = "librccl.so lacks an expected symbol";
     return r;
@@ -73,7 +82,57 @@ struct eg_dp {
   Comm comm = nullptr;
   int rank = 0, world = 1;
   int last_pieces = 0;  // all-reduce calls of the last eg_model_step_dp (2+: early gradients went under the contraction)
+  bool split = true;    // early / late split of the bucket allowed (eg_dp_set_split; EG_DP_NO_SPLIT=1 starts with false)
+  int reserve_cus = 8;  // compute units the last long contraction leaves to the early collective (EG_DP_RESERVE_CUS)
+  int64_t* agree_buf = nullptr;  // device scratch of the cross-rank comparison: 2 x 32 int64
 };
+
+namespace {
+// ncclCommInitRank blocks until every rank has joined.  A rank that never arrives (crashed, took another code path)
+// would leave the others inside it for ever; the call runs on a helper thread and is given up after
+// EG_DP_INIT_TIMEOUT_S seconds (default 180) with an error the host can act on (bench.py: every rank falls back to the
+// torch.distributed exchange).  The helper thread of a call that was given up stays blocked and is abandoned.
+struct InitState {
+  std::mutex mu;
+  std::condition_variable cv;
+  bool done = false;
+  int status = 0;
+  Comm comm = nullptr;
+};
+
+int init_with_watchdog(int device, int world, const UniqueId& id, int rank, Comm* out) {
+  double timeout_s = 180;
+  if (const char* e = getenv("EG_DP_INIT_TIMEOUT_S")) timeout_s = atof(e);
+  auto st = std::make_shared<InitState>();
+  std::thread([st, device, world, id, rank] {
+    hipSetDevice(device);
+    Comm c = nullptr;
+    const int r = rccl().CommInitRank(&c, world, id, rank);
+    std::lock_guard<std::mutex> lock(st->mu);
+    st->status = r;
+    st->comm = c;
+    st->done = true;
+    st->cv.notify_all();
+  }).detach();
+  std::unique_lock<std::mutex> lock(st->mu);
+  if (!st->cv.wait_for(lock, std::chrono::duration<double>(timeout_s > 0 ? timeout_s : 1e9), [&] { return st->done; })) {
+    ::eg::set_error("ncclCommInitRank (rank %d of %d) did not return within %.0f s: another rank never joined", rank, world,
+                    timeout_s);
+    return EG_ERR_RUNTIME;
+  }
+  if (st->status != 0) {
+    ::eg::set_error("ncclCommInitRank failed: %s (%d)", rccl().GetErrorString(st->status), st->status);
+    return EG_ERR_HIP;
+  }
+  *out = st->comm;
+  return EG_OK;
+}
+
+bool env_on(const char* name) {
+  const char* e = getenv(name);
+  return e && e[0] && e[0] != '0';
+}
+}  // namespace
 
 extern "C" {
 
@@ -95,12 +154,15 @@ int eg_dp_init(eg_ctx* ctx, const void* id128, int rank, int world, eg_dp** out)
   UniqueId id;
   memcpy(&id, id128, sizeof(id));
   Comm comm = nullptr;
-  EG_RCCL_CHECK(rccl().CommInitRank(&comm, world, id, rank));
+  rc = init_with_watchdog(ctx->device, world, id, rank, &comm);
+  if (rc) return rc;
   eg_dp* dp = new eg_dp();
   dp->ctx = ctx;
   dp->comm = comm;
   dp->rank = rank;
   dp->world = world;
+  dp->split = !env_on("EG_DP_NO_SPLIT");
+  if (const char* e = getenv("EG_DP_RESERVE_CUS")) dp->reserve_cus = atoi(e);
   *out = dp;
   return EG_OK;
 }
@@ -112,12 +174,31 @@ int eg_dp_free(eg_dp* dp) {
     hipStreamSynchronize(dp->ctx->stream);
     rccl().CommDestroy(dp->comm);
   }
+  if (dp->agree_buf) hipFree(dp->agree_buf);
   delete dp;
   return EG_OK;
 }
 
 int eg_dp_world(const eg_dp* dp) { return dp ? dp->world : 0; }
 int eg_dp_rank(const eg_dp* dp) { return dp ? dp->rank : -1; }
+
+// What RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank): -1 when the library lacks the symbols.
+int eg_dp_rccl_count(const eg_dp* dp) {
+  int n = -1;
+  if (dp && dp->comm && rccl().CommCount && rccl().CommCount(dp->comm, &n) != 0) n = -1;
+  return n;
+}
+int eg_dp_rccl_rank(const eg_dp* dp) {
+  int r = -1;
+  if (dp && dp->comm && rccl().CommUserRank && rccl().CommUserRank(dp->comm, &r) != 0) r = -1;
+  return r;
+}
+
+int eg_dp_set_split(eg_dp* dp, int enabled) {
+  EG_REQUIRE(dp, EG_ERR_INVALID, "eg_dp_set_split: NULL group");
+  dp->split = enabled != 0;
+  return EG_OK;
+}
 
 int eg_dp_allreduce_sum_f32(eg_dp* dp, float* device_buf, int64_t count) {
   EG_REQUIRE(dp && dp->comm, EG_ERR_INVALID, "eg_dp_allreduce_sum_f32: NULL communicator");
@@ -147,9 +228,35 @@ int eg_model_step_dp(eg_model* model, const char* target, eg_dp* dp, int mean) {
   if (rc) return rc;
   eg::GradExchange gx;
   gx.user = dp;
+  gx.split = dp->split;
+  // (EG_DP_TEST_AS_MULTI=1: a one-rank group takes the multi-rank code paths — comparison collective, reserved compute
+  // units — so that a one-GPU box exercises them)
+  const bool multi = dp->world > 1 || env_on("EG_DP_TEST_AS_MULTI");
+  gx.reserve_cus = multi ? dp->reserve_cus : 0;
   gx.allreduce = [](void* user, float* buf, long count) {
     return eg_dp_allreduce_sum_f32(static_cast<eg_dp*>(user), buf, (int64_t)count);
   };
+  if (multi)
+    gx.agree = [](void* user, const int64_t* values, int n, int* same) {
+      // MAX over the ranks of [v, -v]: all ranks hold the same v  <=>  max(v) == -max(-v) element by element
+      eg_dp* d = static_cast<eg_dp*>(user);
+      EG_REQUIRE(n >= 1 && n <= 32, EG_ERR_INVALID, "eg_dp: comparison of %d values", n);
+      if (!d->agree_buf) EG_HIP_CHECK(hipMalloc((void**)&d->agree_buf, 64 * sizeof(int64_t)));
+      int64_t host[64];
+      for (int i = 0; i < n; ++i) {
+        host[i] = values[i];
+        host[n + i] = -values[i];
+      }
+      hipStream_t s = d->ctx->stream;
+      EG_HIP_CHECK(hipMemcpyAsync(d->agree_buf, host, 2 * n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+      EG_RCCL_CHECK(rccl().AllReduce(d->agree_buf, d->agree_buf, (size_t)(2 * n), /*ncclInt64*/ 4, /*ncclMax*/ 2, d->comm, s));
+      EG_HIP_CHECK(hipMemcpyAsync(host, d->agree_buf, 2 * n * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+      EG_HIP_CHECK(hipStreamSynchronize(s));
+      *same = 1;
+      for (int i = 0; i < n; ++i)
+        if (host[i] != -host[n + i]) *same = 0;
+      return (int)EG_OK;
+    };
   rc = eg::model_backward_with_exchange(model, target, gx, &dp->last_pieces);
   if (rc) return rc;
   return eg_model_run_update(model, target);

@@ -139,7 +139,14 @@ int copy_segments(eg_ctx* ctx, const CopySegments& seg);
 // (host/run.cpp plan_exchange); the rest after it.  *pieces (optional) = all-reduce calls issued.
 struct GradExchange {
   int (*allreduce)(void* user, float* buf, long count) = nullptr;
+  // Do all ranks hold the same `n` numbers?  (*same = 1 / 0; one small collective + a host read, once per plan.)
+  // Ranks that would cut the bucket differently — unequal shards through the C ABI, an environment toggle on one rank —
+  // would issue different sequences of all-reduce calls on one communicator: a hang or silently mixed gradients.
+  // NULL: not checked (a one-rank group).
+  int (*agree)(void* user, const int64_t* values, int n, int* same) = nullptr;
   void* user = nullptr;
+  bool split = true;    // allow the early / late split of the bucket (EG_DP_NO_SPLIT, eg_dp_set_split)
+  int reserve_cus = 0;  // compute units the last long contraction leaves free for the collective's kernel
 };
 int model_backward_with_exchange(eg_model* model, const char* target, const GradExchange& gx, int* pieces);
 eg_ctx* model_context(eg_model* model);

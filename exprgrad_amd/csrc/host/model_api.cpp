@@ -46,11 +46,31 @@ int model_backward_with_exchange(eg_model* m, const char* target, const GradExch
     }
     return (int)EG_OK;
   };
-  static const bool no_split = [] {
-    const char* e = getenv("EG_DP_NO_SPLIT");
-    return e && e[0] && e[0] != '0';
-  }();
-  if (ex.big == -1 || no_split) {
+  // The split is a per-rank decision (plan.overlaps depends on this rank's shapes and environment); every rank must
+  // make the SAME one.  Once per plan the piece list is compared across the ranks; where it differs, every rank
+  // exchanges the whole bucket in one call (and if even the bucket sizes differ, the step is refused).
+  bool split = gx.split && ex.big >= 0 && !plan->pipe.active;
+  if (gx.agree && plan->dp_agreed == 0) {
+    std::vector<int64_t> finger = {(int64_t)ts->bucket_floats, split ? 1 : 0, split ? (int64_t)ex.early.size() : 0,
+                                   split ? (int64_t)ex.late.size() : 0};
+    if (split) {
+      for (auto& seg : ex.early) { finger.push_back(seg.first); finger.push_back(seg.second); }
+      for (auto& seg : ex.late) { finger.push_back(seg.first); finger.push_back(seg.second); }
+    }
+    finger.resize(32, -1);  // fixed length: ranks with different piece counts still meet in one collective
+    int same = 0, same_bucket = 0;
+    rc = gx.agree(gx.user, finger.data(), (int)finger.size(), &same);
+    if (rc) return rc;
+    if (!same) {
+      rc = gx.agree(gx.user, finger.data(), 1, &same_bucket);
+      if (rc) return rc;
+      EG_REQUIRE(same_bucket, EG_ERR_INVALID,
+                 "data-parallel step: the ranks hold gradient buckets of different sizes (different models or targets)");
+    }
+    plan->dp_agreed = same ? 1 : 2;
+  }
+  if (plan->dp_agreed == 2) split = false;
+  if (!split) {
     // nothing to overlap with: the captured backward range, then one all-reduce of the whole bucket
     rc = run_range(m, *ts, *plan, 0, plan->n_backward, true, 1);
     if (rc) return rc;
@@ -58,22 +78,37 @@ int model_backward_with_exchange(eg_model* m, const char* target, const GradExch
     if (ts->bucket_floats > 0) whole.push_back({0, ts->bucket_floats});
     rc = reduce(whole);
   } else {
-    struct Early {
-      decltype(reduce)* reduce;
-      const ExchangePlan* ex;
-    } early = {&reduce, &ex};
-    SideHook hook;
-    hook.big = ex.big;
-    hook.user = &early;
-    hook.fn = [](void* u) {
-      Early* e = static_cast<Early*>(u);
-      return (*e->reduce)(e->ex->early);
-    };
-    rc = eg::set_device(m->ctx);
+    // Three captured ranges around the two collectives (a collective is not captured: RCCL decides that):
+    //   main lane:  [0, first)  ......................  [big, n_backward)  ..  all-reduce(late)
+    //   side lane:              [first, big)  all-reduce(early)  ......  join ^
+    // [first, big) are the bandwidth-bound launches of the overlap group (the small weight gradient, column sums):
+    // they and the early exchange run under the long contraction `big`, which leaves gx.reserve_cus compute units
+    // free so that the collective's kernel has somewhere to run.
+    int first = -1;
+    for (auto& ov : plan->overlaps)
+      if (ov.big == ex.big) first = ov.first;
+    EG_REQUIRE(first >= 0 && first <= ex.big, EG_ERR_RUNTIME, "data-parallel step: the overlap group of launch %d is gone", ex.big);
+    eg_ctx* ctx = m->ctx;
+    rc = eg::set_device(ctx);
     if (rc) return rc;
-    // launched one by one (a collective in the middle): the range is a dozen launches against a
-    // millisecond of matrix work, the host stays far ahead of the device
-    rc = run_range_eager(m, *ts, *plan, 0, plan->n_backward, true, &hook);
+    rc = run_range(m, *ts, *plan, 0, first, true, 3);
+    if (rc) return rc;
+    EG_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+    EG_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+    int side_rc = EG_OK;
+    {
+      LaneSwap lane(ctx);
+      side_rc = run_range(m, *ts, *plan, first, ex.big, false, 4);
+      if (!side_rc) side_rc = reduce(ex.early);
+      // (recorded whatever happened: the main lane below waits for it, and a failed step must not leave the side
+      // stream unjoined)
+      hipEventRecord(ctx->ev_join, ctx->stream);
+    }
+    const int cus = ctx->compute_units;
+    if (gx.reserve_cus > 0 && gx.reserve_cus < cus) ctx->compute_units = cus - gx.reserve_cus;
+    rc = side_rc ? side_rc : run_range(m, *ts, *plan, ex.big, plan->n_backward, false, 5);
+    ctx->compute_units = cus;
+    EG_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if (rc) return rc;
     rc = reduce(ex.late);
   }

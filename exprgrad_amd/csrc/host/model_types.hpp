@@ -185,7 +185,8 @@ struct Plan {
     std::string key;  // everything baked into the captured kernel arguments
     int runs = 0;
   };
-  Captured graphs[3];
+  Captured graphs[6];  // 0 whole call, 1 backward part, 2 update part; data-parallel split: 3 head, 4 side lane, 5 tail
+  int dp_agreed = 0;   // data-parallel exchange plan compared across the ranks: 0 not yet, 1 the same everywhere (split allowed), 2 differs (one bucket)
 };
 
 struct TargetState {

@@ -119,6 +119,20 @@ class RcclGroup:
         call("eg_dp_unique_id", ctypes.cast(buf, ctypes.c_void_p))
         return bytes(buf)
 
+    def rccl_count(self):
+        """Ranks of the communicator as RCCL reports them (ncclCommCount), -1 if the library cannot say."""
+        from ._lib import call
+        return call("eg_dp_rccl_count", self.handle)
+
+    def set_split(self, enabled):
+        """Allow / forbid the early exchange under the last long contraction (every rank the same)."""
+        from ._lib import call
+        call("eg_dp_set_split", self.handle, int(bool(enabled)))
+
+    def last_pieces(self):
+        from ._lib import call
+        return call("eg_dp_last_pieces", self.handle)
+
     def all_reduce(self, tensor):
         """In-place SUM of a float32 device tensor, asynchronous on the context's stream."""
         import ctypes

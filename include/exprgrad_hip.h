@@ -322,10 +322,19 @@ const char* eg_model_source_text(eg_model* model);
  * librccl.so is opened on first use.
  * ------------------------------------------------------------------------------------------- */
 int eg_dp_unique_id(void* id128);                     /* ncclGetUniqueId: 128 opaque bytes */
+/* Blocks until every rank has joined; gives up with EG_ERR_RUNTIME after EG_DP_INIT_TIMEOUT_S seconds (default 180). */
 int eg_dp_init(eg_ctx* ctx, const void* id128, int rank, int world, eg_dp** out);
 int eg_dp_free(eg_dp* dp);
 int eg_dp_rank(const eg_dp* dp);
 int eg_dp_world(const eg_dp* dp);
+/* What RCCL itself reports for the communicator (ncclCommCount / ncclCommUserRank), -1 if it cannot say: the figure a
+ * benchmark line should carry as "ranks the collective ran over". */
+int eg_dp_rccl_count(const eg_dp* dp);
+int eg_dp_rccl_rank(const eg_dp* dp);
+/* eg_model_step_dp may exchange the gradients that are complete early under the backward pass's last long contraction
+ * (two all-reduce calls per step instead of one).  enabled = 0 keeps the single exchange after the backward pass
+ * (initial value: 1, or 0 with EG_DP_NO_SPLIT=1); lets a host time both forms in one run.  Every rank must choose the same. */
+int eg_dp_set_split(eg_dp* dp, int enabled);
 /* In-place SUM over the ranks of `count` floats at `device_buf`; asynchronous on the stream. */
 int eg_dp_allreduce_sum_f32(eg_dp* dp, float* device_buf, int64_t count);
 /* One training step on this rank's shard of the batch (inputs bound with eg_model_set_input_*):

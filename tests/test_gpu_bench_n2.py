@@ -26,6 +26,8 @@ def test_bench_two_ranks_on_one_gpu(scaling):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == scaling
     assert line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 8192
-    assert line["config"]["rccl_ranks"] == 2 and "gloo" in line["config"]["collective"]
+    # two ranks over gloo: no RCCL communicator ran, and the line says so
+    assert line["config"]["rccl_ranks"] == 0 and "gloo" in line["config"]["collective"]
+    assert line["exchange"]["allreduce_us"] > 0 and line["exchange"]["allreduce_floats"] == line["config"]["grad_bucket_floats"]
     assert line["value"] > 0 and line["single_gpu_reference"]["value"] > 0
     assert line["unit"] == "samples/s" and line["dtype"] == "f32" and line["roofline"]["frac"] > 0

@@ -293,3 +293,53 @@ def test_cfg5_native_step_overlaps_the_early_exchange(gpu_ctx):
         whole.close()
         split.close()
         group.close()
+
+
+def test_native_step_split_toggle_comparison_collective_and_reserved_units(gpu_ctx, monkeypatch):
+    """What the first multi-GPU run relies on, on one GPU: RCCL's own rank count, the split switched on and off inside one
+    process (eg_dp_set_split: bench.py times both forms), and — with EG_DP_TEST_AS_MULTI=1 — the code paths a one-rank
+    group otherwise skips: the once-per-plan comparison of the exchange plan across the ranks (an int64 MAX all-reduce)
+    and the long contraction leaving compute units to the early collective (another slice count: same sums, another
+    order, so that variant is compared at 1e-5 instead of bit for bit)."""
+    torch = pytest.importorskip("torch")
+    from exprgrad_amd.parallel import NativeDataParallel, RcclGroup
+    import exprgrad_amd as eg
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = eg.newGpuContext(0, stream=stream.cuda_stream)
+        x = torch.rand((16384, 784), device="cuda")
+        y = torch.nn.functional.one_hot(torch.randint(0, 10, (16384,), device="cuda"), 10).to(torch.float32).contiguous()
+
+        def run(env, split_sequence):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            group = RcclGroup(ctx, RcclGroup.unique_id(), rank=0, world=1)
+            assert group.rccl_count() == 1
+            model = egm.compile(*refcases.dense_softmax_net(), gpu=ctx)
+            rng = np.random.default_rng(15)
+            for tid in model.params.ids():
+                model.params[tid] = (rng.random(model.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+            dp = NativeDataParallel(model, "train", group, reduction="mean")
+            pieces = []
+            for allowed in split_sequence:
+                group.set_split(allowed)
+                for _ in range(3):          # eager, captured, replayed
+                    dp.step([("x", x), ("y", y)])
+                stream.synchronize()
+                pieces.append(group.last_pieces())
+            params = {tid: model.params[tid].copy() for tid in model.params.ids()}
+            model.close()
+            group.close()
+            for k in env:
+                monkeypatch.delenv(k)
+            return params, pieces
+
+        plain, p0 = run({}, [True, False, True])
+        if not debug_toggles_active():
+            assert p0 == [2, 1, 2], p0
+        same_kernels, p1 = run({"EG_DP_TEST_AS_MULTI": "1", "EG_DP_RESERVE_CUS": "0"}, [True, False, True])
+        for tid in plain:
+            assert np.array_equal(plain[tid], same_kernels[tid]), tid       # the comparison collective changes nothing
+        reserved, p2 = run({"EG_DP_TEST_AS_MULTI": "1", "EG_DP_RESERVE_CUS": "8"}, [True, False, True])
+        for tid in plain:
+            assert rel_err(reserved[tid], plain[tid]) <= TOL, tid
