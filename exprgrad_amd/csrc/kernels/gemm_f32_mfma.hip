@@ -428,6 +428,68 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
       return EG_OK;
     }
   }
+  // Extra rows (GemmArgs::x_rows): a TN product with a long K (a weight gradient: K = the batch) whose M is a few rows
+  // beyond whole 256-row tiles and whose tiles cannot fill the chip by themselves.  The last tile row's blocks carry the
+  // extra rows as a ninth accumulator block (+ 1/8 matrix work) and get proportionally more, shorter k-slices, so every
+  // block finishes together; no ragged tile row exists.  EG_GEMM_NO_XROW=1: the ragged tile row of round 2.
+  static const bool xrow_on = getenv("EG_GEMM_NO_XROW") == nullptr;
+  if (xrow_on && !conv && vec_ok && !a_vec_only && !a_kc && !b_kc && M > 256 && M % 256 > 0 && M % 256 <= 32 && N % 256 == 0 &&
+      K % BK == 0 && args.ldc % 4 == 0 && getenv("EG_GEMM_FORCE_TILE") == nullptr) {
+    const long tm = M / 256, tn = N / 256, k_tiles = K / BK, slots = ctx->compute_units;
+    const long full = (tm - 1) * tn;
+    long best_s1 = 0, best_s2 = 0;
+    double best_t = 0;
+    static const double xw = [] {  // k-tile of a strip-carrying block relative to a plain one (tuning aid: EG_XROW_WEIGHT)
+      const char* e = getenv("EG_XROW_WEIGHT");
+      return e ? atof(e) : 1.2;  // measured on 784 x 512 x 65536: 1.0 449 us, 1.125 441, 1.2 428, 1.3 446, 1.4 452 (the strip adds 2 DMA pieces and 16 LDS reads per k-tile to its 4 MFMAs)
+    }();
+    for (long s1 = 2; full * s1 + tn * 2 <= slots && s1 <= k_tiles / 8; ++s1) {
+      long s2 = (slots - full * s1) / tn;
+      if (s2 > k_tiles / 8) s2 = k_tiles / 8;
+      if (s2 < 2) continue;
+      const long per1 = (k_tiles + s1 - 1) / s1, per2 = (k_tiles + s2 - 1) / s2;
+      const double t = std::max((double)per1, xw * (double)per2);  // k-tiles of the slowest block, in whole-tile units
+      if (best_s1 == 0 || t < best_t) {
+        best_t = t;
+        best_s1 = s1;
+        best_s2 = s2;
+      }
+    }
+    if (full == 0) {  // a single tile row: every block carries the strip
+      long s2 = slots / tn;
+      if (s2 > k_tiles / 8) s2 = k_tiles / 8;
+      if (s2 >= 2) best_s1 = best_s2 = s2;
+    }
+    if (best_s1 >= 2 && best_s2 >= 2) {
+      const long per1 = (k_tiles + best_s1 - 1) / best_s1, per2 = (k_tiles + best_s2 - 1) / best_s2;
+      const long s1 = (k_tiles + per1 - 1) / per1, s2 = (k_tiles + per2 - 1) / per2;
+      args.tiles_m = (int)tm;
+      args.tiles_n = (int)tn;
+      args.x_rows = (int)(M % 256);
+      args.splits = (int)s1;
+      args.k_per_split = per1 * BK;
+      args.edge_splits = (int)s2;
+      args.k_per_split_edge = per2 * BK;
+      args.wide_store = wide_store_ok(args, true);
+      args.prio = side_priority(ctx);
+      args.nt_store = nt_store_enabled();
+      const long total = M * N, slabs = std::max(s1, s2);
+      int rc = eg::ensure_workspace(ctx, (((size_t)slabs * total + 3) & ~(size_t)3) * sizeof(float));
+      if (rc) return rc;
+      args.partial = static_cast<float*>(ctx->workspace);
+      const unsigned grid = (unsigned)(full * s1 + tn * s2);
+      hipLaunchKernelGGL((gemm_f32_mfma_kernel<256, 256, BK, 128, 64, 1, false, false, 4, true, 0, 0, true, true>), dim3(grid), dim3(512),
+                         0, ctx->stream, args);
+      EG_HIP_CHECK(hipGetLastError());
+      long blocks = (total + 255) / 256;
+      if (blocks > 2048) blocks = 2048;
+      // rows of the last tile row and the extra rows were cut into s2 slices, the others into s1
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, args.partial, args.C, args.bias,
+                         M, N, args.ldc, (int)s1, args.accumulate, (tm - 1) * 256, (int)s2);
+      EG_HIP_CHECK(hipGetLastError());
+      return EG_OK;
+    }
+  }
   // (32-deep k-tiles for the 256x256 tile were measured in round 2: +1 % at 4096^3, -7 % at K = 784, 0 elsewhere)
   // the convolution's filter gradient (M = F = 64 rows, 64 x 64 tiles, K = every output pixel): a block has
   // little matrix work per barrier, so its k-tiles are 32 deep like the forward gather's (EG_CONVGF_BK16=1: 16)

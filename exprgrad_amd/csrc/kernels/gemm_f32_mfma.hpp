@@ -84,6 +84,12 @@ struct GemmArgs {
   // measured at 208 us next to a 256x256 one (rocprofv3 timeline, profiles/r02_pipeline_trace.txt).
   int prio;
   int nt_store;  // wide stores as nontemporal stores (host: nt_store_enabled)
+  // Extra rows (XR kernels; split-K launches of the TN form): M = tiles_m * BM + x_rows with 0 < x_rows <= 32.  The blocks of
+  // the LAST tile row carry a ninth accumulator block per wave for rows [tiles_m * BM, M) — a [k][32] strip of A staged
+  // next to the tile, multiplied with the B tile the block stages anyway — instead of a ragged tile row of its own that
+  // would stage whole B tiles for 1/8 of the matrix work (784 x 512 x 65536: the 16 (+1 virtual) rows beyond 768 cost
+  // 47 us as a tile row).  Those blocks get edge_splits (more, shorter) k-slices.
+  int x_rows;
 };
 
 // Epilogue functor of the library kernels: plain store.  A generated epilogue (ACTIVE = true)
@@ -854,6 +860,75 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
   }
 }
 
+// K loop of a block that carries the extra rows (GemmArgs::x_rows): the interior LDS-DMA loop of the TN form plus a
+// [k][32] strip of A (rows m_blk + BM .., clamped at a_rows; it may hold the virtual row of ones) and one more accumulator
+// block per wave: wave w multiplies the strip with columns [32 w, 32 w + 32) of the B tile.
+template <int BM, int BN, int BK, int WM, int WN>
+__device__ __forceinline__ void gemm_mainloop_dma_x(const GemmArgs& a, float* lds, f32x16 (&acc)[WM / 32][WN / 32], f32x16& accx,
+                                                    long m_blk, long n_blk, long k_begin, int nk, int tid, int wm0, int wn0) {
+  constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
+  constexpr int MI = WM / 32, NI = WN / 32;
+  constexpr int BUF = BK * (BM + BN);
+  static_assert(Interleaved<false, MI>::value && Interleaved<false, NI>::value && BN / 32 == NT / 64,
+                "extra rows: the 256 x 256 tile of the TN form (one 32-column block of the strip per wave)");
+  using DmaA = DmaLoader<BM, BK, NT, false, false>;
+  using DmaB = DmaLoader<BN, BK, NT, false, false>;
+  using DmaX = DmaLoader<32, BK, NT, false, false, true, false>;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, hi = lane >> 5;
+  float* xs = lds + 2 * BUF;  // two stages of the strip, [BK][32] each
+  DmaA da;
+  DmaB db;
+  DmaX dx;
+  da.init(a, m_blk, wave, lane, a.a_rows, a.lda);
+  db.init(a, n_blk, wave, lane, a.N, a.ldb);
+  dx.init(a, m_blk + BM, wave, lane, a.a_rows, a.lda, a.ones_row != 0);
+  const float* ones = a.ones_row ? a.ones : nullptr;
+  auto issue = [&](int kt) {
+    const long k0 = k_begin + (long)kt * BK;
+    float* stage = lds + (kt & 1) * BUF;
+    da.issue(a, a.A, a.lda, m_blk, k0, stage, wave, lane);
+    db.issue(a, a.B, a.ldb, n_blk, k0, stage + BK * BM, wave, lane, a.N);
+    dx.issue(a, a.A, a.lda, m_blk + BM, k0, xs + (kt & 1) * BK * 32, wave, lane, a.a_rows, 0, ones);
+  };
+  if (nk > 0) issue(0);
+  dma_publish_barrier();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) issue(kt + 1);
+    const float* As = lds + (kt & 1) * BUF;
+    const float* Bs = As + BK * BM;
+    const float* Xs = xs + (kt & 1) * BK * 32;
+#pragma unroll
+    for (int pp = 0; pp < BK / 8; ++pp) {
+      float av[MI][4], bv[NI][4], ax[4], bx[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 8 * pp + j + 4 * hi;
+        typedef float vecA __attribute__((ext_vector_type(MI)));
+        typedef float vecB __attribute__((ext_vector_type(NI)));
+        const vecA va = *reinterpret_cast<const vecA*>(As + k * BM + wm0 + MI * i);
+        const vecB vb = *reinterpret_cast<const vecB*>(Bs + k * BN + wn0 + NI * i);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) av[mi][j] = va[mi];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) bv[ni][j] = vb[ni];
+        ax[j] = Xs[k * 32 + i];
+        bx[j] = Bs[k * BN + wave * 32 + i];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+        accx = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[j], bx[j], accx, 0, 0, 0);
+      }
+    }
+    dma_publish_barrier();
+  }
+}
+
 // MINB: blocks per CU the register allocator must leave room for (waves/SIMD = MINB * WAVES / 4).
 // EDGE kernels still run their interior tiles on the unpredicated loop.
 // DMA: interior tiles use the LDS-DMA loop (requires VEC == 4, BK in {16, 32}; with CONV the host
@@ -861,13 +936,13 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
 // CONV: 0 = plain operands, 1 = A is the im2col matrix of an NHWC image (forward convolution),
 // 2 = B is that matrix with k = output pixel, n = tap (filter-gradient contraction).
 template <int BM, int BN, int BK, int WM, int WN, bool A_KC, bool B_KC, int VEC, bool EDGE, int CONV, int ABL, bool DMA,
-          class Epi>
+          class Epi, bool XR = false>
 __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   constexpr int WAVES_N = BN / WN;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int SA = LdsStride<BM, BK, A_KC>::value, SB = LdsStride<BN, BK, B_KC>::value;
 
-  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (SA + SB)];
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (SA + SB) + (XR ? 2 * BK * 32 : 0)];  // (XR: + the strip's stages)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -943,8 +1018,27 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   // every k-tile clamped, against 973 us for K = 4112).
   const bool k_tail_only = EDGE && DMA && CONV == 0 && !whole_k && k_end > k_begin && m_blk + BM <= a.a_rows && n_blk + BN <= a.N;
   bool done = false;
+  if constexpr (XR) {
+    // extra rows: the blocks of the last tile row multiply and store the strip [tiles_m * BM, M) as well (split-K only:
+    // the strip goes to this block's slab)
+    if (a.x_rows > 0 && m_blk == (long)(a.tiles_m - 1) * BM) {
+      f32x16 accx;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accx[r] = 0.f;
+      gemm_mainloop_dma_x<BM, BN, BK, WM, WN>(a, lds, acc, accx, m_blk, n_blk, k_begin, nk, tid, wm0, wn0);
+      float* slab = a.partial + (long)split * a.M * a.N;
+      const long n = n_blk + wave * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long m = m_blk + BM + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < a.M) slab[m * a.N + n] = accx[r];
+      }
+      done = true;
+    }
+  }
   if constexpr (DMA) {  // kernels without the DMA loop (tuning harness: BK = 8) never instantiate it
-    if (!EDGE || interior || k_tail_only) {
+    if (done) {
+    } else if (!EDGE || interior || k_tail_only) {
       const int n_main = (EDGE && k_tail_only) ? nk - 1 : nk;
       if (n_main > 0)
         gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, CONV, false, true, false, ABL>(a, lds, acc, m_blk, n_blk, k_begin, n_main, tid, wm0, wn0);
@@ -1183,10 +1277,10 @@ struct WavesPerSimd {
 };
 
 template <int BM, int BN, int BK, int WM, int WN, int MINB, bool A_KC, bool B_KC, int VEC, bool EDGE, int CONV,
-          int ABL = 0, bool DMA = false>
+          int ABL = 0, bool DMA = false, bool XR = false>
 __global__ __launch_bounds__((Geometry<BM, BN, WM, WN>::NT), (WavesPerSimd<BM, BN, WM, WN, MINB, EDGE, VEC>::value)) void
 gemm_f32_mfma_kernel(GemmArgs a) {
-  gemm_block<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, EDGE, CONV, ABL, DMA, EpiNone>(a);
+  gemm_block<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, EDGE, CONV, ABL, DMA, EpiNone, XR>(a);
 }
 
 // Second pass of split-K: C[m,n] = (accumulate ? C : 0) + sum_z partial[z][m][n] + bias[n],

@@ -390,3 +390,25 @@ def test_mid_size_and_remainder_contractions(gpu_ctx, case):
     scale = max(np.abs(want).max(), 0.25 * np.sqrt(K) * 0.3)
     assert np.abs(outs[0] - want).max() <= TOL * scale, case
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("shape", [(784, 512, 16384), (785, 512, 8192), (272, 256, 32768), (260, 512, 20000 // 16 * 16), (1040, 768, 8192),
+                                   (288, 256, 16384), (513, 256, 16384)])
+def test_extra_rows_ride_along_with_the_last_tile_row(gpu_ctx, shape):
+    """TN products (weight gradients: K = the batch) whose M is 1 .. 32 rows beyond whole 256-row tiles: the blocks of the
+    last tile row carry the extra rows as a ninth accumulator block (GemmArgs::x_rows) instead of a ragged tile row.
+    Against the float64 product, and bit-identical from run to run (fixed-order second pass)."""
+    m, n, k = shape
+    rng = np.random.default_rng(m + k)
+    a = (rng.random((k, m), dtype=np.float32) - 0.5).astype(np.float32)
+    b = (rng.random((k, n), dtype=np.float32) - 0.5).astype(np.float32)
+    da, db = dev(gpu_ctx, a), dev(gpu_ctx, b)
+    outs = []
+    for _ in range(2):
+        dc = gpu_ctx.allocTensor((m, n))
+        ops.fill(gpu_ctx, m * n, 7.0, dc)           # must be overwritten completely
+        ops.sgemm(gpu_ctx, m, n, k, da, m, db, n, dc, n, trans_a=True)
+        outs.append(dc.read())
+    want = a.astype(np.float64).T @ b.astype(np.float64)
+    assert rel_err(outs[0], want) <= TOL
+    assert np.array_equal(outs[0], outs[1])
