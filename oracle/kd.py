@@ -820,9 +820,12 @@ def _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch, f64=False):
         raise RuntimeError(f"ref_interp_kernel2 failed ({rc})")
 
 
-def run_kernel(k, bounds, vals, shapes, tensors, epoch=0, f64=False):
-    """f64: the float64 shadow of the kernel (oracle/refinterp_body.h) on float64 tensors."""
+def run_kernel(k, bounds, vals, shapes, tensors, epoch=0, f64=False, abs_into=None):
+    """f64: the float64 shadow of the kernel (oracle/refinterp_body.h) on float64 tensors.
+    abs_into: instead of the written tensor, add the MAGNITUDE of every term to this array (affine kernels only)."""
     if k.index_instrs:
+        if abs_into is not None:
+            raise NotImplementedError("term magnitudes of a kernel with computed indices")
         return _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch, f64)
     lib = refcpu.lib()
     interp = lib.ref_interp_kernel_f64 if f64 else lib.ref_interp_kernel
@@ -890,9 +893,9 @@ def run_kernel(k, bounds, vals, shapes, tensors, epoch=0, f64=False):
     instr_c = (c_i32 * max(len(instr_words), 1))(*instr_words)
     lits_c = (ctypes.c_double * max(ninstr, 1))(*lits)
     waff = (c_i64 * (1 + nl))(*affine(k.write))
-    out = tensors[k.write.tensor]
+    out = tensors[k.write.tensor] if abs_into is None else abs_into
     rc = interp(nl, starts, stops, lregs, k.nregs + 1, nreads, rptrs, rregs, raff_c, ninstr, instr_c,
-                lits_c, k.result, ctypes.c_void_p(out.ctypes.data), waff, 0)
+                lits_c, k.result, ctypes.c_void_p(out.ctypes.data), waff, 0 if abs_into is None else 2)
     if rc != 0:
         raise RuntimeError(f"ref_interp_kernel failed ({rc})")
 
@@ -950,6 +953,10 @@ class Model:
         # the numbers another implementation drew (random_override[tensor id]).
         self.rng = np.random.default_rng(0)
         self.random_override = {}
+        # shadow only: for the tensors in track_abs, abs_terms[t] = sum of the magnitudes of the terms every kernel adds
+        # into t (same shape as t) — what a float32 summation error of t is proportional to (tests/parity.py)
+        self.track_abs = set()
+        self.abs_terms = {}
         for tid, t in self.prog.tensors.items():
             if t["kind"] == "param":
                 self.params[tid] = np.zeros(t["shape"], dtype=self.dtype)
@@ -999,6 +1006,21 @@ class Model:
             refcpu.sgemm(tensors[a_op.tensor], tensors[b_op.tensor], ta, tb, out=tensors[wt], threads=self.threads)
         else:
             run_kernel(k, bounds, vals, shapes, tensors, self.epoch, f64=shadow)
+        if shadow and wt in self.track_abs:
+            acc = self.abs_terms.setdefault(wt, np.zeros(shapes[wt], dtype=np.float64))
+            if acc is None:
+                pass
+            elif k.is_seed:
+                acc += abs(float(np.float32(grad_scale)))
+            elif pat is not None:
+                a_op, b_op, ta, tb = pat
+                a, b = np.abs(tensors[a_op.tensor]), np.abs(tensors[b_op.tensor])
+                acc += (a.T if ta else a) @ (b.T if tb else b)
+            else:
+                try:
+                    run_kernel(k, bounds, vals, shapes, tensors, self.epoch, f64=True, abs_into=acc)
+                except NotImplementedError:
+                    self.abs_terms[wt] = None       # (a writer with computed indices: no magnitude sum for this tensor)
 
     def _forward_backward(self, target, inputs, grad_scale, stop_at_update):
         if target not in self.compiled:
@@ -1046,6 +1068,7 @@ class Model:
                 first_update = i
                 break
         stop = first_update if stop_at_update else len(kernels)
+        self.abs_terms = {}
         for k in kernels[:stop]:
             self._run_one(k, infos, shapes, tensors, grad_scale)
         # gradient tensors of parameters must exist even if nothing wrote them

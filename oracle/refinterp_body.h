@@ -66,7 +66,9 @@ static inline int FN(exec_instrs)(REG_T* regs, int ninstr, const int32_t* instr,
  *             sum_l read_affine[r*(1+nloops)+1+l] * iter_l ; value goes to register read_reg[r]
  * instrs:     ninstr x 5 int32: opcode, res, a0, a1, a2 ; literal i in instr_lit[i]
  * write:      flat index by write_affine (same layout), value = regs[result_reg]
- * overwrite:  0 -> out[idx] += value (InstrWrite) ; 1 -> out[idx] = value (InstrOverwrite)
+ * overwrite:  0 -> out[idx] += value (InstrWrite) ; 1 -> out[idx] = value (InstrOverwrite) ;
+ *             2 -> out[idx] += |value|: the sum of the magnitudes of the terms a reduction adds up — the scale its
+ *             rounding error is measured against (tests/parity.py; never part of a model's arithmetic)
  */
 EXPORT int FN(ref_interp_kernel)(int nloops, const int64_t* loop_start, const int64_t* loop_stop, const int32_t* loop_reg,
                              int nregs, int nreads, const REAL* const* read_ptr, const int32_t* read_reg,
@@ -97,8 +99,10 @@ EXPORT int FN(ref_interp_kernel)(int nloops, const int64_t* loop_start, const in
       int64_t idx = write_affine[0];
       for (int l = 0; l < nloops; ++l) idx += write_affine[1 + l] * it[l];
       const REAL v = regs[result_reg].f;
-      if (overwrite)
+      if (overwrite == 1)
         write_ptr[idx] = v;
+      else if (overwrite == 2)
+        write_ptr[idx] = write_ptr[idx] + (v < 0 ? -v : v);
       else
         write_ptr[idx] = write_ptr[idx] + v;
     }

@@ -25,7 +25,9 @@ out = {
     #  and compare the shadow with itself on the oracle side)
     "backend_farther_than_twice_the_oracle_and_above_1e-5": sum(1 for r in above if r["e_gpu"] > 2 * r["e_ref"] and "(cap only)" not in r["what"]),
     "cap_only_comparisons_above_1e-5": sum(1 for r in above if "(cap only)" in r["what"]),
-    "note": "distances relative to max|exact| of the compared tensor; the rule of tests/parity.py: backend <= max(1e-5, min(2 x oracle, 1e-3))",
+    "note": "distances relative to max|exact| of the compared tensor — for gradients of fewer than 64 elements relative, element by "
+            "element, to the sum of the magnitudes of the summed terms (lines marked 'vs sum of |terms|'); the rule of "
+            "tests/parity.py: backend <= max(1e-5, min(2 x oracle, 1e-3)).  No cap-only comparisons since round 3.",
 }
 json.dump(out, open(dst, "w"), indent=1)
 print({k: v for k, v in out.items() if not isinstance(v, list)})
