@@ -109,10 +109,13 @@ int load_table(eg_model* m, TK kind, Reader& r, const char* what) {
   const int64_t count = r.i64();
   EG_REQUIRE(r.ok && count >= 0, EG_ERR_INVALID, "model state: truncated %s table", what);
   std::vector<float> host;
+  std::set<int> seen;  // every tensor of this kind exactly once: a table that leaves some out would load as a partly
+                       // random (mt19937-initialised) or partly zero model; the reference always writes the full tables
   for (int64_t e = 0; e < count; ++e) {
     const int64_t tid = r.i64();
     const bool is_nil = r.byte() != 0;
     EG_REQUIRE(r.ok, EG_ERR_INVALID, "model state: truncated %s table", what);
+    EG_REQUIRE(seen.insert((int)tid).second, EG_ERR_INVALID, "model state: tensor %ld appears twice in the %s table", (long)tid, what);
     auto it = m->params.find((int)tid);
     EG_REQUIRE(tid >= 1 && it != m->params.end() && m->prog.tensors[(size_t)tid].kind == kind, EG_ERR_INVALID,
                "model state: tensor %ld is not one of the model's %s", (long)tid, what);
@@ -136,6 +139,9 @@ int load_table(eg_model* m, TK kind, Reader& r, const char* what) {
       if (rc) return rc;
     }
   }
+  for (auto& p : m->params)
+    if (m->prog.tensors[(size_t)p.first].kind == kind)
+      EG_REQUIRE(seen.count(p.first), EG_ERR_INVALID, "model state: the %s table lacks tensor %d of the model", what, p.first);
   return EG_OK;
 }
 

@@ -6,6 +6,7 @@ allocBuffer, write, fill, readInto, read, compile, arg, run, GpuTensor.  snake_c
 provided (Nim identifiers are style-insensitive, the reference itself mixes both).
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -103,6 +104,7 @@ class GpuContext:
         if self.handle:
             _lib.lib().eg_ctx_destroy(self.handle)
             self.handle = None
+            pinned_pool.trim()      # (page-locked result blocks nobody references any more)
 
 
 def newGpuContext(device=None, stream=None):
@@ -239,7 +241,15 @@ class PinnedPool:
     time (readOutput, model.nim:375-376), but a fresh 64 MiB numpy array page-faults inside the
     device-to-host copy.  Arrays handed out here are numpy views of pinned blocks; when the last view
     of a block is garbage collected the block goes back to the pool and the next result of that size
-    reuses it: direct DMA, no page faults."""
+    class reuses it: direct DMA, no page faults.
+
+    Blocks come in size classes (powers of two and 1.5 x powers of two: at most 33 % slack), so a model
+    whose output size varies from call to call does not page-lock a new block (milliseconds) per size.
+    `trim()` gives the free blocks back; EG_NO_PINNED_POOL=1 switches the pool off (plain numpy arrays).
+    The arrays are ordinary numpy arrays to the caller with one caveat that comes with pinned memory: a
+    host that starts its OWN asynchronous copy out of such an array on another stream must keep the array
+    alive until that copy has finished — once garbage collected, its block may be the target of the next
+    result's DMA."""
 
     MIN_BYTES = 1 << 20
     MAX_FREE_BYTES = 1 << 30
@@ -247,34 +257,53 @@ class PinnedPool:
     def __init__(self):
         self._free = {}
         self._free_bytes = 0
+        self.enabled = os.environ.get("EG_NO_PINNED_POOL", "0") in ("", "0")
+
+    @staticmethod
+    def size_class(nbytes):
+        p = 1 << (nbytes - 1).bit_length()          # next power of two
+        return p * 3 // 4 if nbytes <= p * 3 // 4 else p
 
     def empty(self, shape):
         n = int(np.prod(shape, dtype=np.int64))
         nbytes = n * 4
-        if nbytes < self.MIN_BYTES:
+        if nbytes < self.MIN_BYTES or not self.enabled:
             return np.empty(shape, dtype=np.float32)
         import weakref
-        blocks = self._free.get(nbytes)
+        cls = self.size_class(nbytes)
+        blocks = self._free.get(cls)
         if blocks:
             ptr = blocks.pop()
-            self._free_bytes -= nbytes
+            self._free_bytes -= cls
         else:
             p = ctypes.c_void_p()
-            call("eg_host_alloc", nbytes, ctypes.byref(p))
+            call("eg_host_alloc", cls, ctypes.byref(p))
             ptr = p.value
         buf = (ctypes.c_float * n).from_address(ptr)
-        weakref.finalize(buf, self._release, ptr, nbytes)
+        weakref.finalize(buf, self._release, ptr, cls)
         return np.frombuffer(buf, dtype=np.float32).reshape(shape)
 
-    def _release(self, ptr, nbytes):
-        if self._free_bytes + nbytes > self.MAX_FREE_BYTES:
-            try:
-                call("eg_host_free", ctypes.c_void_p(ptr))
-            except Exception:  # noqa: BLE001 - interpreter shutdown
-                pass
+    def _release(self, ptr, cls):
+        if self._free_bytes + cls > self.MAX_FREE_BYTES:
+            self._free_block(ptr)
             return
-        self._free.setdefault(nbytes, []).append(ptr)
-        self._free_bytes += nbytes
+        self._free.setdefault(cls, []).append(ptr)
+        self._free_bytes += cls
+
+    @staticmethod
+    def _free_block(ptr):
+        try:
+            call("eg_host_free", ctypes.c_void_p(ptr))
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def trim(self):
+        """Give every free block back to the system (blocks still referenced by live arrays stay)."""
+        for blocks in self._free.values():
+            for ptr in blocks:
+                self._free_block(ptr)
+        self._free.clear()
+        self._free_bytes = 0
 
 
 pinned_pool = PinnedPool()

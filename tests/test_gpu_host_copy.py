@@ -53,3 +53,24 @@ def test_model_call_with_large_host_arrays(gpu_ctx, refcpu):
     want2 = a2.astype(np.float64) @ b.astype(np.float64)
     assert np.max(np.abs(got2 - want2)) <= 1e-5 * np.max(np.abs(want2))
     m.close()
+
+
+def test_pinned_result_blocks_come_in_size_classes_and_can_be_trimmed(gpu_ctx):
+    """Results of varying sizes reuse page-locked blocks by size class (no eg_host_alloc per distinct size), and trim()
+    returns what nobody references."""
+    from exprgrad_amd.runtime import PinnedPool
+    pool = PinnedPool()
+    assert pool.size_class(3 << 20) == 3 << 20 and pool.size_class((3 << 20) + 4) == 4 << 20 and pool.size_class(1 << 20) == 1 << 20
+    a = pool.empty((1 << 18) + 10,)            # 1 MiB + 40 bytes -> the 1.5 MiB class
+    a[:] = 1.0
+    addr = a.__array_interface__["data"][0]
+    del a
+    import gc
+    gc.collect()
+    b = pool.empty((1 << 18) + 4000,)          # another size, same class: the same block
+    assert b.__array_interface__["data"][0] == addr
+    del b
+    gc.collect()
+    assert pool._free_bytes == (3 << 19)
+    pool.trim()
+    assert pool._free_bytes == 0 and not pool._free

@@ -92,3 +92,37 @@ def test_load_errors(gpu_ctx, tmp_path):
     with pytest.raises(GpuError, match="not one of the model's parameters"):
         m.load_state(bytes(bad))
     m.close()
+
+
+def test_state_tables_must_hold_every_tensor_exactly_once(gpu_ctx):
+    """A table that omits a parameter (or names one twice) is refused: it would load as a partly random model, where the
+    reference always writes and reads the full tables (io/serialize.nim:344-349)."""
+    import struct
+    from exprgrad_amd import dsl, layers
+    from exprgrad_amd._lib import GpuError
+    net = layers.dense(dsl.input("x"), 3, 2).target("predict")
+    net = layers.mse(net, dsl.input("y")).target("loss")
+    model = egm.compile(net.backprop(layers.gradient_descent(0.1)).target("train"), gpu=gpu_ctx)
+    state = model.state_bytes()
+    count = struct.unpack_from("<q", state, 0)[0]
+    assert count == 2                                   # weights [3, 2] and bias [2]
+
+    def entry_end(pos):                                 # int64 id, bool isNil, seq[int] shape, float32 elements
+        pos += 8 + 1
+        rank = struct.unpack_from("<q", state, pos)[0]
+        dims = struct.unpack_from("<%dq" % rank, state, pos + 8)
+        n = 1
+        for d in dims:
+            n *= d
+        return pos + 8 + 8 * rank + 4 * n
+    first_end = entry_end(8)
+    second_end = entry_end(first_end)
+    rest = state[second_end:]                           # the (empty) cache table
+    model.load_state(state)                             # the full tables load
+    only_first = struct.pack("<q", 1) + state[8:first_end] + rest
+    with pytest.raises(GpuError, match="lacks tensor"):
+        model.load_state(only_first)
+    twice = struct.pack("<q", 2) + state[8:first_end] + state[8:first_end] + rest
+    with pytest.raises(GpuError, match="appears twice"):
+        model.load_state(twice)
+    model.close()
