@@ -678,7 +678,9 @@ def compile_latency():
     tool = os.path.join(ROOT, "tools", "compile_time.py")
     out = {}
     with tempfile.TemporaryDirectory() as cache:
-        env = dict(os.environ, EG_KERNEL_CACHE=cache)
+        # comgr keeps a code-object cache of its own (~/.cache/comgr) which the models benchmarked above have
+        # already filled in this process's box: point it at the empty directory too, or "cold" is not cold
+        env = dict(os.environ, EG_KERNEL_CACHE=cache, AMD_COMGR_CACHE_DIR=os.path.join(cache, "comgr"))
         for name in ("cold", "warm"):
             done = subprocess.run([sys.executable, tool], env=env, capture_output=True, text=True, timeout=600)
             if done.returncode != 0:

@@ -7,6 +7,7 @@
 // gradient contractions passes.nim:519-549 derives from it, and for conv2 (dnn.nim:45-49).
 // The kernel itself is in gemm_f32_mfma.hpp; this file is the host-side planning:
 // tile shape, split-K, vector/edge variant, launch, deterministic second pass.
+#include "gemm_skinny.hpp"
 #include "gemm_f32_mfma.hpp"
 
 #include <algorithm>
@@ -669,6 +670,15 @@ bool small_gemm_enabled() {
   return on;
 }
 
+
+bool skinny_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("EG_NO_SKINNY_GEMM");
+    return !(e && e[0] && e[0] != '0');
+  }();
+  return on;
+}
+
 }  // namespace
 
 extern "C" int eg_sgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A,
@@ -690,6 +700,18 @@ extern "C" int eg_sgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_
     const long blocks = (M * N + 3) / 4;
     hipLaunchKernelGGL(gemm_small_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, A, B, C, bias, (long)M, (long)N,
                        (long)K, a_sm, a_sk, b_sk, b_sn, (long)ldc, accumulate);
+    EG_HIP_CHECK(hipGetLastError());
+    return EG_OK;
+  }
+  // tall and skinny: stream A once with B resident in LDS
+  if (!trans_a && !trans_b && N <= 16 && K >= 64 && K <= 1024 && K % 16 == 0 && M >= 4096 && lda % 4 == 0 && aligned16(A) &&
+      skinny_enabled()) {
+    const long groups = (M + 15) / 16;
+    long blocks = (groups + 3) / 4;
+    const long cap = 8L * ctx->compute_units;  // (LDS: K x 64 bytes per block; eight blocks of four waves per CU)
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((eg_skinny::gemm_skinny_nn_kernel<8>), dim3((unsigned)blocks), dim3(256), (size_t)K * 64, ctx->stream, A, B, C, bias, (long)M,
+                       (int)N, (int)K, (long)lda, (long)ldb, (long)ldc, accumulate);
     EG_HIP_CHECK(hipGetLastError());
     return EG_OK;
   }

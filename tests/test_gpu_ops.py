@@ -412,3 +412,32 @@ def test_extra_rows_ride_along_with_the_last_tile_row(gpu_ctx, shape):
     want = a.astype(np.float64).T @ b.astype(np.float64)
     assert rel_err(outs[0], want) <= TOL
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("case", [(65536, 10, 512, True, False), (4096, 16, 64, False, False), (5003, 1, 1024, True, True),
+                                  (8200, 13, 272, False, True), (70001, 10, 512, True, False)])
+def test_tall_products_with_a_few_columns(gpu_ctx, case):
+    """NN products with N <= 16 (the classifier's last layer: 65536 x 10 x 512): gemm_skinny_nn_kernel streams A once with
+    B resident in LDS.  Ragged last row groups, accumulate, bias, lda > K; against the float64 product, and identical
+    from run to run; EG_NO_SKINNY_GEMM's path (the tile kernels) agrees to rounding."""
+    m, n, k, bias, accumulate = case
+    rng = np.random.default_rng(m + n + k)
+    lda = k + 8
+    a_full = (rng.random((m, lda), dtype=np.float32) - 0.5).astype(np.float32)
+    a = a_full[:, :k]
+    b = (rng.random((k, n), dtype=np.float32) - 0.5).astype(np.float32)
+    c0 = (rng.random((m, n), dtype=np.float32) - 0.5).astype(np.float32)
+    bv = (rng.random((n,), dtype=np.float32) - 0.5).astype(np.float32)
+    da, db, dbias = dev(gpu_ctx, a_full), dev(gpu_ctx, b), dev(gpu_ctx, bv)
+    outs = []
+    for _ in range(2):
+        dc = dev(gpu_ctx, c0)
+        ops.sgemm(gpu_ctx, m, n, k, da, lda, db, n, dc, n, accumulate=accumulate, bias=dbias if bias else None)
+        outs.append(dc.read())
+    want = a.astype(np.float64) @ b.astype(np.float64)
+    if accumulate:
+        want = want + c0
+    if bias:
+        want = want + bv
+    assert rel_err(outs[0], want) <= TOL
+    assert np.array_equal(outs[0], outs[1])
