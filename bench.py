@@ -113,6 +113,10 @@ def parse():
     return ap.parse_args()
 
 
+EVENTS_NOTE = ("kernel_ms_avg = one HIP event pair around the K timed steps / K, on the stream the kernels run on; "
+               "kernel_ms_min = shortest step of a second, untimed pass of K steps with an event pair each")
+
+
 class Timer:
     """K steps bracketed by barrier + synchronize on both sides; max over ranks; per-step HIP
     events on the stream the kernels are launched on (torch's current stream == the context's)."""
@@ -157,15 +161,25 @@ class Timer:
         for _ in range(warmup):
             step()
         self.sync()
+        # The timed region carries ONE pair of events around all K steps: an event is a barrier packet with a
+        # timestamp, and a pair between every two steps holds the queue for 10 - 17 us (rocprofv3 timeline of the
+        # train step: the only gap of the step; the XOR step is 25 us long).  Per-step durations (their minimum) come
+        # from a second, untimed pass of K steps with an event pair each.
         t0 = time.perf_counter()
         marks = []
+        starts[0].record(self.stream)
+        for i in range(steps):
+            step()
+            marks.append(time.perf_counter())
+        ends[0].record(self.stream)
+        self.sync()
+        elapsed = time.perf_counter() - t0
+        bracket_ms = starts[0].elapsed_time(ends[0])
         for i in range(steps):
             starts[i].record(self.stream)
             step()
             ends[i].record(self.stream)
-            marks.append(time.perf_counter())
         self.sync()
-        elapsed = time.perf_counter() - t0
         gc.enable()
         if os.environ.get("EG_BENCH_DEBUG"):
             host = [round((b - a) * 1e6) for a, b in zip([t0] + marks[:-1], marks)]
@@ -175,7 +189,7 @@ class Timer:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             elapsed = float(t.item())
         ev = sorted(s.elapsed_time(e) for s, e in zip(starts, ends))
-        return elapsed, sum(ev) / len(ev), ev[0]
+        return elapsed, bracket_ms / steps, ev[0]
 
 
 # ------------------------------------------------------------------------------ CPU baselines
@@ -347,7 +361,7 @@ def run_matmul(args, env):
     elapsed, ev_avg, ev_min = timer.run(lambda: ops.sgemm(ctx, n, n, n, a, n, b, n, c, n), args.steps, args.warmup)
     flops = 2.0 * n * n * n
     # ONE clock for `value` and the roofline fraction: the wall time of the K timed steps (barrier + synchronize on both
-    # sides).  The per-step HIP events are reported next to it (kernel_ms_avg / kernel_ms_min, frac_by_events).
+    # sides).  HIP events are reported next to it (kernel_ms_avg / kernel_ms_min, frac_by_events; EVENTS_NOTE).
     achieved = flops * args.steps / elapsed / 1e12
     achieved_events = flops / (ev_avg * 1e-3) / 1e12
     # what the reference's benchmark times (matmul_gpu.nim:35-46): model.call with host tensors — 128 MiB
@@ -370,7 +384,7 @@ def run_matmul(args, env):
                      **(traffic_fields("matmul4096") if n == 4096 else {"traffic": None}),
                      "kernel": "eg::gemm::gemm_f32_mfma_kernel<256,256,16,128,64,NN,DMA>", "flops_per_launch": flops,
                      "clock": "wall time of the timed steps (the clock `value` uses)",
-                     "kernel_ms_avg": round(ev_avg, 4), "kernel_ms_min": round(ev_min, 4),
+                     "kernel_ms_avg": round(ev_avg, 4), "kernel_ms_min": round(ev_min, 4), "events": EVENTS_NOTE,
                      "frac_by_events": round(achieved_events / F32_MFMA_PEAK_TFLOPS, 4)},
         "spinup_steps": timer.last_spin,
     }
@@ -536,7 +550,7 @@ def run_train(args, env):
                      **(traffic_fields("train") if batch == DENSE["batch"] else {"traffic": None}),
                      "kernel": "whole train step on one GPU (5 contractions dominate: gemm_f32_mfma_kernel)",
                      "flops_per_launch": step_flops, "clock": "wall time of the timed steps (the clock `value` uses)",
-                     "kernel_ms_avg": round(ev_avg, 4), "kernel_ms_min": round(ev_min, 4),
+                     "kernel_ms_avg": round(ev_avg, 4), "kernel_ms_min": round(ev_min, 4), "events": EVENTS_NOTE,
                      "frac_by_events": round(achieved_events / F32_MFMA_PEAK_TFLOPS, 4)},
         "spinup_steps": env["timer"].last_spin,
     }

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "exprgrad_hip.h"
@@ -91,6 +92,15 @@ int copy_h2d(eg_ctx* ctx, void* device, const void* host, size_t bytes);
 int copy_d2h(eg_ctx* ctx, void* host, const void* device, size_t bytes);
 // EG_POISON=1: scratch and to-be-overwritten result storage is filled with NaN patterns before use.
 bool poison_enabled();
+// Zero several float ranges with one launch per ZeroRanges::MAX ranges (kernels/elementwise.hip).
+struct ZeroRanges {
+  static constexpr int MAX = 8;
+  float* ptr[MAX];
+  long floats[MAX];
+  int blocks[MAX];
+  int count;
+};
+int zero_ranges(eg_ctx* ctx, const std::vector<std::pair<float*, long>>& ranges);
 namespace rtc {
 // Source text -> code object through the library's own hiprtc (rtc.cpp), cached on disk.
 int compile(const char* label, const char* source, const std::string& arch, std::vector<char>& code);

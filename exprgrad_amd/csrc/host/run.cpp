@@ -182,11 +182,21 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
 int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero, const SideHook* hook) {
   if (zero) {
     // allocShapes / zeroResultTensor (model.nim:318, 383): results start from zero on every call
-    if (plan.zero_floats > 0)
-      EG_HIP_CHECK(hipMemsetAsync(plan.arena, 0, (size_t)plan.zero_floats * sizeof(float), m->ctx->stream));
-    for (int tid : plan.bucket_zero)
-      EG_HIP_CHECK(hipMemsetAsync(ts.bucket + ts.bucket_offset[tid], 0, (size_t)prod(plan.shapes.at(tid)) * sizeof(float),
-                                  m->ctx->stream));
+    {
+      std::vector<std::pair<float*, long>> ranges;
+      if (plan.zero_floats > 0) ranges.emplace_back(plan.arena, plan.zero_floats);
+      for (int tid : plan.bucket_zero) {
+        float* p = ts.bucket + ts.bucket_offset[tid];
+        const long n = prod(plan.shapes.at(tid));
+        // neighbours in the bucket (a layer's weights and bias) are one range
+        if (!ranges.empty() && ranges.back().first + ranges.back().second == p)
+          ranges.back().second += n;
+        else
+          ranges.emplace_back(p, n);
+      }
+      int rc = eg::zero_ranges(m->ctx, ranges);
+      if (rc) return rc;
+    }
     if (eg::poison_enabled()) {
       // EG_POISON: whatever is not zeroed must be overwritten completely by its first writer
       if (plan.arena_floats > plan.zero_floats)

@@ -291,6 +291,50 @@ int copy_segments(eg_ctx* ctx, const CopySegments& seg) {
 }
 }  // namespace eg
 
+// Results start from zero on every call (allocShapes / zeroResultTensor, model.nim:318, 383): the arena's zero prefix and
+// the accumulated gradients of the bucket, all in ONE launch.  (hipMemsetAsync becomes a runtime kernel with a 10 - 17 us
+// wait in front of it, captured or not: the XOR step is 25 us long.)
+namespace {
+__global__ __launch_bounds__(256) void zero_ranges_kernel(eg::ZeroRanges r) {
+  int which = 0;
+  long block = blockIdx.x;
+  while (which < r.count - 1 && block >= r.blocks[which]) block -= r.blocks[which++];
+  float* p = r.ptr[which];
+  const long n = r.floats[which];
+  // whole 16-byte groups of an aligned range as one store, the rest one by one
+  const long head = ((reinterpret_cast<uintptr_t>(p) & 15) == 0) ? n / 4 : 0;
+  const long stride = (long)r.blocks[which] * 256;
+  for (long i = block * 256 + threadIdx.x; i < head; i += stride) reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long i = head * 4 + block * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+}
+}  // namespace
+
+int eg::zero_ranges(eg_ctx* ctx, const std::vector<std::pair<float*, long>>& ranges) {
+  int rc = eg::set_device(ctx);
+  if (rc) return rc;
+  size_t at = 0;
+  while (at < ranges.size()) {
+    eg::ZeroRanges r = {};
+    long total = 0;
+    for (; at < ranges.size() && r.count < eg::ZeroRanges::MAX; ++at) {
+      if (ranges[at].second <= 0) continue;
+      const long groups = (ranges[at].second + 3) / 4;
+      long blocks = (groups + 255) / 256;
+      const long cap = 8L * ctx->compute_units;
+      if (blocks > cap) blocks = cap;
+      r.ptr[r.count] = ranges[at].first;
+      r.floats[r.count] = ranges[at].second;
+      r.blocks[r.count] = (int)blocks;
+      total += blocks;
+      ++r.count;
+    }
+    if (r.count == 0) break;
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)total), dim3(256), 0, ctx->stream, r);
+    EG_HIP_CHECK(hipGetLastError());
+  }
+  return EG_OK;
+}
+
 extern "C" {
 
 int eg_map(eg_ctx* ctx, int op, int64_t n, const float* in, float* out, float param, int accumulate) {
