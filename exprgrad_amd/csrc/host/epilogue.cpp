@@ -136,6 +136,8 @@ std::string predicate_expression(const PredicateSpec& p, const std::string& x) {
 }
 }  // namespace
 
+const char* const kNoRowProduct = "  static constexpr int RD_N = 0, RD_W = 0, RD_OUT = 0, RD_BIAS = -1, RD_LDW = 0, RD_LDO = 0;\n";
+
 int generate_epilogue(const Kernel& k, const KernelInfo& info, const Shapes& shapes, int c_tensor, bool store_c,
                       bool accumulate, EpilogueSpec& out, const std::map<int, PredicateSpec>* pred_reads,
                       const PredicateSpec* pred_write) {
@@ -169,7 +171,8 @@ int generate_epilogue(const Kernel& k, const KernelInfo& info, const Shapes& sha
   std::string c = "struct EgEpi {\n  static constexpr bool ACTIVE = true;\n  static constexpr int NX = " + nxs + ";\n"
                   "  static constexpr bool STORE_C = " + std::string(store_c ? "true" : "false") + ";\n"
                   "  static constexpr int OUT = " + std::to_string(operand_index(k.write.tensor)) + ";\n"
-                  "  static constexpr int PRED = " + std::to_string(pred_write ? operand_index(c_tensor) : -1) + ";\n"
+                  "  static constexpr int PRED = " + std::to_string(pred_write ? operand_index(c_tensor) : -1) + ";\n" +
+                  std::string(kNoRowProduct) +
                   "  __device__ __forceinline__ static bool predicate(float v) { return " +
                   (pred_write ? predicate_expression(*pred_write, "v") : std::string("false")) + "; }\n"
                   "  __device__ __forceinline__ static void prefetch(const eg::gemm::GemmArgs& a, long idx, float (&x)[" + nxs + "]) {\n";

@@ -42,6 +42,10 @@ struct EpilogueSpec {
 // c_tensor and writes a different tensor it does not read.
 bool epilogue_capable(const Kernel& k, const KernelInfo& info, const Shapes& shapes, int c_tensor, long M, long N);
 
+// The line of every generated functor that says "no row product" (gemm_f32_mfma.hpp, RD_N); fold_row_products
+// (plan_epilogue.cpp) replaces it.
+extern const char* const kNoRowProduct;
+
 // store_c: also write the contraction result itself (it is read again later).
 // accumulate: the consumer adds to its destination instead of overwriting it.
 // pred_reads: operands of `k` that exist as predicate bits only (tensor -> the question they answer).

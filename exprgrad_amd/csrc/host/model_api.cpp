@@ -238,6 +238,9 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
           os << " | consumer kernel " << pe.consumer.lowered << " operands";
           for (int t : pe.spec.operands) os << " t" << t << (pe.pred_reads.count(t) || (pe.pred_write && t == L.c_tensor) ? "(bits)" : "");
           if (pe.pred_write) os << " | t" << L.c_tensor << " stored as predicate bits";
+          if (pe.row_product)
+            os << " | row product NN " << pe.product.M << "x" << pe.product.N << "x" << pe.product.K << " -> t" << pe.product.c_tensor
+               << (pe.product.bias_tensor ? " +bias" : "") << " (kernel " << pe.product.lowered << ")";
         }
         break;
       case StepKind::Conv: os << "conv2 -> t" << L.c_tensor << (L.accumulate ? " accumulate" : ""); break;

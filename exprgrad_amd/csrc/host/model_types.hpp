@@ -128,6 +128,11 @@ struct PlanEpilogue {
   bool pred_write = false;                  // ... as one predicate bit per element (Plan::predicated), not as values
   std::map<int, PredicateSpec> pred_reads;  // operands of the consumer that exist as predicate bits only
   Launch consumer;                          // the consumer as its own launch (split-K fallback)
+  // Row product (fold_row_products): the next layer's narrow contraction computed on the consumer's rows in LDS.
+  bool row_product = false;
+  Launch product;                           // that contraction as its own launch (fallback; its tensors for the checks)
+  std::string plain_struct_code;            // the functor without the row product
+  std::map<std::string, eg_kernel*> built_plain;
   std::map<std::string, eg_kernel*> built;  // by template variant (tile shape, alignment class)
 };
 
@@ -154,6 +159,7 @@ struct Plan {
   long arena_floats = 0;
   long zero_floats = 0;  // leading part of the arena that is zeroed before every run
   std::vector<int> bucket_zero;  // gradient-bucket tensors that need zeroing
+  std::set<int> zero_extra;      // result tensors a fold made accumulate (row products): zeroed with the others
   float* arena = nullptr;
   // The launch sequence of a range (whole call / backward part / update part) is captured into a
   // HIP graph on its second execution and replayed afterwards: the small-batch targets are
@@ -325,6 +331,7 @@ int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool
 // of the same layer becomes the last row of that contraction (a virtual row of ones in A) when gb lies
 // directly behind gW in the gradient bucket; the column-sum launch disappears.
 int fold_bias_gradients(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos);
+int fold_row_products(eg_model* m, TargetState& ts, Plan& plan);
 // plan_pipeline.cpp
 void plan_pipeline(eg_model* m, TargetState& ts, Plan& plan);
 // One half of a sliced launch: rows [row0, row0 + rows) of the batch; second = the later half (reductions accumulate).

@@ -538,6 +538,10 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
     int rc = fold_bias_gradients(m, ts, plan, infos);
     if (rc) return rc;
   }
+  {
+    int rc = fold_row_products(m, ts, plan);
+    if (rc) return rc;
+  }
 
   plan_overlap(m, ts, plan);
   plan_pipeline(m, ts, plan);
@@ -556,7 +560,8 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
         if (pass == 0 && needs_zero.count(tid)) plan.bucket_zero.push_back(tid);
         continue;
       }
-      const bool z = needs_zero.count(tid) != 0 || plan.predicated.count(tid) != 0;  // (predicate bits may be OR-ed in)
+      // (predicate bits may be OR-ed in; a row product is added to its destination)
+      const bool z = needs_zero.count(tid) != 0 || plan.predicated.count(tid) != 0 || plan.zero_extra.count(tid) != 0;
       if ((pass == 0) != z) continue;
       plan.arena_offset[tid] = off;
       off += align4(storage_floats(plan, tid));

@@ -80,6 +80,11 @@ void launch_io(eg_model* m, TargetState& ts, const Plan& plan, const Launch& L, 
       for (auto& r : ck.reads)
         if (r.tensor != L.c_tensor) rd(r.tensor);
       wr(ck.write.tensor, pe.consumer.accumulate);
+      if (pe.row_product) {  // adds to its destination: that must be zeroed
+        rd(pe.product.b_tensor);
+        rd(pe.product.bias_tensor);
+        wr(pe.product.c_tensor, true);
+      }
       break;
     }
     case StepKind::GenericA:
@@ -167,6 +172,7 @@ int check_plan(eg_model* m, TargetState& ts, Plan& plan) {
         case StepKind::GemmFused:
           mark(L.lowered);
           mark(plan.epilogues[L.epilogue]->consumer.lowered);
+          if (plan.epilogues[L.epilogue]->row_product) mark(plan.epilogues[L.epilogue]->product.lowered);
           break;
         default:
           mark(L.lowered);

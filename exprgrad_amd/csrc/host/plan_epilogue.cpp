@@ -172,6 +172,89 @@ int fuse_epilogues(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
   return predicate_tensors(m, ts, plan, infos);
 }
 
+// Row products.  `dense(…, 512) -> relu -> dense(512, 10)` (examples: the classifier head of cfg 5): the second layer's
+// contraction `z[y, x] ++= a[y, it] * W2[it, x]` + bias (dnn.nim:19-24) has 10 columns — its whole cost is reading a, the
+// 134 MB the first layer's fused epilogue has just written.  When the first layer runs on whole 256 x 256 tiles, the
+// rows of a pass through LDS on their way out (wide-store pass, gemm_f32_mfma.hpp), and the second layer's product is
+// taken there: 16 x 16 x 4 MFMAs over the staged rows against the tile's 256 rows of W2, each N-tile adding its partial
+// product to z with one float atomic per element.  z is zeroed with the other accumulated results; with at most two
+// N-tiles an element is 0 + p + q in either order — bit-identical from run to run (more N-tiles: not folded).
+// The narrow contraction disappears from the launch list (36 us at cfg 5).  EG_NO_ROW_PRODUCT=1 switches it off.
+int fold_row_products(eg_model* m, TargetState& ts, Plan& plan) {
+  plan.zero_extra.clear();
+  for (const char* name : {"EG_NO_ROW_PRODUCT", "EG_PIPELINE"}) {  // read per plan: a test compares folded and unfolded plans
+    const char* e = getenv(name);
+    if (e && e[0] && e[0] != '0') return EG_OK;
+  }
+  const Target& t = *ts.target;
+  auto shares_storage = [&](int x) {
+    bool s = plan.alias.count(x) != 0;
+    for (auto& kv : plan.alias) s = s || kv.second == x;
+    return s;
+  };
+  for (size_t gi = 0; gi + 1 < plan.launches.size(); ++gi) {
+    Launch& G = plan.launches[gi];
+    if (G.kind != StepKind::GemmFused || G.accumulate) continue;
+    PlanEpilogue& pe = *plan.epilogues[G.epilogue];
+    if (pe.row_product || pe.consumer.accumulate) continue;
+    if (G.M % 256 != 0 || G.N % 256 != 0 || G.N > 512 || G.ldc != G.N) continue;  // whole tiles, at most two N-tiles
+    if ((int)pe.spec.operands.size() + 3 > eg::gemm::MAX_EPILOGUE_OPERANDS) continue;
+    eg::gemm::FusedLaunch probe;
+    float* aligned = reinterpret_cast<float*>(uintptr_t(256));
+    if (eg::gemm::plan_fused(m->ctx, G.trans_a, G.trans_b, G.M, G.N, G.K, aligned, G.lda, aligned, G.ldb, aligned, G.ldc, nullptr,
+                             probe)) {
+      eg::clear_error();
+      continue;
+    }
+    if (probe.bm != 256 || probe.bn != 256 || probe.splits > 1 || !eg::gemm::fused_wide_store(probe)) continue;
+    const int R = t.all[ts.lowered[pe.consumer.lowered].all_index].write.tensor;  // the rows the product is taken of
+    // the narrow contraction: the next launches up to it may not touch what moves
+    for (size_t pj = gi + 1; pj < plan.launches.size() && pj <= gi + 3; ++pj) {
+      const Launch& P = plan.launches[pj];
+      if (P.kind != StepKind::Gemm && P.kind != StepKind::GenericA && P.kind != StepKind::GenericB) break;
+      if (P.consumer >= 0 || P.ones_tensor) break;
+      const bool candidate = P.kind == StepKind::Gemm && !P.trans_a && !P.trans_b && P.a_tensor == R && P.lda == G.N &&
+                             P.M == G.M && P.K == G.N && P.N >= 1 && P.N <= 16 && !P.accumulate && P.ldc == P.N;
+      if (!candidate) {
+        const Kernel& kx = t.all[ts.lowered[P.lowered].all_index];
+        if (kx.write.tensor == R) break;
+        continue;
+      }
+      const int Z = P.c_tensor;
+      // (the target's output lives in the arena like any other result: zeroed with it)
+      if (ts.bucket_offset.count(Z) || m->prog.tensors[Z].kind != TK::Result || shares_storage(Z) || plan.predicated.count(Z))
+        break;
+      if ((int)gi < plan.n_backward && (int)pj >= plan.n_backward) break;
+      bool legal = true;
+      for (size_t x = gi + 1; x < pj && legal; ++x) {
+        const Kernel& kx = t.all[ts.lowered[plan.launches[x].lowered].all_index];
+        if (kx.write.tensor == Z || kx.write.tensor == P.b_tensor || (P.bias_tensor && kx.write.tensor == P.bias_tensor)) legal = false;
+        for (auto& rd : kx.reads)
+          if (rd.tensor == Z) legal = false;
+      }
+      if (!legal) break;
+      pe.row_product = true;
+      pe.product = P;
+      pe.plain_struct_code = pe.spec.struct_code;
+      const int iw = (int)pe.spec.operands.size();
+      pe.spec.operands.push_back(P.b_tensor);
+      pe.spec.operands.push_back(Z);
+      if (P.bias_tensor) pe.spec.operands.push_back(P.bias_tensor);
+      char line[256];
+      snprintf(line, sizeof(line), "  static constexpr int RD_N = %ld, RD_W = %d, RD_OUT = %d, RD_BIAS = %d, RD_LDW = %ld, RD_LDO = %ld;\n",
+               P.N, iw, iw + 1, P.bias_tensor ? iw + 2 : -1, P.ldb, P.ldc);
+      const size_t at = pe.spec.struct_code.find(kNoRowProduct);
+      EG_REQUIRE(at != std::string::npos, EG_ERR_RUNTIME, "generated epilogue without the row-product line");
+      pe.spec.struct_code.replace(at, strlen(kNoRowProduct), line);
+      plan.zero_extra.insert(Z);
+      plan.launches.erase(plan.launches.begin() + (long)pj);
+      if (plan.n_backward > (int)pj) plan.n_backward--;
+      break;
+    }
+  }
+  return EG_OK;
+}
+
 // dense = `out[y,x] ++= in[y,it] * W[it,x]` + `out[y,x] ++= b[x]` (dnn.nim:19-24); derive turns the two into
 // `gW[it,x] ++= in[y,it] * g[y,x]` and `gb[x] ++= g[y,x]` (passes.nim:519-549): two reductions over the same
 // batch that both stream g.  With A = [in | 1] they are ONE contraction whose last row is gb — the

@@ -54,11 +54,18 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
         if (rc) return rc;
         return run_launch(m, ts, plan, pe.consumer);
       }
+      void* operands[eg::gemm::MAX_EPILOGUE_OPERANDS] = {};
+      for (size_t o = 0; o < pe.spec.operands.size(); ++o) operands[o] = tensor_ptr(m, ts, plan, pe.spec.operands[o]);
+      eg::gemm::set_epilogue_operands(f, operands, (int)pe.spec.operands.size(), m->grad_scale, m->epoch);
+      // a row product rides on whole 256 x 256 tiles that leave through LDS; anything else (cannot happen for the shapes
+      // the plan was made for, unless an operand turns out unaligned) runs the plain functor and the product by itself
+      const bool with_product = pe.row_product && f.bm == 256 && f.bn == 256 && eg::gemm::fused_wide_store(f);
       const std::string variant = eg::gemm::fused_variant(f);
-      eg_kernel*& handle = pe.built[variant];
+      eg_kernel*& handle = (pe.row_product && !with_product) ? pe.built_plain[variant] : pe.built[variant];
+      const std::string& struct_code = (pe.row_product && !with_product) ? pe.plain_struct_code : pe.spec.struct_code;
       if (!handle) {
         const std::string name = "eg_gemm_epi" + std::to_string(m->kernel_serial++);
-        const std::string src = eg::gemm::fused_source(f, pe.spec.struct_code, pe.spec.struct_name, name);
+        const std::string src = eg::gemm::fused_source(f, struct_code, pe.spec.struct_name, name);
         if (const char* dump = getenv("EG_DUMP_FUSED")) {  // debugging aid: the generated translation unit
           if (FILE* fp = fopen((std::string(dump) + "/" + name + "_" + variant + ".hip").c_str(), "w")) {
             fputs(src.c_str(), fp);
@@ -68,17 +75,16 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
         rc = eg_kernel_compile(ctx, name.c_str(), src.c_str(), &handle);
         if (rc) {
           std::string msg = eg_last_error();
-          set_error("%s\n--- generated epilogue (%s) ---\n%s", msg.c_str(), variant.c_str(), pe.spec.struct_code.c_str());
+          set_error("%s\n--- generated epilogue (%s) ---\n%s", msg.c_str(), variant.c_str(), struct_code.c_str());
           handle = nullptr;
           return rc;
         }
         m->kernels.push_back(handle);
       }
-      void* operands[eg::gemm::MAX_EPILOGUE_OPERANDS] = {};
-      for (size_t o = 0; o < pe.spec.operands.size(); ++o) operands[o] = tensor_ptr(m, ts, plan, pe.spec.operands[o]);
-      eg::gemm::set_epilogue_operands(f, operands, (int)pe.spec.operands.size(), m->grad_scale, m->epoch);
       void* args[] = {f.args};
-      return eg::kernel_launch_raw(handle, f.grid, 1, 1, (unsigned)f.nt, args);
+      rc = eg::kernel_launch_raw(handle, f.grid, 1, 1, (unsigned)f.nt, args);
+      if (rc || !pe.row_product || with_product) return rc;
+      return run_launch(m, ts, plan, pe.product);
     }
     case StepKind::ConvGradFilter:
       return eg_conv2_nhwc_grad_filter(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, tensor_ptr(m, ts, plan, L.a_tensor),

@@ -1071,6 +1071,10 @@ void set_epilogue_operands(FusedLaunch& f, void* const* ptrs, int count, float g
   a->epi_ep = epoch;
 }
 
+bool fused_wide_store(const FusedLaunch& f) {
+  return reinterpret_cast<const GemmArgs*>(f.args)->wide_store != 0 && !f.edge;
+}
+
 std::string fused_variant(const FusedLaunch& f) {
   char buf[96];
   snprintf(buf, sizeof(buf), "%dx%dx%d_%dx%d_%d_%c%c_v%d%s%s", f.bm, f.bn, f.bk, f.wm, f.wn, f.minb, f.a_kc ? 'k' : 'm',

@@ -103,6 +103,7 @@ struct EpiNone {
   static constexpr int NX = 1;
   static constexpr int OUT = 0;
   static constexpr int PRED = -1;
+  static constexpr int RD_N = 0, RD_W = 0, RD_OUT = 0, RD_BIAS = -1, RD_LDW = 0, RD_LDO = 0;
   __device__ __forceinline__ static bool predicate(float) { return false; }
   __device__ __forceinline__ static void prefetch(const GemmArgs&, long, float (&)[1]) {}
   __device__ __forceinline__ static void prefetch4(const GemmArgs&, long, f32x4 (&)[1]) {}
@@ -117,6 +118,12 @@ struct EpiNone {
 // one yes / no question of it (the relu gradient's `0 <= h`, dnn.nim:26-27 differentiated), so instead of v the kernel
 // stores predicate(v), one bit per element — bit (idx & 31) of word idx >> 5 of a.epi[PRED], zeroed before the run —
 // and the readers fetch the bit: 1/32 of the bytes in both directions.
+// RD_N > 0 (a "row product", host/plan_epilogue.cpp fold_row_products): the NEXT layer's contraction
+// `out2[y, x] ++= res[y, it] * W2[it, x]` (dense, dnn.nim:19-24) with x < RD_N <= 16 columns runs on the rows of the
+// consumer's result while they sit in LDS on their way out (wide-store pass of a 256 x 256 tile): a.epi[RD_W] = W2
+// (row stride RD_LDW), a.epi[RD_OUT] = out2 (row stride RD_LDO, zeroed before the run), a.epi[RD_BIAS] = its bias or
+// RD_BIAS < 0.  Every N-tile adds its 256-column partial product to out2 with one float atomic per element; the host
+// folds only when there are at most TWO N-tiles, so an element is 0 + p + q in either order: the same bits.
 template <class Epi>
 __device__ __forceinline__ void epi_apply(const GemmArgs& a, long idx, float v, const float (&x)[Epi::NX]) {
   const float r = Epi::compute(a, idx, v, x);
@@ -942,7 +949,11 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr int SA = LdsStride<BM, BK, A_KC>::value, SB = LdsStride<BN, BK, B_KC>::value;
 
-  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (SA + SB) + (XR ? 2 * BK * 32 : 0)];  // (XR: + the strip's stages)
+  // (XR: + the strip's stages; a row product: two padded stages of parked rows + the 256 x 16 piece of W2 + one hand-over block)
+  constexpr bool RD = Epi::RD_N > 0;
+  constexpr int RD_FLOATS = RD ? 2 * (BM / WM) * 32 * (BN + 4) + BN * 16 + 4 * 64 * 4 : 0;
+  constexpr int OPERAND_FLOATS = 2 * BK * (SA + SB) + (XR ? 2 * BK * 32 : 0);
+  __shared__ __attribute__((aligned(16))) float lds[RD_FLOATS > OPERAND_FLOATS ? RD_FLOATS : OPERAND_FLOATS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1010,6 +1021,18 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  if constexpr (RD) {
+    // a row product's piece of W2 (rows n_blk .. n_blk + BN, 16 columns) goes to LDS behind the two stages of parked
+    // rows — outside the operand buffers, so it is fetched here, under the k loop's prologue, and published by the
+    // barriers of the k loop: [k / 4][16][k % 4] (one ds_read_b128 per 16-k window and lane)
+    constexpr int RT_ = (BM / WM) * 32, NTHREADS = Geometry<BM, BN, WM, WN>::NT;
+    float* w2s = lds + 2 * RT_ * (BN + 4);
+    const float* w2 = static_cast<const float*>(a.epi[Epi::RD_W]);
+    for (int e = tid; e < BN * 16; e += NTHREADS) {
+      const int k = e >> 4, c = e & 15;
+      w2s[(((k >> 2) * 16 + c) << 2) + (k & 3)] = c < Epi::RD_N ? w2[(n_blk + k) * (long)Epi::RD_LDW + c] : 0.f;
+    }
+  }
   static_assert(!DMA || VEC == 4, "LDS-DMA loop: 16-byte aligned operands");
   const bool whole_k = (k_end - k_begin) % BK == 0;
   const bool interior = m_blk + BM <= a.a_rows && n_blk + BN <= a.N && whole_k;
@@ -1099,7 +1122,10 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
     constexpr int RT = WAVES_M * 32;            // staged rows per pass
     constexpr int C4 = BN / 4;                  // 16-byte chunks per staged row
     constexpr int NT_ = WAVES_M * WAVES_N * 64;
-    static_assert(RT * BN <= 2 * BK * (SA + SB), "the staged rows fit the operand buffers");
+    static_assert(RD || RT * BN <= 2 * BK * (SA + SB), "the staged rows fit the operand buffers");
+    static_assert(!RD || (BM == 256 && BN == 256 && WAVES_M * WAVES_N == 8), "row products ride on the 256 x 256 tile");
+    constexpr int PS = RD ? BN + 4 : BN;        // row stride of the parked rows (padded: the row product reads them as MFMA fragments)
+    float* w2s = lds + 2 * RT * PS;             // RD: W2[n_blk .. n_blk + BN) x 16 as [k / 4][16][k % 4], staged before the k loop
     const int wmi = wave / WAVES_N;
     static_assert(NT_ % C4 == 0, "a thread keeps its column chunk");
     constexpr int NQ = (RT * C4 + NT_ - 1) / NT_;  // chunks per thread and pass
@@ -1107,8 +1133,34 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
     const long n = n_blk + c4 * 4;
     f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
     if (has_bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+    float rd_half[4] = {0.f, 0.f, 0.f, 0.f};  // RD: this wave's half of the row product of the previous pass
+    float* rdx = w2s + BN * 16;                 // RD: [4 blocks][64 lanes][4]: the second column half, waves 4 .. 7 -> 0 .. 3
+    // out2 += partial product of pass `pass` (+ bias from the first N-tile).  Lane l of wave w < 4 holds column l % 16 of
+    // staged rows 16 w + 4 (l / 16) + v.  Float atomics without return — nothing waits for them (a compare-and-swap loop
+    // costs a memory round trip behind the tile's own store burst: +14 us per tile).  gfx950's global_atomic_add_f32
+    // honours the denormal mode (tests/test_gpu_epilogue.py holds a denormal result to the bit).
+    auto rd_send = [&](int pass) {
+      if constexpr (RD) {
+        const int r = lane & 15, g = lane >> 4;
+        if (wave < 4 && r < Epi::RD_N) {
+          typedef float rd4 __attribute__((ext_vector_type(4)));
+          const rd4 other = *reinterpret_cast<const rd4*>(rdx + (wave * 64 + lane) * 4);
+          float bias2 = 0.f;
+          if (Epi::RD_BIAS >= 0 && n_blk == 0) bias2 = static_cast<const float*>(a.epi[Epi::RD_BIAS >= 0 ? Epi::RD_BIAS : 0])[r];
+          float* out2 = static_cast<float*>(a.epi[Epi::RD_OUT]);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const int srow = wave * 16 + 4 * g + v;
+            const long m = m_blk + (long)(srow >> 5) * WM + sub_index<MI>(ail, pass, srow & 31);
+            atomicAdd(out2 + m * (long)Epi::RD_LDO + r, (rd_half[v] + other[v]) + bias2);
+          }
+        }
+      }
+    };
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+      // (RD: passes alternate between two stages, so the row product of pass i reads its rows while pass i + 1 parks)
+      float* park = lds + (RD ? (i & 1) * RT * PS : 0);
       if (bil) {  // the lane's NI columns are adjacent: one 8- / 16-byte LDS write per row
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -1116,16 +1168,17 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
           vecN v;
 #pragma unroll
           for (int j = 0; j < NI; ++j) v[j] = acc[i][j][r];
-          *reinterpret_cast<vecN*>(&lds[(wmi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BN + wn0 + NI * (lane & 31)]) = v;
+          *reinterpret_cast<vecN*>(&park[(wmi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * PS + wn0 + NI * (lane & 31)]) = v;
         }
       } else {
 #pragma unroll
         for (int j = 0; j < NI; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            lds[(wmi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BN + wn0 + j * 32 + (lane & 31)] = acc[i][j][r];
+            park[(wmi * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * PS + wn0 + j * 32 + (lane & 31)] = acc[i][j][r];
       }
       __syncthreads();
+      if (RD && i > 0) rd_send(i - 1);
       // A thread's chunks of one pass: q = q0 + tid, q0 a multiple of the block size — the same 16-byte column chunk c4 of
       // NQ different rows (C4 divides the block size), so the bias chunk is loaded once.  The loads of all NQ chunks (a
       // generated epilogue's operands, an accumulating launch's old values) are issued BEFORE the first store: loads and
@@ -1153,7 +1206,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
         if ((RT * C4) % NT_ != 0 && c * NT_ + tid >= RT * C4) break;
         const int row = (c * NT_ + tid) / C4;
         const long idx = index_of(c);
-        f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * BN + c4 * 4]);
+        f32x4 v = *reinterpret_cast<const f32x4*>(&park[row * PS + c4 * 4]);
         if (Epi::ACTIVE) {
           f32x4 res;
           unsigned nibble = 0;
@@ -1180,6 +1233,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
               atomicOr(bits + (idx >> 5), nibble << (idx & 31));  // (idx is a multiple of 4: a nibble never straddles words)
             }
           }
+          if constexpr (RD) *reinterpret_cast<f32x4*>(&park[row * PS + c4 * 4]) = res;  // (this thread's own chunk)
           if (a.nt_store) {
             if (Epi::STORE_C) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.C + idx));
             __builtin_nontemporal_store(res, reinterpret_cast<f32x4*>(static_cast<float*>(a.epi[Epi::OUT]) + idx));
@@ -1202,9 +1256,42 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
       }
       }
       __syncthreads();
+      if constexpr (RD) {
+        // Row product of the RT = 64 rows of this pass: wave w takes the 16 rows of block w % 4 and the column half w / 4,
+        // v_mfma_f32_16x16x4_f32 over 16-wide windows — lane (r = l % 16, g = l / 16) reads res[row r][16 s + 4 g .. + 3]
+        // and W2[16 s + 4 g .. + 3][column r] as one ds_read_b128 each (stride BN + 4: 4 r + g covers the 64 banks once);
+        // MFMA j of a window multiplies k = 16 s + 4 g + j on both sides.  Two accumulators, windows alternating.
+        // Waves 4 .. 7 hand their half over through LDS (rdx); waves 0 .. 3 pick it up behind the NEXT barrier every wave
+        // passes anyway (the one that publishes the next pass's parked rows) and send the sums off there.
+        typedef float rd4 __attribute__((ext_vector_type(4)));
+        const int r = lane & 15, g = lane >> 4, mb = wave & 3, kh = wave >> 2;
+        const float* arow = park + (mb * 16 + r) * PS + 4 * g + kh * (BN / 2);
+        const float* brow = w2s + ((g * 16 + r) << 2) + kh * (BN / 2) * 16;
+        rd4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < BN / 32; s2 += 2) {
+          const rd4 a0 = *reinterpret_cast<const rd4*>(arow + 16 * s2);
+          const rd4 b0 = *reinterpret_cast<const rd4*>(brow + 256 * s2);
+          const rd4 a1 = *reinterpret_cast<const rd4*>(arow + 16 * s2 + 16);
+          const rd4 b1 = *reinterpret_cast<const rd4*>(brow + 256 * s2 + 256);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], d1, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) rd_half[v] = d0[v] + d1[v];
+        if (kh == 1) *reinterpret_cast<rd4*>(rdx + (mb * 64 + lane) * 4) = rd4{rd_half[0], rd_half[1], rd_half[2], rd_half[3]};
+      }
+    }
+    if constexpr (RD) {
+      __syncthreads();
+      rd_send(MI - 1);
     }
     return;
   }
+  if constexpr (RD) __builtin_trap();  // the host launches a row product only where every tile takes the wide-store pass
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
 #pragma unroll

@@ -39,6 +39,9 @@ int sgemm_ones_row(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K
 // Tensors the generated epilogue reads / writes (a.epi[i]), the seed-gradient scale and the epoch.
 void set_epilogue_operands(FusedLaunch& f, void* const* ptrs, int count, float grad_scale, long epoch);
 
+// Does every tile of the planned launch leave through the wide-store pass (after set_epilogue_operands)?
+bool fused_wide_store(const FusedLaunch& f);
+
 // Identifies the template instantiation (cache key / kernel name suffix).
 std::string fused_variant(const FusedLaunch& f);
 

@@ -268,3 +268,92 @@ def test_predicate_bits_on_zero_and_denormal_preactivations(gpu_ctx, monkeypatch
     t.step("train", {"x": x, "y": y}, n=batch)
     assert "stored as predicate bits" in t.gpu.launch_plan("train")
     t.close()
+
+
+# ---- row products (plan_epilogue.cpp fold_row_products): the narrow next layer inside the epilogue ----
+
+def _head(gpu_ctx, monkeypatch, dims, x, y, steps, folded):
+    monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", "0")
+    if folded:
+        monkeypatch.delenv("EG_NO_ROW_PRODUCT", raising=False)
+    else:
+        monkeypatch.setenv("EG_NO_ROW_PRODUCT", "1")
+    gpu = egm.compile(*mlp(act="relu", dims=dims), gpu=gpu_ctx)
+    rng = np.random.default_rng(5)
+    start = {}
+    for tid in sorted(gpu.params.ids()):
+        start[tid] = (rng.random(gpu.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+        gpu.params[tid] = start[tid]
+    out = gpu.call("predict", {"x": x}).copy()
+    for _ in range(steps):       # eager, captured, replayed
+        gpu.apply("train", {"x": x, "y": y})
+    plans = gpu.launch_plan("predict"), gpu.launch_plan("train")
+    params = {t: gpu.params[t].copy() for t in sorted(gpu.params.ids())}
+    gpu.close()
+    return plans, start, out, params
+
+
+@pytest.mark.parametrize("dims,batch,force", [((784, 512, 10), 32768, True), ((64, 256, 16), 65536, True), ((96, 512, 1), 32768, True),
+                                              ((32, 512, 7), 65536, True)])
+def test_narrow_next_layer_rides_in_the_epilogue(gpu_ctx, monkeypatch, dims, batch, force):
+    """dense -> relu -> dense(., <= 16) on whole 256 x 256 tiles: the second contraction is taken of the rows of relu(h)
+    while they pass through LDS (gemm_f32_mfma.hpp, RD_N).  Against the float64 product; against the unfolded plan (same
+    values to rounding: the 256-column partial sums are formed in another order); run-to-run bit-identical (two N-tiles
+    add to a zeroed element in either order)."""
+    if force:   # small problems would run on smaller tiles: the row product lives on the 256 x 256 tile
+        monkeypatch.setenv("EG_GEMM_FORCE_TILE", "256,256")
+    rng = np.random.default_rng(batch + dims[1])
+    x = (rng.random((batch, dims[0]), dtype=np.float32) - 0.5).astype(np.float32)
+    y = rng.random((batch, dims[-1]), dtype=np.float32)
+    plans, start, out, params = _head(gpu_ctx, monkeypatch, dims, x, y, 3, folded=True)
+    assert "row product" in plans[0] and "row product" in plans[1], plans
+    _, _, out_again, params_again = _head(gpu_ctx, monkeypatch, dims, x, y, 3, folded=True)
+    assert np.array_equal(out, out_again)
+    for t in params:
+        assert np.array_equal(params[t], params_again[t]), t
+    plans_plain, _, out_plain, params_plain = _head(gpu_ctx, monkeypatch, dims, x, y, 3, folded=False)
+    assert "row product" not in plans_plain[0] + plans_plain[1]
+    ids = sorted(start)
+    w1, b1, w2, b2 = (start[t].astype(np.float64) for t in ids)
+    if w1.ndim == 1:
+        w1, b1 = b1, w1
+    if w2.ndim == 1:
+        w2, b2 = b2, w2
+    want = np.maximum(x.astype(np.float64) @ w1 + b1, 0.0) @ w2 + b2
+    assert rel_err(out, want) <= TOL
+    assert rel_err(out_plain, want) <= TOL
+    for t in params:
+        assert rel_err(params[t], params_plain[t].astype(np.float64)) <= 2 * TOL, t
+
+
+def test_row_product_keeps_denormal_sums(gpu_ctx, monkeypatch):
+    """The partial products reach their destination through global_atomic_add_f32: a denormal sum must arrive as it is
+    (W2 = 0 and a denormal bias: every output is exactly the bias), and so must a sum of two denormal partial products."""
+    monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", "0")
+    monkeypatch.setenv("EG_GEMM_FORCE_TILE", "256,256")
+    monkeypatch.delenv("EG_NO_ROW_PRODUCT", raising=False)
+    dims = (32, 512, 7)
+    gpu = egm.compile(*mlp(act="relu", dims=dims), gpu=gpu_ctx)
+    ids = sorted(gpu.params.ids())
+    shapes = {t: gpu.params[t].shape for t in ids}
+    w1 = next(t for t in ids if shapes[t] == (32, 512))
+    b1 = next(t for t in ids if shapes[t] == (512,))
+    w2 = next(t for t in ids if shapes[t] == (512, 7))
+    b2 = next(t for t in ids if shapes[t] == (7,))
+    tiny = np.float32(1e-42)
+    gpu.params[w1] = np.zeros((32, 512), dtype=np.float32)
+    gpu.params[b1] = np.ones(512, dtype=np.float32)            # relu(h) = 1 everywhere
+    gpu.params[w2] = np.zeros((512, 7), dtype=np.float32)
+    gpu.params[b2] = np.full(7, tiny, dtype=np.float32)
+    x = np.zeros((32768, 32), dtype=np.float32)                 # 256 tiles of 256 x 256: no k-slices, the product is folded
+    out = gpu.call("predict", {"x": x})
+    assert "row product" in gpu.launch_plan("predict")
+    assert np.all(out == tiny), out[:2]
+    # 256 columns of 1e-45-sized products per N-tile: 256 * 4e-45 per tile, two tiles, no bias contribution
+    step = np.float32(4e-45)                                   # a multiple of the smallest denormal (1.4e-45): 3 ulps
+    gpu.params[w2] = np.full((512, 7), step, dtype=np.float32)
+    gpu.params[b2] = np.zeros(7, dtype=np.float32)
+    out = gpu.call("predict", {"x": x})
+    want = np.float32(512) * step                              # exact: integers times the denormal unit
+    assert np.all(out == want), (out[:2], want)
+    gpu.close()
