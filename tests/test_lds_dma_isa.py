@@ -24,6 +24,7 @@ struct EgEpi {
   static constexpr bool STORE_C = false;
   static constexpr int OUT = 0;
   static constexpr int PRED = -1;
+  static constexpr int RD_N = 0, RD_W = 0, RD_OUT = 0, RD_BIAS = -1, RD_LDW = 0, RD_LDO = 0;
   __device__ __forceinline__ static bool predicate(float) { return false; }
   __device__ __forceinline__ static void prefetch(const eg::gemm::GemmArgs&, long, float (&)[1]) {}
   __device__ __forceinline__ static void prefetch4(const eg::gemm::GemmArgs&, long, eg::gemm::f32x4 (&)[1]) {}

@@ -16,6 +16,7 @@ struct Relu {
   static constexpr bool STORE_C = STORE;
   static constexpr int OUT = 0;
   static constexpr int PRED = PREDV;
+  static constexpr int RD_N = 0, RD_W = 0, RD_OUT = 0, RD_BIAS = -1, RD_LDW = 0, RD_LDO = 0;
   __device__ __forceinline__ static bool predicate(float v) { return 0.0f <= v; }
   __device__ __forceinline__ static void prefetch(const GemmArgs&, long, float (&)[1]) {}
   __device__ __forceinline__ static void prefetch4(const GemmArgs&, long, f32x4 (&)[1]) {}
