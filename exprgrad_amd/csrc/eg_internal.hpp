@@ -67,6 +67,8 @@ struct eg_ctx {
   std::vector<hipEvent_t> pipe_events;  // batch pipeline (host/plan_pipeline.cpp): per-stage, per-half dependencies between the lanes
   eg::HostStager* stager = nullptr;  // created by the first large host copy
   float* ones = nullptr;             // {1,1,1,1, 1,0,0,0}: source of a contraction's virtual row of ones (GemmArgs::ones)
+  float* zeros = nullptr;            // zeros_floats zeros: what a convolution's virtual padding reads (conv2_halo.hip)
+  size_t zeros_floats = 0;
   int compute_units = 256;
   std::string arch;
   // kernels a library call specialises at run time (hiprtc) and keeps: by name
@@ -114,6 +116,9 @@ int kernels_compile_batch(eg_ctx* ctx, const char* label, const char* source, co
 int kernel_launch_raw(eg_kernel* kernel, unsigned gx, unsigned gy, unsigned gz, unsigned block, void** args);
 // Column sum with caller-provided scratch (colsum_scratch_floats(...) floats); see reduce.hip.
 long colsum_scratch_floats(const eg_ctx* ctx, long rows, long cols);
+// One-launch sum of k-slice slabs into a small output (reduce.hip); fixed order.
+bool slab_sum_supported(long total, const float* slab, const float* out);
+int slab_sum(eg_ctx* ctx, long slabs, long total, const float* slab, float* out, int accumulate);
 int colsum_with_scratch(eg_ctx* ctx, long rows, long cols, const float* in, float* out, int accumulate,
                         float* scratch);
 // Second stage of a row-fused kernel's batch reductions (host/rowfuse.hpp): partial is
@@ -132,6 +137,8 @@ int conv2_direct_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long F
 int conv2_direct_grad_filter_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
                                  const float* gout, float* gflt, int accumulate, bool* launched);
 // LDS-halo convolution (kernels/conv2_halo.hip); *launched = false when the problem does not suit it.
+int conv2_halo_try_padded(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, long py, long px,
+                          const float* img, const float* flt, float* out, int accumulate, bool* launched);
 int conv2_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
                    const float* flt, float* out, int accumulate, bool* launched);
 // Several contiguous device-to-device float copies in one launch (kernels/elementwise.hip).

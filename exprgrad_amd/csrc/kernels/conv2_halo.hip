@@ -46,6 +46,11 @@ struct HaloArgs {
   const float* flt;
   float* out;
   long N, H, W, C, F, FH, FW, Ho, Wo;
+  // Virtual zero padding (the image gradient: a "full" correlation of the output gradient, gemm_f32_mfma.hip
+  // eg_conv2_nhwc_grad_image): output pixel (y, x) reads image rows y - py .. and columns x - px ..; pixels outside the
+  // image come from `zeros` (>= C floats of zeros) instead of a padded copy of the image.  Ho = H + 2 py - FH + 1.
+  long py, px;
+  const float* zeros;
   int tiles_x, tiles_y, tiles_f;
   int accumulate;
   long items;  // N * tiles_y * tiles_x * tiles_f
@@ -110,7 +115,8 @@ __global__ __launch_bounds__(NT, 2) void conv2_halo_kernel(HaloArgs a) {
   // halo: instruction t covers halo pixels 16t .. 16t+15, lane l -> pixel 16t + l/4, slot l%4
   // filters: per tap 64 rows x 4 chunks = 4 instructions; instruction u = tap * 4 + v covers rows
   // 16v .. 16v+15
-  long halo_src[HALO_PER_WAVE], flt_src[FLT_PER_WAVE];
+  const float* halo_src[HALO_PER_WAVE];
+  long flt_src[FLT_PER_WAVE];
   auto sources = [&](const Item& it) {
 #pragma unroll
     for (int t = 0; t < HALO_PER_WAVE; ++t) {
@@ -118,11 +124,15 @@ __global__ __launch_bounds__(NT, 2) void conv2_halo_kernel(HaloArgs a) {
       int q = instr * 16 + (lane >> 2);
       if (q >= halo) q = halo - 1;
       const int qy = q / HW, qx = q - qy * HW;
-      long yy = it.y0 + qy, xx = it.x0 + qx;
-      if (yy > a.H - 1) yy = a.H - 1;
+      long yy = it.y0 + qy - a.py, xx = it.x0 + qx - a.px;
+      const bool outside = yy < 0 || xx < 0 || yy > a.H - 1 || xx > a.W - 1;
+      if (yy > a.H - 1) yy = a.H - 1;  // (without padding: the rows / columns of a ragged patch, never stored)
       if (xx > a.W - 1) xx = a.W - 1;
+      if (yy < 0) yy = 0;
+      if (xx < 0) xx = 0;
       const int chunk = (lane & 3) ^ swz(instr * 16 + (lane >> 2));
-      halo_src[t] = ((it.n * a.H + yy) * a.W + xx) * a.C + chunk * 4;
+      halo_src[t] = a.img + ((it.n * a.H + yy) * a.W + xx) * a.C + chunk * 4;
+      if (outside && a.zeros) halo_src[t] = a.zeros + chunk * 4;
     }
 #pragma unroll
     for (int t = 0; t < FLT_PER_WAVE; ++t) {
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(NT, 2) void conv2_halo_kernel(HaloArgs a) {
   constexpr int PIECES = HALO_PER_WAVE + FLT_PER_WAVE;
   auto issue_piece = [&](int piece, int c0, float* stage) {
     if (piece < HALO_PER_WAVE) {
-      dma16(a.img + halo_src[piece] + c0, stage + (wave + piece * 8) * 256);
+      dma16(halo_src[piece] + c0, stage + (wave + piece * 8) * 256);
     } else {
       const int t = piece - HALO_PER_WAVE;
       dma16(a.flt + flt_src[t] + c0, stage + HALO_FLOATS + (wave + t * 8) * 256);
@@ -270,14 +280,19 @@ namespace eg {
 // Launches the halo kernel if the problem suits it; *launched tells the caller whether it did.
 int conv2_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
                    const float* flt, float* out, int accumulate, bool* launched) {
+  return conv2_halo_try_padded(ctx, N, H, W, C, F, FH, FW, 0, 0, img, flt, out, accumulate, launched);
+}
+
+int conv2_halo_try_padded(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, long py, long px,
+                          const float* img, const float* flt, float* out, int accumulate, bool* launched) {
   *launched = false;
   static const bool off = [] {
     const char* e = getenv("EG_CONV_NO_HALO");
     return e && e[0] && e[0] != '0';
   }();
   if (off) return EG_OK;
-  const long Ho = H - FH + 1, Wo = W - FW + 1;
-  if (FH > 3 || FW > 3 || C % CK != 0 || C < CK) return EG_OK;
+  const long Ho = H + 2 * py - FH + 1, Wo = W + 2 * px - FW + 1;
+  if (FH > 3 || FW > 3 || C % CK != 0 || C < CK || Ho <= 0 || Wo <= 0) return EG_OK;
   if ((reinterpret_cast<uintptr_t>(img) & 15) || (reinterpret_cast<uintptr_t>(flt) & 15)) return EG_OK;
   const long tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH, tiles_f = (F + FB - 1) / FB;
   const long blocks = N * tiles_y * tiles_x * tiles_f;
@@ -301,6 +316,24 @@ int conv2_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH,
   a.tiles_y = (int)tiles_y;
   a.tiles_f = (int)tiles_f;
   a.accumulate = accumulate;
+  a.py = py;
+  a.px = px;
+  a.zeros = nullptr;
+  if (py > 0 || px > 0) {
+    if (ctx->zeros_floats < (size_t)C) {  // once per context (and channel count): a block of zeros the padding reads
+      if (ctx->zeros) {
+        EG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        EG_HIP_CHECK(hipFree(ctx->zeros));
+        ctx->zeros = nullptr;
+        ctx->zeros_floats = 0;
+      }
+      const size_t want = ((size_t)C + 1023) & ~(size_t)1023;
+      EG_HIP_CHECK(hipMalloc((void**)&ctx->zeros, want * sizeof(float)));
+      EG_HIP_CHECK(hipMemset(ctx->zeros, 0, want * sizeof(float)));
+      ctx->zeros_floats = want;
+    }
+    a.zeros = ctx->zeros;
+  }
   const void* kernel = FH == 3 && FW == 3   ? reinterpret_cast<const void*>(&conv2_halo_kernel<MAX_TAPS, 3, 3>)
                        : FH == 1 && FW == 1 ? reinterpret_cast<const void*>(&conv2_halo_kernel<MAX_TAPS, 1, 1>)
                                             : reinterpret_cast<const void*>(&conv2_halo_kernel<MAX_TAPS, 0, 0>);

@@ -622,7 +622,10 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     return EG_OK;
   }
   if (splits > 1) {
-    if (tree_reduce) return eg::colsum_with_scratch(ctx, splits, total, args.partial, args.C, args.accumulate, scratch);
+    if (tree_reduce) {
+      if (eg::slab_sum_supported(total, args.partial, args.C)) return eg::slab_sum(ctx, splits, total, args.partial, args.C, args.accumulate);
+      return eg::colsum_with_scratch(ctx, splits, total, args.partial, args.C, args.accumulate, scratch);
+    }
     long blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, args.partial,
@@ -968,14 +971,31 @@ extern "C" int eg_conv2_nhwc_grad_image(eg_ctx* ctx, int64_t N, int64_t H, int64
   if (FH == 1 && FW == 1)  // plain contraction: gimg[P,C] = gout[P,F] * flt[F,C]
     return eg_sgemm(ctx, 0, 0, N * H * W, C, F, gout, F, flt, C, gimg, C, accumulate, nullptr);
   const long Hp = Ho + 2 * (FH - 1), Wp = Wo + 2 * (FW - 1);
-  const size_t pad_floats = ((size_t)(N * Hp * Wp * F) + 3) & ~(size_t)3;
   const size_t flt_floats = (size_t)(C * FH * FW * F);
+  EG_REQUIRE(flt_floats < (1UL << 32), EG_ERR_INVALID, "eg_conv2_nhwc_grad_image: filter bank exceeds 2^32 elements");
+  // The halo kernel pads by itself (pixels outside the gradient come from a block of zeros): only the flipped bank is
+  // prepared — no padded copy of the gradient is written and read back (cfg 4: 2 x 17 MB, 8 -> 3 us of preparation).
+  // EG_CONV_NO_VIRTUAL_PAD=1: the padded copy of rounds 1 and 2.
+  const bool virtual_pad = getenv("EG_CONV_NO_VIRTUAL_PAD") == nullptr;  // (read per call: a test compares the two routes)
+  if (virtual_pad && FH <= 3 && FW <= 3 && F % 16 == 0 && aligned16(gout)) {
+    rc = eg::ensure_aux(ctx, flt_floats * sizeof(float));
+    if (rc) return rc;
+    float* flipped_only = static_cast<float*>(ctx->aux);
+    const long fb = std::min<long>(((long)flt_floats + 255) / 256, 2L * ctx->compute_units);
+    hipLaunchKernelGGL(grad_image_operands_kernel<1>, dim3((unsigned)fb), dim3(256), 0, ctx->stream, gout, flipped_only, 0u,
+                       (unsigned)Hp, (unsigned)Wp, (unsigned)Ho, (unsigned)Wo, (unsigned)F, (unsigned)(FH - 1), (unsigned)(FW - 1),
+                       0u, flt, flipped_only, (unsigned)FH, (unsigned)FW, (unsigned)C);
+    EG_HIP_CHECK(hipGetLastError());
+    bool launched = false;
+    rc = eg::conv2_halo_try_padded(ctx, N, Ho, Wo, F, C, FH, FW, FH - 1, FW - 1, gout, flipped_only, gimg, accumulate, &launched);
+    if (rc || launched) return rc;
+  }
+  const size_t pad_floats = ((size_t)(N * Hp * Wp * F) + 3) & ~(size_t)3;
   rc = eg::ensure_aux(ctx, (pad_floats + flt_floats) * sizeof(float));
   if (rc) return rc;
   float* padded = static_cast<float*>(ctx->aux);
   float* flipped = padded + pad_floats;
   EG_REQUIRE(N * Hp * Wp * F < (1L << 32), EG_ERR_INVALID, "eg_conv2_nhwc_grad_image: padded gradient exceeds 2^32 elements");
-  EG_REQUIRE(flt_floats < (1UL << 32), EG_ERR_INVALID, "eg_conv2_nhwc_grad_image: filter bank exceeds 2^32 elements");
   const bool vec4 = F % 4 == 0 && aligned16(gout);
   const long work = N * Hp * Wp * (vec4 ? F / 4 : F);
   const long blocks = std::min<long>((work + 255) / 256, 16L * ctx->compute_units);

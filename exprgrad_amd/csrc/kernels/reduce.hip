@@ -156,6 +156,75 @@ int colsum_with_scratch(eg_ctx* ctx, long rows, long cols, const float* in, floa
   return EG_OK;
 }
 
+// Sum of `slabs` slabs of `total` floats (the k-slices of a contraction with a small output: a classifier's 512 x 10
+// weight gradient in 41 slices, a convolution's 36 864-float filter gradient in 113) in ONE launch: the column sum above
+// takes two (partials, then their sum: 7 + 5 us for 0.8 MB).  A block owns G 16-byte groups of the output and splits the
+// slabs over 256 / G lanes each: lane s of a group adds slabs s, s + L, s + 2 L, ... in that order, a fixed tree in LDS
+// folds the L partial sums — run-to-run identical.  G groups x 16 bytes are contiguous in every slab.
+template <bool ACC>
+__global__ __launch_bounds__(NT) void slab_sum_kernel(const float* __restrict__ slab, float* out, long total, int slabs, int G) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ f4 part[NT];
+  const int L = NT / G;                       // slab lanes per group
+  const int gi = threadIdx.x % G, sl = threadIdx.x / G;
+  const long group = (long)blockIdx.x * G + gi;
+  const bool live = group * 4 < total;
+  f4 s = {0.f, 0.f, 0.f, 0.f};
+  if (live)
+    for (int z = sl; z < slabs; z += L) {
+      const f4 v = *reinterpret_cast<const f4*>(slab + (long)z * total + group * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] += v[j];
+    }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int h = L >> 1; h >= 1; h >>= 1) {
+    if (sl < h) {
+      const f4 o = part[(sl + h) * G + gi];
+      f4 m = part[sl * G + gi];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[j] += o[j];
+      part[sl * G + gi] = m;
+    }
+    __syncthreads();
+  }
+  if (sl == 0 && live) {
+    f4 r = part[gi];
+    f4* p = reinterpret_cast<f4*>(out + group * 4);
+    if (ACC) {
+      const f4 o = *p;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r[j] = o[j] + r[j];
+    }
+    *p = r;
+  }
+}
+
+bool slab_sum_supported(long total, const float* slab, const float* out) {
+  static const bool off = [] {
+    const char* e = getenv("EG_NO_SLAB_SUM");
+    return e && e[0] && e[0] != '0';
+  }();
+  return !off && total > 0 && total % 4 == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+}
+
+int slab_sum(eg_ctx* ctx, long slabs, long total, const float* slab, float* out, int accumulate) {
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  const long groups = total / 4;
+  // enough blocks to fill the chip, enough slab lanes to keep a lane's chain short
+  int G = 16;
+  while (G > 1 && (groups / G < 2L * ctx->compute_units || slabs / (NT / G) > 16)) G >>= 1;
+  const long blocks = (groups + G - 1) / G;
+  if (accumulate)
+    hipLaunchKernelGGL((slab_sum_kernel<true>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, slab, out, total, (int)slabs, G);
+  else
+    hipLaunchKernelGGL((slab_sum_kernel<false>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, slab, out, total, (int)slabs, G);
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+
 __global__ __launch_bounds__(NT) void row_finalize_kernel(const float* __restrict__ partial, int nblocks, int E,
                                                           RowFinalizeArgs a) {
   __shared__ float red[4];

@@ -178,3 +178,34 @@ def test_few_channel_convolutions_use_the_direct_kernels(gpu_ctx, refcpu, shape)
     again.write(fbase)
     ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dg, again, accumulate=True)
     assert np.array_equal(again.read(), gflt.read())
+
+
+PADDED_HALO_SHAPES = [  # N, H, W, C, F, FH, FW — enough patches of the IMAGE (the gradient's output) for the halo kernel
+    (8, 66, 66, 16, 64, 3, 3), (2, 130, 130, 32, 64, 3, 3), (3, 100, 120, 48, 48, 2, 3), (1, 250, 131, 24, 128, 3, 1),
+    (2, 129, 97, 8, 16, 3, 3),
+]
+
+
+@pytest.mark.parametrize("shape", PADDED_HALO_SHAPES)
+def test_image_gradient_with_virtual_padding(gpu_ctx, refcpu, monkeypatch, shape):
+    """gImg is a full correlation of gOut with the flipped bank: the halo kernel reads the (FH - 1, FW - 1) border from a
+    block of zeros instead of a padded copy of gOut.  Against the oracle, with and without accumulate, and bit for bit
+    against the padded-copy route of rounds 1 and 2 (same kernel, same operand values, same order)."""
+    N, H, W, C, F, FH, FW = shape
+    rng = np.random.default_rng(sum(shape))
+    flt = (rng.random((F, FH, FW, C), dtype=np.float32) * 2 - 1).astype(np.float32)
+    gout = (rng.random((N, H - FH + 1, W - FW + 1, F), dtype=np.float32) - 0.5).astype(np.float32)
+    want = refcpu.conv2_nhwc_grad_image(flt, gout, (N, H, W, C))
+    dflt, dg = dev(gpu_ctx, flt), dev(gpu_ctx, gout)
+    gimg = gpu_ctx.allocTensor((N, H, W, C))
+    gimg.write(np.full((N, H, W, C), 3.0, dtype=np.float32))
+    ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dg, gimg)
+    got = gimg.read()
+    assert rel_err(got, want) <= TOL
+    base = rng.random((N, H, W, C), dtype=np.float32)
+    gimg.write(base)
+    ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dg, gimg, accumulate=True)
+    assert rel_err(gimg.read(), want + base) <= TOL
+    monkeypatch.setenv("EG_CONV_NO_VIRTUAL_PAD", "1")
+    ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dg, gimg)
+    assert np.array_equal(gimg.read(), got)
