@@ -486,6 +486,13 @@ struct DmaLoader {
   static constexpr int CHUNKS = BK / 4;  // 16-byte chunks per k-contiguous row
 
   long row_off[PER_WAVE];  // CONV: element offset of this lane's output pixel's top-left input pixel
+  // CONV, filter-gradient operand, whole k-tiles: the k loop walks the output pixels in order, so the window origin of
+  // this lane's pixel is carried from k-tile to k-tile (x += BK with carries into y and the image) instead of being
+  // recomputed with three 32-bit divisions per 16-byte load (two loads per thread and k-tile next to 16 MFMAs per wave:
+  // the divisions cost as many issue cycles as the matrix work).
+  mutable long pix_off[PER_WAVE];  // element offset of that origin for the k-tile at pix_next
+  mutable int pix_x[PER_WAVE], pix_y[PER_WAVE];
+  mutable long pix_next = -1;
 
   __device__ __forceinline__ static int swizzle(int r) { return BK == 16 ? (r >> 2) & 3 : (r >> 1) & 7; }
 
@@ -592,6 +599,21 @@ struct DmaLoader {
       const unsigned tap = (unsigned)k0 / C, c0 = (unsigned)k0 % C;
       tap_off = (long)((tap / FW) * (unsigned)a.cW + tap % FW) * C + c0;
     }
+    if constexpr (CONV && !KC && !CLAMP) {
+      if (k0 != pix_next) {  // (block-uniform) the first k-tile of this block: one full decode
+#pragma unroll
+        for (int t = 0; t < PER_WAVE; ++t) {
+          constexpr int CPR = BMN / 4;
+          const int q = (wave + t * WAVES) * 64 + lane;
+          const unsigned gk = (unsigned)(k0 + q / CPR);
+          const unsigned hw = (unsigned)(a.cHo * a.cWo);
+          const unsigned img = gk / hw, rem = gk % hw;
+          pix_y[t] = (int)(rem / (unsigned)a.cWo);
+          pix_x[t] = (int)(rem % (unsigned)a.cWo);
+          pix_off[t] = (((long)img * a.cH + pix_y[t]) * a.cW + pix_x[t]) * a.cC;
+        }
+      }
+    }
 #pragma unroll
     for (int t = 0; t < PER_WAVE; ++t) {
       const int instr = wave + t * WAVES;
@@ -612,7 +634,9 @@ struct DmaLoader {
       } else {
         constexpr int CPR = BMN / 4;
         const int k = q / CPR, col = (q % CPR) * 4;
-        if (CONV) {  // k -> output pixel (n, y, x) -> its window's top-left input pixel
+        if (CONV && !CLAMP) {
+          src = base + pix_off[t] + row_off[t];
+        } else if (CONV) {  // k -> output pixel (n, y, x) -> its window's top-left input pixel
           const unsigned gk = (unsigned)(CLAMP ? min(k0 + k, k_lim - 1) : k0 + k);
           const unsigned hw = (unsigned)(a.cHo * a.cWo);
           const unsigned img = gk / hw, rem = gk % hw;
@@ -625,6 +649,24 @@ struct DmaLoader {
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(tile + instr * 256), 16, 0, 0);
+    }
+    if constexpr (CONV && !KC && !CLAMP) {  // on to the pixels of the next k-tile
+      const int Wo = (int)a.cWo, Ho = (int)a.cHo;
+      const long row_step = (a.cW - a.cWo) * a.cC, image_step = (a.cH - a.cHo) * a.cW * a.cC;
+#pragma unroll
+      for (int t = 0; t < PER_WAVE; ++t) {
+        pix_x[t] += BK;
+        pix_off[t] += (long)BK * a.cC;
+        while (pix_x[t] >= Wo) {
+          pix_x[t] -= Wo;
+          pix_off[t] += row_step;
+          if (++pix_y[t] >= Ho) {
+            pix_y[t] = 0;
+            pix_off[t] += image_step;
+          }
+        }
+      }
+      pix_next = k0 + BK;
     }
   }
 };
