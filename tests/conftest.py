@@ -69,4 +69,5 @@ def debug_toggles_active():
     """EG_NO_GRAPH / EG_NO_OVERLAP / EG_NO_ROWFUSE (tools/stress_suite.sh cycles through them) change the launch
     plan on purpose: assertions about the plan's STRUCTURE only hold without them; numbers must hold always."""
     return any(os.environ.get(k, "") not in ("", "0") for k in ("EG_NO_GRAPH", "EG_NO_OVERLAP", "EG_NO_ROWFUSE", "EG_NO_EPILOGUE",
-                                                                  "EG_NO_INLINE", "EG_NO_ONES_ROW"))
+                                                                  "EG_NO_INLINE", "EG_NO_ONES_ROW", "EG_NO_PREDICATE",
+                                                                  "EG_NO_ROW_PRODUCT", "EG_PIPELINE"))

@@ -167,6 +167,9 @@ def test_cfg5_dense_train_step_batch_65536(gpu_ctx):
     plan = gpu.launch_plan("train")
     if not debug_toggles_active():
         assert plan.count("side lane") == 1 and "+ones-row" in plan, plan
+        # the pre-activation of the hidden layer exists as predicate bits only, and the 10-wide second layer is computed in
+        # the first layer's epilogue (its own launch is gone)
+        assert "stored as predicate bits" in plan and "row product NN 65536x10x512" in plan, plan
     serial = egm.compile(*refcases.dense_softmax_net(), gpu=gpu_ctx)
     for tid in sorted(ref.params):
         serial.params[tid] = gpu.params[tid]
