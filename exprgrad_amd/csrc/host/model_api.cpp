@@ -165,7 +165,7 @@ int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out) try 
     ts.bucket_floats = off;
     if (off > 0) {
       EG_HIP_CHECK(hipMalloc((void**)&ts.bucket, (size_t)off * sizeof(float)));
-      EG_HIP_CHECK(hipMemset(ts.bucket, 0, (size_t)off * sizeof(float)));
+      EG_HIP_CHECK(hipMemsetAsync(ts.bucket, 0, (size_t)off * sizeof(float), ctx->stream));  // (ordered against the launches that follow)
       ts.bucket_owned = true;
     }
     rc = lower_target(m.get(), ts);

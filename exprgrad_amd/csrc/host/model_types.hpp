@@ -126,6 +126,7 @@ struct PlanEpilogue {
   EpilogueSpec spec;
   bool store_c = false;                     // the contraction result itself is written too (something else reads it)
   bool pred_write = false;                  // ... as one predicate bit per element (Plan::predicated), not as values
+  bool pred_whole_words = false;            // every tile is whole and leaves through LDS: whole 32-bit words are stored, no OR
   std::map<int, PredicateSpec> pred_reads;  // operands of the consumer that exist as predicate bits only
   Launch consumer;                          // the consumer as its own launch (split-K fallback)
   // Row product (fold_row_products): the next layer's narrow contraction computed on the consumer's rows in LDS.
@@ -160,6 +161,7 @@ struct Plan {
   long zero_floats = 0;  // leading part of the arena that is zeroed before every run
   std::vector<int> bucket_zero;  // gradient-bucket tensors that need zeroing
   std::set<int> zero_extra;      // result tensors a fold made accumulate (row products): zeroed with the others
+  std::set<int> pred_unzeroed;   // predicate tensors whose words are stored whole by their producer: not in the zero prefix
   float* arena = nullptr;
   // The launch sequence of a range (whole call / backward part / update part) is captured into a
   // HIP graph on its second execution and replayed afterwards: the small-batch targets are

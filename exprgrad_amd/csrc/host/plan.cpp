@@ -561,7 +561,8 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
         continue;
       }
       // (predicate bits may be OR-ed in; a row product is added to its destination)
-      const bool z = needs_zero.count(tid) != 0 || plan.predicated.count(tid) != 0 || plan.zero_extra.count(tid) != 0;
+      const bool z = needs_zero.count(tid) != 0 || (plan.predicated.count(tid) != 0 && plan.pred_unzeroed.count(tid) == 0) ||
+                     plan.zero_extra.count(tid) != 0;
       if ((pass == 0) != z) continue;
       plan.arena_offset[tid] = off;
       off += align4(storage_floats(plan, tid));

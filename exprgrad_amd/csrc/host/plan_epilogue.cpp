@@ -18,6 +18,7 @@ namespace model {
 // EG_NO_PREDICATE=1 switches it off.
 static int predicate_tensors(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos) {
   plan.predicated.clear();
+  plan.pred_unzeroed.clear();
   {
     const char* e = getenv("EG_NO_PREDICATE");
     if (e && e[0] && e[0] != '0') return EG_OK;
@@ -82,6 +83,23 @@ static int predicate_tensors(eg_model* m, TargetState& ts, Plan& plan, const std
       if (rc) return rc;
     }
     plan.predicated[T] = spec;
+    {
+      // Bits are OR-ed into zeroed words by ragged tiles and by launches whose operands turn out unaligned; a launch
+      // whose tiles are all whole and leave through LDS stores whole words (gemm_f32_mfma.hpp: `packed`), and its
+      // tensor can stay out of the zero prefix (4 MB per step at cfg 5).  run.cpp zeroes it by hand if the launch
+      // cannot take that path after all.
+      eg::gemm::FusedLaunch probe;
+      float* aligned = reinterpret_cast<float*>(uintptr_t(256));
+      if (eg::gemm::plan_fused(m->ctx, G.trans_a, G.trans_b, G.M, G.N, G.K, aligned, G.lda, aligned, G.ldb, aligned, G.ldc, nullptr,
+                               probe) == EG_OK) {
+        if (probe.splits <= 1 && eg::gemm::fused_wide_store(probe) && G.N % 32 == 0 && G.ldc == G.N) {
+          pe.pred_whole_words = true;
+          plan.pred_unzeroed.insert(T);
+        }
+      } else {
+        eg::clear_error();
+      }
+    }
   }
   return EG_OK;
 }

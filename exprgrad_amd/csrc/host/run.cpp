@@ -59,6 +59,11 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       eg::gemm::set_epilogue_operands(f, operands, (int)pe.spec.operands.size(), m->grad_scale, m->epoch);
       // a row product rides on whole 256 x 256 tiles that leave through LDS; anything else (cannot happen for the shapes
       // the plan was made for, unless an operand turns out unaligned) runs the plain functor and the product by itself
+      if (pe.pred_write && plan.pred_unzeroed.count(L.c_tensor) && !eg::gemm::fused_wide_store(f)) {
+        // planned to store whole words of predicate bits, but this launch will OR single bits in: zero the words first
+        rc = eg::zero_ranges(ctx, {{tensor_ptr(m, ts, plan, L.c_tensor), storage_floats(plan, L.c_tensor)}});
+        if (rc) return rc;
+      }
       const bool with_product = pe.row_product && f.bm == 256 && f.bn == 256 && eg::gemm::fused_wide_store(f);
       const std::string variant = eg::gemm::fused_variant(f);
       eg_kernel*& handle = (pe.row_product && !with_product) ? pe.built_plain[variant] : pe.built[variant];

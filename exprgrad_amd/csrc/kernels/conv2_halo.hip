@@ -329,7 +329,9 @@ int conv2_halo_try_padded(eg_ctx* ctx, long N, long H, long W, long C, long F, l
       }
       const size_t want = ((size_t)C + 1023) & ~(size_t)1023;
       EG_HIP_CHECK(hipMalloc((void**)&ctx->zeros, want * sizeof(float)));
-      EG_HIP_CHECK(hipMemset(ctx->zeros, 0, want * sizeof(float)));
+      // on the context's stream: a legacy-stream hipMemset returns before the fill has run and is not ordered against
+      // the kernel launched below (the first padded launch of a context read its border from unfilled memory)
+      EG_HIP_CHECK(hipMemsetAsync(ctx->zeros, 0, want * sizeof(float), ctx->stream));
       ctx->zeros_floats = want;
     }
     a.zeros = ctx->zeros;
