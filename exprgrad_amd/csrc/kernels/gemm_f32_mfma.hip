@@ -713,7 +713,7 @@ extern "C" int eg_sgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_
     long blocks = (groups + 3) / 4;
     const long cap = 8L * ctx->compute_units;  // (LDS: K x 64 bytes per block; eight blocks of four waves per CU)
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((eg_skinny::gemm_skinny_nn_kernel<8>), dim3((unsigned)blocks), dim3(256), (size_t)K * 64, ctx->stream, A, B, C, bias, (long)M,
+    hipLaunchKernelGGL((eg_skinny::gemm_skinny_nn_kernel<4>), dim3((unsigned)blocks), dim3(256), (size_t)K * 64, ctx->stream, A, B, C, bias, (long)M,
                        (int)N, (int)K, (long)lda, (long)ldb, (long)ldc, accumulate);
     EG_HIP_CHECK(hipGetLastError());
     return EG_OK;
