@@ -109,6 +109,12 @@ int run_conv(eg_ctx* ctx, GemmArgs args, bool vec) {
     args.k_per_split = ((args.K + bk - 1) / bk) * bk;
   };
   if (args.N > 64 || v == 9) return -1;  // wide filter banks: the generic tile choice
+  // narrow filter banks (the second layer of the fashion_mnist network: 8 -> 16 channels, 5 x 5; its image gradient:
+  // 16 -> 8): a 64-column tile multiplies 48 .. 56 columns of padding; 128 x 32 tiles (EG_CONV_VARIANT=5 forces them)
+  if ((v == 0 && args.N <= 32 && args.M >= 128L * 4 * ctx->compute_units) || v == 5) {
+    tiles(128, 32, 16);
+    return launch_conv<128, 32, 16, 32, 32, 4>(ctx, args, vec);
+  }
   switch (v) {
     // measured on cfg 4 (256x256x64 -> 64, 3x3): 64x64x32 66 TF, 128x64x32 64, 256x64x32 63, 128x64x16 62
     case 1: tiles(128, 64, 32); return launch_conv<128, 64, 32, 64, 32, 2>(ctx, args, vec);
