@@ -357,3 +357,42 @@ def test_row_product_keeps_denormal_sums(gpu_ctx, monkeypatch):
     want = np.float32(512) * step                              # exact: integers times the denormal unit
     assert np.all(out == want), (out[:2], want)
     gpu.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_row_product_with_other_activations_and_widths(gpu_ctx, monkeypatch, seed):
+    """Random heads: activation (relu / leaky_relu keep predicate bits, tanh / sigmoid keep the values), hidden width 256 or
+    512, 1 .. 16 outputs, input width: folded and unfolded plans agree to rounding, the folded one with the float64 product."""
+    rng = np.random.default_rng(900 + seed)
+    act = ["relu", "tanh", "leaky_relu", "sigmoid", "relu", "tanh"][seed]
+    hidden = int(rng.choice([256, 512]))
+    outs = int(rng.integers(1, 17))
+    width = int(rng.choice([16, 48, 112]))      # (whole 16-deep k-tiles: a ragged K takes the element-wise epilogue, no row product)
+    batch = 65536 if hidden == 256 else 32768          # 256 tiles of 256 x 256: one per compute unit, no k-slices
+    monkeypatch.setenv("EG_GEMM_FORCE_TILE", "256,256")
+    dims = (width, hidden, outs)
+    x = (rng.random((batch, width), dtype=np.float32) - 0.5).astype(np.float32)
+    y = rng.random((batch, outs), dtype=np.float32)
+    monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", "0")
+    results = {}
+    for folded in (True, False):
+        if folded:
+            monkeypatch.delenv("EG_NO_ROW_PRODUCT", raising=False)
+        else:
+            monkeypatch.setenv("EG_NO_ROW_PRODUCT", "1")
+        gpu = egm.compile(*mlp(act=act, dims=dims), gpu=gpu_ctx)
+        prng = np.random.default_rng(5)
+        for tid in sorted(gpu.params.ids()):
+            gpu.params[tid] = (prng.random(gpu.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+        out = gpu.call("predict", {"x": x}).copy()
+        for _ in range(2):
+            gpu.apply("train", {"x": x, "y": y})
+        plan = gpu.launch_plan("train")
+        params = {t: gpu.params[t].copy() for t in sorted(gpu.params.ids())}
+        gpu.close()
+        results[folded] = (plan, out, params)
+    assert "row product" in results[True][0], results[True][0]
+    assert "row product" not in results[False][0]
+    assert rel_err(results[True][1], results[False][1].astype(np.float64)) <= 2 * TOL
+    for t in results[True][2]:
+        assert rel_err(results[True][2][t], results[False][2][t].astype(np.float64)) <= 2 * TOL, t
