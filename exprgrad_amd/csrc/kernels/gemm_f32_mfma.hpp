@@ -1426,13 +1426,30 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
     // 16 bytes per lane: a 4-wide group never straddles a row
     for (long i4 = tid; i4 < (total >> 2); i4 += nthreads) {
       const long i = i4 << 2, m = i / N, n = i % N;
-      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      // four interleaved chains (slabs z = c, c + 4, ...), combined ((s0 + s1) + (s2 + s3)): eight loads in flight per
+      // thread instead of a serial walk (67 MB of slabs for the cfg-5 weight gradient: 16.5 us = 4.1 TB/s)
+      f32x4 c4[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) c4[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int nz = m >= edge_row ? edge_splits : splits;
-      for (int z = 0; z < nz; ++z) {
+      int z = 0;
+      for (; z + 8 <= nz; z += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(partial + (long)(z + u) * total + i);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) c4[u & 3][j] += v[u][j];
+      }
+      for (; z < nz; ++z) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(partial + (long)z * total + i);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s[j] += v[j];
+        for (int j = 0; j < 4; ++j) c4[z & 3][j] += v[j];
       }
+      f32x4 s;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s[j] = (c4[0][j] + c4[1][j]) + (c4[2][j] + c4[3][j]);
       f32x4* p = reinterpret_cast<f32x4*>(C + m * ldc + n);
       if (accumulate) {
         const f32x4 o = *p;
