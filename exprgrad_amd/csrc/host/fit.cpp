@@ -64,6 +64,7 @@ int eg_model_fit(eg_model* m, const char* target, int n_inputs, const char* cons
   hipStream_t stream = m->ctx->stream;
 
   // ---- staging buffers of one batch (what the captured kernels read)
+  m->inputs_gen++;
   for (auto& c : cols) {
     BoundInput& b = *c.in;
     const long count = batch_size * c.row_floats;

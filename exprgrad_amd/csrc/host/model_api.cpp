@@ -362,6 +362,7 @@ static int bind_input(eg_model* m, const char* name, const float* device, const 
   EG_REQUIRE(it != m->prog.inputs.end(), EG_ERR_RUNTIME, "%s is not an input to the model", name);
   EG_REQUIRE(rank >= 0 && rank <= 8 && (rank == 0 || shape), EG_ERR_INVALID, "bad input rank");
   BoundInput& b = m->inputs[it->second];
+  m->inputs_gen++;
   b.bound = true;
   b.shape.assign(shape, shape + rank);
   const long count = prod(b.shape);
@@ -404,6 +405,7 @@ int eg_model_clear_inputs(eg_model* m) try {
   EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
   // Host-staged inputs keep their staging buffer (reused by the next host bind); only the
   // bindings are forgotten.  No synchronisation: nothing is freed.
+  m->inputs_gen++;
   for (auto it = m->inputs.begin(); it != m->inputs.end();) {
     if (it->second.owned) {
       it->second.device = nullptr;

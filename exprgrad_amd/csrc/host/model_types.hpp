@@ -192,6 +192,12 @@ struct Plan {
     hipGraphExec_t exec = nullptr;
     std::string key;  // everything baked into the captured kernel arguments
     int runs = 0;
+    // The same facts as plain words, compared first: a replay of a launch-bound step (XOR: 14 us of kernels) should not
+    // format a string per call.  stamp = eg_model::inputs_gen when `key` was formed (any binding change bumps it).
+    uint64_t stamp = ~0ull;
+    const void* ptrs[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    float grad_scale = 0;
+    long epoch = 0;
   };
   Captured graphs[6];  // 0 whole call, 1 backward part, 2 update part; data-parallel split: 3 head, 4 side lane, 5 tail
   int dp_agreed = 0;   // data-parallel exchange plan compared across the ranks: 0 not yet, 1 the same everywhere (split allowed), 2 differs (one bucket)
@@ -208,6 +214,7 @@ struct TargetState {
   long bucket_floats = 0;
   float* bucket = nullptr;
   bool bucket_owned = false;
+  uint64_t last_stamp = ~0ull;  // eg_model::inputs_gen for which `last` was looked up
 };
 
 struct BoundInput {
@@ -227,6 +234,7 @@ struct eg_model {
   std::map<std::string, eg::model::TargetState> targets;
   std::map<int, eg::model::DevTensor> params;  // device-resident parameters (model.params)
   std::map<int, eg::model::BoundInput> inputs;
+  uint64_t inputs_gen = 0;  // bumped by every change of `inputs` (bind, clear, fit): caches keyed on the bindings compare it
   float grad_scale = 1.0f;
   long epoch = 0;
   int kernel_serial = 0;

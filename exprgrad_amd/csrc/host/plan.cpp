@@ -595,6 +595,11 @@ int get_plan(eg_model* m, const char* target, TargetState** ts_out, Plan** plan_
   // model.nim:395-396
   EG_REQUIRE(it != m->targets.end(), EG_ERR_RUNTIME, "%s is not a target of the model", target);
   TargetState& ts = it->second;
+  if (ts.last && ts.last_stamp == m->inputs_gen) {  // same bindings as the last lookup: same shapes, same plan
+    *ts_out = &ts;
+    *plan_out = ts.last;
+    return EG_OK;
+  }
   const std::string key = shape_key(m);
   auto p = ts.plans.find(key);
   if (p == ts.plans.end()) {
@@ -608,6 +613,7 @@ int get_plan(eg_model* m, const char* target, TargetState** ts_out, Plan** plan_
     p = ts.plans.emplace(key, std::move(plan)).first;
   }
   ts.last = p->second.get();
+  ts.last_stamp = m->inputs_gen;
   *ts_out = &ts;
   *plan_out = p->second.get();
   return EG_OK;
