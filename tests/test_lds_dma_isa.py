@@ -103,3 +103,46 @@ def test_every_barrier_after_an_lds_dma_load_is_preceded_by_its_wait(variant, tm
     loads, bad = unpublished_barriers(isa)
     assert loads >= 4, loads            # the LDS-DMA loops are in there
     assert not bad, bad
+
+
+ROW_PRODUCT = """
+struct EgEpi {
+  static constexpr bool ACTIVE = true;
+  static constexpr int NX = 1;
+  static constexpr bool STORE_C = false;
+  static constexpr int OUT = 0;
+  static constexpr int PRED = 1;
+  static constexpr int RD_N = 10, RD_W = 2, RD_OUT = 3, RD_BIAS = 4, RD_LDW = 10, RD_LDO = 10;
+  __device__ __forceinline__ static bool predicate(float v) { return 0.0f <= v; }
+  __device__ __forceinline__ static void prefetch(const eg::gemm::GemmArgs&, long, float (&)[1]) {}
+  __device__ __forceinline__ static void prefetch4(const eg::gemm::GemmArgs&, long, eg::gemm::f32x4 (&)[1]) {}
+  __device__ __forceinline__ static float compute(const eg::gemm::GemmArgs&, long, float v, const float (&)[1]) {
+    return v > 0.0f ? v : 0.0f;
+  }
+};
+extern "C" __global__ __launch_bounds__(512, 2) void k(eg::gemm::GemmArgs a) {
+  eg::gemm::gemm_block<256, 256, 16, 128, 64, true, false, 4, false, false, 0, true, EgEpi>(a);
+}
+"""
+
+
+def test_the_row_product_variant_builds_without_a_device(tmp_path):
+    """The fused forward of a classifier head (predicate bits + the narrow next layer in the epilogue, gemm_f32_mfma.hpp
+    RD_N) only exists as a hiprtc build at run time: compile it here, with the compiler the process resolves, so that a
+    change that breaks it fails the CPU suite — and hold it to what the GPU relies on: no scratch, the 16 x 16 x 4 MFMAs
+    and float atomics without return are there, LDS stays under the CU's 160 KiB, and the LDS-DMA publish rule holds."""
+    rtc = bundled_hiprtc()
+    if rtc is None or not os.path.exists(OBJDUMP):
+        pytest.skip("no bundled hiprtc / llvm-objdump")
+    with open(os.path.join(ROOT, "exprgrad_amd", "csrc", "kernels", "gemm_f32_mfma.hpp")) as f:
+        header = f.read()
+    isa = compile_to_isa(rtc, header + ROW_PRODUCT, str(tmp_path))
+    loads, bad = unpublished_barriers(isa)
+    assert loads >= 4 and not bad, (loads, bad)
+    assert "v_mfma_f32_16x16x4" in isa and "v_mfma_f32_32x32x2" in isa
+    assert "global_atomic_add_f32" in isa
+    assert "scratch_" not in isa                      # no spill
+    notes = subprocess.run([OBJDUMP.replace("llvm-objdump", "llvm-readelf"), "--notes", os.path.join(str(tmp_path), "k.co")],
+                           capture_output=True, text=True).stdout
+    lds = [int(line.split(":")[1]) for line in notes.splitlines() if ".group_segment_fixed_size" in line]
+    assert lds and max(lds) <= 160 * 1024, lds
