@@ -113,6 +113,8 @@ def parse():
     return ap.parse_args()
 
 
+SPINUP_S = 0.2   # untimed seconds of the same step in front of the W warmup steps (Timer.run): a sustained-clock figure
+
 EVENTS_NOTE = ("kernel_ms_avg = one HIP event pair around the K timed steps / K, on the stream the kernels run on; "
                "kernel_ms_min = shortest step of a second, untimed pass of K steps with an event pair each")
 
@@ -152,7 +154,7 @@ class Timer:
             t = torch.tensor([per_step], device="cuda", dtype=torch.float64)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             per_step = float(t.item())
-        spin = min(4096, max(8, int(0.2 / max(per_step, 1e-6))))
+        spin = min(4096, max(8, int(SPINUP_S / max(per_step, 1e-6))))
         self.last_spin = 8 + spin   # untimed steps before the W warmup steps (8 to estimate the step, then ~0.2 s of them)
         for i in range(spin):
             step()
@@ -378,7 +380,10 @@ def run_matmul(args, env):
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "config": {"workload": f"matmul M=N=K={n} float32 (BASELINE configs[1]): C = A*B through eg_sgemm "
                                "(MFMA + LDS tiled HIP kernel), A, B ~ U[0,1) resident in HBM",
-                   "parallelism": "single" if env["world"] == 1 else f"{env['world']} independent replicas"},
+                   "parallelism": "single" if env["world"] == 1 else f"{env['world']} independent replicas",
+                   "timed_steps": args.steps, "sustained_clock_spinup_s": SPINUP_S,
+                   "spinup_note": "value is a sustained-clock figure: ~0.2 s of the same launch run untimed before the W "
+                                  "warmup steps (spinup_steps), because W = 5 steps of a 1 ms kernel end inside the clock ramp"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                      **(traffic_fields("matmul4096") if n == 4096 else {"traffic": None}),
@@ -544,7 +549,8 @@ def run_train(args, env):
                                             else "RCCL all-reduce through torch.distributed (nccl backend)")}[env.get("dp_path", "none")],
                    "rccl_ranks": env.get("rccl_ranks", 0),
                    "scaling": "strong" if strong else "weak",
-                   "grad_bucket_floats": model.grad_bucket("train")[1]},
+                   "grad_bucket_floats": model.grad_bucket("train")[1],
+                   "timed_steps": args.steps, "sustained_clock_spinup_s": SPINUP_S},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                      **(traffic_fields("train") if batch == DENSE["batch"] else {"traffic": None}),
@@ -556,6 +562,11 @@ def run_train(args, env):
     }
     if single:
         out["single_gpu_reference"] = single
+        # the N-GPU value over N times the one-GPU value of the same step measured in this run (weak scaling: per-GPU
+        # work is the same in both); 1 -> N speed-up = N x this.  With --scaling strong the one-GPU point runs the
+        # shard's batch too, so the figure is the exchange's cost only and the line says which.
+        out["scaling_efficiency"] = round(out["value"] / (world * single["value"]), 4)
+        out["speedup_vs_single_gpu_reference"] = round(out["value"] / single["value"], 3)
     if exchange:
         out["exchange"] = exchange
     if env.get("dp_fallback_reason"):
@@ -580,6 +591,9 @@ def run_xor(args, env):
     gbs = XOR_BYTES_PER_SAMPLE * batch * steps / elapsed / 1e9      # the clock `value` uses (see run_matmul)
     return {"metric": "train steps/s XOR net (examples/xor_from_scratch) batch 65536", "value": round(steps / elapsed, 1),
             "unit": "steps/s", "samples_per_s": round(batch * steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "config": {"workload": f"examples/xor_from_scratch train step, batch {batch} (BASELINE configs[2]), Model.apply on "
+                                   f"device-resident inputs; timed steps = max(--steps, 50) = {steps}",
+                       "timed_steps": steps, "sustained_clock_spinup_s": SPINUP_S},
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 4),
                          **(traffic_fields("xor") if batch == 65536 else {"traffic": None}),
@@ -645,6 +659,9 @@ def run_conv2(args, env):
                 "grad_image_ms": round(gi_avg, 4), "grad_image_tflops": round(flops / (gi_avg * 1e-3) / 1e12, 2)}
     return {"metric": "GFLOP/s conv2 3x3 256x256x64->64 f32", "value": round(flops * steps / elapsed / 1e9, 1),
             "unit": "GFLOP/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "config": {"workload": f"benchmarks/conv2 3x3, 1x256x256x64 -> 64 filters float32 NHWC (BASELINE configs[3]) through "
+                                   f"eg_conv2_nhwc; timed steps = max(--steps, 50) = {steps}",
+                       "timed_steps": steps, "sustained_clock_spinup_s": SPINUP_S},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                          **traffic_fields("conv2"),
@@ -706,12 +723,42 @@ def compile_latency():
             "note": "seconds per model: eg_model_compile, then the first and second run of the train target at the config's batch"}
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves (one process per
+    GPU, torch.distributed.run on 127.0.0.1 with a free port) and pass their exit code on.  Under a launcher
+    (WORLD_SIZE set) the world must be the N that was asked for: the line never reports another n_gpus than --gpus."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch {args.gpus} ranks "
+                  f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}), or run "
+                  f"`python bench.py --gpus {args.gpus}` without a launcher and it starts them itself", file=sys.stderr)
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    launch_ranks(args)
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, (world, args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # test hook (one-GPU boxes): EG_BENCH_ONE_GPU=1 puts every rank on cuda:0 and exchanges over gloo,
@@ -785,6 +832,8 @@ def main():
                 out, model = run_train(small, env)
                 return out
             guarded("train", train)
+            if "config" in extra.get("train", {}):
+                extra["train"]["config"]["workload"] += f"; extra.* figures time min(--steps, 20) = {small.steps} steps"
             guarded("xor", lambda: run_xor(small, env))
             guarded("conv2", lambda: run_conv2(small, env))
             guarded("fashion_mnist_fit", lambda: run_fashion_fit(small, env))
