@@ -50,7 +50,14 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
                                     tensor_ptr(m, ts, plan, L.b_tensor), L.ldb, tensor_ptr(m, ts, plan, L.c_tensor), L.ldc,
                                     bias, f);
       if (rc) return rc;
-      if (f.splits > 1) {  // cannot happen for the shapes the plan was made for; stay correct anyway
+      // The tile model may ask for k-slices at run time where it did not when the plan was made (it depends on
+      // ctx->compute_units, which the data-parallel tail range lowers around its launches).  The unfused route below is
+      // only valid when C holds plain values and the consumer reads plain values: a predicate tensor has M*N/32 words of
+      // storage (eg_sgemm would overrun it), predicate operands hold bits, and a row product's destination would stay
+      // zero.  Those launches run fused on one slice — the args of plan_fused always describe the whole K.
+      const bool must_fuse = pe.pred_write || !pe.pred_reads.empty() || pe.row_product || !pe.store_c;
+      if (f.splits > 1 && must_fuse) f.splits = 1;
+      if (f.splits > 1) {
         rc = eg_sgemm(ctx, L.trans_a, L.trans_b, L.M, L.N, L.K, tensor_ptr(m, ts, plan, L.a_tensor), L.lda,
                       tensor_ptr(m, ts, plan, L.b_tensor), L.ldb, tensor_ptr(m, ts, plan, L.c_tensor), L.ldc, 0, bias);
         if (rc) return rc;

@@ -320,14 +320,14 @@ int conv2_halo_try_padded(eg_ctx* ctx, long N, long H, long W, long C, long F, l
   a.px = px;
   a.zeros = nullptr;
   if (py > 0 || px > 0) {
-    if (ctx->zeros_floats < (size_t)C) {  // once per context (and channel count): a block of zeros the padding reads
-      if (ctx->zeros) {
-        EG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        EG_HIP_CHECK(hipFree(ctx->zeros));
-        ctx->zeros = nullptr;
-        ctx->zeros_floats = 0;
-      }
-      const size_t want = ((size_t)C + 1023) & ~(size_t)1023;
+    if (ctx->zeros_floats < (size_t)C) {  // once per context: a block of zeros the padding reads
+      // An outgrown block stays allocated until the context goes: launch sequences captured into HIP graphs hold its
+      // address in their kernel arguments, and hipFree is not allowed while a stream capture is in progress.  The first
+      // block is generous (64 KiB), so in practice there is exactly one.
+      if (ctx->zeros) ctx->zeros_retired.push_back(ctx->zeros);
+      ctx->zeros = nullptr;
+      ctx->zeros_floats = 0;
+      const size_t want = std::max<size_t>(16384, ((size_t)C + 1023) & ~(size_t)1023);
       EG_HIP_CHECK(hipMalloc((void**)&ctx->zeros, want * sizeof(float)));
       // on the context's stream: a legacy-stream hipMemset returns before the fill has run and is not ordered against
       // the kernel launched below (the first padded launch of a context read its border from unfilled memory)

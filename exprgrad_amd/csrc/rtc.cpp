@@ -17,6 +17,7 @@
 // one file per (source text, options, compiler identity); EG_NO_KERNEL_CACHE=1 switches it off.  Written to a
 // temporary name and renamed, so concurrent processes (one per GPU) never see a partial file.
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <unistd.h>
@@ -173,28 +174,62 @@ std::string cache_key(const Api& a, const char* source, const std::vector<std::s
   return name;
 }
 
+// A cache entry is the code object followed by a 16-byte trailer {magic, length, FNV-1a of the bytes}: a short or
+// damaged file (a writer that died, a disk that filled up) is recognised, removed and recompiled instead of being
+// handed to hipModuleLoadData.
+constexpr uint32_t kTrailerMagic = 0x45474b43u;  // "EGKC"
+
+uint64_t content_hash(const char* p, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; ++i) h = (h ^ (unsigned char)p[i]) * 1099511628211ull;
+  return h;
+}
+
 bool read_file(const std::string& path, std::vector<char>& out) {
   FILE* fp = fopen(path.c_str(), "rb");
   if (!fp) return false;
   fseek(fp, 0, SEEK_END);
   const long n = ftell(fp);
   fseek(fp, 0, SEEK_SET);
-  bool ok = n > 0;
+  bool ok = n > 20;
   if (ok) {
     out.resize((size_t)n);
     ok = fread(out.data(), 1, (size_t)n, fp) == (size_t)n;
   }
   fclose(fp);
-  return ok && out.size() > 4 && memcmp(out.data(), "\x7f" "ELF", 4) == 0;  // a code object is an ELF file
+  if (ok) {
+    uint32_t magic, length;
+    uint64_t sum;
+    memcpy(&magic, out.data() + n - 16, 4);
+    memcpy(&length, out.data() + n - 12, 4);
+    memcpy(&sum, out.data() + n - 8, 8);
+    ok = magic == kTrailerMagic && (long)length == n - 16 && memcmp(out.data(), "\x7f" "ELF", 4) == 0 &&
+         sum == content_hash(out.data(), (size_t)length);
+    if (ok) out.resize((size_t)length);
+  }
+  if (!ok) unlink(path.c_str());  // never serve it again; the caller compiles and rewrites the entry
+  return ok;
 }
 
 void write_file_atomic(const std::string& path, const std::vector<char>& data) {
+  // the temporary name is unique per writer (process, and a counter for the threads of one process compiling the same
+  // source for different contexts), opened exclusively
+  static std::atomic<unsigned> serial{0};
   char tmp[4200];
-  snprintf(tmp, sizeof(tmp), "%s.%d.tmp", path.c_str(), (int)getpid());
-  FILE* fp = fopen(tmp, "wb");
-  if (!fp) return;
-  const bool ok = fwrite(data.data(), 1, data.size(), fp) == data.size();
-  fclose(fp);
+  snprintf(tmp, sizeof(tmp), "%s.%d.%u.tmp", path.c_str(), (int)getpid(), serial.fetch_add(1));
+  const int fd = open(tmp, O_WRONLY | O_CREAT | O_EXCL, 0644);
+  if (fd < 0) return;
+  FILE* fp = fdopen(fd, "wb");
+  if (!fp) {
+    close(fd);
+    unlink(tmp);
+    return;
+  }
+  const uint32_t magic = kTrailerMagic, length = (uint32_t)data.size();
+  const uint64_t sum = content_hash(data.data(), data.size());
+  bool ok = fwrite(data.data(), 1, data.size(), fp) == data.size();
+  ok = ok && fwrite(&magic, 4, 1, fp) == 1 && fwrite(&length, 4, 1, fp) == 1 && fwrite(&sum, 8, 1, fp) == 1;
+  ok = (fclose(fp) == 0) && ok;
   if (!ok || rename(tmp, path.c_str()) != 0) unlink(tmp);
 }
 

@@ -1,0 +1,105 @@
+#!/usr/bin/env python
+"""Chain length of a batch-reducing contraction against its distance from the exact value.
+
+The weight gradients of BASELINE configs[4] are 65 536-term sums whose terms cancel: gW1 = x^T gh (784 x 512 x 65536) and
+gW2 = a^T gz (512 x 10 x 65536), with gh / gz what the dense net's backward pass produces from random-initialised
+parameters.  Every output element is one f32 FMA chain per k-slice; the slices meet in a fixed-order second pass.
+This tool runs the same contraction with the slice count forced (EG_GEMM_FORCE_SPLITS, ragged tile row on the plain
+path: EG_GEMM_NO_XROW=1), and prints per slice count: the chain length, max |backend - exact| / max |exact| (exact = the
+float64 product of the same float32 operands), and the time per call with back-to-back launches.
+
+Run on the GPU box:  python tools/chain_length.py [out.json]
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+
+import exprgrad_amd as eg
+from exprgrad_amd import ops
+
+B, I, H, O = 65536, 784, 512, 10
+
+
+def operands():
+    """x, a, gh, gz of one dense-net train step (float32, on the device) from seeded random parameters."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    w1 = torch.rand((I, H), device="cuda", generator=g) * 0.2 - 0.1
+    b1 = torch.rand((H,), device="cuda", generator=g) * 0.2 - 0.1
+    w2 = torch.rand((H, O), device="cuda", generator=g) * 0.2 - 0.1
+    b2 = torch.rand((O,), device="cuda", generator=g) * 0.2 - 0.1
+    g.manual_seed(100)
+    x = torch.rand((B, I), device="cuda", generator=g)
+    lab = torch.randint(0, O, (B,), device="cuda", generator=g)
+    y = torch.nn.functional.one_hot(lab, O).float()
+    h = x @ w1 + b1
+    a = torch.relu(h)
+    z = a @ w2 + b2
+    e = torch.exp(z)
+    q = e / e.sum(1, keepdim=True)
+    gz = (q - y) / B            # what derive makes of softmax + crossEntropy, in closed form
+    gh = (gz @ w2.T) * (h >= 0)
+    return x.contiguous(), a.contiguous(), gh.contiguous(), gz.contiguous()
+
+
+def timed(run, reps=10):
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(torch.cuda.current_stream())
+    for _ in range(reps):
+        run()
+    e.record(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3
+
+
+def main():
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    ctx = eg.newGpuContext(0, stream=stream.cuda_stream)
+    x, a, gh, gz = operands()
+    rows = []
+    for name, A, Bm, M, N in (("gW1 = x^T gh (784 x 512 x 65536)", x, gh, I, H), ("gW2 = a^T gz (512 x 10 x 65536)", a, gz, H, O)):
+        exact = A.double().T @ Bm.double()
+        scale = exact.abs().max().item()
+        terms = (A.double().abs().T @ Bm.double().abs()).max().item()     # largest sum of |terms| of any element
+        C = torch.empty((M, N), device="cuda")
+        seq = None
+        for splits in (0, 8, 16, 32, 42, 64, 128, 256, 512, 1024):
+            if N < 64 and splits > 256:
+                continue
+            os.environ.pop("EG_GEMM_FORCE_SPLITS", None)
+            os.environ.pop("EG_GEMM_NO_XROW", None)
+            if splits:
+                os.environ["EG_GEMM_FORCE_SPLITS"] = str(splits)
+                os.environ["EG_GEMM_NO_XROW"] = "1"
+            run = lambda: ops.sgemm(ctx, M, N, B, A, A.shape[1], Bm, Bm.shape[1], C, N, trans_a=True)
+            us = timed(run)
+            err = ((C.double() - exact).abs().max() / scale).item()
+            row = {"contraction": name, "forced_slices": splits or "planner", "chain_length": (B // splits) if splits else None,
+                   "rel_err_vs_exact": err, "err_over_sum_abs_terms": (C.double() - exact).abs().max().item() / terms, "us": round(us, 1)}
+            rows.append(row)
+            print(row, flush=True)
+        # the reference's order: one sequential f32 chain of 65 536 separately rounded multiply-adds per element
+        # (torch.cumsum is not that order; a strided loop over k on the device is)
+        acc = torch.zeros((M, N), device="cuda")
+        step = 64
+        for k0 in range(0, B, step):
+            for k in range(k0, k0 + step):
+                acc = acc + A[k].unsqueeze(1) * Bm[k].unsqueeze(0)
+        seq = ((acc.double() - exact).abs().max() / scale).item()
+        rows.append({"contraction": name, "forced_slices": "reference order (one 65 536-step chain, separate multiply and add)",
+                     "rel_err_vs_exact": seq})
+        print(rows[-1], flush=True)
+    if len(sys.argv) > 1:
+        with open(sys.argv[1], "w") as f:
+            json.dump(rows, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
