@@ -119,12 +119,73 @@ EVENTS_NOTE = ("kernel_ms_avg = one HIP event pair around the K timed steps / K,
                "kernel_ms_min = shortest step of a second, untimed pass of K steps with an event pair each")
 
 
+class Telemetry:
+    """Shader clock, memory clock, socket power and temperatures of THIS GPU while a workload runs, read from the
+    amdgpu hwmon files of its PCI device (no tool is spawned, nothing touches the device): the same binary ran the dense
+    step 8 % apart on two boxes with the matmul kernel within 0.2 % — the line now says what the box
+    was doing.  A daemon thread samples every 10 ms from the first spin-up step to the end of the timed region."""
+
+    FILES = (("sclk_mhz", "freq1_input", 1e-6), ("mclk_mhz", "freq2_input", 1e-6), ("power_w", "power1_input", 1e-6),
+             ("temp_junction_c", "temp2_input", 1e-3), ("temp_mem_c", "temp3_input", 1e-3))
+
+    def __init__(self, torch, device_index):
+        self.dir = None
+        try:
+            import glob
+            props = torch.cuda.get_device_properties(device_index)
+            bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+            found = sorted(glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*"))
+            self.dir = found[0] if found else None
+            self.bdf = bdf
+        except Exception:  # noqa: BLE001 - telemetry is optional
+            self.dir = None
+        self.samples, self._stop, self._thread = [], None, None
+
+    def _read(self):
+        row = {}
+        for key, name, scale in self.FILES:
+            try:
+                with open(os.path.join(self.dir, name)) as f:
+                    row[key] = int(f.read().strip()) * scale
+            except (OSError, ValueError):
+                pass
+        return row
+
+    def start(self):
+        if not self.dir:
+            return
+        import threading
+        self.samples, self._stop = [self._read()], threading.Event()
+
+        def loop():
+            while not self._stop.wait(0.01):
+                self.samples.append(self._read())
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        if not self.dir or self._thread is None:
+            return {"available": False}
+        self._stop.set()
+        self._thread.join()
+        self._thread = None
+        self.samples.append(self._read())
+        out = {"available": True, "pci": self.bdf, "samples": len(self.samples), "period_ms": 10,
+               "covers": "spin-up + warmup + timed steps of this workload"}
+        for key, _, _ in self.FILES:
+            vals = [r[key] for r in self.samples if key in r]
+            if vals:
+                out[key] = {"min": round(min(vals), 1), "mean": round(sum(vals) / len(vals), 1), "max": round(max(vals), 1)}
+        return out
+
+
 class Timer:
     """K steps bracketed by barrier + synchronize on both sides; max over ranks; per-step HIP
     events on the stream the kernels are launched on (torch's current stream == the context's)."""
 
-    def __init__(self, torch, dist, world, stream):
+    def __init__(self, torch, dist, world, stream, telemetry=None):
         self.torch, self.dist, self.world, self.stream = torch, dist, world, stream
+        self.telemetry, self.last_telemetry = telemetry, None
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -145,6 +206,8 @@ class Timer:
         gc.disable()  # a generation-2 collection inside a 25 us step would dominate it
         # The number of spin-up steps must be the same on every rank (a step may contain a
         # collective): time 8 steps, agree on the slowest rank's estimate, derive the count from it.
+        if self.telemetry:
+            self.telemetry.start()
         t_probe = time.perf_counter()
         for _ in range(8):
             step()
@@ -176,6 +239,8 @@ class Timer:
         ends[0].record(self.stream)
         self.sync()
         elapsed = time.perf_counter() - t0
+        if self.telemetry:
+            self.last_telemetry = self.telemetry.stop()
         bracket_ms = starts[0].elapsed_time(ends[0])
         for i in range(steps):
             starts[i].record(self.stream)
@@ -391,7 +456,7 @@ def run_matmul(args, env):
                      "clock": "wall time of the timed steps (the clock `value` uses)",
                      "kernel_ms_avg": round(ev_avg, 4), "kernel_ms_min": round(ev_min, 4), "events": EVENTS_NOTE,
                      "frac_by_events": round(achieved_events / F32_MFMA_PEAK_TFLOPS, 4)},
-        "spinup_steps": timer.last_spin,
+        "spinup_steps": timer.last_spin, "telemetry": timer.last_telemetry,
     }
 
 
@@ -506,6 +571,7 @@ def run_train(args, env):
     else:
         step = lambda: dp.step(inputs)
     elapsed, ev_avg, ev_min = env["timer"].run(step, args.steps, args.warmup)
+    telemetry = env["timer"].last_telemetry
     exchange = None
     if world > 1:
         # One run decides whether exchanging the early gradients under the last long contraction pays: the same step
@@ -558,7 +624,7 @@ def run_train(args, env):
                      "flops_per_launch": step_flops, "clock": "wall time of the timed steps (the clock `value` uses)",
                      "kernel_ms_avg": round(ev_avg, 4), "kernel_ms_min": round(ev_min, 4), "events": EVENTS_NOTE,
                      "frac_by_events": round(achieved_events / F32_MFMA_PEAK_TFLOPS, 4)},
-        "spinup_steps": env["timer"].last_spin,
+        "spinup_steps": env["timer"].last_spin, "telemetry": telemetry,
     }
     if single:
         out["single_gpu_reference"] = single
@@ -589,7 +655,7 @@ def run_xor(args, env):
     steps = max(args.steps, 50)
     elapsed, ev_avg, ev_min = env["timer"].run(lambda: model.apply("train", inputs), steps, args.warmup)
     gbs = XOR_BYTES_PER_SAMPLE * batch * steps / elapsed / 1e9      # the clock `value` uses (see run_matmul)
-    return {"metric": "train steps/s XOR net (examples/xor_from_scratch) batch 65536", "value": round(steps / elapsed, 1),
+    return {"telemetry": env["timer"].last_telemetry, "metric": "train steps/s XOR net (examples/xor_from_scratch) batch 65536", "value": round(steps / elapsed, 1),
             "unit": "steps/s", "samples_per_s": round(batch * steps / elapsed, 1), "ms_per_step": round(elapsed / steps * 1e3, 4),
             "config": {"workload": f"examples/xor_from_scratch train step, batch {batch} (BASELINE configs[2]), Model.apply on "
                                    f"device-resident inputs; timed steps = max(--steps, 50) = {steps}",
@@ -647,6 +713,7 @@ def run_conv2(args, env):
     elapsed, ev_avg, ev_min = env["timer"].run(
         lambda: ops.conv2_nhwc(ctx, N, H, W, C, F, FH, FW, img, flt, out), steps, args.warmup)
     flops = 2.0 * N * (H - FH + 1) * (W - FW + 1) * F * FH * FW * C
+    telemetry = env["timer"].last_telemetry
     achieved = flops * steps / elapsed / 1e12                          # the clock `value` uses (see run_matmul)
     # the two gradients derive makes of conv2 (same FLOP count each), for the record
     gout = torch.rand(out.shape, device="cuda", generator=gen) - 0.5
@@ -657,7 +724,7 @@ def run_conv2(args, env):
         lambda: ops.conv2_nhwc_grad_image(ctx, N, H, W, C, F, FH, FW, flt, gout, gimg), steps, args.warmup)
     backward = {"grad_filter_ms": round(gf_avg, 4), "grad_filter_tflops": round(flops / (gf_avg * 1e-3) / 1e12, 2),
                 "grad_image_ms": round(gi_avg, 4), "grad_image_tflops": round(flops / (gi_avg * 1e-3) / 1e12, 2)}
-    return {"metric": "GFLOP/s conv2 3x3 256x256x64->64 f32", "value": round(flops * steps / elapsed / 1e9, 1),
+    return {"telemetry": telemetry, "metric": "GFLOP/s conv2 3x3 256x256x64->64 f32", "value": round(flops * steps / elapsed / 1e9, 1),
             "unit": "GFLOP/s", "ms_per_step": round(elapsed / steps * 1e3, 4),
             "config": {"workload": f"benchmarks/conv2 3x3, 1x256x256x64 -> 64 filters float32 NHWC (BASELINE configs[3]) through "
                                    f"eg_conv2_nhwc; timed steps = max(--steps, 50) = {steps}",
@@ -784,7 +851,7 @@ def main():
     # N > 1: the C ABI's own RCCL group unless --torch-dp; the one-GPU test mode has no second device for RCCL
     native = world > 1 and not args.torch_dp and not one_gpu
     env = {"torch": torch, "ops": ops, "ctx": ctx, "world": world, "rank": rank, "native_dp": native,
-           "timer": Timer(torch, dist, world, stream)}
+           "timer": Timer(torch, dist, world, stream, Telemetry(torch, local_rank) if rank == 0 else None)}
 
     workload = args.workload
     if workload == "auto":

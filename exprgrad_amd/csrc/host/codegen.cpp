@@ -289,8 +289,9 @@ bool split_reduction_capable(const Kernel& k) {
 int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out) {
   for (auto& ins : k.index_instrs)
     if (ins.kind == IK::Shape || ins.kind == IK::Len || ins.kind == IK::ShapeLen || ins.kind == IK::Epoch) {
-      set_error("shape()/len()/epoch() inside a computed tensor index is not supported");
-      return EG_ERR_UNSUPPORTED;
+      // cannot happen: the parser moves iterator-independent index instructions into the setup (kd.cpp, hoist_host_indices)
+      set_error("internal: host-evaluated builtin left among the index instructions of a kernel");
+      return EG_ERR_INVALID;
     }
   Emitter em(k);
   out = GenericSource();

@@ -334,6 +334,32 @@ int parse(const char* text, Program& prog) {
     }
   }
   if (!header) P_FAIL("kd: missing 'kd 1 f32' header");
+  // An "idx" instruction whose value does not change inside the loop nest — a literal, shape() / len() / epoch(), or
+  // arithmetic on those (`x mod shape(t)[0]`: the literal and the shape) — is a host value: it joins the kernel's setup
+  // and reaches the kernel as an argument.  The reference lowers such an instruction like any other index instruction
+  // (passes.nim:787-843); the Nim emitter already writes them as "setup" (hipmodel.nim emitKernel), text from another
+  // producer is normalised here, so the generated kernels only ever see iterator-dependent index instructions.
+  auto hoist_host_indices = [](Kernel& k) {
+    std::set<int> varying;
+    for (auto& lp : k.loops) varying.insert(lp.reg);
+    std::vector<Instr> stay;
+    for (auto& ins : k.index_instrs) {
+      bool v = false;
+      for (int a : ins.args) v = v || varying.count(a) != 0;
+      if (v) {
+        varying.insert(ins.res);
+        stay.push_back(ins);
+      } else {
+        k.setup.push_back(ins);
+      }
+    }
+    k.index_instrs.swap(stay);
+  };
+  for (auto& t : prog.targets)
+    for (auto& k : t.source) {
+      hoist_host_indices(k);
+      for (auto& g : k.custom_grad) hoist_host_indices(g);
+    }
   // validate tensor references
   auto check_tid = [&](int t) { return t >= 1 && t < (int)prog.tensors.size(); };
   for (auto& t : prog.targets) {

@@ -431,14 +431,9 @@ def reshape(fun, shape):
     shape = [int(d) for d in shape]
     if sum(1 for d in shape if d < 0) > 1:
         raise ParserError("reshape: at most one extent may be -1")
-    prod = 1
-    for d in shape:
-        if d >= 0:
-            prod *= d
-    it = iter_in("reshape.it", 0, fun.len())
-    r = Fun(name="reshape")
-    r.raw[it] += fun.raw[it]
-    r.with_shape(*[literal(d) if d >= 0 else fun.len() // prod for d in shape])
+    r = Fun("reshape", "reshape")
+    r.children = [fun]
+    r.reshape_dims = shape
     return r
 
 
@@ -531,9 +526,10 @@ class LinearIndex:
         self.constant, self.factors, self.setup = constant, dict(factors or {}), list(setup or [])
 
     def tokens(self):
-        out = ["L", str(self.constant), str(len(self.factors))]
-        for r, f in self.factors.items():
-            out += [str(r), str(f)]
+        regs = sorted(r for r, f in self.factors.items() if f != 0)   # kdLinear: register order, deterministic
+        out = ["L", str(self.constant), str(len(regs))]
+        for r in regs:
+            out += [str(r), str(self.factors[r])]
         return out
 
 
@@ -600,69 +596,69 @@ def _build(expr, instrs, block, ctx):
     return res
 
 
-def _fold(expr, ctx):
-    """foldLinearIndices for the affine index expressions the hot path uses: iter, literal,
-    +, -, * literal, shape()/len().  Returns LinearIndex or None if not affine."""
-    if expr.kind == "iter":
-        reg = _build(expr, [], -1, ctx)
-        return LinearIndex(0, {reg: 1})
-    if expr.kind != "instr":
-        return None
-    if expr.instr == "index":
-        return LinearIndex(int(expr.lit))
-    if expr.instr in ("shape", "len"):
-        setup = []
-        reg = _build(expr, setup, ctx.block(), ctx)
-        ctx.kernel.setup.extend(setup)
-        return LinearIndex(0, {reg: 1})
-    if expr.instr in ("add", "sub"):
-        a, b = _fold(expr.children[0], ctx), _fold(expr.children[1], ctx)
-        if a is None or b is None:
-            return None
-        sign = 1 if expr.instr == "add" else -1
-        out = LinearIndex(a.constant + sign * b.constant, a.factors)
-        for r, f in b.factors.items():
-            out.factors[r] = out.factors.get(r, 0) + sign * f
-        out.factors = {r: f for r, f in out.factors.items() if f != 0}
-        return out
-    if expr.instr == "negate":
-        a = _fold(expr.children[0], ctx)
-        if a is None:
-            return None
-        return LinearIndex(-a.constant, {r: -f for r, f in a.factors.items()})
-    if expr.instr == "mul":
-        a, b = _fold(expr.children[0], ctx), _fold(expr.children[1], ctx)
-        if a is None or b is None:
-            return None
-        if not a.factors:
-            a, b = b, a
-        if b.factors:
-            return None
-        return LinearIndex(a.constant * b.constant, {r: f * b.constant for r, f in a.factors.items() if f * b.constant})
-    return None
+def _lin_scale(a, b):
+    """LinearIndex * int (ir.nim:626-631): zero when b == 0."""
+    if b == 0:
+        return LinearIndex()
+    return LinearIndex(a.constant * b, {r: f * b for r, f in a.factors.items()})
 
 
-def _build_linear(expr, ctx, host=False):
-    """An index expression as a LinearIndex.  Affine parts fold into constant + factors; any other
-    Index sub-expression (`y div 2`, `x mod 3`: LinearIndex.setup in the reference, ir.nim:120-123)
-    becomes index instructions of the kernel whose result register enters with factor 1.
-    host=True (shape constraints, loop bounds): the instructions go to the host-evaluated setup."""
-    lin = _fold(expr, ctx)
-    if lin is not None:
-        return lin
-    if expr.kind == "instr" and expr.instr in ("add", "sub"):
-        a, b = _build_linear(expr.children[0], ctx, host), _build_linear(expr.children[1], ctx, host)
-        sign = 1 if expr.instr == "add" else -1
-        out = LinearIndex(a.constant + sign * b.constant, a.factors)
-        for r, f in b.factors.items():
-            out.factors[r] = out.factors.get(r, 0) + sign * f
-        out.factors = {r: f for r, f in out.factors.items() if f != 0}
-        return out
+def _lin_add(a, b):
+    """LinearIndex + LinearIndex (ir.nim:633-643)."""
+    out = LinearIndex(a.constant + b.constant, a.factors)
+    for r, f in b.factors.items():
+        if r in out.factors:
+            out.factors[r] += f
+            if out.factors[r] == 0:
+                del out.factors[r]
+        else:
+            out.factors[r] = f
+    return out
+
+
+def _fold_setup(setup, reg, ctx):
+    """foldSetup (passes.nim:195-244): the instructions an index expression was built into (every node of the
+    expression got a register, parser.nim:155-217) collapse into constant + sum(factor * register) as far as they are
+    affine in the iterators; what is not (`y div 2`, shape(), len(), a product of two iterators) stays behind as setup
+    instructions whose result enters with factor 1.  Register numbers keep the gaps the folded instructions leave."""
+    regs = {r: LinearIndex(0, {r: 1}) for r in ctx.iters.values()}
+    get = lambda r: regs.get(r, LinearIndex())
+    for (kind, res, args, extra) in setup:
+        if kind == "index":
+            regs[res] = LinearIndex(int(extra))
+        elif kind == "add":
+            regs[res] = _lin_add(get(args[0]), get(args[1]))
+        elif kind == "sub":
+            regs[res] = _lin_add(get(args[0]), _lin_scale(get(args[1]), -1))
+        elif kind == "negate":
+            regs[res] = _lin_scale(get(args[0]), -1)
+        elif kind == "mul" and not get(args[0]).factors:
+            regs[res] = _lin_scale(get(args[1]), get(args[0]).constant)
+        elif kind == "mul" and not get(args[1]).factors:
+            regs[res] = _lin_scale(get(args[0]), get(args[1]).constant)
+        else:
+            regs[res] = LinearIndex(0, {res: 1})
+    total = get(reg)
+    used = set(total.factors)
+    kept = []
+    for ins in reversed(setup):
+        if ins[1] in used:
+            kept.append(ins)
+            used.update(ins[2])
+    kept.reverse()
+    return LinearIndex(total.constant, total.factors, kept)
+
+
+def _build_linear(expr, ctx, fold=True):
+    """buildLinearIndex (parser.nim:155-157) followed by foldSetup.  fold=False: shape constraints, which
+    foldLinearIndices never visits (passes.nim:246-262 walks kernels only) — they keep every instruction."""
     if expr.typ != INDEX:
         raise ParserError("tensor indices must be Index expressions")
-    sink = ctx.kernel.setup if host else ctx.kernel.index_instrs
-    reg = _build(expr, sink, -2 if host else -3, ctx)
-    return LinearIndex(0, {reg: 1})
+    setup = []
+    reg = _build(expr, setup, ctx.block(), ctx)
+    if not fold:
+        return LinearIndex(0, {reg: 1}, setup)
+    return _fold_setup(setup, reg, ctx)
 
 
 def _clear(expr):
@@ -710,6 +706,7 @@ class Target:
     def __init__(self, name, output):
         self.name, self.output = name, output
         self.kernels = []
+        self.shapes = []   # user shape constraints in flatten order (Target.shapes, ir.nim)
 
 
 class Program:
@@ -717,7 +714,6 @@ class Program:
         self.tensors = []   # dicts: kind, name, shape, range
         self.inputs = {}
         self.targets = {}
-        self.shape_constraints = []  # ("copy", dest, src) | ("dims", dest, [LinearIndex])
 
     def alloc_tensor(self, **kw):
         self.tensors.append(kw)
@@ -737,35 +733,88 @@ class Program:
             if t["kind"] in ("param", "random"):
                 line += [repr(t["range"][0]), repr(t["range"][1])]
             out.append(" ".join(line))
-        for c in self.shape_constraints:
-            if c[0] == "copy":
-                out.append(f"shapecopy {c[1]} {c[2]}")
-            else:
-                toks = ["shapedims", str(c[1]), str(len(c[2]))]
-                for d in c[2]:
-                    toks += d.tokens()
-                out.append(" ".join(toks))
-                for ins in (c[3] if len(c) > 3 else ()):
-                    out.append(f"shapesetup {c[1]} " + _ins_text(ins))
-        for name, tgt in self.targets.items():
+        # toKd (nim/exprgrad/runtimes/hipmodel.nim): targets in name order; a tensor's shape lines are written once, where
+        # the walk over the sorted targets first meets them (a reshape kernel's constraint while its kernel is emitted,
+        # a target's user constraints after its kernels); all shape lines precede all targets in the text
+        shape_lines, shaped, target_lines = [], set(), []
+        for name in sorted(self.targets):
+            tgt = self.targets[name]
             # the text is whitespace-separated tokens: a tensor name loses its blanks (above), a target
             # name is the key callers look the target up by and must survive the round trip unchanged
             if not name or any(ch.isspace() for ch in name):
                 raise ValueError(f"target name {name!r}: empty or contains whitespace (kernel-description text is token based)")
-            out.append(f"target {name} {tgt.output}")
+            target_lines.append(f"target {name} {tgt.output}")
             for k in tgt.kernels:
-                if k.generator:
-                    out.append(" ".join(str(x) for x in k.generator))
+                if k.generator and k.generator[0] == "reshape":
+                    _reshape_text(k.generator, target_lines, shape_lines, shaped)
+                elif k.generator:
+                    target_lines.append(" ".join(str(x) for x in k.generator))
+                else:
+                    _kernel_text(k, target_lines)
+            target_lines.append("endtarget")
+            for c in tgt.shapes:
+                if c[1] in shaped:
                     continue
-                _kernel_text(k, out)
-            out.append("endtarget")
+                shaped.add(c[1])
+                if c[0] == "copy":
+                    shape_lines.append(f"shapecopy {c[1]} {c[2]}")
+                else:
+                    toks = ["shapedims", str(c[1]), str(len(c[2]))]
+                    for d in c[2]:
+                        toks += d.tokens()
+                    shape_lines.append(" ".join(toks))
+                    for ins in (c[3] if len(c) > 3 else ()):
+                        shape_lines.append(f"shapesetup {c[1]} " + _ins_text(ins))
+        out += shape_lines + target_lines
         return "\n".join(out) + "\n"
 
 
+def _reshape_text(gen, out, shape_lines, shaped):
+    """GenReshape as generate expands it (passes.nim:643-688; emitReshape of hipmodel.nim): a raw copy over len(source)
+    — data register 1, iterator 2, len 3 — plus a ShapeDims constraint whose -1 entry is len(source) div the product of
+    the others (registers 1, 2, 3 of the constraint)."""
+    _, src, dest, dims = gen
+    out += ["kernel 3", f"setup len 3 0 {src}", "loop 2 reshape.it 1 L 0 0 L 0 1 3 1", f"read {src} 1 1 1 L 0 1 2 1", "result 1",
+            f"write {dest} 1 1 1 L 0 1 2 1", "endkernel"]
+    if dest in shaped:
+        return
+    shaped.add(dest)
+    prod = 1
+    for size in dims:
+        if size >= 0:
+            prod *= size
+    line, setup = f"shapedims {dest} {len(dims)}", []
+    for size in dims:
+        if size >= 0:
+            line += f" L {size} 0"
+        else:
+            setup += [f"shapesetup {dest} len 1 0 {src}", f"shapesetup {dest} index 2 0 {prod}", f"shapesetup {dest} indexdiv 3 2 1 2"]
+            line += " L 0 1 3 1"
+    shape_lines.append(line)
+    shape_lines += setup
+
+
 def _kernel_text(k, out):
+    """emitKernel of nim/exprgrad/runtimes/hipmodel.nim, statement for statement: host-evaluated instructions first
+    (the setup of explicit loop bounds, then the operand-index instructions that do not depend on an iterator), the
+    loops, then the operand-index instructions that do ("idx"), reads, instructions, result, write."""
     out.append(f"kernel {k.nregs}")
     for ins in k.setup:
         out.append("setup " + _ins_text(ins))
+    for (reg, nm, bounds) in k.loops:
+        if bounds:
+            for b in bounds:
+                for ins in b.setup:
+                    out.append("setup " + _ins_text(ins))
+    operand_setup = [ins for (_, _, _, dims) in k.reads for d in dims for ins in d.setup]
+    operand_setup += [ins for d in k.write[3] for ins in d.setup]
+    varying = {reg for (reg, _, _) in k.loops}
+    for (_, res, args, _) in operand_setup:       # dependsOnIterators: in list order, transitively
+        if any(a in varying for a in args):
+            varying.add(res)
+    for ins in operand_setup:
+        if ins[1] not in varying:
+            out.append("setup " + _ins_text(ins))
     for (reg, nm, bounds) in k.loops:
         if bounds:
             out.append(" ".join(["loop", str(reg), nm, "1"] + bounds[0].tokens() + bounds[1].tokens()))
@@ -773,6 +822,9 @@ def _kernel_text(k, out):
             out.append(f"loop {reg} {nm} 0")
     for ins in k.index_instrs:
         out.append("idx " + _ins_text(ins))
+    for ins in operand_setup:
+        if ins[1] in varying:
+            out.append("idx " + _ins_text(ins))
     for (tid, reg, raw, dims) in k.reads:
         toks = ["read", str(tid), str(reg), "1" if raw else "0", str(len(dims))]
         for d in dims:
@@ -822,7 +874,7 @@ def _alloc_tensors(fun, program):
                 raise ParserError(f'Expected shapes for input "{fun.name}" do not match.')
         elif k == "param":
             fun.tensor = program.alloc_tensor(kind="param", name=fun.name, shape=list(fun.param_shape), range=fun.init_range)
-        elif k in ("result", "gradient"):
+        elif k in ("result", "gradient", "reshape"):
             fun.tensor = program.alloc_tensor(kind="result", name=fun.name)
         elif k == "random":                                  # parser.nim:281-285
             fun.tensor = program.alloc_tensor(kind="random", name=fun.name, range=fun.random_range)
@@ -863,19 +915,29 @@ def _flatten(fun, target, program):
             if fun.shape_constr[0] == "copy":
                 c = ("copy", fun.tensor, fun.shape_constr[1].tensor)
             else:
-                # the dims are evaluated on the host from the shapes of the tensors they name; their
-                # instructions travel with the constraint (ShapeConstraint.dims[].setup in the reference)
-                ctx = _Ctx()
+                # ShapeDims (parser.nim:345-357): every dimension is built with a register file of its own and never
+                # folded; the text shares one "shapesetup" list per constraint, so the registers of dimension d are
+                # shifted by the highest register of the dimensions before it (emitShapeConstraint, hipmodel.nim)
+                dims, setup, offset = [], [], 0
                 for d in fun.shape_constr[1]:
                     _clear(d)
-                dims = [_build_linear(d, ctx, host=True) for d in fun.shape_constr[1]]
-                c = ("dims", fun.tensor, dims, tuple(ctx.kernel.setup))
-            if all(c[:2] != o[:2] for o in program.shape_constraints):
-                program.shape_constraints.append(c)
+                    lin = _build_linear(d, _Ctx(), fold=False)
+                    highest = 0
+                    for (kind, res, args, extra) in lin.setup:
+                        setup.append((kind, res + offset, [a + offset for a in args], extra))
+                        highest = res if res > highest else highest
+                    for r in lin.factors:
+                        highest = r if r > highest else highest
+                    dims.append(LinearIndex(lin.constant, {r + offset: f for r, f in lin.factors.items()}))
+                    offset += highest
+                c = ("dims", fun.tensor, dims, tuple(setup))
+            target.shapes.append(c)
     elif fun.kind == "random":                               # parser.nim:378-383: shaped like its argument
-        c = ("copy", fun.tensor, fun.children[0].tensor)
-        if all(c[:2] != o[:2] for o in program.shape_constraints):
-            program.shape_constraints.append(c)
+        target.shapes.append(("copy", fun.tensor, fun.children[0].tensor))
+    elif fun.kind == "reshape":                              # parser.nim:358-367: GenReshape
+        k = Kernel()
+        k.generator = ("reshape", fun.children[0].tensor, fun.tensor, tuple(fun.reshape_dims))
+        target.kernels.append(k)
     elif fun.kind == "cond":                                 # parser.nim:368-377
         child = fun.cond.get(target.name, fun.cond_else)
         if child is None:

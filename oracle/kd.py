@@ -214,6 +214,17 @@ def parse(text):
             cur.result = int(toks[1])
         elif t == "write":
             cur.write = _op(toks)
+            # (the last statement of a kernel body) index instructions that do not change inside the loop nest are host
+            # values — the Nim emitter writes them as "setup" already (hipmodel.nim emitKernel); text from another
+            # producer is normalised the same way
+            varying, stay = {lp.reg for lp in cur.loops}, []
+            for ins in cur.index_instrs:
+                if any(a in varying for a in ins.args):
+                    varying.add(ins.res)
+                    stay.append(ins)
+                else:
+                    cur.setup.append(ins)
+            cur.index_instrs = stay
         elif t == "backwards":
             k = Kernel()
             k.generator = ("backwards", int(toks[1]))
@@ -802,7 +813,10 @@ def _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch, f64=False):
     for op in list(k.reads) + [k.write]:
         offsets.append(len(packed))
         packed += terms(op)
-    idx_words, idx_lits = _encode_instrs(k.index_instrs, typ, shapes, epoch)
+    # host values (setup registers) an index instruction may name enter the interpreter's register file as literals
+    host = [Instr("index", r, [], int(v)) for r, v in sorted(vals.items())]
+    idx_all = host + list(k.index_instrs)
+    idx_words, idx_lits = _encode_instrs(idx_all, typ, shapes, epoch)
     words, lits = _encode_instrs(k.instrs, typ, shapes, epoch)
     nreads = len(k.reads)
     out = tensors[k.write.tensor]
@@ -810,7 +824,7 @@ def _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch, f64=False):
     rc = interp(
         nl, arr(c_i64, [bounds[lp.reg][0] for lp in k.loops]), arr(c_i64, [bounds[lp.reg][1] for lp in k.loops]),
         arr(c_i32, [lp.reg for lp in k.loops]), k.nregs + 1,
-        len(k.index_instrs), arr(c_i32, idx_words), arr(ctypes.c_double, idx_lits),
+        len(idx_all), arr(c_i32, idx_words), arr(ctypes.c_double, idx_lits),
         nreads, arr(ctypes.c_void_p, [tensors[r.tensor].ctypes.data for r in k.reads]),
         arr(c_i32, [r.reg for r in k.reads]), arr(c_i64, packed), arr(c_i32, offsets),
         len(k.instrs), arr(c_i32, words), arr(ctypes.c_double, lits), k.result,
