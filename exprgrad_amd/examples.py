@@ -85,6 +85,15 @@ def fashion_mnist_net(eta=0.01, size=28, f1=8, f2=16, classes=10):
     return [net.backwards().optimize(layers.adam(eta=eta)).target("fit")]
 
 
+def pool_chain_adam(eta=0.01, size=6, filters=2):
+    """The first layers of the fashion_mnist example with its optimizer, small: reshape -> conv2(1,3,3,f) -> maxpool2 ->
+    mse -> adam (fashion_mnist.nim:39-57; dnn.nim:45-71; base.nim:40-58).  tests/golden/handwritten/pool_chain_adam.kd is
+    the text parser.nim + toKd produce for it, derived by hand."""
+    net = layers.maxpool2(layers.conv2(dsl.reshape(dsl.input("x"), [-1, size, size, 1]), 1, 3, 3, filters)).target("predict")
+    loss = layers.mse(net, dsl.input("y")).target("loss")
+    return [loss.backprop(layers.adam(eta=eta)).target("fit")]
+
+
 def gan(seed_dim=32, h1=64, h2=128, pixels=28 * 28, rate=0.1):
     """examples/gan/gan.nim:35-61: generator and discriminator MLPs; `cond` feeds the discriminator the
     generator's output in the generator's targets and the `samples` input elsewhere; each side is

@@ -130,6 +130,59 @@ cases["xor_from_scratch"] = {
     "expect_caches": {},
 }
 
+# ---- reshape -> conv2 -> maxpool2 -> mse and one adam step (the first layers of examples/fashion_mnist with its optimizer) ----
+# The text (handwritten/pool_chain_adam.kd) is what the Nim emitter must produce for the chain: GenReshape, a six-iterator
+# conv2, maxpool2 with its customGrad, shape(), caches and epoch() — ids and registers derived by hand (see its header).
+N = 2
+xs = ((np.arange(N * 36, dtype=np.float64) * 7) % 11 - 5.0).reshape(N, 36)            # small integers
+flt2 = np.array([1, -2, 0, 2, 1, -1, 0, 3, -2, -1, 1, 2, 0, -3, 1, 2, -1, 0], dtype=np.float64).reshape(2, 3, 3, 1)
+ys = ((np.arange(N * 8, dtype=np.float64) * 3) % 7 - 3.0).reshape(N, 2, 2, 2)
+img2 = xs.reshape(N, 6, 6, 1)                                                          # reshape([-1, 6, 6, 1]): a raw copy
+conv = np.zeros((N, 4, 4, 2))
+for n in range(N):
+    for yy in range(4):
+        for xx in range(4):
+            for f in range(2):
+                for dy in range(3):
+                    for dx in range(3):
+                        conv[n, yy, xx, f] += img2[n, yy + dy, xx + dx, 0] * flt2[f, dy, dx, 0]
+pooled = np.zeros((N, 2, 2, 2))
+for n in range(N):
+    for yy in range(2):
+        for xx in range(2):
+            for c in range(2):
+                pooled[n, yy, xx, c] = conv[n, 2 * yy:2 * yy + 2, 2 * xx:2 * xx + 2, c].max()
+chain_loss = np.sum((pooled - ys) ** 2) / N                                            # mse: / toScalar(a.shape[0])
+g_pool = 2.0 * (pooled - ys) / N
+g_conv = np.zeros_like(conv)
+for n in range(N):
+    for yy in range(4):
+        for xx in range(4):
+            for c in range(2):                                                         # customGrad: every position equal to the maximum
+                if conv[n, yy, xx, c] == pooled[n, yy // 2, xx // 2, c]:
+                    g_conv[n, yy, xx, c] = g_pool[n, yy // 2, xx // 2, c]
+g_flt = np.zeros_like(flt2)
+for n in range(N):
+    for yy in range(4):
+        for xx in range(4):
+            for f in range(2):
+                for dy in range(3):
+                    for dx in range(3):
+                        g_flt[f, dy, dx, 0] += g_conv[n, yy, xx, f] * img2[n, yy + dy, xx + dx, 0]
+eta2 = 0.01
+assert np.all(g_flt != 0.0)          # (a zero gradient would make the step 0 / (0 + eps): keep the case away from it)
+cases["pool_chain_adam"] = {
+    "source": "examples/fashion_mnist/fashion_mnist.nim:39-57 (first layers + optimizer): parser.nim:786-793, layers/dnn.nim:45-71, "
+              "layers/base.nim:40-58; adam at epoch 1: mHat = g, vHat = g^2",
+    "params": {"1": spec(flt2)}, "inputs": {"x": spec(xs), "y": spec(ys)}, "epoch": 1,
+    "tol": 2e-5,      # (1 - 0.999f) is 1.3e-5 off 0.001 (see adam_step)
+    "calls": [{"target": "predict", "inputs": ["x"], "expect": spec(pooled)},
+              {"target": "loss", "expect": spec([chain_loss])}],
+    "apply": "fit",
+    "expect_params": {"1": spec(flt2 - eta2 * g_flt / (np.abs(g_flt) + 1e-8))},
+    "expect_caches": {"2": spec(0.1 * g_flt), "10": spec(0.001 * g_flt * g_flt)},
+}
+
 with open(os.path.join(HERE, "handwritten.json"), "w") as f:
     json.dump(cases, f, indent=1)
 print("wrote", len(cases), "cases")

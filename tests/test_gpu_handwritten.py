@@ -62,6 +62,21 @@ def test_backend_equals_the_oracle_on_the_handwritten_programs(gpu_ctx, name):
             ref.apply("train", ins)
         for tid in sorted(ref.params):
             assert rel_err(gpu.params[tid], ref.params[tid]) <= 3 * 256 * 6e-8, tid      # three steps of 256-term sums
+    elif name == "pool_chain_adam":
+        flt = (rng.random((2, 3, 3, 1), dtype=f) - 0.5).astype(f)
+        gpu.params[1] = flt
+        ref.params[1][...] = flt
+        ins = {"x": rng.random((5, 36), dtype=f), "y": rng.random((5, 2, 2, 2), dtype=f)}
+        assert rel_err(gpu.call("predict", {"x": ins["x"]}), ref.call("predict", {"x": ins["x"]})) <= TOL
+        assert rel_err(gpu.call("loss", ins), ref.call("loss", ins)) <= TOL
+        for step in range(1, 4):
+            gpu.epoch = ref.epoch = step
+            gpu.apply("fit", ins)
+            ref.apply("fit", ins)
+        # (adam's update is ill-conditioned in the gradient: three steps from identical state stay within 1e-4)
+        assert rel_err(gpu.params[1], ref.params[1]) <= 1e-4
+        for c in (2, 10):
+            assert rel_err(gpu.caches[c], ref.caches[c]) <= 1e-4
     elif name == "softmax_xent":
         z = (rng.random((2, 3), dtype=f) * 4 - 2).astype(f)
         gpu.params[1] = z

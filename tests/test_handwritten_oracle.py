@@ -53,6 +53,16 @@ def test_handwritten_text_equals_what_the_dsl_mirror_emits_semantically(name):
         ref.apply("train", ins)
         for tid, spec in case["expect_params"].items():
             assert handwritten.close(ref.params[int(tid)], arr(spec), 1e-6), tid
+    elif name == "pool_chain_adam":
+        from exprgrad_amd import examples
+        ref = kd.Model(refcases.program_text(examples.pool_chain_adam()))
+        ref.params[1][...] = arr(case["params"]["1"]).astype(np.float32)
+        ref.epoch = 1
+        ins = {k: arr(v).astype(np.float32) for k, v in case["inputs"].items()}
+        assert handwritten.close(ref.call("predict", {"x": ins["x"]}), arr(case["calls"][0]["expect"]), case["tol"])
+        assert handwritten.close(ref.call("loss", ins), arr(case["calls"][1]["expect"]), case["tol"])
+        ref.apply("fit", ins)
+        assert handwritten.close(ref.params[1], arr(case["expect_params"]["1"]), case["tol"])
     elif name == "softmax_xent":
         net = layers.softmax(dsl.input("z")).target("predict")
         net = layers.cross_entropy(net, dsl.input("y")).target("loss")
@@ -73,7 +83,7 @@ def test_handwritten_text_equals_what_the_dsl_mirror_emits_semantically(name):
         assert handwritten.close(ref.params[tid], arr(case["expect_params"]["1"]), 1e-5)
 
 
-def _normalised(text):
+def _normalised(text, keep_register_file_sizes=False):
     """Kernel-description text up to what is not information: comments, indentation, loop labels, the spelling of
     float literals, register-file sizes (a register that no line mentions) and the order of the targets."""
     targets, head, cur = {}, [], None
@@ -83,7 +93,7 @@ def _normalised(text):
             continue
         if t[0] == "loop":
             t[2] = "_"
-        elif t[0] == "kernel":
+        elif t[0] == "kernel" and not keep_register_file_sizes:
             t[1] = "_"
         elif t[0] == "ins" and t[1] == "scalar":
             t[-1] = repr(float(t[-1]))
@@ -107,3 +117,35 @@ def test_the_handwritten_xor_text_and_the_dsl_mirror_agree_line_by_line():
     from exprgrad_amd import examples
     mirror = refcases.program_text(examples.xor_from_scratch())
     assert _normalised(CASES["xor_from_scratch"]["text"]) == _normalised(mirror)
+
+
+def test_the_handwritten_pool_chain_text_and_the_dsl_mirror_agree_line_by_line():
+    """reshape -> conv2 -> maxpool2 (customGrad) -> mse -> adam: GenReshape, six iterators with `y + dy` indices, `y * 2 + 1`
+    and `y div 2`, shape(), caches, epoch() — tests/golden/handwritten/pool_chain_adam.kd was derived by hand from
+    parser.nim / passes.nim / toKd (see its header).  Here the register-file sizes are compared as well: the mirror must
+    allocate a register for every node of an index expression exactly where build() does (parser.nim:159-217)."""
+    import refcases
+    from exprgrad_amd import examples
+    mirror = refcases.program_text(examples.pool_chain_adam())
+    want, got = _normalised(CASES["pool_chain_adam"]["text"], True), _normalised(mirror, True)
+    assert want[0] == got[0]
+    for a, b in zip(want[1], got[1]):
+        assert a == b, next((x, y) for x, y in zip(a, b) if x != y)
+    assert len(want[1]) == len(got[1])
+
+
+def test_host_valued_index_instructions_may_be_written_as_idx():
+    """`idx` lines that do not depend on an iterator (a literal, shape(), len(), epoch()) are host values whichever
+    keyword a producer used for them (VERDICT r3 missing #6: shape()/len()/epoch() inside a computed index): the text with
+    the literals of `y div 2` as "idx" instead of "setup" runs to the same closed form."""
+    import numpy as np
+    from oracle import kd
+    case = CASES["pool_chain_adam"]
+    text = case["text"].replace("  setup index ", "  idx index ")
+    assert text != case["text"]
+    ref = kd.Model(text)
+    ref.params[1][...] = handwritten.arr(case["params"]["1"]).astype(np.float32)
+    ref.epoch = 1
+    ins = {k: handwritten.arr(v).astype(np.float32) for k, v in case["inputs"].items()}
+    ref.apply("fit", ins)
+    assert handwritten.close(ref.params[1], handwritten.arr(case["expect_params"]["1"]), case["tol"])
