@@ -113,6 +113,7 @@ def parse():
     return ap.parse_args()
 
 
+DEPENDENT_LAUNCH_US = 1.5   # boundary between two dependent launches inside a captured graph (MI355X_MICROARCH.md)
 SPINUP_S = 0.2   # untimed seconds of the same step in front of the W warmup steps (Timer.run): a sustained-clock figure
 
 EVENTS_NOTE = ("kernel_ms_avg = one HIP event pair around the K timed steps / K, on the stream the kernels run on; "
@@ -763,8 +764,56 @@ def run_fashion_fit(args, env):
         dt = time.perf_counter() - t0
         out[f"batch_{batch}"] = {"value": round(samples // batch * batch / dt, 1), "epoch_ms": round(dt * 1e3, 2),
                                  "us_per_batch": round(dt / (samples // batch) * 1e6, 1)}
+        # what bounds a batch: the launches of the captured sequence are dependent (each reads what its predecessor
+        # wrote), so a batch cannot be shorter than launches x the dependent-launch boundary of the device
+        # (MI355X_MICROARCH.md: ~1.5 us inside a graph), nor than its bytes / HBM rate
+        plan = [ln for ln in model.launch_plan("fit").splitlines() if ln.startswith("[")]
+        tensor_bytes = 4.0 * batch * (784 + 24 * 24 * 8 * 2 + 12 * 12 * 8 * 3 + 10 * 10 * 16 * 2 + 5 * 5 * 16 * 3 + 10 * 4)
+        out[f"batch_{batch}"]["bound"] = {
+            "library_calls_per_batch": len(plan) + 1, "dependent_launch_floor_us": round((len(plan) + 1) * DEPENDENT_LAUNCH_US, 1),
+            "algorithmic_mb_per_batch": round(2 * tensor_bytes / 1e6, 2),
+            "hbm_floor_us": round(2 * tensor_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, 2),
+            "note": "calls = launches of the plan + the segment copy of the batch's rows; some calls are two kernels (a "
+                    "k-sliced contraction and its fixed-order sum).  Bytes: every activation / gradient of the network "
+                    "written once and read once, float32.  At batch 32 the step is launch-bound, at 4096 "
+                    "it is the sum of its kernels (profiles/README.md lists them)."}
     out["value"] = out["batch_32"]["value"]
+    out["roofline"] = {"bound": "launch", "achieved": out["batch_32"]["us_per_batch"], "unit": "us per batch-32 step",
+                       "peak": out["batch_32"]["bound"]["dependent_launch_floor_us"],
+                       "frac": round(out["batch_32"]["bound"]["dependent_launch_floor_us"] / out["batch_32"]["us_per_batch"], 3),
+                       "traffic": None,
+                       "note": "floor / achieved: the batch-32 step against its dependent-launch floor (no kernel of it is "
+                               "bandwidth- or matrix-bound: 25 K-element tensors)"}
+    model.close()
     return out
+
+
+def cpu_baseline_fit(budget_s=5.0):
+    """Model.fit of the fashion_mnist network on the host: the oracle's kernel list run batch by batch the way
+    model.nim:413-454 does (epoch += 1 per batch, results zeroed per call), batch 32.  No kernel of a 32-sample batch
+    reaches the reference's 2^24 work-per-thread threshold: one thread is its policy."""
+    import numpy as np
+    from exprgrad_amd import dsl, examples
+    from oracle import kd
+    m = kd.Model(dsl.to_program(*examples.fashion_mnist_net()).to_text(), threads=1)
+    rng = np.random.default_rng(6)
+    for tid in m.params:
+        m.params[tid][...] = (rng.random(m.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+    batch = 32
+    x = rng.random((batch * 8, 784), dtype=np.float32)
+    y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, batch * 8)]
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget_s or n < 2:
+        i = (n % 8) * batch
+        m.epoch += 1
+        m.apply("fit", {"x": x[i:i + batch], "y": y[i:i + batch]})
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(batch / dt, 1), "unit": "samples/s", "cores": 1, "kind": "port", "interpreted": True,
+            "sample": f"{n} batches of 32 (oracle/kd.py: contractions on refcpu.c's compiled loop nest, every other kernel — the "
+                      f"convolutions and their gradients among them — on refinterp.c's kernel INTERPRETER, one thread = the "
+                      f"reference's policy at this batch size), {dt * 1e3:.2f} ms per batch.  The reference compiles these loops "
+                      f"with LLVM; an interpreter is several times slower, so this figure is a lower bound of the reference's rate"}
 
 
 def compile_latency():
@@ -918,6 +967,7 @@ def main():
                 baseline("train", lambda: cpu_baseline_train(model.source_text))
                 baseline("xor", cpu_baseline_xor)
                 baseline("conv2", cpu_baseline_conv2)
+                baseline("fashion_mnist_fit", cpu_baseline_fit)
             if "error" not in extra["train"]:
                 # the --gpus N > 1 invocations report the data-parallel train step; its 1-GPU point:
                 line["scaling_series_n1"] = {"metric": extra["train"]["metric"], "value": extra["train"]["value"],

@@ -1143,6 +1143,19 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
     }
   }
 
+  if constexpr ((ABL & 128) != 0) {
+    // tuning harness only: no epilogue at all (the accumulators are folded into one value that is never equal to the
+    // constant, so the matrix work stays) — what a step would cost if its tile stores were free
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    if (s == 1.2345678e-30f) a.C[0] = s;
+    return;
+  }
   // ---- epilogue.  32x32 accumulator block: register r of lane l holds
   //      row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31.
   const bool to_partial = a.tail_tiles > 0 ? tail_slab >= 0 : a.partial != nullptr;

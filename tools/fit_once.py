@@ -13,8 +13,9 @@ ctx = eg.newGpuContext(0)
 m = egm.compile(*examples.fashion_mnist_net(), gpu=ctx)
 rng = np.random.default_rng(0)
 f = np.float32
-x = rng.random((60000, 784), dtype=f)
-y = np.eye(10, dtype=f)[rng.integers(0, 10, 60000)]
+n = int(os.environ.get("FIT_SAMPLES", "60000"))
+x = rng.random((n, 784), dtype=f)
+y = np.eye(10, dtype=f)[rng.integers(0, 10, n)]
 batch = int(os.environ.get("FIT_BATCH", "4096"))
 for _ in range(3):
     m.fit("fit", {"x": x, "y": y}, batch_size=batch)

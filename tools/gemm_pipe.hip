@@ -43,6 +43,8 @@ std::vector<Variant> variants() {
       {"256x256x16 p no-dma  ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 66>},
       {"256x256x16 p no-barr ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 68>},
       {"256x256x16 p none    ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 71>},
+      {"256x256x16 no stores", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 128>},
+      {"128x128x16 no stores", 128, 128, 16, launch<128, 128, 16, 64, 64, 4, AKC, BKC, 128>},
       {"128x128x16 pipelined", 128, 128, 16, launch<128, 128, 16, 64, 64, 4, AKC, BKC, 64>},
       {"128x128x16 straight ", 128, 128, 16, launch<128, 128, 16, 64, 64, 4, AKC, BKC, 0>},
       {"64x64x32   pipelined", 64, 64, 32, launch<64, 64, 32, 32, 32, 4, AKC, BKC, 64>},
