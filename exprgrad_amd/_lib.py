@@ -85,6 +85,7 @@ _SIGS = {
     "eg_model_plan_text": (c_char_p, [c_void_p]),
     "eg_model_launch_text": (c_char_p, [c_void_p, c_char_p]),
     "eg_model_set_seed": (c_int, [c_void_p, ctypes.c_uint64]),
+    "eg_model_keep_values": (c_int, [c_void_p, c_int]),
     "eg_fill_uniform": (c_int, [c_void_p, c_i64, ctypes.c_float, ctypes.c_float, c_void_p, ctypes.c_uint64, c_void_p]),
     "eg_rng_advance": (c_int, [c_void_p, c_void_p]),
     "eg_model_kernel_count": (c_int, [c_void_p, c_char_p]),

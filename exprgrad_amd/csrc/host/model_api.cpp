@@ -50,14 +50,32 @@ int model_backward_with_exchange(eg_model* m, const char* target, const GradExch
   // make the SAME one.  Once per plan the piece list is compared across the ranks; where it differs, every rank
   // exchanges the whole bucket in one call (and if even the bucket sizes differ, the step is refused).
   bool split = gx.split && ex.big >= 0 && !plan->pipe.active;
-  if (gx.agree && plan->dp_agreed == 0) {
-    std::vector<int64_t> finger = {(int64_t)ts->bucket_floats, split ? 1 : 0, split ? (int64_t)ex.early.size() : 0,
-                                   split ? (int64_t)ex.late.size() : 0};
+  // (agreed once per plan AND per split setting: eg_dp_set_split after an agreement makes the ranks agree again — every
+  // rank changes the setting together, that is the contract of eg_dp_set_split.  What this cannot see is ONE rank
+  // arriving with a new plan while the others replay an agreed one — unequal shards in one step only: ranks must
+  // change their input shapes in the same step, INTEGRATION.md "data parallel".)
+  const int want_agreed_for = gx.split ? 1 : 2;
+  if (gx.agree && (plan->dp_agreed == 0 || plan->dp_agreed_for != want_agreed_for)) {
+    plan->dp_agreed = 0;
+    plan->dp_agreed_for = want_agreed_for;
+    // fixed length whatever the piece count, so ranks with different piece lists still meet in one collective: the
+    // bucket size, the decision, the two piece counts and a 128-bit hash of the complete piece list (no truncation)
+    uint64_t h1 = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull;
+    auto mix = [&](int64_t v) {
+      for (int b = 0; b < 8; ++b) {
+        const unsigned char c = (unsigned char)((uint64_t)v >> (8 * b));
+        h1 = (h1 ^ c) * 1099511628211ull;
+        h2 = (h2 + c + 0x9e3779b97f4a7c15ull) * 0xbf58476d1ce4e5b9ull;
+        h2 ^= h2 >> 29;
+      }
+    };
     if (split) {
-      for (auto& seg : ex.early) { finger.push_back(seg.first); finger.push_back(seg.second); }
-      for (auto& seg : ex.late) { finger.push_back(seg.first); finger.push_back(seg.second); }
+      for (auto& seg : ex.early) { mix(seg.first); mix(seg.second); }
+      mix(-1);
+      for (auto& seg : ex.late) { mix(seg.first); mix(seg.second); }
     }
-    finger.resize(32, -1);  // fixed length: ranks with different piece counts still meet in one collective
+    std::vector<int64_t> finger = {(int64_t)ts->bucket_floats, split ? 1 : 0, split ? (int64_t)ex.early.size() : 0,
+                                   split ? (int64_t)ex.late.size() : 0, (int64_t)(h1 >> 1), (int64_t)(h2 >> 1)};
     int same = 0, same_bucket = 0;
     rc = gx.agree(gx.user, finger.data(), (int)finger.size(), &same);
     if (rc) return rc;
@@ -482,7 +500,7 @@ static int read_tensor(eg_model* m, TargetState& ts, int tid, float* host, int64
   EG_REQUIRE(count == n, EG_ERR_SIZE, "Buffer size is not equal to target size (%ld vs %ld)", n, (long)count);
   if (n == 0) return EG_OK;
   EG_REQUIRE(!ts.last->predicated.count(tid), EG_ERR_INVALID,
-             "tensor %d exists only as predicate bits in the last run's plan (EG_NO_PREDICATE=1 keeps its values)", tid);
+             "tensor %d exists only as predicate bits in the last run's plan (eg_model_keep_values(model, 1) makes the plans keep values)", tid);
   float* p = tensor_ptr(m, ts, *ts.last, tid);
   EG_REQUIRE(p, EG_ERR_INVALID, "tensor %d was not materialised by the last run", tid);
   return eg::copy_d2h(m->ctx, host, p, (size_t)n * sizeof(float));
@@ -549,6 +567,16 @@ int eg_model_set_epoch(eg_model* m, int64_t epoch) try {
 EG_CATCH_ALL
 
 int64_t eg_model_epoch(eg_model* m) { return m ? m->epoch : 0; }
+
+int eg_model_keep_values(eg_model* m, int on) try {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  if (m->keep_values != (on != 0)) {
+    m->keep_values = on != 0;
+    m->inputs_gen++;  // the plan key changed: the next run looks its plan up again
+  }
+  return EG_OK;
+}
+EG_CATCH_ALL
 
 int eg_model_set_seed(eg_model* m, uint64_t seed) try {
   EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");

@@ -201,6 +201,7 @@ struct Plan {
   };
   Captured graphs[6];  // 0 whole call, 1 backward part, 2 update part; data-parallel split: 3 head, 4 side lane, 5 tail
   int dp_agreed = 0;   // data-parallel exchange plan compared across the ranks: 0 not yet, 1 the same everywhere (split allowed), 2 differs (one bucket)
+  int dp_agreed_for = 0;  // the split setting (1 allowed, 2 forbidden) the agreement was made under
 };
 
 struct TargetState {
@@ -234,6 +235,7 @@ struct eg_model {
   std::map<std::string, eg::model::TargetState> targets;
   std::map<int, eg::model::DevTensor> params;  // device-resident parameters (model.params)
   std::map<int, eg::model::BoundInput> inputs;
+  bool keep_values = false;  // eg_model_keep_values: plans keep result values where they would keep predicate bits
   uint64_t inputs_gen = 0;  // bumped by every change of `inputs` (bind, clear, fit): caches keyed on the bindings compare it
   float grad_scale = 1.0f;
   long epoch = 0;

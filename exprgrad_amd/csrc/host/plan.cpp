@@ -190,6 +190,7 @@ std::string shape_key(eg_model* m) {
     os << ";";
   }
   os << "e" << 0;
+  if (m->keep_values) os << "v";
   return os.str();
 }
 

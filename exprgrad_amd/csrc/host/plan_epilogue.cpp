@@ -19,6 +19,7 @@ namespace model {
 static int predicate_tensors(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos) {
   plan.predicated.clear();
   plan.pred_unzeroed.clear();
+  if (m->keep_values) return EG_OK;  // eg_model_keep_values
   {
     const char* e = getenv("EG_NO_PREDICATE");
     if (e && e[0] && e[0] != '0') return EG_OK;

@@ -53,6 +53,7 @@ struct HaloArgs {
   const float* zeros;
   int tiles_x, tiles_y, tiles_f;
   int accumulate;
+  int wide_store;  // whole patches leave through LDS as 16-byte stores (needs F % 4 == 0 and a 16-byte aligned output)
   long items;  // N * tiles_y * tiles_x * tiles_f
 };
 
@@ -243,7 +244,29 @@ __global__ __launch_bounds__(NT, 2) void conv2_halo_kernel(HaloArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] += acc_odd[j][r];
     const bool whole = cur_item.y0 + TH <= a.Ho && cur_item.x0 + TW <= a.Wo && cur_item.f0 + FB <= a.F;
-    if (whole && !a.accumulate) {  // branch-free: the 32 stores of a lane are issued back to back
+    if (whole && !a.accumulate && a.wide_store) {
+      // The wave's 32 pixels x 64 filters leave through LDS: parked as [pixel][filter] in the stage the last chunk has
+      // just released (this wave's own 8 KiB of it — no other wave touches them, so no block barrier on the way in),
+      // then written as 16 bytes per lane: four whole pixels (1 KiB, contiguous when F = 64) per wave instruction instead
+      // of 128-byte pieces of two pixels.  The barrier behind it keeps the next item's DMA (which every wave issues into
+      // this stage) away from a slower wave's parked values.
+      float* park = lds + (stage ^ 1) * STAGE + wave * (TW * FB);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = (r & 3) + 8 * (r >> 2) + 4 * hi;
+          park[p * FB + j * 32 + i] = acc[j][r];
+        }
+      float* base = a.out + ((cur_item.n * a.Ho + cur_item.y0 + wave) * a.Wo + cur_item.x0) * a.F + cur_item.f0;
+#pragma unroll
+      for (int it = 0; it < TW * FB / 256; ++it) {
+        const int e = it * 256 + lane * 4;  // element of the wave's [32][64] tile
+        const f32x4 v = *reinterpret_cast<const f32x4*>(park + e);
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(base + (long)(e / FB) * a.F + (e % FB)));
+      }
+      if (w_next < a.items) __syncthreads();
+    } else if (whole && !a.accumulate) {  // branch-free: the 32 stores of a lane are issued back to back
       float* base = a.out + ((cur_item.n * a.Ho + cur_item.y0 + wave) * a.Wo + cur_item.x0) * a.F + cur_item.f0 + i;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -353,6 +376,8 @@ int conv2_halo_try_padded(eg_ctx* ctx, long N, long H, long W, long C, long F, l
     return EG_OK;
   }
   a.items = blocks;
+  static const bool wide_off = getenv("EG_CONV_NO_WIDE_STORE") != nullptr;
+  a.wide_store = !wide_off && F % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   // one block per CU (LDS); several rounds of work run as persistent blocks
   const long grid = blocks < (long)ctx->compute_units ? blocks : (long)ctx->compute_units;
   void* params[] = {&a};

@@ -117,6 +117,11 @@ class Model:
     def epoch(self, v):
         call("eg_model_set_epoch", self.handle, int(v))
 
+    def keep_values(self, on=True):
+        """Plans keep the values of every result tensor (no predicate-bit tensors): read_tensor works for any
+        intermediate, as in the reference where every kernel's output is a tensor (model.nim:295-300)."""
+        call("eg_model_keep_values", self.handle, 1 if on else 0)
+
     def set_seed(self, seed):
         """Seed of the model's random tensors (`rand`, dropout masks); the reference uses Nim's global
         generator (`randomize(seed)`)."""

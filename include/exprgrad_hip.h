@@ -284,6 +284,13 @@ int eg_model_read_tensor(eg_model* model, const char* target, int tensor_id, flo
                          int64_t count);
 int eg_model_tensor_ptr(eg_model* model, const char* target, int tensor_id, float** device_ptr,
                         int64_t* count);
+/* Intermediates are an implementation matter of a plan: a tensor every reader of which is fused away may never exist,
+ * and one of which every reader only asks a yes / no question (relu's gradient, dnn.nim:26-27) may exist as one bit
+ * per element — eg_model_read_tensor then refuses it, whatever the shapes made the planner decide.  on != 0: from the
+ * next run on, every plan of this model keeps the VALUES of its result tensors where it would have kept bits (the
+ * reference's own behaviour: every kernel's output is a tensor, model.nim:295-300); slower, for debugging and parity
+ * tests.  The switch is part of the plan key: turning it back off returns to the plans made before. */
+int eg_model_keep_values(eg_model* model, int on);
 
 /* Model.epoch (model.nim:39, bumped by fit at model.nim:436). */
 int eg_model_set_epoch(eg_model* model, int64_t epoch);

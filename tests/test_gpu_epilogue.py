@@ -238,6 +238,51 @@ def test_predicate_bits_agree_bit_for_bit_with_stored_values(gpu_ctx, monkeypatc
         assert np.array_equal(with_bits[t], with_vals[t]), (t, np.max(np.abs(with_bits[t] - with_vals[t])))
 
 
+def test_keep_values_is_a_per_model_switch(gpu_ctx, monkeypatch):
+    """eg_model_keep_values: a tensor the plan keeps as predicate bits is refused by read_tensor; with the switch on the
+    same model re-plans with values (no environment variable, no new process), the tensor reads back as the oracle's
+    pre-activation, the parameters of the step are bit-identical, and switching off returns to the plan with bits."""
+    import re
+    from exprgrad_amd._lib import GpuError
+    monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", "0")
+    monkeypatch.delenv("EG_NO_PREDICATE", raising=False)
+    dims = (96, 128, 96, 8)
+    rng = np.random.default_rng(11)
+    x = (rng.random((256, dims[0]), dtype=np.float32) - 0.5).astype(np.float32)
+    y = rng.random((256, dims[-1]), dtype=np.float32)
+    states = []
+    for keep in (False, True):
+        gpu = egm.compile(*mlp(act="relu", dims=dims), gpu=gpu_ctx)
+        prng = np.random.default_rng(5)
+        for tid in sorted(gpu.params.ids()):
+            gpu.params[tid] = (prng.random(gpu.params[tid].shape, dtype=np.float32) * 0.6 - 0.3).astype(np.float32)
+        if keep:
+            gpu.keep_values(True)
+        gpu.apply("train", {"x": x, "y": y})
+        plan = gpu.launch_plan("train")
+        bits = [int(t) for t in re.findall(r"t(\d+) stored as predicate bits", plan)]
+        if not keep:
+            assert bits, plan
+            with pytest.raises(GpuError, match="eg_model_keep_values"):
+                gpu.read_tensor("train", bits[0])
+            gpu.keep_values(True)                         # the same model, switched: the next run re-plans
+            first = {t: gpu.params[t].copy() for t in sorted(gpu.params.ids())}
+            gpu.apply("train", {"x": x, "y": y})
+            assert "predicate bits" not in gpu.launch_plan("train")
+            h = gpu.read_tensor("train", bits[0])
+            assert h.shape == (256, dims[1]) and np.isfinite(h).all() and (h < 0).any() and (h > 0).any()
+            gpu.keep_values(False)
+            gpu.apply("train", {"x": x, "y": y})
+            assert "stored as predicate bits" in gpu.launch_plan("train")
+            states.append(first)
+        else:
+            assert not bits, plan
+            states.append({t: gpu.params[t].copy() for t in sorted(gpu.params.ids())})
+        gpu.close()
+    for t in states[0]:
+        assert np.array_equal(states[0][t], states[1][t]), t
+
+
 @pytest.mark.parametrize("act", ["tanh", "sigmoid"])
 def test_activations_that_use_the_value_keep_it(gpu_ctx, monkeypatch, act):
     dims = (96, 128, 96, 8)
