@@ -138,6 +138,9 @@ int conv2_direct_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long F
 int conv2_direct_grad_filter_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
                                  const float* gout, float* gflt, int accumulate, bool* launched);
 // LDS-halo convolution (kernels/conv2_halo.hip); *launched = false when the problem does not suit it.
+// kernels/conv2_gradf_halo.hip: the filter gradient of a 3 x 3 convolution with the halo in LDS (C, F multiples of 32)
+int conv2_gradf_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img, const float* gout,
+                         float* gflt, int accumulate, bool* launched);
 int conv2_halo_try_padded(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, long py, long px,
                           const float* img, const float* flt, float* out, int accumulate, bool* launched);
 int conv2_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,

@@ -931,6 +931,11 @@ extern "C" int eg_conv2_nhwc_grad_filter(eg_ctx* ctx, int64_t N, int64_t H, int6
   }
   EG_REQUIRE(P < (1L << 31) && FH * FW * C < (1L << 31), EG_ERR_INVALID,
              "eg_conv2_nhwc_grad_filter: more than 2^31 output pixels or taps");
+  if (FH == 3 && FW == 3 && C % 32 == 0 && F % 32 == 0) {  // the halo form: every image pixel staged once per row step, not once per tap
+    bool launched = false;
+    rc = eg::conv2_gradf_halo_try(ctx, N, H, W, C, F, FH, FW, img, gout, gflt, accumulate, &launched);
+    if (rc || launched) return rc;
+  }
   GemmArgs args = {};
   args.A = gout;
   args.B = img;

@@ -56,6 +56,44 @@ def test_conv2_gradients_against_the_oracle(gpu_ctx, refcpu, shape):
     assert rel_err(gimg.read(), refcpu.conv2_nhwc_grad_image(flt, gout, img.shape, out=base.copy())) <= TOL
 
 
+HALO_SHAPES = [  # N, H, W, C, F: 3 x 3 filters, channels and filters multiples of 32 -> kernels/conv2_gradf_halo.hip
+    (1, 34, 34, 64, 64),      # one segment per row, one pixel range
+    (1, 66, 66, 64, 64),      # two whole segments per row
+    (2, 40, 70, 32, 96),      # a ragged last segment (4 of 32 pixels), three filter blocks
+    (3, 30, 34, 96, 32),      # three channel blocks, three images
+    (1, 130, 258, 64, 64),    # 64 pixel ranges: the XCD-aware block order
+    (2, 50, 100, 128, 64),    # eight quadrants
+]
+
+
+@pytest.mark.parametrize("shape", HALO_SHAPES)
+def test_filter_gradient_halo_form_against_the_oracle_and_the_contraction(gpu_ctx, refcpu, monkeypatch, shape):
+    """The halo form of the filter gradient (every image pixel staged once per row step) against the oracle's loop nest,
+    against the one-contraction form it replaces (EG_CONV_NO_GRADF_HALO=1), with accumulation, and twice for identity."""
+    N, H, W, C, F = shape
+    rng = np.random.default_rng(sum(shape))
+    img = rng.random((N, H, W, C), dtype=np.float32)
+    gout = (rng.random((N, H - 2, W - 2, F), dtype=np.float32) - 0.5).astype(np.float32)
+    dimg, dg = dev(gpu_ctx, img), dev(gpu_ctx, gout)
+    gflt = gpu_ctx.allocTensor((F, 3, 3, C))
+    gflt.write(np.full((F, 3, 3, C), 7.0, dtype=np.float32))         # must be overwritten
+    monkeypatch.delenv("EG_CONV_NO_GRADF_HALO", raising=False)
+    ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, 3, 3, dimg, dg, gflt)
+    halo = gflt.read()
+    ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, 3, 3, dimg, dg, gflt)
+    assert np.array_equal(gflt.read(), halo)                          # fixed summation order: run-to-run identical
+    want = refcpu.conv2_nhwc_grad_filter(img, gout, (F, 3, 3, C))
+    assert rel_err(halo, want) <= TOL
+    monkeypatch.setenv("EG_CONV_NO_GRADF_HALO", "1")
+    ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, 3, 3, dimg, dg, gflt)
+    assert rel_err(halo, gflt.read()) <= TOL
+    monkeypatch.delenv("EG_CONV_NO_GRADF_HALO")
+    base = rng.random((F, 3, 3, C), dtype=np.float32)
+    gflt.write(base)
+    ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, 3, 3, dimg, dg, gflt, accumulate=True)
+    assert rel_err(gflt.read(), refcpu.conv2_nhwc_grad_filter(img, gout, (F, 3, 3, C), out=base.copy())) <= TOL
+
+
 def test_gradient_kernels_are_deterministic(gpu_ctx):
     N, H, W, C, F, FH, FW = 2, 40, 40, 16, 32, 3, 3      # split-K over 2888 pixels
     rng = np.random.default_rng(0)
