@@ -7,15 +7,17 @@
 // MFMA), and 85 - 113 k-slices of a 147 KB output leave 12 - 17 MB of slabs: 50.7 + 4.9 us at cfg 4 for 30.2 us of matrix
 // work.  Here the loop nest is turned around like in conv2_halo.hip:
 //   * the output [F, 9, C] is cut into 32 x 32 (filter, channel) quadrants; a block owns ONE quadrant for all nine taps
-//     and a range of output pixels; its four waves split the range, and every wave holds the quadrant's nine 32 x 32
+//     and a range of output pixels; its eight waves split the range, and every wave holds the quadrant's nine 32 x 32
 //     accumulator blocks (144 registers): one A fragment (gout) and nine B fragments (the image at the nine tap shifts)
 //     feed nine MFMAs — 1.1 LDS reads per MFMA, every image pixel fetched once per row step instead of once per tap;
-//   * a wave walks its pixels in segments of 32 consecutive pixels of one output row: per segment the 3 x 34 halo of its
-//     32 channels and the 32 x 32 piece of gout go to the wave's OWN stage of LDS by LDS-DMA, double buffered — no
+//   * a wave walks its pixels in segments of 16 consecutive pixels of one output row: per segment the 3 x 18 halo of its
+//     32 channels and the 16 x 32 piece of gout go to the wave's OWN stage of LDS by LDS-DMA, double buffered — no
 //     block barrier anywhere in the loop (a wave waits for its own loads: s_waitcnt vmcnt(<loads of the next stage>));
-//   * the fragment reads of k-step j + 1 are issued in front of the MFMAs of k-step j (one wave per SIMD: nothing else
-//     hides the LDS latency);
-//   * at the end the four waves of a block add their accumulators through LDS in a fixed order and the block writes its
+//   * the fragment reads of k-step j + 1 are issued in front of the MFMAs of k-step j, the loads of the next segment
+//     behind the first MFMAs of the first k-steps.  Two waves per SIMD: with ONE (segments of 32 pixels, 34 KB of LDS per
+//     wave) every instruction a wave issues between two MFMAs idles the matrix pipe — cycle stamps gave 78 cycles per
+//     MFMA instead of 64, 56 of them per LDS-DMA piece and 7 per LDS read whether or not they stood behind an MFMA;
+//   * at the end the eight waves of a block add their accumulators through LDS in a fixed order and the block writes its
 //     quadrant of slab `range`; eg::slab_sum folds the ranges (64 slabs at cfg 4: 9.4 MB instead of 12 - 17) in a fixed
 //     order: run-to-run identical, no float atomics.
 // Pixels past the end of a row segment multiply a zero gradient (their A fragment is masked in registers).
@@ -33,19 +35,19 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int SEG = 32;                      // output pixels per segment (one k-step = 2 pixels: 16 k-steps)
+constexpr int SEG = 16;                      // output pixels per segment (one k-step = 2 pixels: 8 k-steps)
 constexpr int HW = SEG + 2;                  // halo pixels per row
 constexpr int QB = 32;                       // quadrant: 32 filters x 32 channels
 constexpr int TAPS = 9;
-constexpr int HALO_PX = 3 * HW;              // 102 halo pixels
-constexpr int HALO_INSTR = (HALO_PX * 8 + 63) / 64;   // 1 KiB DMA instructions per halo (8 lanes of 16 B per pixel): 13
-constexpr int GOUT_INSTR = SEG * 8 / 64;              // 4
-constexpr int PER_STAGE = HALO_INSTR + GOUT_INSTR;    // 17 loads per stage and wave
-constexpr int HALO_FLOATS = HALO_INSTR * 256;         // 3328 (the last instruction's tail is never read)
-constexpr int STAGE_FLOATS = HALO_FLOATS + GOUT_INSTR * 256;   // 4352
-constexpr int WAVES = 4;
-constexpr int LOOP_FLOATS = WAVES * 2 * STAGE_FLOATS;          // 34 816 floats = 136 KiB
-constexpr int FOLD_FLOATS = WAVES * TAPS * QB * QB;            // 36 864 floats = 144 KiB
+constexpr int HALO_PX = 3 * HW;              // 54 halo pixels
+constexpr int HALO_INSTR = (HALO_PX * 8 + 63) / 64;   // 1 KiB DMA instructions per halo (8 lanes of 16 B per pixel): 7
+constexpr int GOUT_INSTR = SEG * 8 / 64;              // 2
+constexpr int PER_STAGE = HALO_INSTR + GOUT_INSTR;    // 9 loads per stage and wave
+constexpr int HALO_FLOATS = HALO_INSTR * 256;         // 1792 (the last instruction's tail is never read)
+constexpr int STAGE_FLOATS = HALO_FLOATS + GOUT_INSTR * 256;   // 2304
+constexpr int WAVES = 8;                                       // two per SIMD: a wave's LDS reads and loads issue under the other's MFMAs
+constexpr int LOOP_FLOATS = WAVES * 2 * STAGE_FLOATS;          // 36 864 floats = 144 KiB
+constexpr int FOLD_FLOATS = 4 * TAPS * QB * QB;                // 36 864 floats = 144 KiB (the eight waves meet in two rounds)
 constexpr int LDS_BYTES = (LOOP_FLOATS > FOLD_FLOATS ? LOOP_FLOATS : FOLD_FLOATS) * (int)sizeof(float);
 
 struct GradFArgs {
@@ -204,10 +206,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv2_gradf_halo_kernel(GradFAr
       __builtin_amdgcn_sched_barrier(0);
       // (masked where it is used, not where it is loaded: the select would wait for the read just issued)
       const float A = 2 * j + hi < nvalid ? av[j & 1] : 0.f;   // a ragged last segment of a row
-      // The 17 loads of the next stage ride behind the MFMAs of the first nine k-steps, one behind each of the first two
-      // MFMAs: issuing an LDS-DMA piece takes the wave 60 - 180 cycles (MI355X_MICROARCH.md), and a wave that has its SIMD
-      // to itself pays them in full when they stand in front of the loop (17 pieces = 0.8 us per 3.8 us step); behind an
-      // MFMA they overlap its 64 cycles.  The last piece is issued seven k-steps (1.7 us) before the stage is needed.
+      // The nine loads of the next stage ride behind the first two MFMAs of the first five k-steps (three k-steps of
+      // MFMAs, twice that with the SIMD's other wave, separate the last one from the wait at the end of the segment).
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A, bv[j & 1][t], acc[t], 0, 0, 0);
@@ -220,25 +220,46 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv2_gradf_halo_kernel(GradFAr
     stamp();   // 4 + 2 s: next stage landed
   }
 
-  // ---- the four waves' accumulators meet in LDS: [wave][tap][f 32][c 32], summed (w0 + w1) + (w2 + w3)
+  // ---- the eight waves' accumulators meet in LDS in a fixed order, four at a time ([wave & 3][tap][f 32][c 32] fills the
+  //      144 KiB): waves 0 - 3 park theirs and every thread sums its elements of the four, ((0 + 1) + (2 + 3)), into
+  //      registers; then waves 4 - 7 park theirs, ((4 + 5) + (6 + 7)) is added, and the thread stores its 16-byte groups.
+  //      (Waves 4 - 7 adding onto the parked values in place — a read and a write per element — took twice as long.)
   __syncthreads();   // every wave is done with its stages
   stamp();   // after the loop's barrier
-  float* fold = lds + wave * (TAPS * QB * QB);
+  float* fold = lds + (wave & 3) * (TAPS * QB * QB);
+  constexpr int GROUPS = (TAPS * QB * QB / 4 + WAVES * 64 - 1) / (WAVES * 64);   // 16-byte groups per thread: 5 (the last one half used)
+  f32x4 sum[GROUPS];
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int half = 0; half < 2; ++half) {
+    if ((wave >> 2) == half) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) fold[t * (QB * QB) + ((r & 3) + 8 * (r >> 2) + 4 * hi) * QB + i] = acc[t][r];
-  __syncthreads();
+      for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) fold[t * (QB * QB) + ((r & 3) + 8 * (r >> 2) + 4 * hi) * QB + i] = acc[t][r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+      const int e = (g * WAVES * 64 + tid) * 4;
+      if (e >= TAPS * QB * QB) break;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(lds + e), w1 = *reinterpret_cast<const f32x4*>(lds + TAPS * QB * QB + e);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(lds + 2 * TAPS * QB * QB + e),
+                  w3 = *reinterpret_cast<const f32x4*>(lds + 3 * TAPS * QB * QB + e);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = (w0[k] + w1[k]) + (w2[k] + w3[k]);
+        sum[g][k] = half == 0 ? v : sum[g][k] + v;
+      }
+    }
+    if (half == 0) __syncthreads();   // the parked values are read: the second half may overwrite them
+  }
   float* slab = a.slabs + (long)range * (a.F * TAPS * a.C);
-  for (int e = tid * 4; e < TAPS * QB * QB; e += WAVES * 64 * 4) {
-    const f32x4 w0 = *reinterpret_cast<const f32x4*>(lds + e), w1 = *reinterpret_cast<const f32x4*>(lds + TAPS * QB * QB + e);
-    const f32x4 w2 = *reinterpret_cast<const f32x4*>(lds + 2 * TAPS * QB * QB + e),
-                w3 = *reinterpret_cast<const f32x4*>(lds + 3 * TAPS * QB * QB + e);
-    f32x4 v;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (w0[k] + w1[k]) + (w2[k] + w3[k]);
+  for (int g = 0; g < GROUPS; ++g) {
+    const int e = (g * WAVES * 64 + tid) * 4;
+    if (e >= TAPS * QB * QB) break;
     const int t = e / (QB * QB), f = (e / QB) % QB, c = e % QB;
-    *reinterpret_cast<f32x4*>(slab + ((f0 + f) * TAPS + t) * a.C + c0 + c) = v;
+    *reinterpret_cast<f32x4*>(slab + ((f0 + f) * TAPS + t) * a.C + c0 + c) = sum[g];
   }
   stamp();   // end
 }

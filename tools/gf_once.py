@@ -1,3 +1,5 @@
+"""Four calls of the filter gradient at BASELINE configs[3] (debugging aid: EG_GRADF_TRACE=1 prints the per-wave cycle stamps of
+kernels/conv2_gradf_halo.hip — prologue, every segment, the fold).  GPU box: EG_GRADF_TRACE=1 python tools/gf_once.py"""
 import sys; sys.path.insert(0,'/root/repo')
 import torch, exprgrad_amd as eg
 from exprgrad_amd import ops
