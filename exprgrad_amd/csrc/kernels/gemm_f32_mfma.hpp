@@ -875,6 +875,44 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
     return;
   }
 
+  if constexpr (!KCL && NT >= 512 && BK / 8 >= 2 && !(ABL & 256)) {
+    // ---- skewed waves (round 4).  A wave that issues anything between two MFMAs idles the matrix pipe of its SIMD for
+    // that long — measured on a one-wave-per-SIMD kernel (conv2_gradf_halo.hip): 56 cycles per LDS-DMA piece, 7 per LDS
+    // read, whether or not the instruction stands behind an MFMA — and the two waves that share a SIMD here (2 s and
+    // 2 s + 1) run the same code between the same barriers, so they issue their loads and fragment reads at the same
+    // moments and both stop multiplying: the three costs of the k loop ADD (972 us at 4096^3 against 903 without them).
+    // Here the ODD waves run one k-group late: they read the last k-group of a tile in front of the barrier and multiply
+    // it behind it, while the even waves issue their loads and reads; then the odd waves load and read while the even
+    // ones multiply.  Same MFMAs on the same accumulators in the same k order: bit-identical.  LDS hazards are
+    // unchanged — every read of a stage still precedes the barrier that frees it.  4096^3: 965 -> 944 us (145.7 TFLOP/s,
+    // 0.926 of peak); with the UPPER HALF of the block late instead (waves 4 - 7: not SIMD neighbours) nothing changes
+    // (966 us) — which is how the wave-to-SIMD assignment was found (ABL bit 9 of the tuning harness selects that split).
+    constexpr int NPP = BK / 8;
+    if ((ABL & 512) ? wave >= NT / 128 : (wave & 1) != 0) {
+      float avp[MI][4], bvp[NI][4];
+      for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt > 0) multiply(avp, bvp);   // tile kt - 1, last k-group
+        if (kt + 1 < nk) {
+          const long k0 = k_begin + (long)(kt + 1) * BK;
+          float* nxt = lds + (cur ^ 1) * BUF;
+          da.issue(a, a.A, a.lda, m_blk, k0, nxt, wave, lane, a.a_rows, k_end, ones);
+          db.issue(a, a.B, a.ldb, n_blk, k0, nxt + BK * BM, wave, lane, a.N, k_end);
+        }
+        const float* As = lds + cur * BUF;
+#pragma unroll
+        for (int pp = 0; pp + 1 < NPP; ++pp) {
+          float av[MI][4], bv[NI][4];
+          fragments(As, pp, av, bv);
+          multiply(av, bv);
+        }
+        fragments(As, NPP - 1, avp, bvp);
+        dma_publish_barrier();
+      }
+      if (nk > 0) multiply(avp, bvp);
+      return;
+    }
+  }
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
@@ -942,37 +980,64 @@ __device__ __forceinline__ void gemm_mainloop_dma_x(const GemmArgs& a, float* ld
   };
   if (nk > 0) issue(0);
   dma_publish_barrier();
+  // fragments of k-group pp of the tile at stage `st` (A / B interleaved: one read per k brings every block's value; the
+  // strip's A value and this wave's 32 columns of B for the ninth block)
+  auto fragments = [&](int st, int pp, float (&av)[MI][4], float (&bv)[NI][4], float (&ax)[4], float (&bx)[4]) {
+    const float* As = lds + st * BUF;
+    const float* Bs = As + BK * BM;
+    const float* Xs = xs + st * BK * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = 8 * pp + j + 4 * hi;
+      typedef float vecA __attribute__((ext_vector_type(MI)));
+      typedef float vecB __attribute__((ext_vector_type(NI)));
+      const vecA va = *reinterpret_cast<const vecA*>(As + k * BM + wm0 + MI * i);
+      const vecB vb = *reinterpret_cast<const vecB*>(Bs + k * BN + wn0 + NI * i);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) av[mi][j] = va[mi];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bv[ni][j] = vb[ni];
+      ax[j] = Xs[k * 32 + i];
+      bx[j] = Bs[k * BN + wave * 32 + i];
+    }
+  };
+  auto multiply = [&](const float (&av)[MI][4], const float (&bv)[NI][4], const float (&ax)[4], const float (&bx)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
+      accx = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[j], bx[j], accx, 0, 0, 0);
+    }
+  };
+  constexpr int NPP = BK / 8;
+  if (NPP >= 2 && (wave & 1)) {
+    // the odd waves run one k-group late (gemm_mainloop_dma, "skewed waves"): same MFMAs in the same order
+    float avp[MI][4], bvp[NI][4], axp[4], bxp[4];
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt > 0) multiply(avp, bvp, axp, bxp);
+      if (kt + 1 < nk) issue(kt + 1);
+#pragma unroll
+      for (int pp = 0; pp + 1 < NPP; ++pp) {
+        float av[MI][4], bv[NI][4], ax[4], bx[4];
+        fragments(kt & 1, pp, av, bv, ax, bx);
+        multiply(av, bv, ax, bx);
+      }
+      fragments(kt & 1, NPP - 1, avp, bvp, axp, bxp);
+      dma_publish_barrier();
+    }
+    if (nk > 0) multiply(avp, bvp, axp, bxp);
+    return;
+  }
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) issue(kt + 1);
-    const float* As = lds + (kt & 1) * BUF;
-    const float* Bs = As + BK * BM;
-    const float* Xs = xs + (kt & 1) * BK * 32;
 #pragma unroll
-    for (int pp = 0; pp < BK / 8; ++pp) {
+    for (int pp = 0; pp < NPP; ++pp) {
       float av[MI][4], bv[NI][4], ax[4], bx[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int k = 8 * pp + j + 4 * hi;
-        typedef float vecA __attribute__((ext_vector_type(MI)));
-        typedef float vecB __attribute__((ext_vector_type(NI)));
-        const vecA va = *reinterpret_cast<const vecA*>(As + k * BM + wm0 + MI * i);
-        const vecB vb = *reinterpret_cast<const vecB*>(Bs + k * BN + wn0 + NI * i);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) av[mi][j] = va[mi];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) bv[ni][j] = vb[ni];
-        ax[j] = Xs[k * 32 + i];
-        bx[j] = Bs[k * BN + wave * 32 + i];
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NI; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][j], bv[ni][j], acc[mi][ni], 0, 0, 0);
-        accx = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[j], bx[j], accx, 0, 0, 0);
-      }
+      fragments(kt & 1, pp, av, bv, ax, bx);
+      multiply(av, bv, ax, bx);
     }
     dma_publish_barrier();
   }

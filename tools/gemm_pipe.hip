@@ -37,8 +37,9 @@ void launch(const GemmArgs& a, dim3 grid, hipStream_t s) {
 template <bool AKC, bool BKC>
 std::vector<Variant> variants() {
   return {
-      {"256x256x16 pipelined", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 64>},
-      {"256x256x16 straight ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 0>},
+      {"256x256x16 unskewed ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 256>},
+      {"256x256x16 skewed   ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 0>},
+      {"256x256x16 skew half", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 512>},
       {"256x256x16 p no-reads", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 65>},
       {"256x256x16 p no-dma  ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 66>},
       {"256x256x16 p no-barr ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 68>},
@@ -120,7 +121,7 @@ int main(int argc, char** argv) {
   for (size_t vi = 0; vi < vs.size(); ++vi) {
     if (out[vi].empty()) continue;
     const size_t other = vi ^ 1;
-    const bool same = !out[other].empty() && memcmp(out[vi].data(), out[other].data(), out[vi].size() * 4) == 0;
+    const bool same = other < out.size() && !out[other].empty() && out[other].size() == out[vi].size() && memcmp(out[vi].data(), out[other].data(), out[vi].size() * 4) == 0;
     printf("  %s  %9.1f us  %7.2f TFLOP/s   %s\n", vs[vi].name, best[vi] * 1e3, 2.0 * M * N * K / best[vi] / 1e9,
            same ? "bit-identical to its twin" : "DIFFERS from its twin");
   }
