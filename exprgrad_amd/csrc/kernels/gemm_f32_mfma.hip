@@ -480,6 +480,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
       args.wide_store = wide_store_ok(args, true);
       args.prio = side_priority(ctx);
       args.nt_store = nt_store_enabled();
+  args.no_skew = getenv("EG_GEMM_NO_SKEW") != nullptr;
       const long total = M * N, slabs = std::max(s1, s2);
       int rc = eg::ensure_workspace(ctx, (((size_t)slabs * total + 3) & ~(size_t)3) * sizeof(float));
       if (rc) return rc;
@@ -577,6 +578,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   args.wide_store = wide_store_ok(args, splits > 1);
   args.prio = side_priority(ctx);
   args.nt_store = nt_store_enabled();
+  args.no_skew = getenv("EG_GEMM_NO_SKEW") != nullptr;
   float* scratch = nullptr;
   if (args.tail_tiles > 0) {
     int rc = eg::ensure_workspace(ctx, (size_t)tail_slab_floats * sizeof(float));
@@ -1088,6 +1090,7 @@ int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, co
   args.wide_store = wide_store_ok(args, false, true);   // set_epilogue_operands withdraws it for unaligned operands
   args.prio = side_priority(ctx);
   args.nt_store = nt_store_enabled();
+  args.no_skew = getenv("EG_GEMM_NO_SKEW") != nullptr;
   memcpy(out.args, &args, sizeof(args));
   out.args_size = sizeof(args);
   return EG_OK;

@@ -84,6 +84,7 @@ struct GemmArgs {
   // measured at 208 us next to a 256x256 one (rocprofv3 timeline, profiles/r02_pipeline_trace.txt).
   int prio;
   int nt_store;  // wide stores as nontemporal stores (host: nt_store_enabled)
+  int no_skew;   // EG_GEMM_NO_SKEW=1: every wave of a block runs the k loop in phase (the round-3 loop; A/B aid)
   // Extra rows (XR kernels; split-K launches of the TN form): M = tiles_m * BM + x_rows with 0 < x_rows <= 32.  The blocks of
   // the LAST tile row carry a ninth accumulator block per wave for rows [tiles_m * BM, M) — a [k][32] strip of A staged
   // next to the tile, multiplied with the B tile the block stages anyway — instead of a ragged tile row of its own that
@@ -888,7 +889,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(const GemmArgs& a, float* lds,
     // 0.926 of peak); with the UPPER HALF of the block late instead (waves 4 - 7: not SIMD neighbours) nothing changes
     // (966 us) — which is how the wave-to-SIMD assignment was found (ABL bit 9 of the tuning harness selects that split).
     constexpr int NPP = BK / 8;
-    if ((ABL & 512) ? wave >= NT / 128 : (wave & 1) != 0) {
+    if (!a.no_skew && ((ABL & 512) ? wave >= NT / 128 : (wave & 1) != 0)) {
       float avp[MI][4], bvp[NI][4];
       for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -1013,7 +1014,7 @@ __device__ __forceinline__ void gemm_mainloop_dma_x(const GemmArgs& a, float* ld
     }
   };
   constexpr int NPP = BK / 8;
-  if (NPP >= 2 && (wave & 1)) {
+  if (NPP >= 2 && (wave & 1) && !a.no_skew) {
     // the odd waves run one k-group late (gemm_mainloop_dma, "skewed waves"): same MFMAs in the same order
     float avp[MI][4], bvp[NI][4], axp[4], bxp[4];
     for (int kt = 0; kt < nk; ++kt) {
