@@ -598,6 +598,23 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   const bool edge = conv || !(vec && M % BM == 0 && N % BN == 0 && K % KB == 0 && K > 0);
 
   int rc;
+  // Whole 256 x 256 tiles of a long, unsliced product: 32-deep k-tiles (half the barriers and half the load issues per
+  // MFMA; 128 KB of LDS, still one block per CU).  With the skewed waves of round 4 on top: 4096^3 949 -> 941 us in the
+  // harness (+0.8 %); short products keep 16 (K = 784: round 2 measured -7 % with 32).  EG_GEMM_NO_BK32=1: 16 everywhere.
+  static const bool bk32_on = getenv("EG_GEMM_NO_BK32") == nullptr;
+  if (bk32_on && BM == 256 && BN == 256 && !edge && !conv && splits <= 1 && args.tail_tiles == 0 && args.edge_splits == 0 &&
+      K % 32 == 0 && K >= 2048 && args.k_per_split == K) {
+    dim3 grid((unsigned)((long)args.tiles_m * args.tiles_n)), block(512);
+#define EG_BK32(AKC, BKC) \
+  hipLaunchKernelGGL((gemm_f32_mfma_kernel<256, 256, 32, 128, 64, 1, AKC, BKC, 4, false, 0, 0, true>), grid, block, 0, ctx->stream, args)
+    if (a_kc && !b_kc) EG_BK32(true, false);
+    else if (a_kc && b_kc) EG_BK32(true, true);
+    else if (!a_kc && !b_kc) EG_BK32(false, false);
+    else EG_BK32(false, true);
+#undef EG_BK32
+    EG_HIP_CHECK(hipGetLastError());
+    return EG_OK;
+  }
   if (BN == 32)
     rc = launch_config<128, 32, 32, 32, 4>(ctx, a_kc, b_kc, args, launch_splits, vec, edge, conv, a_vec_only && !vec);
   else if (BN == 64 && BM == 256)
