@@ -34,6 +34,7 @@ proc eg_model_param_write(model: ptr EgModel, tensor: cint, host: ptr float32, c
 proc eg_model_param_read(model: ptr EgModel, tensor: cint, host: ptr float32, count: int64): cint
 proc eg_model_set_epoch(model: ptr EgModel, epoch: int64): cint
 proc eg_model_epoch(model: ptr EgModel): int64
+proc eg_model_keep_values(model: ptr EgModel, on: cint): cint
 proc eg_model_plan_text(model: ptr EgModel): cstring
 proc eg_model_launch_text(model: ptr EgModel, target: cstring): cstring
 proc eg_model_state_bytes(model: ptr EgModel, bytes: ptr csize_t): cint
@@ -532,6 +533,10 @@ proc writeParam*[T](model: HipModel[T], id: TensorId, value: Tensor[T]) =
 
 proc epoch*[T](model: HipModel[T]): int = int(eg_model_epoch(model.handle))
 proc `epoch=`*[T](model: HipModel[T], value: int) = check eg_model_set_epoch(model.handle, int64(value))
+proc keepValues*[T](model: HipModel[T], on = true) =
+  ## Plans keep the values of every result tensor (the reference's own behaviour: every kernel's output is a tensor,
+  ## model.nim:295-300) instead of, where all readers allow it, one predicate bit per element — for debugging
+  check eg_model_keep_values(model.handle, cint(ord(on)))
 proc emitIr*[T](model: HipModel[T]): string = $eg_model_plan_text(model.handle)                    # model.nim:262-264
 proc launches*[T](model: HipModel[T], target: string): string = $eg_model_launch_text(model.handle, target.cstring)
 
