@@ -453,7 +453,7 @@ def run_matmul(args, env):
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
                      **(traffic_fields("matmul4096") if n == 4096 else {"traffic": None}),
-                     "kernel": "eg::gemm::gemm_f32_mfma_kernel<256,256,16,128,64,NN,DMA>", "flops_per_launch": flops,
+                     "kernel": "eg::gemm::gemm_f32_mfma_kernel<256,256,32,128,64,NN,DMA> (skewed waves, 32-deep k-tiles)", "flops_per_launch": flops,
                      "clock": "wall time of the timed steps (the clock `value` uses)",
                      "kernel_ms_avg": round(ev_avg, 4), "kernel_ms_min": round(ev_min, 4), "events": EVENTS_NOTE,
                      "frac_by_events": round(achieved_events / F32_MFMA_PEAK_TFLOPS, 4)},
