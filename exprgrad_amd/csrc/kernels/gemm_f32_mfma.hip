@@ -601,7 +601,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   // Whole 256 x 256 tiles of a long, unsliced product: 32-deep k-tiles (half the barriers and half the load issues per
   // MFMA; 128 KB of LDS, still one block per CU).  With the skewed waves of round 4 on top: 4096^3 949 -> 941 us in the
   // harness (+0.8 %); short products keep 16 (K = 784: round 2 measured -7 % with 32).  EG_GEMM_NO_BK32=1: 16 everywhere.
-  static const bool bk32_on = getenv("EG_GEMM_NO_BK32") == nullptr;
+  const bool bk32_on = getenv("EG_GEMM_NO_BK32") == nullptr;   // (read per call: a test compares the two loops)
   if (bk32_on && BM == 256 && BN == 256 && !edge && !conv && splits <= 1 && args.tail_tiles == 0 && args.edge_splits == 0 &&
       K % 32 == 0 && K >= 2048 && args.k_per_split == K) {
     dim3 grid((unsigned)((long)args.tiles_m * args.tiles_n)), block(512);

@@ -183,6 +183,32 @@ def test_cfg5_dense_train_step_batch_65536(gpu_ctx):
     gpu.close()
 
 
+def test_cfg5_step_with_skewed_waves_equals_the_in_phase_loops(gpu_ctx, monkeypatch):
+    """Round 4: the two long contractions of the step (fused forward, weight gradient with its extra rows) run with the
+    odd wave of every SIMD pair one k-group late.  Same MFMAs in the same order: three steps from the same state with
+    EG_GEMM_NO_SKEW=1 (every wave in phase, the round-3 loops) must leave the same bits in every parameter."""
+    torch = pytest.importorskip("torch")
+    x = torch.rand((65536, 784), device="cuda")
+    y = torch.nn.functional.one_hot(torch.randint(0, 10, (65536,), device="cuda"), 10).to(torch.float32).contiguous()
+    states = []
+    for no_skew in (False, True):
+        if no_skew:
+            monkeypatch.setenv("EG_GEMM_NO_SKEW", "1")
+        else:
+            monkeypatch.delenv("EG_GEMM_NO_SKEW", raising=False)
+        m = egm.compile(*refcases.dense_softmax_net(), gpu=gpu_ctx)
+        rng = np.random.default_rng(21)
+        for tid in m.params.ids():
+            m.params[tid] = (rng.random(m.params[tid].shape, dtype=np.float32) * 0.2 - 0.1).astype(np.float32)
+        for _ in range(3):
+            m.apply("train", [("x", x), ("y", y)])
+        gpu_ctx.sync()
+        states.append({tid: m.params[tid].copy() for tid in m.params.ids()})
+        m.close()
+    for tid in states[0]:
+        assert np.array_equal(states[0][tid], states[1][tid]), tid
+
+
 def test_cfg5_split_step_equals_whole_step(gpu_ctx):
     """The data-parallel form of the step (run_backward | exchange | run_update, here on one rank
     without a process group) at the full per-GPU batch, where the side lane is active inside the

@@ -441,3 +441,37 @@ def test_tall_products_with_a_few_columns(gpu_ctx, case):
         want = want + bv
     assert rel_err(outs[0], want) <= TOL
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("mode", ["nn", "nt", "tn", "tt"])
+def test_skewed_and_deep_k_loops_equal_the_in_phase_loop_bit_for_bit(gpu_ctx, monkeypatch, mode):
+    """Round 4: the odd wave of every SIMD pair runs one k-group late, and long whole-tile products use 32-deep k-tiles —
+    same MFMAs on the same accumulators in the same k order.  4096 x 4096 x 2048 (256 x 256 tiles) in the four layouts, with
+    a bias and onto an existing C: the default, EG_GEMM_NO_SKEW=1 and EG_GEMM_NO_BK32=1 must agree to the bit, and the
+    result with a float64 product on sampled rows."""
+    M = N = 4096
+    K = 2048
+    ta, tb = mode[0] == "t", mode[1] == "t"
+    rng = np.random.default_rng(11)
+    a = (rng.random((K, M) if ta else (M, K), dtype=np.float32) - 0.5).astype(np.float32)
+    b = (rng.random((N, K) if tb else (K, N), dtype=np.float32) - 0.5).astype(np.float32)
+    bias = rng.random((N,), dtype=np.float32)
+    base = rng.random((M, N), dtype=np.float32)
+    da, db, dbias = dev(gpu_ctx, a), dev(gpu_ctx, b), dev(gpu_ctx, bias)
+    dc = gpu_ctx.allocTensor((M, N))
+    outs = []
+    for env in ({}, {"EG_GEMM_NO_SKEW": "1"}, {"EG_GEMM_NO_BK32": "1"}, {"EG_GEMM_NO_SKEW": "1", "EG_GEMM_NO_BK32": "1"}):
+        for k in ("EG_GEMM_NO_SKEW", "EG_GEMM_NO_BK32"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dc.write(base)
+        ops.sgemm(gpu_ctx, M, N, K, da, a.shape[1], db, b.shape[1], dc, N, trans_a=ta, trans_b=tb, accumulate=True, bias=dbias)
+        outs.append(dc.read())
+    for other in outs[1:]:
+        assert np.array_equal(outs[0], other)
+    rows = np.sort(rng.choice(M, size=16, replace=False))
+    a64 = (a.T if ta else a).astype(np.float64)[rows]
+    b64 = (b.T if tb else b).astype(np.float64)
+    want = base[rows].astype(np.float64) + a64 @ b64 + bias.astype(np.float64)
+    assert rel_err(outs[0][rows], want) <= TOL
