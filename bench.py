@@ -120,6 +120,18 @@ EVENTS_NOTE = ("kernel_ms_avg = one HIP event pair around the K timed steps / K,
                "kernel_ms_min = shortest step of a second, untimed pass of K steps with an event pair each")
 
 
+def clock_fields(telemetry, achieved_tflops):
+    """`frac` prices against the 2.4 GHz peak; a box that is power-limited runs the step at a lower shader clock (the dense
+    step has been seen at 1.95 - 2.35 GHz mean on different boxes).  When the hwmon files are readable the roofline also
+    says what fraction of the matrix peak AT THE CLOCK THE TIMED STEPS RAN AT the kernel reached (64 FLOP / clk / SIMD x
+    1024 SIMDs x mean sclk)."""
+    t = (telemetry or {}).get("sclk_mhz_timed")
+    if not t or not t.get("mean"):
+        return {}
+    peak = 64 * 1024 * t["mean"] * 1e6 / 1e12
+    return {"sclk_mhz_timed_mean": t["mean"], "peak_at_clock": round(peak, 1), "frac_at_clock": round(achieved_tflops / peak, 4)}
+
+
 class Telemetry:
     """Shader clock, memory clock, socket power and temperatures of THIS GPU while a workload runs, read from the
     amdgpu hwmon files of its PCI device (no tool is spawned, nothing touches the device): the same binary ran the dense
@@ -140,7 +152,11 @@ class Telemetry:
             self.bdf = bdf
         except Exception:  # noqa: BLE001 - telemetry is optional
             self.dir = None
-        self.samples, self._stop, self._thread = [], None, None
+        self.samples, self._stop, self._thread, self._timed_from = [], None, None, None
+
+    def mark_timed(self):
+        """The samples from here on belong to the K timed steps (Timer.run calls this behind the barrier)."""
+        self._timed_from = len(self.samples)
 
     def _read(self):
         row = {}
@@ -177,6 +193,14 @@ class Telemetry:
             vals = [r[key] for r in self.samples if key in r]
             if vals:
                 out[key] = {"min": round(min(vals), 1), "mean": round(sum(vals) / len(vals), 1), "max": round(max(vals), 1)}
+        # the K timed steps alone (the last sample is taken behind the final synchronize: the device is already idle)
+        if self._timed_from is not None:
+            timed = self.samples[self._timed_from:-1]
+            for key in ("sclk_mhz", "power_w"):
+                vals = [r[key] for r in timed if key in r]
+                if vals:
+                    out[key + "_timed"] = {"samples": len(vals), "min": round(min(vals), 1),
+                                           "mean": round(sum(vals) / len(vals), 1), "max": round(max(vals), 1)}
         return out
 
 
@@ -231,6 +255,8 @@ class Timer:
         # timestamp, and a pair between every two steps holds the queue for 10 - 17 us (rocprofv3 timeline of the
         # train step: the only gap of the step; the XOR step is 25 us long).  Per-step durations (their minimum) come
         # from a second, untimed pass of K steps with an event pair each.
+        if self.telemetry:
+            self.telemetry.mark_timed()
         t0 = time.perf_counter()
         marks = []
         starts[0].record(self.stream)
@@ -451,7 +477,7 @@ def run_matmul(args, env):
                    "spinup_note": "value is a sustained-clock figure: ~0.2 s of the same launch run untimed before the W "
                                   "warmup steps (spinup_steps), because W = 5 steps of a 1 ms kernel end inside the clock ramp"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), **clock_fields(timer.last_telemetry, achieved),
                      **(traffic_fields("matmul4096") if n == 4096 else {"traffic": None}),
                      "kernel": "eg::gemm::gemm_f32_mfma_kernel<256,256,32,128,64,NN,DMA> (skewed waves, 32-deep k-tiles)", "flops_per_launch": flops,
                      "clock": "wall time of the timed steps (the clock `value` uses)",
@@ -459,6 +485,33 @@ def run_matmul(args, env):
                      "frac_by_events": round(achieved_events / F32_MFMA_PEAK_TFLOPS, 4)},
         "spinup_steps": timer.last_spin, "telemetry": timer.last_telemetry,
     }
+
+
+def run_matmul_sizes(args, env):
+    """Square products below and around the headline size through the same entry point (eg_sgemm picks tile, k-tile depth
+    and slicing per shape): what a user's own layer sizes get.  Same clock discipline as every other figure of the line
+    (Timer.run: ~0.2 s of the same launch, then W warmup steps, then the timed steps)."""
+    torch, ops, ctx, timer = env["torch"], env["ops"], env["ctx"], env["timer"]
+    steps = max(args.steps, 50)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(7)
+    rows = {}
+    for n in (512, 1024, 1536, 2048, 3072):
+        a = torch.rand((n, n), device="cuda", dtype=torch.float32, generator=gen)
+        b = torch.rand((n, n), device="cuda", dtype=torch.float32, generator=gen)
+        c = torch.empty((n, n), device="cuda", dtype=torch.float32)
+        elapsed, ev_avg, _ = timer.run(lambda: ops.sgemm(ctx, n, n, n, a, n, b, n, c, n), steps, args.warmup)
+        tflops = 2.0 * n * n * n * steps / elapsed / 1e12
+        rows[str(n)] = {"us_per_launch": round(elapsed / steps * 1e6, 2), "tflops": round(tflops, 2),
+                        "frac_of_mfma_peak": round(tflops / F32_MFMA_PEAK_TFLOPS, 4), "kernel_us_by_events": round(ev_avg * 1e3, 2)}
+    return {"metric": "TFLOP/s of C = A*B, M = N = K, float32, through eg_sgemm", "unit": "TFLOP/s", "sizes": rows,
+            "timed_steps": steps, "sustained_clock_spinup_s": SPINUP_S,
+            "roofline": {"bound": "mfma", "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "achieved": rows["1024"]["tflops"], "frac": rows["1024"]["frac_of_mfma_peak"],
+                         "kernel": "1024^3: gemm_pair_kernel<64,64,32,32,NN,64-deep k-tiles> (one block per CU, two waves per "
+                                   "sub-tile); 512^3 likewise; 1536^3 - 3072^3: gemm_f32_mfma_kernel<64,64,...>, four waves, "
+                                   "up to four blocks per CU",
+                         "traffic": None}}
 
 
 def build_dense(env, batch):
@@ -619,7 +672,7 @@ def run_train(args, env):
                    "grad_bucket_floats": model.grad_bucket("train")[1],
                    "timed_steps": args.steps, "sustained_clock_spinup_s": SPINUP_S},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), **clock_fields(telemetry, achieved),
                      **(traffic_fields("train") if batch == DENSE["batch"] else {"traffic": None}),
                      "kernel": "whole train step on one GPU (5 contractions dominate: gemm_f32_mfma_kernel)",
                      "flops_per_launch": step_flops, "clock": "wall time of the timed steps (the clock `value` uses)",
@@ -731,7 +784,7 @@ def run_conv2(args, env):
                                    f"eg_conv2_nhwc; timed steps = max(--steps, 50) = {steps}",
                        "timed_steps": steps, "sustained_clock_spinup_s": SPINUP_S},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                         "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), **clock_fields(telemetry, achieved),
                          **traffic_fields("conv2"),
                          "kernel": "conv2_halo_kernel<9,3,3> (LDS-resident 10x34 halo, 8x32 patch x 64 filters per block)", "flops_per_launch": flops,
                          "clock": "wall time of the timed steps", "kernel_ms_avg": round(ev_avg, 4),
@@ -953,6 +1006,7 @@ def main():
             guarded("xor", lambda: run_xor(small, env))
             guarded("conv2", lambda: run_conv2(small, env))
             guarded("fashion_mnist_fit", lambda: run_fashion_fit(small, env))
+            guarded("matmul_sizes", lambda: run_matmul_sizes(small, env))
             guarded("compile_latency", compile_latency)
             line["extra"] = extra
             if not args.no_cpu_baseline:
@@ -968,6 +1022,7 @@ def main():
                 baseline("xor", cpu_baseline_xor)
                 baseline("conv2", cpu_baseline_conv2)
                 baseline("fashion_mnist_fit", cpu_baseline_fit)
+                baseline("matmul_sizes", lambda: cpu_baseline_matmul(1024, budget_s=2.0))
             if "error" not in extra["train"]:
                 # the --gpus N > 1 invocations report the data-parallel train step; its 1-GPU point:
                 line["scaling_series_n1"] = {"metric": extra["train"]["metric"], "value": extra["train"]["value"],

@@ -8,7 +8,7 @@
 // The kernel itself is in gemm_f32_mfma.hpp; this file is the host-side planning:
 // tile shape, split-K, vector/edge variant, launch, deterministic second pass.
 #include "gemm_skinny.hpp"
-#include "gemm_f32_mfma.hpp"
+#include "gemm_f32_pair.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -216,7 +216,7 @@ struct WideTile {
 const WideTile kWideTiles[] = {
     {256, 256, 128, 64, 1, 3.80, 1.30, 1.30, 8.0},
     {128, 128, 64, 64, 4, 1.05, 0.70, 0.70, 8.0},
-    {64, 64, 32, 32, 4, 0.275, 0.44, 0.30, 4.5},
+    {64, 64, 32, 32, 4, 0.25, 0.44, 0.27, 4.5},   // (0.275 / 0.30 until round 4; re-measured with sustained clocks: 2048^3 131.6 us, 3072^3 432; one block per CU = the wave-pair kernel: 1024 x 1024 x 4096 73.4)
 };
 
 // Matrix time of a tile with `rows` x `cols` valid outputs relative to a whole tile.  A ragged tile skips
@@ -239,7 +239,7 @@ double ragged_tile_factor(const WideTile& t, long rows, long cols) {
   return (double)worst / (double)whole;
 }
 
-double wide_tile_time(const WideTile& t, long M, long N, long k_tiles, int cus, bool vec, int& splits_out) {
+double wide_tile_time(const WideTile& t, long M, long N, long k_tiles, int cus, bool vec, int& splits_out, bool k64 = false) {
   const long tm = (M + t.bm - 1) / t.bm, tn = (N + t.bn - 1) / t.bn;
   const long tiles = tm * tn;
   const long slots = (long)cus * t.blocks_per_cu;
@@ -274,16 +274,27 @@ double wide_tile_time(const WideTile& t, long M, long N, long k_tiles, int cus, 
     const long blocks = tiles * s;
     if (s > 1 && blocks > 2 * slots) break;  // more slices than the chip can hold at once only add slabs
     const long on_cu = (blocks + cus - 1) / cus, rounds = (blocks + slots - 1) / slots;
-    const double alone = (vec && t.bm == 64 && on_cu <= 2) ? t.alone_k32 : t.alone;
-    // the busiest CU: its blocks are a sample of the tiles, never faster than one of the slowest kind
-    double matrix = t.mfma * ((double)on_cu * mean > worst ? (double)on_cu * mean : worst);
+    // (one unsliced block per CU of whole 64 x 64 tiles with K a multiple of 64: the wave-pair kernel, 0.27; otherwise the
+    // four-wave kernel with 32-deep k-tiles, 0.30)
+    const bool pair = s == 1 && on_cu == 1 && k64 && m_rest == 0 && n_rest == 0;
+    const double alone = (vec && t.bm == 64 && on_cu <= 2) ? (pair ? t.alone_k32 : 0.30) : t.alone;
+    // the busiest CU: its blocks are a sample of the tiles, never faster than one of the slowest kind.  More blocks than
+    // slots of a tile that shares its CU four ways: the CUs pick up blocks as slots free up, so the busiest one carries
+    // the average plus about half a block, not the next whole number (2304^3 on 64 x 64 tiles, 5.06 blocks per CU:
+    // 202 us measured; "6 blocks" predicted 225 and lost to a sliced 256 x 256 launch that takes 230)
+    double load = (double)on_cu;
+    if (blocks > slots && t.blocks_per_cu >= 4) {
+      const double avg = (double)blocks / (double)cus;
+      load = blocks % cus == 0 ? avg : avg + 0.5;
+    }
+    double matrix = t.mfma * (load * mean > worst ? load * mean : worst);
     if (s > 1 && rounds == 1 && m_rest != 0 && m_rest * 2 <= t.bm && tm >= 2)  // run_gemm: ragged rows get fewer slices
       matrix = t.mfma * (double)on_cu * ((double)(tm - 1) * tn + tn * ragged_tile_share(t.bm, m_rest)) / (double)tiles;
     const double step = matrix > alone * rounds ? matrix : alone * rounds;
     double time = (double)per * step + t.fixed * rounds;
     if (s > 1) {
       const double mb = (double)M * N * 4e-6;           // one slab, MB
-      time += 3.0 + mb * (double)s / 4.0 + mb * (double)(s + 1) / 4.5;  // slabs out at ~4 TB/s, second pass at ~4.5
+      time += 4.5 + mb * (double)s / 4.0 + mb * (double)(s + 1) / 4.5;  // second launch (3.0 until round 4: 384^3 and 512^3 sliced 11.0 / 13.1 us, unsliced 9.7 / 11.9) + slabs out at ~4 TB/s, second pass at ~4.5
     }
     if (best == 0 || time < best) {
       best = time;
@@ -304,7 +315,7 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
     double best = 0;
     for (const WideTile& t : kWideTiles) {
       int sp;
-      const double time = wide_tile_time(t, M, N, k_tiles, ctx->compute_units, vec, sp);
+      const double time = wide_tile_time(t, M, N, k_tiles, ctx->compute_units, vec, sp, K % 64 == 0);
       if (debug_tile) fprintf(stderr, "[eg] tile model %ld x %ld x %ld: %d x %d, %d slices: %.1f us\n", M, N, K, t.bm, t.bn, sp, time);
       if (best == 0 || time < best * 0.97) {  // larger tiles listed first: a smaller one has to win by 3 %
         best = time;
@@ -506,8 +517,10 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   // 64 x 64 tiles with at most two blocks per CU are bound by the LDS-DMA round trip of the next k-tile, not
   // by matrix work: 32-deep k-tiles halve the round trips (1024^3: 28.1 -> 23.9 us; four blocks per CU hide
   // it by themselves: 2048^3 142.5 vs 146.5 us).  EG_GEMM_SMALL_BK16=1: 16.
+  // Round 4, sustained clocks: 32 also wins with up to four blocks per CU (1536^3 81.4 -> 77.0 us, 1792^3 120.8 -> 114.4,
+  // 2048^3 137.9 -> 131.6); beyond that the two are equal within 1 % (2304^3 202 / 206, 3072^3 432 / 439): 16 stays there.
   if (!conv && BM == 64 && BN == 64 && vec_ok && K >= 256 && getenv("EG_GEMM_SMALL_BK16") == nullptr &&
-      (M + 63) / 64 * ((N + 63) / 64) * splits <= 2L * ctx->compute_units)
+      (M + 63) / 64 * ((N + 63) / 64) * splits <= 4L * ctx->compute_units)
     KB = 32;
   if (getenv("EG_GEMM_SMALL_BK32") != nullptr && !conv && BM == 64 && BN == 64 && vec_ok && K >= 256) KB = 32;  // tuning aid
   const long k_tiles = (K + KB - 1) / KB;
@@ -612,6 +625,25 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     else if (!a_kc && !b_kc) EG_BK32(false, false);
     else EG_BK32(false, true);
 #undef EG_BK32
+    EG_HIP_CHECK(hipGetLastError());
+    return EG_OK;
+  }
+  // Wave pairs (gemm_f32_pair.hpp): whole 64 x 64 tiles of an unsliced product with at most one block per CU — one wave
+  // per SIMD on the four-wave kernel, where a k-tile costs 1.36x its matrix time (barrier + fragment reads, measured with
+  // the loads removed).  Two waves per sub-tile split every 64-deep k-tile, the odd one a k-group late: 1024^3 22.1 ->
+  // 20.9 us (NN / NT), 23.1 -> 19.8 (TN), 512^3 12.3 -> 11.6.  With two or more blocks per CU the four-wave kernel is
+  // as fast or faster (1536^3, 3072^3), so those keep it.  Not bit-identical to it (two f32 chains per element instead
+  // of one); EG_GEMM_NO_PAIR=1 (read per call) keeps the four-wave kernel.
+  const bool pair_on = getenv("EG_GEMM_NO_PAIR") == nullptr;
+  if (pair_on && BM == 64 && BN == 64 && !edge && !conv && splits <= 1 && args.tail_tiles == 0 && args.edge_splits == 0 &&
+      K % 64 == 0 && args.wide_store && !args.ones_row && (long)args.tiles_m * args.tiles_n <= ctx->compute_units) {
+    dim3 grid((unsigned)((long)args.tiles_m * args.tiles_n)), block(512);
+#define EG_PAIR(AKC, BKC) hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 32, 32, AKC, BKC, 0, 2, 64>), grid, block, 0, ctx->stream, args)
+    if (a_kc && !b_kc) EG_PAIR(true, false);
+    else if (a_kc && b_kc) EG_PAIR(true, true);
+    else if (!a_kc && !b_kc) EG_PAIR(false, false);
+    else EG_PAIR(false, true);
+#undef EG_PAIR
     EG_HIP_CHECK(hipGetLastError());
     return EG_OK;
   }

@@ -495,7 +495,7 @@ struct DmaLoader {
   mutable int pix_x[PER_WAVE], pix_y[PER_WAVE];
   mutable long pix_next = -1;
 
-  __device__ __forceinline__ static int swizzle(int r) { return BK == 16 ? (r >> 2) & 3 : (r >> 1) & 7; }
+  __device__ __forceinline__ static int swizzle(int r) { return BK == 16 ? (r >> 2) & 3 : BK == 32 ? (r >> 1) & 7 : r & 15; }
 
   __device__ __forceinline__ void init(const GemmArgs& a, long mn0, int wave, int lane, long limit = 0, long ld = 0,
                                        bool ones = false) {

@@ -475,3 +475,47 @@ def test_skewed_and_deep_k_loops_equal_the_in_phase_loop_bit_for_bit(gpu_ctx, mo
     b64 = (b.T if tb else b).astype(np.float64)
     want = base[rows].astype(np.float64) + a64 @ b64 + bias.astype(np.float64)
     assert rel_err(outs[0][rows], want) <= TOL
+
+
+@pytest.mark.parametrize("mode", ["nn", "nt", "tn", "tt"])
+@pytest.mark.parametrize("shape", [(1024, 1024, 1024), (512, 768, 320), (64, 64, 256), (1024, 960, 128)])
+def test_wave_pair_kernel_against_the_exact_product_and_the_four_wave_kernel(gpu_ctx, monkeypatch, mode, shape):
+    """Round 4 (kernels/gemm_f32_pair.hpp): whole 64 x 64 tiles with at most one block per CU run two waves per sub-tile
+    that split every 64-deep k-tile.  Four layouts, a bias, onto an existing C; the odd wave's skew changes nothing
+    (EG_GEMM_NO_SKEW=1: bit-identical); against the four-wave kernel (EG_GEMM_NO_PAIR=1) the result differs by rounding
+    only — an element is the sum of two f32 chains instead of one — and both meet the float64 product of the operands."""
+    M, N, K = shape
+    ta, tb = mode[0] == "t", mode[1] == "t"
+    rng = np.random.default_rng(M + N + K)
+    a = (rng.random((K, M) if ta else (M, K), dtype=np.float32) - 0.5).astype(np.float32)
+    b = (rng.random((N, K) if tb else (K, N), dtype=np.float32) - 0.5).astype(np.float32)
+    bias = rng.random((N,), dtype=np.float32)
+    base = rng.random((M, N), dtype=np.float32)
+    da, db, dbias = dev(gpu_ctx, a), dev(gpu_ctx, b), dev(gpu_ctx, bias)
+    dc = gpu_ctx.allocTensor((M, N))
+    outs = []
+    for env in ({}, {"EG_GEMM_NO_SKEW": "1"}, {"EG_GEMM_NO_PAIR": "1"}):
+        for k in ("EG_GEMM_NO_SKEW", "EG_GEMM_NO_PAIR"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        dc.write(base)
+        ops.sgemm(gpu_ctx, M, N, K, da, a.shape[1], db, b.shape[1], dc, N, trans_a=ta, trans_b=tb, accumulate=True, bias=dbias)
+        outs.append(dc.read())
+    assert np.array_equal(outs[0], outs[1])
+    want = base.astype(np.float64) + (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64) + bias
+    assert rel_err(outs[0], want) <= TOL
+    assert rel_err(outs[2], want) <= TOL
+    assert rel_err(outs[0], outs[2].astype(np.float64)) <= 5e-6
+
+
+def test_wave_pair_kernel_without_accumulation_and_bias(gpu_ctx):
+    """C = A * B on the pair kernel: C starts as NaN, so a chunk the row walk skipped would show."""
+    M, N, K = 512, 512, 512
+    rng = np.random.default_rng(5)
+    a = (rng.random((M, K), dtype=np.float32) - 0.5).astype(np.float32)
+    b = (rng.random((K, N), dtype=np.float32) - 0.5).astype(np.float32)
+    dc = gpu_ctx.allocTensor((M, N))
+    dc.write(np.full((M, N), np.nan, dtype=np.float32))
+    ops.sgemm(gpu_ctx, M, N, K, dev(gpu_ctx, a), K, dev(gpu_ctx, b), N, dc, N)
+    assert rel_err(dc.read(), a.astype(np.float64) @ b.astype(np.float64)) <= TOL

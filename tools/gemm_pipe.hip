@@ -8,8 +8,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <ctime>
 
-#include "../exprgrad_amd/csrc/kernels/gemm_f32_mfma.hpp"
+#include "../exprgrad_amd/csrc/kernels/gemm_f32_pair.hpp"
 
 using namespace eg::gemm;
 
@@ -34,6 +35,11 @@ void launch(const GemmArgs& a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, MINB, AKC, BKC, 4, false, 0, ABL, true>), grid, dim3(NT), 0, s, a);
 }
 
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int ABL, int ST = 3, int KB = 32>
+void launch_pair(const GemmArgs& a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_pair_kernel<BM, BN, WM, WN, AKC, BKC, ABL, ST, KB>), grid, dim3(PairGeometry<BM, BN, WM, WN, ST, KB>::NT), 0, s, a);
+}
+
 template <bool AKC, bool BKC>
 std::vector<Variant> variants() {
   return {
@@ -53,6 +59,27 @@ std::vector<Variant> variants() {
       {"128x128x16 straight ", 128, 128, 16, launch<128, 128, 16, 64, 64, 4, AKC, BKC, 0>},
       {"64x64x32   pipelined", 64, 64, 32, launch<64, 64, 32, 32, 32, 4, AKC, BKC, 64>},
       {"64x64x32   straight ", 64, 64, 32, launch<64, 64, 32, 32, 32, 4, AKC, BKC, 0>},
+      {"64x64 pair skewed   ", 64, 64, 32, launch_pair<64, 64, 32, 32, AKC, BKC, 0>},
+      {"64x64 pair in phase ", 64, 64, 32, launch_pair<64, 64, 32, 32, AKC, BKC, 256>},
+      {"64x64 pair loads only", 64, 64, 32, launch_pair<64, 64, 32, 32, AKC, BKC, 257>},
+      {"64x64 pair mfma only ", 64, 64, 32, launch_pair<64, 64, 32, 32, AKC, BKC, 258>},
+      {"64x64 pair mfma nobar", 64, 64, 32, launch_pair<64, 64, 32, 32, AKC, BKC, 262>},
+      {"64x64 pair mfma noread", 64, 64, 32, launch_pair<64, 64, 32, 32, AKC, BKC, 266>},
+      {"64x64 pair mfma bare ", 64, 64, 32, launch_pair<64, 64, 32, 32, AKC, BKC, 270>},
+      {"64x64 pair 2st bk64  ", 64, 64, 64, launch_pair<64, 64, 32, 32, AKC, BKC, 0, 2, 64>},
+      {"64x64 pair 2st bk64 i", 64, 64, 64, launch_pair<64, 64, 32, 32, AKC, BKC, 256, 2, 64>},
+      {"64x64 pair 3st bk64  ", 64, 64, 64, launch_pair<64, 64, 32, 32, AKC, BKC, 0, 3, 64>},
+      {"64x64 pair 2st bk128 ", 64, 64, 128, launch_pair<64, 64, 32, 32, AKC, BKC, 0, 2, 128>},
+      {"128x128 pair 2st bk64", 128, 128, 64, launch_pair<128, 128, 64, 64, AKC, BKC, 0, 2, 64>},
+      {"128x64 pair 2st bk64 ", 128, 64, 64, launch_pair<128, 64, 64, 32, AKC, BKC, 0, 2, 64>},
+      {"64x64 pair 2 stages  ", 64, 64, 32, launch_pair<64, 64, 32, 32, AKC, BKC, 0, 2>},
+      {"64x64 pair 2st loads ", 64, 64, 32, launch_pair<64, 64, 32, 32, AKC, BKC, 257, 2>},
+      {"64x64 pair 5 stages  ", 64, 64, 32, launch_pair<64, 64, 32, 32, AKC, BKC, 0, 5>},
+      {"64x64 pair 5st loads ", 64, 64, 32, launch_pair<64, 64, 32, 32, AKC, BKC, 257, 5>},
+      {"128x128 pair skewed ", 128, 128, 32, launch_pair<128, 128, 64, 64, AKC, BKC, 0>},
+      {"128x128 pair in phas", 128, 128, 32, launch_pair<128, 128, 64, 64, AKC, BKC, 256>},
+      {"128x64 pair skewed  ", 128, 64, 32, launch_pair<128, 64, 64, 32, AKC, BKC, 0>},
+      {"128x64 pair in phase", 128, 64, 32, launch_pair<128, 64, 64, 32, AKC, BKC, 256>},
   };
 }
 
@@ -104,6 +131,16 @@ int main(int argc, char** argv) {
         continue;
       }
       for (int i = 0; i < 3; ++i) v.launch(a, grid, s);
+      if (getenv("SPIN_MS")) {  // sustained clocks: keep the device busy with this launch for SPIN_MS first
+        const double spin = atof(getenv("SPIN_MS")) * 1e-3;
+        timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        do {
+          for (int i = 0; i < 50; ++i) v.launch(a, grid, s);
+          CHECK(hipStreamSynchronize(s));
+          clock_gettime(CLOCK_MONOTONIC, &t1);
+        } while ((t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9 < spin);
+      }
       CHECK(hipEventRecord(e0, s));
       for (int i = 0; i < per; ++i) v.launch(a, grid, s);
       CHECK(hipEventRecord(e1, s));
@@ -125,8 +162,15 @@ int main(int argc, char** argv) {
     if (out[vi].empty()) continue;
     const size_t other = vi ^ 1;
     const bool same = other < out.size() && !out[other].empty() && out[other].size() == out[vi].size() && memcmp(out[vi].data(), out[other].data(), out[vi].size() * 4) == 0;
-    printf("  %s  %9.1f us  %7.2f TFLOP/s   %s\n", vs[vi].name, best[vi] * 1e3, 2.0 * M * N * K / best[vi] / 1e9,
-           same ? "bit-identical to its twin" : "DIFFERS from its twin");
+    size_t ref = 0;
+    while (out[ref].empty()) ++ref;
+    double dmax = 0, scale = 0;
+    for (size_t e = 0; e < out[vi].size(); ++e) {
+      dmax = std::max(dmax, (double)std::abs(out[vi][e] - out[ref][e]));
+      scale = std::max(scale, (double)std::abs(out[ref][e]));
+    }
+    printf("  %s  %9.1f us  %7.2f TFLOP/s   %s   vs first variant %.1e\n", vs[vi].name, best[vi] * 1e3, 2.0 * M * N * K / best[vi] / 1e9,
+           same ? "bit-identical to its twin" : "DIFFERS from its twin", dmax / scale);
   }
   return 0;
 }

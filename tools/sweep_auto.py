@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """The library's own tile choice over a list of shapes, old cost model beside the new one is a matter of
-running it twice (EG_GEMM_OLD_TILE_MODEL=1): tools/sweep_auto.py [nn|tn|nt] MxNxK ..."""
+running it twice (EG_GEMM_OLD_TILE_MODEL=1): [SPIN_MS=100] tools/sweep_auto.py [nn|tn|nt] MxNxK ..."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
@@ -19,6 +19,13 @@ for spec in sys.argv[2:]:
     run = lambda: ops.sgemm(ctx, M, N, K, A, A.shape[1], B, B.shape[1], C, N, trans_a=ta, trans_b=tb)
     for _ in range(3):
         run()
+    if os.environ.get("SPIN_MS"):  # sustained clocks: keep the device busy with this launch first (bench.py does the same)
+        import time
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < float(os.environ["SPIN_MS"]) * 1e-3:
+            for _ in range(50):
+                run()
+            torch.cuda.synchronize()
     best = 1e9
     for rep in range(4):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
