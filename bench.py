@@ -121,15 +121,14 @@ EVENTS_NOTE = ("kernel_ms_avg = one HIP event pair around the K timed steps / K,
 
 
 def clock_fields(telemetry, achieved_tflops):
-    """`frac` prices against the 2.4 GHz peak; a box that is power-limited runs the step at a lower shader clock (the dense
-    step has been seen at 1.95 - 2.35 GHz mean on different boxes).  When the hwmon files are readable the roofline also
-    says what fraction of the matrix peak AT THE CLOCK THE TIMED STEPS RAN AT the kernel reached (64 FLOP / clk / SIMD x
-    1024 SIMDs x mean sclk)."""
+    """The shader clock hwmon showed during the timed steps, next to the fraction.  It is a sampled reading (10 ms period,
+    a handful of samples per timed region), not the effective clock of the kernel: dividing the achieved rate by a peak
+    scaled with it gave 1.09 for the 4096^3 product on one box, so no clock-scaled fraction is derived from it; the
+    reading is reported as it is (a power-limited box shows 1.95 - 2.35 GHz mean under the dense step)."""
     t = (telemetry or {}).get("sclk_mhz_timed")
     if not t or not t.get("mean"):
         return {}
-    peak = 64 * 1024 * t["mean"] * 1e6 / 1e12
-    return {"sclk_mhz_timed_mean": t["mean"], "peak_at_clock": round(peak, 1), "frac_at_clock": round(achieved_tflops / peak, 4)}
+    return {"sclk_mhz_timed_mean": t["mean"]}
 
 
 class Telemetry:
