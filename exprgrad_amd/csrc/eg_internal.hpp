@@ -141,6 +141,15 @@ int conv2_direct_grad_filter_try(eg_ctx* ctx, long N, long H, long W, long C, lo
 // kernels/conv2_gradf_halo.hip: the filter gradient of a 3 x 3 convolution with the halo in LDS (C, F multiples of 32)
 int conv2_gradf_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img, const float* gout,
                          float* gflt, int accumulate, bool* launched);
+// kernels/conv2_tiny.hip: conv2 and its gradients for problems of a few million multiply-adds (*launched says whether it ran)
+int conv2_tiny_forward_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
+                           const float* flt, float* out, int accumulate, bool* launched);
+int conv2_tiny_grad_image_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* flt,
+                              const float* gout, float* gimg, int accumulate, bool* launched);
+int conv2_tiny_grad_filter_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
+                               const float* gout, float* gflt, int accumulate, bool* launched);
+bool conv2_halo_suits(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, long py, long px, const float* img,
+                      bool flt_aligned);
 int conv2_halo_try_padded(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, long py, long px,
                           const float* img, const float* flt, float* out, int accumulate, bool* launched);
 int conv2_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,

@@ -306,22 +306,33 @@ int conv2_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH,
   return conv2_halo_try_padded(ctx, N, H, W, C, F, FH, FW, 0, 0, img, flt, out, accumulate, launched);
 }
 
-int conv2_halo_try_padded(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, long py, long px,
-                          const float* img, const float* flt, float* out, int accumulate, bool* launched) {
-  *launched = false;
+// Whether conv2_halo_try_padded would launch for this problem (the image-gradient route asks before it prepares the
+// flipped filter bank: a batch-32 `fit` step paid a 2 us launch for a bank the declining halo kernel never read).
+// flt_aligned: the filter bank the caller will pass is 16-byte aligned.
+bool conv2_halo_suits(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, long py, long px, const float* img,
+                      bool flt_aligned) {
   static const bool off = [] {
     const char* e = getenv("EG_CONV_NO_HALO");
     return e && e[0] && e[0] != '0';
   }();
-  if (off) return EG_OK;
+  if (off) return false;
   const long Ho = H + 2 * py - FH + 1, Wo = W + 2 * px - FW + 1;
-  if (FH > 3 || FW > 3 || C % CK != 0 || C < CK || Ho <= 0 || Wo <= 0) return EG_OK;
-  if ((reinterpret_cast<uintptr_t>(img) & 15) || (reinterpret_cast<uintptr_t>(flt) & 15)) return EG_OK;
+  if (FH > 3 || FW > 3 || C % CK != 0 || C < CK || Ho <= 0 || Wo <= 0) return false;
+  if ((reinterpret_cast<uintptr_t>(img) & 15) || !flt_aligned) return false;
   const long tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH, tiles_f = (F + FB - 1) / FB;
   const long blocks = N * tiles_y * tiles_x * tiles_f;
   // worth it when the patches are reasonably full and the chip is busy
   const double fill = (double)(Ho * Wo) / (double)(tiles_y * TH * tiles_x * TW) * (double)F / (double)(tiles_f * FB);
-  if (fill < 0.7 || blocks < ctx->compute_units / 2 || blocks > (1L << 30)) return EG_OK;
+  return !(fill < 0.7 || blocks < ctx->compute_units / 2 || blocks > (1L << 30));
+}
+
+int conv2_halo_try_padded(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, long py, long px,
+                          const float* img, const float* flt, float* out, int accumulate, bool* launched) {
+  *launched = false;
+  if (!conv2_halo_suits(ctx, N, H, W, C, F, FH, FW, py, px, img, (reinterpret_cast<uintptr_t>(flt) & 15) == 0)) return EG_OK;
+  const long Ho = H + 2 * py - FH + 1, Wo = W + 2 * px - FW + 1;
+  const long tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH, tiles_f = (F + FB - 1) / FB;
+  const long blocks = N * tiles_y * tiles_x * tiles_f;
   HaloArgs a = {};
   a.img = img;
   a.flt = flt;

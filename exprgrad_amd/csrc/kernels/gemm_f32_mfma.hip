@@ -865,6 +865,11 @@ extern "C" int eg_conv2_nhwc(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64
   if (rc) return rc;
   if (FH == 1 && FW == 1 && C > 0)  // a 1x1 filter bank is a plain contraction over the channels: out[P,F] = img[P,C] * flt[F,C]^T
     return eg_sgemm(ctx, 0, 1, N * H * W, F, C, img, C, flt, C, out, F, accumulate, nullptr);
+  if (C > 0) {  // a few million multiply-adds in all (a batch-32 step of a small network): one thread per output element
+    bool launched = false;
+    rc = eg::conv2_tiny_forward_try(ctx, N, H, W, C, F, FH, FW, img, flt, out, accumulate, &launched);
+    if (rc || launched) return rc;
+  }
   if (C > 0 && C <= 16) {  // few channels (an image network's first layers): per-pixel kernel specialised for the filter geometry
     bool launched = false;
     rc = eg::conv2_direct_try(ctx, N, H, W, C, F, FH, FW, img, flt, out, accumulate, &launched);
@@ -975,6 +980,11 @@ extern "C" int eg_conv2_nhwc_grad_filter(eg_ctx* ctx, int64_t N, int64_t H, int6
   EG_REQUIRE(img && gout, EG_ERR_INVALID, "eg_conv2_nhwc_grad_filter: NULL tensor");
   if (FH == 1 && FW == 1)  // plain contraction: gflt[F,C] = gout[P,F]^T * img[P,C]
     return eg_sgemm(ctx, 1, 0, F, C, P, gout, F, img, C, gflt, C, accumulate, nullptr);
+  {  // a few million multiply-adds in all: blocks of pixels, every output element per block, slabs folded in a fixed order
+    bool launched = false;
+    rc = eg::conv2_tiny_grad_filter_try(ctx, N, H, W, C, F, FH, FW, img, gout, gflt, accumulate, &launched);
+    if (rc || launched) return rc;
+  }
   if (C <= 4) {
     bool launched = false;
     rc = eg::conv2_direct_grad_filter_try(ctx, N, H, W, C, F, FH, FW, img, gout, gflt, accumulate, &launched);
@@ -1032,6 +1042,11 @@ extern "C" int eg_conv2_nhwc_grad_image(eg_ctx* ctx, int64_t N, int64_t H, int64
   EG_REQUIRE(flt && gout, EG_ERR_INVALID, "eg_conv2_nhwc_grad_image: NULL tensor");
   if (FH == 1 && FW == 1)  // plain contraction: gimg[P,C] = gout[P,F] * flt[F,C]
     return eg_sgemm(ctx, 0, 0, N * H * W, C, F, gout, F, flt, C, gimg, C, accumulate, nullptr);
+  {  // a few million multiply-adds in all: one thread per image element, no flipped bank, no padded gradient
+    bool launched = false;
+    rc = eg::conv2_tiny_grad_image_try(ctx, N, H, W, C, F, FH, FW, flt, gout, gimg, accumulate, &launched);
+    if (rc || launched) return rc;
+  }
   const long Hp = Ho + 2 * (FH - 1), Wp = Wo + 2 * (FW - 1);
   const size_t flt_floats = (size_t)(C * FH * FW * F);
   EG_REQUIRE(flt_floats < (1UL << 32), EG_ERR_INVALID, "eg_conv2_nhwc_grad_image: filter bank exceeds 2^32 elements");
@@ -1039,7 +1054,8 @@ extern "C" int eg_conv2_nhwc_grad_image(eg_ctx* ctx, int64_t N, int64_t H, int64
   // prepared — no padded copy of the gradient is written and read back (cfg 4: 2 x 17 MB, 8 -> 3 us of preparation).
   // EG_CONV_NO_VIRTUAL_PAD=1: the padded copy of rounds 1 and 2.
   const bool virtual_pad = getenv("EG_CONV_NO_VIRTUAL_PAD") == nullptr;  // (read per call: a test compares the two routes)
-  if (virtual_pad && FH <= 3 && FW <= 3 && F % 16 == 0 && aligned16(gout)) {
+  if (virtual_pad && FH <= 3 && FW <= 3 && F % 16 == 0 && aligned16(gout) &&
+      eg::conv2_halo_suits(ctx, N, Ho, Wo, F, C, FH, FW, FH - 1, FW - 1, gout, true)) {   // (the bank goes to ctx->aux: aligned)
     rc = eg::ensure_aux(ctx, flt_floats * sizeof(float));
     if (rc) return rc;
     float* flipped_only = static_cast<float*>(ctx->aux);

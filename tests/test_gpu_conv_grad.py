@@ -247,3 +247,81 @@ def test_image_gradient_with_virtual_padding(gpu_ctx, refcpu, monkeypatch, shape
     monkeypatch.setenv("EG_CONV_NO_VIRTUAL_PAD", "1")
     ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dg, gimg)
     assert np.array_equal(gimg.read(), got)
+
+
+TINY_SHAPES = [  # N, H, W, C, F, FH, FW: a few million multiply-adds in all -> kernels/conv2_tiny.hip
+    (32, 28, 28, 1, 8, 5, 5),     # fashion_mnist, first layer at the reference's batch (fashion_mnist.nim:39-57)
+    (32, 12, 12, 8, 16, 3, 3),    # ... second layer
+    (5, 9, 11, 3, 7, 2, 4),       # nothing a multiple of anything
+    (1, 3, 3, 2, 4, 3, 3),        # one output pixel
+    (2, 6, 5, 4, 12, 1, 3),       # one filter row
+    (64, 12, 12, 8, 16, 3, 3),    # 7.4 M multiply-adds: past the limit, the contraction route (both settings the same)
+    (3, 10, 10, 16, 96, 3, 3),    # 13 824 filter-gradient outputs: more than the tiny kernel's eight per thread -> contraction route for that one
+]
+
+
+@pytest.mark.parametrize("shape", TINY_SHAPES)
+def test_tiny_convolutions_against_the_oracle_and_the_contraction_route(gpu_ctx, refcpu, monkeypatch, shape):
+    """Round 4: conv2 and both gradients of problems of a few million multiply-adds run as one thread per output element
+    (filter gradient: blocks of pixels + the fixed-order slab sum).  Against the oracle's loop nests, against the
+    contraction route (EG_CONV_NO_TINY=1), onto existing values, and twice for run-to-run identity."""
+    N, H, W, C, F, FH, FW = shape
+    Ho, Wo = H - FH + 1, W - FW + 1
+    rng = np.random.default_rng(sum(shape))
+    img = rng.random((N, H, W, C), dtype=np.float32)
+    flt = (rng.random((F, FH, FW, C), dtype=np.float32) * 2 - 1).astype(np.float32)
+    gout = (rng.random((N, Ho, Wo, F), dtype=np.float32) - 0.5).astype(np.float32)
+    dimg, dflt, dg = dev(gpu_ctx, img), dev(gpu_ctx, flt), dev(gpu_ctx, gout)
+    base_out = rng.random((N, Ho, Wo, F), dtype=np.float32)
+    base_flt = rng.random(flt.shape, dtype=np.float32)
+    base_img = rng.random(img.shape, dtype=np.float32)
+    want = {
+        "out": refcpu.conv2_nhwc(img, flt), "out+": refcpu.conv2_nhwc(img, flt, out=base_out.copy()),
+        "gflt": refcpu.conv2_nhwc_grad_filter(img, gout, flt.shape),
+        "gflt+": refcpu.conv2_nhwc_grad_filter(img, gout, flt.shape, out=base_flt.copy()),
+        "gimg": refcpu.conv2_nhwc_grad_image(flt, gout, img.shape),
+        "gimg+": refcpu.conv2_nhwc_grad_image(flt, gout, img.shape, out=base_img.copy()),
+    }
+
+    def run():
+        got = {}
+        out = gpu_ctx.allocTensor(base_out.shape)
+        out.write(np.full(base_out.shape, np.nan, dtype=np.float32))        # must be overwritten
+        ops.conv2_nhwc(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dflt, out)
+        got["out"] = out.read()
+        out.write(base_out)
+        ops.conv2_nhwc(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dflt, out, accumulate=True)
+        got["out+"] = out.read()
+        gflt = gpu_ctx.allocTensor(flt.shape)
+        gflt.write(np.full(flt.shape, np.nan, dtype=np.float32))
+        ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dg, gflt)
+        got["gflt"] = gflt.read()
+        gflt.write(base_flt)
+        ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dg, gflt, accumulate=True)
+        got["gflt+"] = gflt.read()
+        gimg = gpu_ctx.allocTensor(img.shape)
+        gimg.write(np.full(img.shape, np.nan, dtype=np.float32))
+        ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dg, gimg)
+        got["gimg"] = gimg.read()
+        gimg.write(base_img)
+        ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dg, gimg, accumulate=True)
+        got["gimg+"] = gimg.read()
+        return got
+
+    monkeypatch.delenv("EG_CONV_NO_TINY", raising=False)
+    tiny, again = run(), run()
+    monkeypatch.setenv("EG_CONV_NO_TINY", "1")
+    other = run()
+    for key, ref in want.items():
+        assert rel_err(tiny[key], ref) <= TOL, key
+        assert rel_err(other[key], ref) <= TOL, key
+        assert np.array_equal(tiny[key], again[key]), key
+        assert rel_err(tiny[key], other[key].astype(np.float64)) <= TOL, key
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv2_gradients_on_the_contraction_route(gpu_ctx, refcpu, monkeypatch, shape):
+    """The shapes of test_conv2_gradients_against_the_oracle are small enough for kernels/conv2_tiny.hip now; the
+    contraction / halo / per-pixel routes they used to exercise stay covered with EG_CONV_NO_TINY=1."""
+    monkeypatch.setenv("EG_CONV_NO_TINY", "1")
+    test_conv2_gradients_against_the_oracle(gpu_ctx, refcpu, shape)
