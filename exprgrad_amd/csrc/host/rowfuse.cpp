@@ -269,7 +269,15 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
     sig += gt.role == RowGroupTensor::RowLocal ? ", float* t" : ", const float* __restrict__ t";
     sig += std::to_string(t);
   }
-  sig += ", long B, float GS, long EP)";
+  sig += ", long B, float GS, long EP";
+  // One block (a batch of at most 256 rows): the totals go straight to their destinations.  In a captured graph a
+  // dependent launch costs ~4.5 us whatever it does, and row_finalize of one partial row does nothing but copy
+  // (p + 0 + 0 + 0 in its tree: the same value).
+  g.single_block = g.B <= 256 && g.red_total > 0 && getenv("EG_NO_ROW_DIRECT") == nullptr;
+  if (g.single_block)
+    for (auto& kv : g.tensors)
+      if (kv.second.role == RowGroupTensor::Reduction) sig += ", float* d" + std::to_string(kv.first);
+  sig += ")";
 
   std::string& c = em.code;
   c += "  const long y = (long)blockIdx.x * 256 + threadIdx.x;\n  const bool active = y < B;\n";
@@ -311,9 +319,21 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
       c += "    if (lane == 0) red[wave * " + E + " + " + std::to_string(t.red_offset) + " + j] = v;\n  }\n";
     }
     c += "  __syncthreads();\n";
-    c += "  for (int e = threadIdx.x; e < " + E + "; e += 256)\n";
-    c += "    partial[(long)blockIdx.x * " + E + " + e] = (red[e] + red[" + E + " + e]) + (red[2 * " + E + " + e] + red[3 * " +
-         E + " + e]);\n";
+    if (g.single_block) {
+      for (auto& kv : g.tensors) {
+        const RowGroupTensor& t = kv.second;
+        if (t.role != RowGroupTensor::Reduction) continue;
+        const std::string id = std::to_string(kv.first), off = std::to_string(t.red_offset);
+        c += "  for (int j = threadIdx.x; j < " + std::to_string(t.inner) + "; j += 256) {\n";
+        c += "    const int e = " + off + " + j;\n";
+        c += "    const float s = (red[e] + red[" + E + " + e]) + (red[2 * " + E + " + e] + red[3 * " + E + " + e]);\n";
+        c += std::string("    d") + id + "[j] = " + (t.accumulate ? "d" + id + "[j] + s" : std::string("s")) + ";\n  }\n";
+      }
+    } else {
+      c += "  for (int e = threadIdx.x; e < " + E + "; e += 256)\n";
+      c += "    partial[(long)blockIdx.x * " + E + " + e] = (red[e] + red[" + E + " + e]) + (red[2 * " + E + " + e] + red[3 * " +
+           E + " + e]);\n";
+    }
   }
   g.source = sig + " {\n" + c + "}\n";
   return EG_OK;

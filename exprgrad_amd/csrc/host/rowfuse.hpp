@@ -59,10 +59,13 @@ struct RowGroup {
   long red_total = 0;  // partial row length
   std::string name, source;
   std::vector<int> ptr_args;  // tensor ids in pointer-argument order (after `partial`)
+  // B <= 256: the one block adds its totals to their destinations itself (arguments d<id> behind `epoch`, one per
+  // reduction in segment order) — no second launch; EG_NO_ROW_DIRECT=1: partial row + row_finalize as for many blocks
+  bool single_block = false;
 };
 
 // Emit the fused kernel.  Arguments of the generated kernel:
-//   (float* partial, float* / const float* t<ids>..., long B, float grad_scale, long epoch)
+//   (float* partial, float* / const float* t<ids>..., long B, float grad_scale, long epoch[, float* d<ids>...: single_block])
 int generate_row_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
                        const Shapes& shapes, RowGroup& group);
 

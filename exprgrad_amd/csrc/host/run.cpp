@@ -135,9 +135,15 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       args.push_back(&B);
       args.push_back(&GS);
       args.push_back(&EP);
+      std::vector<float*> dsts;
+      if (pg.g.single_block) {  // the one block adds its totals to their destinations itself (rowfuse.hpp)
+        dsts.reserve(pg.red_tensors.size());
+        for (int tid : pg.red_tensors) dsts.push_back(tensor_ptr(m, ts, plan, tid));
+        for (auto& p : dsts) args.push_back(&p);
+      }
       int rc = eg::kernel_launch_raw(pg.handle, (unsigned)pg.nblocks, 1, 1, 256, args.data());
       if (rc) return rc;
-      if (pg.g.red_total > 0) {
+      if (pg.g.red_total > 0 && !pg.g.single_block) {
         eg::RowFinalizeArgs fa = {};
         fa.nseg = (int)pg.red_tensors.size();
         for (int s = 0; s < fa.nseg; ++s) {
@@ -449,6 +455,10 @@ int run_launch_sliced(eg_model* m, TargetState& ts, Plan& plan, Launch& L, const
       args.push_back(&GS);
       args.push_back(&EP);
       const int nblocks = (int)((sl.rows + 255) / 256);
+      if (pg.g.single_block) {
+        set_error("batch pipeline: a single-block row group cannot be cut");
+        return EG_ERR_RUNTIME;
+      }
       int rc = eg::kernel_launch_raw(pg.handle, (unsigned)nblocks, 1, 1, 256, args.data());
       if (rc) return rc;
       if (pg.g.red_total > 0) {
