@@ -141,6 +141,18 @@ int conv2_direct_grad_filter_try(eg_ctx* ctx, long N, long H, long W, long C, lo
 // kernels/conv2_gradf_halo.hip: the filter gradient of a 3 x 3 convolution with the halo in LDS (C, F multiples of 32)
 int conv2_gradf_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img, const float* gout,
                          float* gflt, int accumulate, bool* launched);
+// kernels/gemm_f32_mfma.hip: contractions small enough for one wave per output element; two independent ones in one launch
+struct SmallGemm {
+  const float *A, *B;
+  float* C;
+  const float* bias;
+  long M, N, K, a_sm, a_sk, b_sk, b_sn, ldc;
+  int accumulate;
+};
+bool gemm_small_suits(long M, long N, long K);
+SmallGemm small_gemm(int trans_a, int trans_b, long M, long N, long K, const float* A, long lda, const float* B, long ldb, float* C,
+                     long ldc, int accumulate, const float* bias);
+int gemm_small_pair(eg_ctx* ctx, const SmallGemm& g0, const SmallGemm& g1);
 // kernels/conv2_tiny.hip: conv2 and its gradients for problems of a few million multiply-adds (*launched says whether it ran)
 int conv2_tiny_forward_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
                            const float* flt, float* out, int accumulate, bool* launched);

@@ -285,6 +285,34 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
       i = big;
       continue;
     }
+    // Two independent tiny contractions next to each other (a dense layer's two gradients at a small batch): one launch
+    // (EG_NO_SMALL_PAIR=1: two).  Independence is checked on the storage: neither writes what the other touches.
+    const bool pair_off = getenv("EG_NO_SMALL_PAIR") != nullptr;   // (read per launch sequence: a test builds one model each way)
+    if (!pair_off && i + 1 < end && i + 1 != plan.n_backward &&
+        !(next_overlap < plan.overlaps.size() && plan.overlaps[next_overlap].first == i + 1)) {
+      const Launch &A = plan.launches[i], &B = plan.launches[i + 1];
+      if (A.kind == StepKind::Gemm && B.kind == StepKind::Gemm && !A.ones_tensor && !B.ones_tensor &&
+          eg::gemm_small_suits(A.M, A.N, A.K) && eg::gemm_small_suits(B.M, B.N, B.K)) {
+        auto ptr = [&](int t) -> float* { return t ? tensor_ptr(m, ts, plan, t) : nullptr; };
+        float *ca = ptr(A.c_tensor), *cb = ptr(B.c_tensor);
+        const float* touched_by_b[] = {ptr(B.a_tensor), ptr(B.b_tensor), ptr(B.bias_tensor), cb};
+        const float* read_by_a[] = {ptr(A.a_tensor), ptr(A.b_tensor), ptr(A.bias_tensor)};
+        bool independent = ca && cb;
+        for (const float* p : touched_by_b) independent = independent && p != ca;
+        for (const float* p : read_by_a) independent = independent && p != cb;
+        if (independent) {
+          int rc = eg::gemm_small_pair(
+              m->ctx,
+              eg::small_gemm(A.trans_a, A.trans_b, A.M, A.N, A.K, ptr(A.a_tensor), A.lda, ptr(A.b_tensor), A.ldb, ca, A.ldc, A.accumulate,
+                             ptr(A.bias_tensor)),
+              eg::small_gemm(B.trans_a, B.trans_b, B.M, B.N, B.K, ptr(B.a_tensor), B.lda, ptr(B.b_tensor), B.ldb, cb, B.ldc, B.accumulate,
+                             ptr(B.bias_tensor)));
+          if (rc) return rc;
+          ++i;
+          continue;
+        }
+      }
+    }
     int rc = run_launch(m, ts, plan, plan.launches[i]);
     if (rc) return rc;
   }

@@ -699,11 +699,10 @@ namespace {
 // Tiny contractions (a 32-sample batch through dense(400, 10): 320 outputs, K = 400): one matrix-core
 // block would walk K alone for ~20 us.  One WAVE per output element instead: lane l sums
 // k = l, l + 64, ... and a shuffle tree folds the 64 partial sums (fixed order: deterministic).
-__global__ __launch_bounds__(256) void gemm_small_kernel(const float* __restrict__ A, const float* __restrict__ B, float* C,
-                                                         const float* __restrict__ bias, long M, long N, long K,
-                                                         long a_sm, long a_sk, long b_sk, long b_sn, long ldc,
-                                                         int accumulate) {
-  const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // 4 waves per block, one output each
+__device__ __forceinline__ void gemm_small_body(long block, const float* __restrict__ A, const float* __restrict__ B, float* C,
+                                                const float* __restrict__ bias, long M, long N, long K, long a_sm, long a_sk,
+                                                long b_sk, long b_sn, long ldc, int accumulate) {
+  const long idx = block * 4 + (threadIdx.x >> 6);  // 4 waves per block, one output each
   if (idx >= M * N) return;
   const int lane = threadIdx.x & 63;
   const long m = idx / N, n = idx - m * N;
@@ -720,6 +719,23 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const float* __restrict
     if (bias) v = v + bias[n];
     *c = v;
   }
+}
+
+__global__ __launch_bounds__(256) void gemm_small_kernel(const float* __restrict__ A, const float* __restrict__ B, float* C,
+                                                         const float* __restrict__ bias, long M, long N, long K,
+                                                         long a_sm, long a_sk, long b_sk, long b_sn, long ldc,
+                                                         int accumulate) {
+  gemm_small_body(blockIdx.x, A, B, C, bias, M, N, K, a_sm, a_sk, b_sk, b_sn, ldc, accumulate);
+}
+
+// Two independent tiny contractions in one launch (a dense layer's weight gradient and input gradient at a small batch:
+// in a captured graph each launch costs ~4.5 us whatever it does).  The first blocks0 blocks run the first, the rest the
+// second; every output element is computed exactly as by gemm_small_kernel.
+__global__ __launch_bounds__(256) void gemm_small_pair_kernel(eg::SmallGemm g0, eg::SmallGemm g1, long blocks0) {
+  const bool second = (long)blockIdx.x >= blocks0;   // block-uniform
+  const eg::SmallGemm& g = second ? g1 : g0;
+  gemm_small_body(second ? (long)blockIdx.x - blocks0 : (long)blockIdx.x, g.A, g.B, g.C, g.bias, g.M, g.N, g.K, g.a_sm, g.a_sk, g.b_sk,
+                  g.b_sn, g.ldc, g.accumulate);
 }
 
 bool small_gemm_enabled() {
@@ -741,6 +757,27 @@ bool skinny_enabled() {
 
 }  // namespace
 
+namespace eg {
+bool gemm_small_suits(long M, long N, long K) {
+  return M * N <= 16384 && K <= 2048 && M * N * K <= (4L << 20) && K > 0 && M > 0 && N > 0 && small_gemm_enabled();
+}
+
+SmallGemm small_gemm(int trans_a, int trans_b, long M, long N, long K, const float* A, long lda, const float* B, long ldb, float* C,
+                     long ldc, int accumulate, const float* bias) {
+  SmallGemm g = {A, B, C, bias, M, N, K, trans_a ? 1 : lda, trans_a ? lda : 1, trans_b ? 1 : ldb, trans_b ? ldb : 1, ldc, accumulate};
+  return g;
+}
+
+int gemm_small_pair(eg_ctx* ctx, const SmallGemm& g0, const SmallGemm& g1) {
+  int rc = set_device(ctx);
+  if (rc) return rc;
+  const long blocks0 = (g0.M * g0.N + 3) / 4, blocks1 = (g1.M * g1.N + 3) / 4;
+  hipLaunchKernelGGL(gemm_small_pair_kernel, dim3((unsigned)(blocks0 + blocks1)), dim3(256), 0, ctx->stream, g0, g1, blocks0);
+  EG_HIP_CHECK(hipGetLastError());
+  return EG_OK;
+}
+}  // namespace eg
+
 extern "C" int eg_sgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const float* A,
                         int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int accumulate,
                         const float* bias) {
@@ -754,7 +791,7 @@ extern "C" int eg_sgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_
   int rc = eg::set_device(ctx);
   if (rc) return rc;
 
-  if (M * N <= 16384 && K <= 2048 && M * N * K <= (4L << 20) && K > 0 && small_gemm_enabled()) {
+  if (eg::gemm_small_suits(M, N, K)) {
     const long a_sm = trans_a ? 1 : lda, a_sk = trans_a ? lda : 1;  // A(m, k)
     const long b_sk = trans_b ? 1 : ldb, b_sn = trans_b ? ldb : 1;  // B(k, n)
     const long blocks = (M * N + 3) / 4;

@@ -186,3 +186,36 @@ def test_fit_of_the_fashion_mnist_network(gpu_ctx):
     # apply loop bit for bit is the first test of this file); what remains to say here: both learn
     assert float(ref.call("loss", {"x": x, "y": y}).sum()) < first
     gpu.close()
+
+
+def test_small_batch_shortcuts_change_no_bit(gpu_ctx, monkeypatch):
+    """Round 4: at a small batch two independent tiny contractions next to each other (a dense layer's weight gradient and
+    input gradient) run as one launch, and a row group of one block adds its batch totals to the destinations itself
+    instead of through row_finalize.  Both shortcuts compute every value exactly as the long way round: a model built
+    with EG_NO_SMALL_PAIR=1 EG_NO_ROW_DIRECT=1 ends three training steps with the same bits, and both are at the
+    oracle's values within the tolerance."""
+    rng = np.random.default_rng(3)
+    x = rng.random((32, 24), dtype=np.float32)
+    y = rng.random((32, 5), dtype=np.float32)
+    results = []
+    for env in ({}, {"EG_NO_SMALL_PAIR": "1", "EG_NO_ROW_DIRECT": "1"}):
+        for k in ("EG_NO_SMALL_PAIR", "EG_NO_ROW_DIRECT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        m = egm.compile(*dense_graphs("adam"), gpu=gpu_ctx)
+        same_start([m], 9)
+        m.epoch = 1          # (adam divides by 1 - beta^epoch)
+        for _ in range(3):
+            m.apply("train", {"x": x, "y": y})
+        results.append({tid: np.array(m.params[tid]) for tid in m.params.ids()})
+    for tid in results[0]:
+        assert np.isfinite(results[0][tid]).all(), tid
+        assert np.array_equal(results[0][tid], results[1][tid]), tid
+    ref = oracle(dense_graphs("adam"))
+    same_start([ref], 9)
+    ref.epoch = 1
+    for _ in range(3):
+        ref.apply("train", {"x": x, "y": y})
+    for tid in results[0]:
+        assert rel_err(results[0][tid], np.asarray(ref.params[tid])) <= TOL, tid
