@@ -256,6 +256,7 @@ TINY_SHAPES = [  # N, H, W, C, F, FH, FW: a few million multiply-adds in all -> 
     (1, 3, 3, 2, 4, 3, 3),        # one output pixel
     (2, 6, 5, 4, 12, 1, 3),       # one filter row
     (64, 12, 12, 8, 16, 3, 3),    # 7.4 M multiply-adds: past the limit, the contraction route (both settings the same)
+    (4, 10, 10, 16, 4, 3, 3),     # filter rows of 48 floats, 576 filter-gradient outputs
     (3, 10, 10, 16, 96, 3, 3),    # 13 824 filter-gradient outputs: more than the tiny kernel's eight per thread -> contraction route for that one
 ]
 
