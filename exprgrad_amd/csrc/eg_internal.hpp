@@ -174,6 +174,8 @@ struct CopySegments {
   int n;
 };
 int copy_segments(eg_ctx* ctx, const CopySegments& seg);
+bool copy_segments_node_params(eg_ctx* ctx, const CopySegments& seg, hipKernelNodeParams* out, void** arg);
+const void* copy_segments_function();
 // Data-parallel step (dp_rccl.cpp -> host/model_api.cpp): run the backward range of `target` and
 // exchange the gradient bucket through `allreduce(user, device pointer, float count)`, which must
 // enqueue an in-place SUM on the context's CURRENT stream.  Gradients that are complete before the

@@ -201,6 +201,10 @@ int eg_model_free(eg_model* m) try {
   if (!m) return EG_OK;
   hipSetDevice(m->ctx->device);
   hipStreamSynchronize(m->ctx->stream);
+  if (m->fit_graph.exec) hipGraphExecDestroy(m->fit_graph.exec);
+  m->fit_graph.exec = nullptr;
+  if (m->fit_graph.graph) hipGraphDestroy(m->fit_graph.graph);
+  m->fit_graph.graph = nullptr;
   for (auto& kv : m->targets) {
     for (auto& p : kv.second.plans) {
       for (auto& g : p.second->graphs)

@@ -252,6 +252,15 @@ struct eg_model {
   hipStream_t copy_stream = nullptr;
   hipEvent_t copy_event = nullptr;
   hipEvent_t main_event = nullptr;  // recorded on the context's stream: "the batches queued so far are done"
+  // eg_model_fit, small batches: `group` consecutive batches (segment copy + launch sequence each) captured as ONE graph; a
+  // launch re-points the copy nodes at the group's rows.  Between two launches of a captured sequence the device idles for
+  // ~8 us: a group pays that once.
+  struct FitGraph {
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph = nullptr;          // kept: the copy nodes are addressed through it
+    std::vector<hipGraphNode_t> copies;  // the group's segment-copy nodes, in batch order
+    std::string key;                     // everything baked into the captured kernel arguments
+  } fit_graph;
 };
 
 namespace eg {
@@ -339,6 +348,8 @@ struct ExchangePlan {
 int plan_exchange(eg_model* m, TargetState& ts, Plan& plan, ExchangePlan& ex);
 bool graphs_enabled();
 int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero, int slot);
+// everything a captured launch sequence bakes into its kernel arguments (input bindings, workspaces, bucket, seed scale, epoch)
+std::string capture_key(eg_model* m, TargetState& ts);
 // plan_epilogue.cpp: a bias gradient `gb[x] ++= g[y,x]` next to the weight gradient `gW[it,x] ++= a[y,it] * g[y,x]`
 // of the same layer becomes the last row of that contraction (a virtual row of ones in A) when gb lies
 // directly behind gW in the gradient bucket; the column-sum launch disappears.

@@ -327,6 +327,15 @@ bool graphs_enabled() {
   return on;
 }
 
+std::string capture_key(eg_model* m, TargetState& ts) {
+  std::ostringstream key;
+  for (auto& in : m->inputs)
+    if (in.second.bound) key << in.first << "=" << (const void*)in.second.device << ";";
+  key << "w" << m->ctx->workspace << "x" << m->ctx->aux << "s" << m->ctx->side_workspace << "y" << m->ctx->side_aux << "b"
+      << (void*)ts.bucket << "g" << m->grad_scale << "e" << m->epoch;
+  return key.str();
+}
+
 // slot: 0 = whole call, 1 = backward part, 2 = update part
 int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero, int slot) {
   int rc = eg::set_device(m->ctx);
@@ -340,12 +349,7 @@ int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool
     EG_HIP_CHECK(hipGraphLaunch(cap.exec, m->ctx->stream));
     return EG_OK;
   }
-  std::ostringstream key;
-  for (auto& in : m->inputs)
-    if (in.second.bound) key << in.first << "=" << (const void*)in.second.device << ";";
-  key << "w" << m->ctx->workspace << "x" << m->ctx->aux << "s" << m->ctx->side_workspace << "y" << m->ctx->side_aux << "b"
-      << (void*)ts.bucket << "g" << m->grad_scale << "e" << m->epoch;
-  const std::string k = key.str();
+  const std::string k = capture_key(m, ts);
   if (cap.exec && cap.key == k) {  // (the bindings were renewed with the same values)
     cap.stamp = m->inputs_gen;
     memcpy(cap.ptrs, now, sizeof(now));

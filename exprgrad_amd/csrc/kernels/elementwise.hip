@@ -279,6 +279,24 @@ __global__ __launch_bounds__(NT) void copy_segments_kernel(eg::CopySegments seg)
 }
 
 namespace eg {
+// The launch copy_segments would make, as graph kernel-node parameters (host/fit.cpp re-points the copy nodes of a captured
+// group of batches): `arg` must stay alive until the parameters have been handed over.
+bool copy_segments_node_params(eg_ctx* ctx, const CopySegments& seg, hipKernelNodeParams* out, void** arg) {
+  long most = 0;
+  for (int i = 0; i < seg.n; ++i) most = seg.count[i] > most ? seg.count[i] : most;
+  if (seg.n <= 0 || most == 0) return false;
+  *out = hipKernelNodeParams{};
+  out->func = reinterpret_cast<void*>(copy_segments_kernel);
+  out->gridDim = dim3(grid_for(ctx, (most + 3) / 4), seg.n);
+  out->blockDim = dim3(NT);
+  out->sharedMemBytes = 0;
+  arg[0] = const_cast<CopySegments*>(&seg);
+  out->kernelParams = arg;
+  out->extra = nullptr;
+  return true;
+}
+const void* copy_segments_function() { return reinterpret_cast<const void*>(copy_segments_kernel); }
+
 int copy_segments(eg_ctx* ctx, const CopySegments& seg) {
   if (seg.n <= 0) return EG_OK;
   EG_REQUIRE(seg.n <= 8, EG_ERR_INVALID, "copy_segments: more than 8 ranges");

@@ -219,3 +219,29 @@ def test_small_batch_shortcuts_change_no_bit(gpu_ctx, monkeypatch):
         ref.apply("train", {"x": x, "y": y})
     for tid in results[0]:
         assert rel_err(results[0][tid], np.asarray(ref.params[tid])) <= TOL, tid
+
+
+@pytest.mark.parametrize("optim", ["sgd", "adam"])
+def test_fit_in_groups_of_batches_changes_no_bit(gpu_ctx, monkeypatch, optim):
+    """Round 4: at a small batch size eg_model_fit captures 16 consecutive batches (segment copy + launch sequence each) as
+    one graph and re-points the copy nodes per launch.  200 batches (two single ones, twelve groups, a tail of six) over
+    two epochs against the same fit with every batch launched by itself (EG_FIT_GROUP=1) and with groups of 5."""
+    rows, batch = 200 * 8, 8
+    rng = np.random.default_rng(4)
+    x = rng.random((rows, 24), dtype=np.float32)
+    y = rng.random((rows, 5), dtype=np.float32)
+    results = []
+    for group in (None, "1", "5"):
+        monkeypatch.delenv("EG_FIT_GROUP", raising=False)
+        if group:
+            monkeypatch.setenv("EG_FIT_GROUP", group)
+        m = egm.compile(*dense_graphs(optim), gpu=gpu_ctx)
+        same_start([m], 12)
+        for _ in range(2):
+            m.fit("train", {"x": x, "y": y}, batch_size=batch)
+        results.append({tid: np.array(m.params[tid]) for tid in m.params.ids()})
+        m.close()
+    for tid in results[0]:
+        assert np.isfinite(results[0][tid]).all(), tid
+        assert np.array_equal(results[0][tid], results[1][tid]), tid
+        assert np.array_equal(results[0][tid], results[2][tid]), tid
