@@ -825,6 +825,13 @@ def run_fashion_fit(args, env):
             "library_calls_per_batch": len(plan) + 1, "dependent_launch_floor_us": round((len(plan) + 1) * DEPENDENT_LAUNCH_US, 1),
             "algorithmic_mb_per_batch": round(2 * tensor_bytes / 1e6, 2),
             "hbm_floor_us": round(2 * tensor_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, 2),
+            "kernels_per_batch": 16 if batch <= 256 else None,
+            "measured_us_per_dependent_kernel": 4.5,
+            "measured_note": "rocprofv3 --kernel-trace with the graphs left on (profiles/r04_fit_timeline.txt): the 16 kernels of a "
+                             "batch-32 step each end 4.4 - 8.0 us after their predecessor, including those that move a few KB "
+                             "(dispatch, first load from memory, last store and completion are serial), and 8 us pass between two "
+                             "launches of the captured sequence (paid once per 16 batches: eg_model::FitGraph).  The floor above "
+                             "uses the guide's 1.5 us; 16 kernels at what is measured here are 72 us.",
             "note": "calls = launches of the plan + the segment copy of the batch's rows; some calls are two kernels (a "
                     "k-sliced contraction and its fixed-order sum).  Bytes: every activation / gradient of the network "
                     "written once and read once, float32.  At batch 32 the step is launch-bound, at 4096 "
