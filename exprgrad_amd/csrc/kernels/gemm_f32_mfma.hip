@@ -274,10 +274,11 @@ double wide_tile_time(const WideTile& t, long M, long N, long k_tiles, int cus, 
     const long blocks = tiles * s;
     if (s > 1 && blocks > 2 * slots) break;  // more slices than the chip can hold at once only add slabs
     const long on_cu = (blocks + cus - 1) / cus, rounds = (blocks + slots - 1) / slots;
-    // (one unsliced block per CU of whole 64 x 64 tiles with K a multiple of 64: the wave-pair kernel, 0.27; otherwise the
+    // (one unsliced block per CU of 64 x 64 tiles: the wave-pair kernel, 0.27 for whole tiles, 0.285 ragged; otherwise the
     // four-wave kernel with 32-deep k-tiles, 0.30)
-    const bool pair = s == 1 && on_cu == 1 && k64 && m_rest == 0 && n_rest == 0;
-    const double alone = (vec && t.bm == 64 && on_cu <= 2) ? (pair ? t.alone_k32 : 0.30) : t.alone;
+    const bool pair = s == 1 && on_cu == 1;
+    const bool pair_whole = pair && k64 && m_rest == 0 && n_rest == 0;
+    const double alone = (vec && t.bm == 64 && on_cu <= 2) ? (pair_whole ? t.alone_k32 : pair ? 0.285 : 0.30) : t.alone;
     // the busiest CU: its blocks are a sample of the tiles, never faster than one of the slowest kind.  More blocks than
     // slots of a tile that shares its CU four ways: the CUs pick up blocks as slots free up, so the busiest one carries
     // the average plus about half a block, not the next whole number (2304^3 on 64 x 64 tiles, 5.06 blocks per CU:
@@ -634,11 +635,19 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   // 20.9 us (NN / NT), 23.1 -> 19.8 (TN), 512^3 12.3 -> 11.6.  With two or more blocks per CU the four-wave kernel is
   // as fast or faster (1536^3, 3072^3), so those keep it.  Not bit-identical to it (two f32 chains per element instead
   // of one); EG_GEMM_NO_PAIR=1 (read per call) keeps the four-wave kernel.
+  // Ragged tiles and a K that ends inside a k-tile take the EDGE form of the same kernel (clamped row / column offsets,
+  // masked stores, the k-tile K ends in loaded in the prologue and multiplied behind the loop): 1000^3 28.1 -> 23.1 us (NN),
+  // 27.5 -> 22.0 (TN), 1000 x 1024 x 4096 90.8 -> 74.6.
   const bool pair_on = getenv("EG_GEMM_NO_PAIR") == nullptr;
-  if (pair_on && BM == 64 && BN == 64 && !edge && !conv && splits <= 1 && args.tail_tiles == 0 && args.edge_splits == 0 &&
-      K % 64 == 0 && args.wide_store && !args.ones_row && (long)args.tiles_m * args.tiles_n <= ctx->compute_units) {
+  if (pair_on && BM == 64 && BN == 64 && vec && !conv && splits <= 1 && args.tail_tiles == 0 && args.edge_splits == 0 &&
+      args.wide_store && !args.ones_row && (long)args.tiles_m * args.tiles_n <= ctx->compute_units) {
+    const bool ragged = edge || K % 64 != 0;
     dim3 grid((unsigned)((long)args.tiles_m * args.tiles_n)), block(512);
-#define EG_PAIR(AKC, BKC) hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 32, 32, AKC, BKC, 0, 2, 64>), grid, block, 0, ctx->stream, args)
+#define EG_PAIR(AKC, BKC)                                                                                                  \
+  do {                                                                                                                     \
+    if (ragged) hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 32, 32, AKC, BKC, 0, 2, 64, true>), grid, block, 0, ctx->stream, args);  \
+    else hipLaunchKernelGGL((gemm_pair_kernel<64, 64, 32, 32, AKC, BKC, 0, 2, 64, false>), grid, block, 0, ctx->stream, args);        \
+  } while (0)
     if (a_kc && !b_kc) EG_PAIR(true, false);
     else if (a_kc && b_kc) EG_PAIR(true, true);
     else if (!a_kc && !b_kc) EG_PAIR(false, false);

@@ -1,4 +1,4 @@
-// Wave-pair contraction kernel (round 4): whole 64 x 64 tiles of a plain f32 product whose tiles fill the chip at most
+// Wave-pair contraction kernel (round 4): 64 x 64 tiles of a plain f32 product whose tiles fill the chip at most
 // once — 1024^3 is 256 blocks on 256 CUs.  The four-wave kernel of gemm_f32_mfma.hpp runs ONE wave per SIMD there, and a
 // k-tile costs it 1.36x its matrix time.  Where that goes was measured on this kernel with parts of the loop removed
 // (tools/gemm_pipe.hip, 1024 x 1024 x K, per 32 k): MFMAs alone 1042 cycles (= the matrix rate); + the barrier 132; + the
@@ -14,7 +14,10 @@
 //   * the pair's two accumulator sets meet on their way out: both waves park their blocks in LDS (two copies of the
 //     staged rows), and the 16-byte row walk of the wide-store pass adds them, even wave's value + odd wave's value.
 // 1024^3: 22.1 -> 20.9 us (NN, NT), 23.1 -> 19.8 (TN) with sustained clocks = 0.65 - 0.69 of the MFMA peak; 512^3 12.3 ->
-// 11.6.  The same design on 128 x 128 tiles: 2048^3 127.2 us against 129.8 for the four-wave 64 x 64 kernel — not taken.
+// 11.6.  Ragged tiles and a K that ends inside a k-tile: the EDGE form (template parameter; 1000^3 28.1 -> 23.1 us).  A first
+// version handled the last k-tile inside the loop (other loaders, a zero fill and a barrier under a block-uniform condition):
+// whole problems ran 14 % slower on it (1024 x 1024 x 4096: 83.3 against 73.3 us) although the condition was never true —
+// the tile now has a stage of its own, is loaded first and multiplied last, and the loop is the whole-tile loop (73.9).  The same design on 128 x 128 tiles: 2048^3 127.2 us against 129.8 for the four-wave 64 x 64 kernel — not taken.
 // Results are deterministic (fixed order) but not bit-identical to the four-wave kernels: an output element is the sum of
 // two f32 chains (the k-groups of the even and of the odd wave) instead of one.
 // ABL (tuning harness only; the library instantiates 0): bit 0 no fragment reads / MFMAs, bit 1 no loads behind the
@@ -26,30 +29,36 @@
 namespace eg {
 namespace gemm {
 
-template <int BM, int BN, int WM, int WN, int ST = 3, int KB = 32>
+template <int BM, int BN, int WM, int WN, int ST = 3, int KB = 32, bool EDGE = false>
 struct PairGeometry {
   static constexpr int SUB = (BM / WM) * (BN / WN);  // sub-tiles = wave pairs
   static constexpr int NT = SUB * 128;
   static constexpr int BK = KB, STAGES = ST;
   static constexpr int BUF = BK * (BM + BN);
   static constexpr int RT = (BM / WM) * 32;  // staged rows per wide-store pass
-  static constexpr int LDS_FLOATS = STAGES * BUF > 2 * RT * BN ? STAGES * BUF : 2 * RT * BN;
+  static constexpr int ALL_STAGES = STAGES + (EDGE ? 1 : 0);   // (EDGE: one more stage for the k-tile K ends in)
+  static constexpr int LDS_FLOATS = ALL_STAGES * BUF > 2 * RT * BN ? ALL_STAGES * BUF : 2 * RT * BN;
   // two blocks per CU where LDS and registers allow it (64 x 64: 48 KB, 16 accumulators)
   static constexpr int WAVES_PER_SIMD = LDS_FLOATS * 4 * 2 <= 160 * 1024 && (WM / 32) * (WN / 32) <= 2 ? 4 : 2;
 };
 
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int ABL = 0, int ST = 3, int KB = 32>
-__global__ __launch_bounds__((PairGeometry<BM, BN, WM, WN, ST, KB>::NT), (PairGeometry<BM, BN, WM, WN, ST, KB>::WAVES_PER_SIMD)) void
+// EDGE: tiles may be ragged in M and N (row / column offsets clamped once per block, stores masked; N a multiple of 4) and K
+// may end inside a k-tile (the last k-tile on the loaders that clamp k as well, its missing k zeroed on the A side in LDS).
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int ABL = 0, int ST = 3, int KB = 32, bool EDGE = false>
+__global__ __launch_bounds__((PairGeometry<BM, BN, WM, WN, ST, KB, EDGE>::NT), (PairGeometry<BM, BN, WM, WN, ST, KB, EDGE>::WAVES_PER_SIMD)) void
 gemm_pair_kernel(GemmArgs a) {
-  using G = PairGeometry<BM, BN, WM, WN, ST, KB>;
+  using G = PairGeometry<BM, BN, WM, WN, ST, KB, EDGE>;
   constexpr int GW = KB / 16;  // k-groups per wave and k-tile
   constexpr int BK = G::BK, NT = G::NT, BUF = G::BUF, S = G::STAGES;
   static_assert(S >= 2 && S <= 5, "two to five stages");
   constexpr int WAVES_N = BN / WN;
   constexpr int MI = WM / 32, NI = WN / 32;
   constexpr bool AIL = Interleaved<A_KC, MI>::value, BIL = Interleaved<B_KC, NI>::value;
-  using DmaA = DmaLoader<BM, BK, NT, A_KC, false>;
-  using DmaB = DmaLoader<BN, BK, NT, B_KC, false>;
+  using DmaA = DmaLoader<BM, BK, NT, A_KC, false, EDGE, false>;
+  using DmaB = DmaLoader<BN, BK, NT, B_KC, false, EDGE, false>;
+  using DmaAT = DmaLoader<BM, BK, NT, A_KC, false, true, true>;   // (EDGE) the k-tile K ends in
+  using DmaBT = DmaLoader<BN, BK, NT, B_KC, false, true, true>;
+  static_assert(!EDGE || (WM == 32 && WN == 32), "ragged tiles: one block per wave (no interleaved rows)");
   static_assert(DmaA::INSTRS % DmaA::WAVES == 0 && DmaB::INSTRS % DmaB::WAVES == 0, "every wave issues the same number of loads per k-tile");
   constexpr int LOADS = DmaA::PER_WAVE + DmaB::PER_WAVE;  // wave instructions per wave and k-tile
   __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
@@ -62,7 +71,8 @@ gemm_pair_kernel(GemmArgs a) {
 
   long m_blk, n_blk;
   tile_origin<BM, BN>(xcd_remap(blockIdx.x, a.tiles_m * a.tiles_n), a.tiles_m, a.tiles_n, m_blk, n_blk);
-  const int nk = (int)(a.K / BK);
+  const int k_tail = EDGE ? (int)(a.K % BK) : 0;          // valid k of a ragged last k-tile (0 = none): it runs behind the loop
+  const int nk = (int)(a.K / BK);                         // whole k-tiles: the loop
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -78,8 +88,8 @@ gemm_pair_kernel(GemmArgs a) {
   db.init(a, n_blk, wave, lane, a.N, a.ldb);
   auto issue_tile = [&](int kt, int stage) {
     float* s = lds + stage * BUF;
-    da.issue(a, a.A, a.lda, m_blk, (long)kt * BK, s, wave, lane);
-    db.issue(a, a.B, a.ldb, n_blk, (long)kt * BK, s + BK * BM, wave, lane);
+    da.issue(a, a.A, a.lda, m_blk, (long)kt * BK, s, wave, lane, a.a_rows, a.K);
+    db.issue(a, a.B, a.ldb, n_blk, (long)kt * BK, s + BK * BM, wave, lane, a.N, a.K);
   };
   // fragments of k-group pp (8 k) of the tile at As, as in gemm_mainloop_dma: av[mi][j] / bv[ni][j] = this lane's A / B
   // value of block mi / ni for MFMA k-step j (k = 8 pp + j in lanes 0 - 31, 8 pp + 4 + j in lanes 32 - 63)
@@ -153,9 +163,21 @@ gemm_pair_kernel(GemmArgs a) {
   };
   auto in_flight = [&](int kt) { return nk - 1 - kt < S - 2 ? nk - 1 - kt : S - 2; };
 
+  // (EDGE) the k-tile K ends in goes to its own stage before anything else, on the loaders that clamp k as well (FLAT
+  // loads); the first barrier of the loop — or the one below — waits for it together with tile 0, so its round trip is not
+  // seen, and the loop itself is the loop of the whole-tile kernel.  Its missing k are re-reads of the last valid ones:
+  // zeroed on the A side behind the loop.
+  if (EDGE && k_tail != 0) {
+    DmaAT dat;
+    DmaBT dbt;
+    float* s = lds + S * BUF;
+    dat.issue(a, a.A, a.lda, m_blk, (long)nk * BK, s, wave, lane, a.a_rows, a.K);
+    dbt.issue(a, a.B, a.ldb, n_blk, (long)nk * BK, s + BK * BM, wave, lane, a.N, a.K);
+  }
 #pragma unroll
   for (int t = 0; t < S - 1; ++t)
     if (t < nk) issue_tile(t, t);
+  if (EDGE && k_tail != 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // s_waitcnt vmcnt(0), as an instruction the wait-count pass sees
   const bool late = kw == 1 && !a.no_skew && !(ABL & 256);
   if (late) {
     float avp[MI][4], bvp[NI][4];
@@ -200,6 +222,28 @@ gemm_pair_kernel(GemmArgs a) {
       cur = cur == S - 1 ? 0 : cur + 1;
     }
   }
+  if (EDGE && k_tail != 0) {   // (block-uniform) the last, partial k-tile: landed long ago (prologue)
+    float* At = lds + S * BUF;
+    __syncthreads();   // (K < BK: nothing has waited for the tile yet)
+    const int width = BK - k_tail;
+    for (int e = tid; e < BM * width; e += NT) {
+      if (A_KC) {
+        const int r = e / width, k = k_tail + e % width;
+        At[r * BK + (((k >> 2) ^ DmaA::swizzle(r)) << 2) + (k & 3)] = 0.f;
+      } else {
+        At[k_tail * BM + e] = 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < GW; ++g) {
+      if (8 * (GW * kw + g) < k_tail) {   // (wave-uniform) a k-group past the end holds zeros only
+        float av[MI][4], bv[NI][4];
+        fragments(At, GW * kw + g, av, bv);
+        multiply(av, bv);
+      }
+    }
+  }
   __syncthreads();  // every wave is done reading the stages: the staged rows may overwrite them
 
   // ---- epilogue: whole tiles only.  Pass mi: every wave parks block row mi of its sub-tile (32 rows x WN columns) in its
@@ -212,7 +256,8 @@ gemm_pair_kernel(GemmArgs a) {
   const int c4 = tid % C4;
   const long n = n_blk + c4 * 4;
   f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-  if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+  const bool n_ok = !EDGE || n + 4 <= a.N;   // (EDGE: N is a multiple of 4: a chunk is inside or outside)
+  if (a.bias && n_ok) b4 = *reinterpret_cast<const f32x4*>(a.bias + n);
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     if (mi > 0) __syncthreads();
@@ -237,8 +282,9 @@ gemm_pair_kernel(GemmArgs a) {
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
       const int row = (c * NT + tid) / C4;
-      idx[c] = (m_blk + (long)(row >> 5) * WM + sub_index<MI>(AIL, mi, row & 31)) * a.ldc + n;
-      if (a.accumulate) old[c] = *reinterpret_cast<const f32x4*>(a.C + idx[c]);
+      const long m = m_blk + (long)(row >> 5) * WM + sub_index<MI>(AIL, mi, row & 31);
+      idx[c] = (!EDGE || (n_ok && m < a.M)) ? m * a.ldc + n : -1;
+      if (a.accumulate && idx[c] >= 0) old[c] = *reinterpret_cast<const f32x4*>(a.C + idx[c]);
     }
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
@@ -249,8 +295,9 @@ gemm_pair_kernel(GemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         v[e] = even[e] + odd[e];
-        v[e] = a.accumulate ? (old[c][e] + v[e]) + b4[e] : v[e] + b4[e];
+        v[e] = (a.accumulate && (!EDGE || idx[c] >= 0)) ? (old[c][e] + v[e]) + b4[e] : v[e] + b4[e];
       }
+      if (EDGE && idx[c] < 0) continue;
       f32x4* p = reinterpret_cast<f32x4*>(a.C + idx[c]);
       if (a.nt_store) __builtin_nontemporal_store(v, p);
       else *p = v;

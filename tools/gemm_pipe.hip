@@ -35,9 +35,9 @@ void launch(const GemmArgs& a, dim3 grid, hipStream_t s) {
   hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, BK, WM, WN, MINB, AKC, BKC, 4, false, 0, ABL, true>), grid, dim3(NT), 0, s, a);
 }
 
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int ABL, int ST = 3, int KB = 32>
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int ABL, int ST = 3, int KB = 32, bool EDGE = false>
 void launch_pair(const GemmArgs& a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL((gemm_pair_kernel<BM, BN, WM, WN, AKC, BKC, ABL, ST, KB>), grid, dim3(PairGeometry<BM, BN, WM, WN, ST, KB>::NT), 0, s, a);
+  hipLaunchKernelGGL((gemm_pair_kernel<BM, BN, WM, WN, AKC, BKC, ABL, ST, KB, EDGE>), grid, dim3(PairGeometry<BM, BN, WM, WN, ST, KB, EDGE>::NT), 0, s, a);
 }
 
 template <bool AKC, bool BKC>
@@ -67,6 +67,7 @@ std::vector<Variant> variants() {
       {"64x64 pair mfma noread", 64, 64, 32, launch_pair<64, 64, 32, 32, AKC, BKC, 266>},
       {"64x64 pair mfma bare ", 64, 64, 32, launch_pair<64, 64, 32, 32, AKC, BKC, 270>},
       {"64x64 pair 2st bk64  ", 64, 64, 64, launch_pair<64, 64, 32, 32, AKC, BKC, 0, 2, 64>},
+      {"64x64 pair bk64 EDGE ", 64, 64, 64, launch_pair<64, 64, 32, 32, AKC, BKC, 0, 2, 64, true>},
       {"64x64 pair 2st bk64 i", 64, 64, 64, launch_pair<64, 64, 32, 32, AKC, BKC, 256, 2, 64>},
       {"64x64 pair 3st bk64  ", 64, 64, 64, launch_pair<64, 64, 32, 32, AKC, BKC, 0, 3, 64>},
       {"64x64 pair 2st bk128 ", 64, 64, 128, launch_pair<64, 64, 32, 32, AKC, BKC, 0, 2, 128>},
