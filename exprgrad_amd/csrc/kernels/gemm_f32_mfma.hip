@@ -403,6 +403,41 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   const long M = args.M, N = args.N, K = args.K;
   int BM, BN, splits;
   choose_tile(ctx, M, N, K, BM, BN, splits, vec_ok, conv == 0);
+  // Small outputs — between half a chip and a whole chip of 32 x 32 tiles (512 x 512: 256 of them, 64 of 64 x 64): one
+  // 32 x 32 tile per block, eight waves that split every 128-deep k-tile (gemm_f32_pair.hpp, KW = 8), unsliced whatever K
+  // is, up to K = 4096: 512^3 13.1 -> 8.0 us NN, 13.4 -> 6.1 TN; 384^3 10.7 -> 6.4; 500 x 500 x 1000 17.3 -> 9.3; 512 x 512 x 2048
+  // 20.1 -> 13.3; equal at K = 4096 (25.3 / 26.4); a long K is bound by the tile's loads (512 x 512 x 65536: 337 us against 282
+  // for sliced 64 x 64 tiles).  EG_GEMM_NO_PAIR=1 (or a forced tile / slice count) keeps the choice below.
+  {
+    const long t32 = ((M + 31) / 32) * ((N + 31) / 32);
+    const bool kw8_on = getenv("EG_GEMM_NO_PAIR") == nullptr && getenv("EG_GEMM_FORCE_TILE") == nullptr &&
+                        getenv("EG_GEMM_FORCE_SPLITS") == nullptr;
+    if (kw8_on && !conv && vec_ok && !a_vec_only && !args.ones_row && t32 <= ctx->compute_units && 2 * t32 >= ctx->compute_units &&
+        K >= 256 && K <= 4096 && N % 4 == 0 && args.ldc % 4 == 0 && aligned16(args.C) && (args.bias == nullptr || aligned16(args.bias))) {
+      args.tiles_m = (int)((M + 31) / 32);
+      args.tiles_n = (int)((N + 31) / 32);
+      args.partial = nullptr;
+      args.splits = 1;
+      args.k_per_split = K;
+      args.prio = side_priority(ctx);
+      args.nt_store = nt_store_enabled();
+      args.no_skew = getenv("EG_GEMM_NO_SKEW") != nullptr;
+      const bool ragged = M % 32 != 0 || N % 32 != 0 || K % 128 != 0;
+      dim3 grid((unsigned)t32), block(512);
+#define EG_KW8(AKC, BKC)                                                                                                       \
+  do {                                                                                                                         \
+    if (ragged) hipLaunchKernelGGL((gemm_pair_kernel<32, 32, 32, 32, AKC, BKC, 0, 2, 128, true, 8>), grid, block, 0, ctx->stream, args);  \
+    else hipLaunchKernelGGL((gemm_pair_kernel<32, 32, 32, 32, AKC, BKC, 0, 2, 128, false, 8>), grid, block, 0, ctx->stream, args);        \
+  } while (0)
+      if (a_kc && !b_kc) EG_KW8(true, false);
+      else if (a_kc && b_kc) EG_KW8(true, true);
+      else if (!a_kc && !b_kc) EG_KW8(false, false);
+      else EG_KW8(false, true);
+#undef EG_KW8
+      EG_HIP_CHECK(hipGetLastError());
+      return EG_OK;
+    }
+  }
   // A few rows / columns beyond whole 256 x 256 tiles of a large output (4100 = 16 x 256 + 4): the ragged
   // tile row and column stage whole operand tiles for 1/64 of the matrix work and push the launch into another
   // round of blocks (4100 x 4096 x 4096: +76 us, 4096 x 4100 x 4096: +154 us over 969 us).  As contractions

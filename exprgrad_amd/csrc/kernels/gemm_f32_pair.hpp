@@ -19,7 +19,7 @@
 // whole problems ran 14 % slower on it (1024 x 1024 x 4096: 83.3 against 73.3 us) although the condition was never true —
 // the tile now has a stage of its own, is loaded first and multiplied last, and the loop is the whole-tile loop (73.9).  The same design on 128 x 128 tiles: 2048^3 127.2 us against 129.8 for the four-wave 64 x 64 kernel — not taken.
 // Results are deterministic (fixed order) but not bit-identical to the four-wave kernels: an output element is the sum of
-// two f32 chains (the k-groups of the even and of the odd wave) instead of one.
+// KW f32 chains (one per wave of its sub-tile, added in wave order) instead of one.
 // ABL (tuning harness only; the library instantiates 0): bit 0 no fragment reads / MFMAs, bit 1 no loads behind the
 // prologue, bit 2 no barriers, bit 3 fragments read once, bit 8 in phase.
 // Reference semantics: c[y, x] ++= a[y, it] * b[it, x] (base.nim:27-28), like every variant of the contraction kernel.
@@ -29,26 +29,29 @@
 namespace eg {
 namespace gemm {
 
-template <int BM, int BN, int WM, int WN, int ST = 3, int KB = 32, bool EDGE = false>
+// KW: waves per sub-tile (2: a pair; 8: one 32 x 32 tile per block, every k-tile split eight ways — small outputs, where 64 x 64
+// tiles would leave three quarters of the chip idle: 512^3 is 64 of them, and 256 of 32 x 32)
+template <int BM, int BN, int WM, int WN, int ST = 3, int KB = 32, bool EDGE = false, int KW = 2>
 struct PairGeometry {
-  static constexpr int SUB = (BM / WM) * (BN / WN);  // sub-tiles = wave pairs
-  static constexpr int NT = SUB * 128;
+  static constexpr int SUB = (BM / WM) * (BN / WN);  // sub-tiles = wave groups
+  static constexpr int NT = SUB * 64 * KW;
   static constexpr int BK = KB, STAGES = ST;
   static constexpr int BUF = BK * (BM + BN);
   static constexpr int RT = (BM / WM) * 32;  // staged rows per wide-store pass
   static constexpr int ALL_STAGES = STAGES + (EDGE ? 1 : 0);   // (EDGE: one more stage for the k-tile K ends in)
-  static constexpr int LDS_FLOATS = ALL_STAGES * BUF > 2 * RT * BN ? ALL_STAGES * BUF : 2 * RT * BN;
+  static constexpr int LDS_FLOATS = ALL_STAGES * BUF > KW * RT * BN ? ALL_STAGES * BUF : KW * RT * BN;
   // two blocks per CU where LDS and registers allow it (64 x 64: 48 KB, 16 accumulators)
   static constexpr int WAVES_PER_SIMD = LDS_FLOATS * 4 * 2 <= 160 * 1024 && (WM / 32) * (WN / 32) <= 2 ? 4 : 2;
 };
 
 // EDGE: tiles may be ragged in M and N (row / column offsets clamped once per block, stores masked; N a multiple of 4) and K
 // may end inside a k-tile (the last k-tile on the loaders that clamp k as well, its missing k zeroed on the A side in LDS).
-template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int ABL = 0, int ST = 3, int KB = 32, bool EDGE = false>
-__global__ __launch_bounds__((PairGeometry<BM, BN, WM, WN, ST, KB, EDGE>::NT), (PairGeometry<BM, BN, WM, WN, ST, KB, EDGE>::WAVES_PER_SIMD)) void
+template <int BM, int BN, int WM, int WN, bool A_KC, bool B_KC, int ABL = 0, int ST = 3, int KB = 32, bool EDGE = false, int KW = 2>
+__global__ __launch_bounds__((PairGeometry<BM, BN, WM, WN, ST, KB, EDGE, KW>::NT), (PairGeometry<BM, BN, WM, WN, ST, KB, EDGE, KW>::WAVES_PER_SIMD)) void
 gemm_pair_kernel(GemmArgs a) {
-  using G = PairGeometry<BM, BN, WM, WN, ST, KB, EDGE>;
-  constexpr int GW = KB / 16;  // k-groups per wave and k-tile
+  using G = PairGeometry<BM, BN, WM, WN, ST, KB, EDGE, KW>;
+  constexpr int GW = KB / 8 / KW;  // k-groups per wave and k-tile
+  static_assert(GW >= 1 && GW * KW * 8 == KB, "the k-groups of a k-tile divide among the waves of a sub-tile");
   constexpr int BK = G::BK, NT = G::NT, BUF = G::BUF, S = G::STAGES;
   static_assert(S >= 2 && S <= 5, "two to five stages");
   constexpr int WAVES_N = BN / WN;
@@ -64,7 +67,7 @@ gemm_pair_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) float lds[G::LDS_FLOATS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sub = wave >> 1, kw = wave & 1;
+  const int sub = wave / KW, kw = wave % KW;
   const int wm0 = (sub / WAVES_N) * WM, wn0 = (sub % WAVES_N) * WN;
   const int i = lane & 31, hi = lane >> 5;
   if (a.prio) __builtin_amdgcn_s_setprio(3);
@@ -178,22 +181,22 @@ gemm_pair_kernel(GemmArgs a) {
   for (int t = 0; t < S - 1; ++t)
     if (t < nk) issue_tile(t, t);
   if (EDGE && k_tail != 0) __builtin_amdgcn_s_waitcnt(0x0F70);   // s_waitcnt vmcnt(0), as an instruction the wait-count pass sees
-  const bool late = kw == 1 && !a.no_skew && !(ABL & 256);
+  const bool late = (wave & 1) != 0 && !a.no_skew && !(ABL & 256);   // (waves 2 s and 2 s + 1 share SIMD s)
   if (late) {
     float avp[MI][4], bvp[NI][4];
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
       publish(in_flight(kt));
-      if (kt > 0) multiply(avp, bvp);  // tile kt - 1, k-group 3
+      if (kt > 0) multiply(avp, bvp);  // tile kt - 1, this wave's last k-group
       if (kt + S - 1 < nk) issue_tile(kt + S - 1, cur >= 1 ? cur - 1 : S - 1);
       const float* As = lds + cur * BUF;
 #pragma unroll
       for (int g = 0; g + 1 < GW; ++g) {
         float av[MI][4], bv[NI][4];
-        fragments(As, GW + g, av, bv);
+        fragments(As, GW * kw + g, av, bv);
         multiply(av, bv);
       }
-      fragments(As, 2 * GW - 1, avp, bvp);
+      fragments(As, GW * kw + GW - 1, avp, bvp);
       cur = cur == S - 1 ? 0 : cur + 1;
     }
     if (nk > 0) multiply(avp, bvp);
@@ -249,8 +252,8 @@ gemm_pair_kernel(GemmArgs a) {
   // ---- epilogue: whole tiles only.  Pass mi: every wave parks block row mi of its sub-tile (32 rows x WN columns) in its
   // copy of the staged rows; then all threads walk the RT staged rows in 16-byte chunks and add the two copies.
   constexpr int RT = G::RT, C4 = BN / 4;
-  static_assert(NT % C4 == 0 && (RT * C4) % NT == 0, "a thread keeps its column chunk; whole passes");
-  constexpr int NQ = RT * C4 / NT;
+  static_assert(NT % C4 == 0, "a thread keeps its column chunk");
+  constexpr int NQ = (RT * C4 + NT - 1) / NT;   // (fewer chunks than threads: the upper threads have none)
   float* park = lds + kw * RT * BN;
   const int wmi = sub / WAVES_N;
   const int c4 = tid % C4;
@@ -282,22 +285,24 @@ gemm_pair_kernel(GemmArgs a) {
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
       const int row = (c * NT + tid) / C4;
+      const bool mine = (RT * C4) % NT == 0 || c * NT + tid < RT * C4;
       const long m = m_blk + (long)(row >> 5) * WM + sub_index<MI>(AIL, mi, row & 31);
-      idx[c] = (!EDGE || (n_ok && m < a.M)) ? m * a.ldc + n : -1;
+      idx[c] = (mine && (!EDGE || (n_ok && m < a.M))) ? m * a.ldc + n : -1;
       if (a.accumulate && idx[c] >= 0) old[c] = *reinterpret_cast<const f32x4*>(a.C + idx[c]);
     }
 #pragma unroll
     for (int c = 0; c < NQ; ++c) {
       const int row = (c * NT + tid) / C4;
-      const f32x4 even = *reinterpret_cast<const f32x4*>(&lds[row * BN + c4 * 4]);
-      const f32x4 odd = *reinterpret_cast<const f32x4*>(&lds[RT * BN + row * BN + c4 * 4]);
-      f32x4 v;
+      if (idx[c] < 0) continue;
+      f32x4 v = *reinterpret_cast<const f32x4*>(&lds[row * BN + c4 * 4]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] = even[e] + odd[e];
-        v[e] = (a.accumulate && (!EDGE || idx[c] >= 0)) ? (old[c][e] + v[e]) + b4[e] : v[e] + b4[e];
+      for (int w = 1; w < KW; ++w) {   // the waves' copies in wave order
+        const f32x4 other = *reinterpret_cast<const f32x4*>(&lds[w * RT * BN + row * BN + c4 * 4]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] + other[e];
       }
-      if (EDGE && idx[c] < 0) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = a.accumulate ? (old[c][e] + v[e]) + b4[e] : v[e] + b4[e];
       f32x4* p = reinterpret_cast<f32x4*>(a.C + idx[c]);
       if (a.nt_store) __builtin_nontemporal_store(v, p);
       else *p = v;

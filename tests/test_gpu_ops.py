@@ -479,11 +479,12 @@ def test_skewed_and_deep_k_loops_equal_the_in_phase_loop_bit_for_bit(gpu_ctx, mo
 
 @pytest.mark.parametrize("mode", ["nn", "nt", "tn", "tt"])
 @pytest.mark.parametrize("shape", [(1024, 1024, 1024), (512, 768, 320), (64, 64, 256), (1024, 960, 128),
-                                   (1000, 1000, 1000), (960, 1000, 200), (196, 260, 136), (1000, 1024, 132)])
+                                   (1000, 1000, 1000), (960, 1000, 200), (196, 260, 136), (1000, 1024, 132),
+                                   (512, 512, 512), (384, 512, 300), (500, 500, 1000), (416, 448, 256)])
 def test_wave_pair_kernel_against_the_exact_product_and_the_four_wave_kernel(gpu_ctx, monkeypatch, mode, shape):
     """Round 4 (kernels/gemm_f32_pair.hpp): 64 x 64 tiles with at most one block per CU run two waves per sub-tile
-    that split every 64-deep k-tile; the last four shapes are ragged in M, N and / or K (clamped loads, masked stores, a
-    zero-filled last k-tile).  Four layouts, a bias, onto an existing C; the odd wave's skew changes nothing
+    that split every 64-deep k-tile; shapes five to eight are ragged in M, N and / or K (clamped loads, masked stores, a
+    zero-filled last k-tile); the last four are small outputs on 32 x 32 tiles with eight waves per tile (128-deep k-tiles).  Four layouts, a bias, onto an existing C; the odd wave's skew changes nothing
     (EG_GEMM_NO_SKEW=1: bit-identical); against the four-wave kernel (EG_GEMM_NO_PAIR=1) the result differs by rounding
     only — an element is the sum of two f32 chains instead of one — and both meet the float64 product of the operands."""
     M, N, K = shape
