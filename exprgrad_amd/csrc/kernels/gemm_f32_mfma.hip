@@ -403,7 +403,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   const long M = args.M, N = args.N, K = args.K;
   int BM, BN, splits;
   choose_tile(ctx, M, N, K, BM, BN, splits, vec_ok, conv == 0);
-  // Small outputs — between half a chip and a whole chip of 32 x 32 tiles (512 x 512: 256 of them, 64 of 64 x 64): one
+  // Small outputs — between half a chip and three chips of 32 x 32 tiles (512 x 512: 256 of them, 64 of 64 x 64): one
   // 32 x 32 tile per block, eight waves that split every 128-deep k-tile (gemm_f32_pair.hpp, KW = 8), unsliced whatever K
   // is, up to K = 4096: 512^3 13.1 -> 8.0 us NN, 13.4 -> 6.1 TN; 384^3 10.7 -> 6.4; 500 x 500 x 1000 17.3 -> 9.3; 512 x 512 x 2048
   // 20.1 -> 13.3; equal at K = 4096 (25.3 / 26.4); a long K is bound by the tile's loads (512 x 512 x 65536: 337 us against 282
@@ -412,7 +412,10 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     const long t32 = ((M + 31) / 32) * ((N + 31) / 32);
     const bool kw8_on = getenv("EG_GEMM_NO_PAIR") == nullptr && getenv("EG_GEMM_FORCE_TILE") == nullptr &&
                         getenv("EG_GEMM_FORCE_SPLITS") == nullptr;
-    if (kw8_on && !conv && vec_ok && !a_vec_only && !args.ones_row && t32 <= ctx->compute_units && 2 * t32 >= ctx->compute_units &&
+    // (whole tiles: 64 KB of LDS, two blocks share a CU — up to three blocks per CU pay: 640^3 14.4 -> 9.4 us, 768^3 16.7 -> 14.9,
+    // 768 x 768 x 2048 35.9 -> 31.6; 896^3 and 1024^3 do not.  Ragged: 96 KB, one block per CU: up to two per CU, 576^3 13.5 -> 12.8)
+    const bool kw8_ragged = M % 32 != 0 || N % 32 != 0 || K % 128 != 0;
+    if (kw8_on && !conv && vec_ok && !a_vec_only && !args.ones_row && t32 <= (kw8_ragged ? 2L : 3L) * ctx->compute_units && 2 * t32 >= ctx->compute_units &&
         K >= 256 && K <= 4096 && N % 4 == 0 && args.ldc % 4 == 0 && aligned16(args.C) && (args.bias == nullptr || aligned16(args.bias))) {
       args.tiles_m = (int)((M + 31) / 32);
       args.tiles_n = (int)((N + 31) / 32);
@@ -422,7 +425,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
       args.prio = side_priority(ctx);
       args.nt_store = nt_store_enabled();
       args.no_skew = getenv("EG_GEMM_NO_SKEW") != nullptr;
-      const bool ragged = M % 32 != 0 || N % 32 != 0 || K % 128 != 0;
+      const bool ragged = kw8_ragged;
       dim3 grid((unsigned)t32), block(512);
 #define EG_KW8(AKC, BKC)                                                                                                       \
   do {                                                                                                                         \
