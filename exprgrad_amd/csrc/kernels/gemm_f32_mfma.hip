@@ -414,8 +414,12 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
                         getenv("EG_GEMM_FORCE_SPLITS") == nullptr;
     // (whole tiles: 64 KB of LDS, two blocks share a CU — up to three blocks per CU pay: 640^3 14.4 -> 9.4 us, 768^3 16.7 -> 14.9,
     // 768 x 768 x 2048 35.9 -> 31.6; 896^3 and 1024^3 do not.  Ragged: 96 KB, one block per CU: up to two per CU, 576^3 13.5 -> 12.8)
+    // (fewer tiles than half a chip: still better than slices with their second launch while K is short — 256 x 256 x 512
+    // 12.0 -> 6.7 us, 256 x 256 x 1024 14.9 -> 8.1, 320 x 320 x 1024 14.7 -> 7.8, 256^3 7.9 -> 6.4; at K = 2048 the slices win, 10.6
+    // against 12.6.  EG_KW8_SMALL_K: tuning aid)
+    static const long kw8_small_k = getenv("EG_KW8_SMALL_K") ? atol(getenv("EG_KW8_SMALL_K")) : 1024;
     const bool kw8_ragged = M % 32 != 0 || N % 32 != 0 || K % 128 != 0;
-    if (kw8_on && !conv && vec_ok && !a_vec_only && !args.ones_row && t32 <= (kw8_ragged ? 2L : 3L) * ctx->compute_units && 2 * t32 >= ctx->compute_units &&
+    if (kw8_on && !conv && vec_ok && !a_vec_only && !args.ones_row && t32 <= (kw8_ragged ? 2L : 3L) * ctx->compute_units && (2 * t32 >= ctx->compute_units || (K <= kw8_small_k && t32 >= 4)) &&
         K >= 256 && K <= 4096 && N % 4 == 0 && args.ldc % 4 == 0 && aligned16(args.C) && (args.bias == nullptr || aligned16(args.bias))) {
       args.tiles_m = (int)((M + 31) / 32);
       args.tiles_n = (int)((N + 31) / 32);

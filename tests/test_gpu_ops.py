@@ -480,7 +480,8 @@ def test_skewed_and_deep_k_loops_equal_the_in_phase_loop_bit_for_bit(gpu_ctx, mo
 @pytest.mark.parametrize("mode", ["nn", "nt", "tn", "tt"])
 @pytest.mark.parametrize("shape", [(1024, 1024, 1024), (512, 768, 320), (64, 64, 256), (1024, 960, 128),
                                    (1000, 1000, 1000), (960, 1000, 200), (196, 260, 136), (1000, 1024, 132),
-                                   (512, 512, 512), (384, 512, 300), (500, 500, 1000), (416, 448, 256)])
+                                   (512, 512, 512), (384, 512, 300), (500, 500, 1000), (416, 448, 256),
+                                   (256, 256, 512), (320, 288, 1000), (128, 160, 900)])
 def test_wave_pair_kernel_against_the_exact_product_and_the_four_wave_kernel(gpu_ctx, monkeypatch, mode, shape):
     """Round 4 (kernels/gemm_f32_pair.hpp): 64 x 64 tiles with at most one block per CU run two waves per sub-tile
     that split every 64-deep k-tile; shapes five to eight are ragged in M, N and / or K (clamped loads, masked stores, a
