@@ -120,15 +120,25 @@ EVENTS_NOTE = ("kernel_ms_avg = one HIP event pair around the K timed steps / K,
                "kernel_ms_min = shortest step of a second, untimed pass of K steps with an event pair each")
 
 
-def clock_fields(telemetry, achieved_tflops):
-    """The shader clock hwmon showed during the timed steps, next to the fraction.  It is a sampled reading (10 ms period,
-    a handful of samples per timed region), not the effective clock of the kernel: dividing the achieved rate by a peak
-    scaled with it gave 1.09 for the 4096^3 product on one box, so no clock-scaled fraction is derived from it; the
-    reading is reported as it is (a power-limited box shows 1.95 - 2.35 GHz mean under the dense step)."""
+def clock_fields(telemetry, achieved_tflops, clock=None):
+    """The effective shader clock of the timed steps next to the fraction: counted on the device (DeviceClock), so
+    clock x 65 536 FLOP/clk (256 CUs x 4 SIMDs x 64) is the matrix rate those steps could have reached and must not be
+    below what they achieved.  The hwmon reading that stood here until round 4 (`sclk_mhz_timed_mean`) is a sampled
+    sensor value and under-reads (2017 MHz next to 145.7 TFLOP/s = 2224 MHz worth of MFMAs): it stays in `telemetry`,
+    labelled as a sensor, and no fraction is derived from it."""
+    out = {}
+    if clock and clock.get("mhz"):
+        peak_at_clock = clock["mhz"] * 1e6 * 65536 / 1e12
+        out["effective_clock_mhz"] = clock["mhz"]
+        out["mfma_rate_at_effective_clock_tflops"] = round(peak_at_clock, 2)
+        out["frac_of_rate_at_effective_clock"] = round(achieved_tflops / peak_at_clock, 4)
+        out["effective_clock_source"] = clock["source"] + "; " + clock.get("pass", "")
+    elif clock:
+        out["effective_clock_error"] = clock.get("error")
     t = (telemetry or {}).get("sclk_mhz_timed")
-    if not t or not t.get("mean"):
-        return {}
-    return {"sclk_mhz_timed_mean": t["mean"]}
+    if t and t.get("mean"):
+        out["hwmon_sclk_mhz_sensor_mean"] = t["mean"]
+    return out
 
 
 class Telemetry:
@@ -203,13 +213,91 @@ class Telemetry:
         return out
 
 
+class DeviceClock:
+    """Effective shader clock of the K timed steps, counted on the device (the hwmon reading
+    `freq1_input` under-reads — 2017 MHz x 65 536 FLOP/clk = 132 TFLOP/s next to 145.7 achieved in the same steps).
+    ONE wave of a probe kernel sits on a stream of its own while the steps run: it waits for a flag a marker kernel on
+    the MAIN stream raises in front of the first timed step, reads s_memtime (shader cycles, MI355X_MICROARCH.md
+    "s_memtime tick = shader cycle") and s_memrealtime (constant 100 MHz), sleeps until the marker behind the last
+    timed step, reads both again: mean clock = d(cycles) / d(realtime) x 100 MHz, both counters read by the same wave
+    on the same compute unit.  The wave sleeps (s_sleep) between polls, touches no LDS and holds 16 registers; the two
+    markers are one-thread kernels outside the event pair.  Every spin is bounded by the realtime counter (8 s)."""
+
+    PROBE = r"""
+extern "C" __global__ void eg_clock_probe(long long* out, int* flags) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const long long born = __builtin_amdgcn_s_memrealtime();
+  const long long limit = 800000000LL;   // 8 s at 100 MHz
+  out[4] = 0;
+  while (__hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    __builtin_amdgcn_s_sleep(32);
+    if (__builtin_amdgcn_s_memrealtime() - born > limit) { out[4] = 1; return; }
+  }
+  const long long c0 = __builtin_readcyclecounter();
+  const long long r0 = __builtin_amdgcn_s_memrealtime();
+  while (__hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+    __builtin_amdgcn_s_sleep(32);
+    if (__builtin_amdgcn_s_memrealtime() - born > limit) { out[4] = 2; return; }
+  }
+  const long long c1 = __builtin_readcyclecounter();
+  const long long r1 = __builtin_amdgcn_s_memrealtime();
+  out[0] = c0; out[1] = r0; out[2] = c1; out[3] = r1;
+}
+"""
+    MARK = r"""
+extern "C" __global__ void eg_clock_mark(int* flags, long which) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(&flags[which], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+"""
+
+    def __init__(self, main_ctx, device_index):
+        import numpy as np
+        import exprgrad_amd as eg
+        self.np = np
+        self.main = main_ctx
+        self.side = eg.newGpuContext(device_index)           # a stream of its own for the probe wave
+        self.flags = main_ctx.allocBuffer(8)
+        self.out = self.side.allocBuffer(5 * 8)
+        self.probe = self.side.compile("eg_clock_probe", self.PROBE).arg(0, self.out).arg(1, self.flags)
+        self.mark = main_ctx.compile("eg_clock_mark", self.MARK).arg(0, self.flags)
+        self.armed = False
+
+    def arm(self):
+        """Main stream idle (the caller has synchronised): clear the flags, start the probe wave."""
+        self.flags.fill(0, self.np.int32)
+        self.main.sync()
+        self.probe.run([1], [64])
+        self.armed = True
+
+    def begin(self):
+        if self.armed:
+            self.mark.arg(1, 0).run([1], [64])
+
+    def end(self):
+        if self.armed:
+            self.mark.arg(1, 1).run([1], [64])
+
+    def result(self):
+        """After the main stream has been synchronised."""
+        if not self.armed:
+            return None
+        self.armed = False
+        v = self.out.read(self.np.int64)
+        if v[4] != 0 or v[3] <= v[1]:
+            return {"error": f"probe wave gave up in phase {int(v[4])}"}
+        cycles, ticks = int(v[2] - v[0]), int(v[3] - v[1])
+        return {"mhz": round(cycles / ticks * 100.0, 1), "cycles": cycles, "realtime_ticks_100mhz": ticks,
+                "source": "s_memtime / s_memrealtime read by one resident wave in front of and behind the timed steps"}
+
+
 class Timer:
     """K steps bracketed by barrier + synchronize on both sides; max over ranks; per-step HIP
     events on the stream the kernels are launched on (torch's current stream == the context's)."""
 
-    def __init__(self, torch, dist, world, stream, telemetry=None):
+    def __init__(self, torch, dist, world, stream, telemetry=None, clock=None):
         self.torch, self.dist, self.world, self.stream = torch, dist, world, stream
         self.telemetry, self.last_telemetry = telemetry, None
+        self.clock, self.last_clock = clock, None
 
     def sync(self):
         self.torch.cuda.synchronize()
@@ -254,19 +342,43 @@ class Timer:
         # timestamp, and a pair between every two steps holds the queue for 10 - 17 us (rocprofv3 timeline of the
         # train step: the only gap of the step; the XOR step is 25 us long).  Per-step durations (their minimum) come
         # from a second, untimed pass of K steps with an event pair each.
+        # Device-side clock of the timed steps (DeviceClock): only when the timed region is long against the two
+        # one-thread marker kernels it adds (a few us each); shorter regions (the XOR step) get it from an extra pass below.
+        clock_inline = self.clock is not None and per_step * steps >= 2e-3
+        if clock_inline:
+            self.clock.arm()
         if self.telemetry:
             self.telemetry.mark_timed()
         t0 = time.perf_counter()
         marks = []
+        if clock_inline:
+            self.clock.begin()
         starts[0].record(self.stream)
         for i in range(steps):
             step()
             marks.append(time.perf_counter())
         ends[0].record(self.stream)
+        if clock_inline:
+            self.clock.end()
         self.sync()
         elapsed = time.perf_counter() - t0
         if self.telemetry:
             self.last_telemetry = self.telemetry.stop()
+        self.last_clock = None
+        if self.clock is not None:
+            try:
+                if not clock_inline:     # the same K steps once more, untimed, between the two markers
+                    self.clock.arm()
+                    self.clock.begin()
+                    for i in range(steps):
+                        step()
+                    self.clock.end()
+                    self.sync()
+                self.last_clock = self.clock.result()
+                if self.last_clock is not None:
+                    self.last_clock["pass"] = "the timed steps" if clock_inline else "a repeat of the timed steps (region too short for markers)"
+            except Exception as exc:  # noqa: BLE001 - a secondary figure
+                self.last_clock = {"error": repr(exc)}
         bracket_ms = starts[0].elapsed_time(ends[0])
         for i in range(steps):
             starts[i].record(self.stream)
@@ -476,7 +588,7 @@ def run_matmul(args, env):
                    "spinup_note": "value is a sustained-clock figure: ~0.2 s of the same launch run untimed before the W "
                                   "warmup steps (spinup_steps), because W = 5 steps of a 1 ms kernel end inside the clock ramp"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), **clock_fields(timer.last_telemetry, achieved),
+                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), **clock_fields(timer.last_telemetry, achieved, timer.last_clock),
                      **(traffic_fields("matmul4096") if n == 4096 else {"traffic": None}),
                      "kernel": "eg::gemm::gemm_f32_mfma_kernel<256,256,32,128,64,NN,DMA> (skewed waves, 32-deep k-tiles)", "flops_per_launch": flops,
                      "clock": "wall time of the timed steps (the clock `value` uses)",
@@ -624,7 +736,7 @@ def run_train(args, env):
     else:
         step = lambda: dp.step(inputs)
     elapsed, ev_avg, ev_min = env["timer"].run(step, args.steps, args.warmup)
-    telemetry = env["timer"].last_telemetry
+    telemetry, device_clock = env["timer"].last_telemetry, env["timer"].last_clock
     exchange = None
     if world > 1:
         # One run decides whether exchanging the early gradients under the last long contraction pays: the same step
@@ -671,7 +783,7 @@ def run_train(args, env):
                    "grad_bucket_floats": model.grad_bucket("train")[1],
                    "timed_steps": args.steps, "sustained_clock_spinup_s": SPINUP_S},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), **clock_fields(telemetry, achieved),
+                     "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), **clock_fields(telemetry, achieved, device_clock),
                      **(traffic_fields("train") if batch == DENSE["batch"] else {"traffic": None}),
                      "kernel": "whole train step on one GPU (5 contractions dominate: gemm_f32_mfma_kernel)",
                      "flops_per_launch": step_flops, "clock": "wall time of the timed steps (the clock `value` uses)",
@@ -766,7 +878,7 @@ def run_conv2(args, env):
     elapsed, ev_avg, ev_min = env["timer"].run(
         lambda: ops.conv2_nhwc(ctx, N, H, W, C, F, FH, FW, img, flt, out), steps, args.warmup)
     flops = 2.0 * N * (H - FH + 1) * (W - FW + 1) * F * FH * FW * C
-    telemetry = env["timer"].last_telemetry
+    telemetry, device_clock = env["timer"].last_telemetry, env["timer"].last_clock
     achieved = flops * steps / elapsed / 1e12                          # the clock `value` uses (see run_matmul)
     # the two gradients derive makes of conv2 (same FLOP count each), for the record
     gout = torch.rand(out.shape, device="cuda", generator=gen) - 0.5
@@ -783,7 +895,7 @@ def run_conv2(args, env):
                                    f"eg_conv2_nhwc; timed steps = max(--steps, 50) = {steps}",
                        "timed_steps": steps, "sustained_clock_spinup_s": SPINUP_S},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), **clock_fields(telemetry, achieved),
+                         "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), **clock_fields(telemetry, achieved, device_clock),
                          **traffic_fields("conv2"),
                          "kernel": "conv2_halo_kernel<9,3,3> (LDS-resident 10x34 halo, 8x32 patch x 64 filters per block)", "flops_per_launch": flops,
                          "clock": "wall time of the timed steps", "kernel_ms_avg": round(ev_avg, 4),
@@ -960,6 +1072,11 @@ def main():
     native = world > 1 and not args.torch_dp and not one_gpu
     env = {"torch": torch, "ops": ops, "ctx": ctx, "world": world, "rank": rank, "native_dp": native,
            "timer": Timer(torch, dist, world, stream, Telemetry(torch, local_rank) if rank == 0 else None)}
+    if rank == 0 and world == 1 and os.environ.get("EG_BENCH_NO_DEVICE_CLOCK") != "1":
+        try:
+            env["timer"].clock = DeviceClock(ctx, local_rank)
+        except Exception as exc:  # noqa: BLE001 - a secondary figure
+            print(f"[bench] device clock probe unavailable: {exc!r}", file=sys.stderr)
 
     workload = args.workload
     if workload == "auto":

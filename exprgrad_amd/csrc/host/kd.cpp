@@ -360,6 +360,18 @@ int parse(const char* text, Program& prog) {
       hoist_host_indices(k);
       for (auto& g : k.custom_grad) hoist_host_indices(g);
     }
+  // epoch() among the host values (written as "setup" or hoisted just now): plans are then made per epoch
+  auto uses_epoch = [](const std::vector<Instr>& v) {
+    for (auto& ins : v)
+      if (ins.kind == IK::Epoch) return true;
+    return false;
+  };
+  for (auto& t : prog.targets)
+    for (auto& k : t.source) {
+      prog.epoch_in_setup = prog.epoch_in_setup || uses_epoch(k.setup);
+      for (auto& g : k.custom_grad) prog.epoch_in_setup = prog.epoch_in_setup || uses_epoch(g.setup);
+    }
+  for (auto& ss : prog.shape_setup) prog.epoch_in_setup = prog.epoch_in_setup || uses_epoch(ss.second);
   // validate tensor references
   auto check_tid = [&](int t) { return t >= 1 && t < (int)prog.tensors.size(); };
   for (auto& t : prog.targets) {

@@ -108,6 +108,10 @@ struct Program {
   std::map<int, std::vector<Instr>> shape_setup;  // dest -> host instructions defining the registers of shape_dims
   std::vector<Target> targets;
   std::map<std::string, int> inputs;
+  // Some host-evaluated value (a kernel's setup, a shape constraint) is epoch() or computed from it: such values are
+  // fixed when a plan is made (loop bounds, kernel arguments, literals of generated code), so plans are keyed by the
+  // epoch as well as by the input shapes (plan.cpp shape_key) — `x[epoch() mod n]` reads another row every epoch.
+  bool epoch_in_setup = false;
   Target* find_target(const std::string& name);
   int alloc_tensor(TK kind, const std::string& name);
 };

@@ -206,13 +206,7 @@ int eg_model_free(eg_model* m) try {
   if (m->fit_graph.graph) hipGraphDestroy(m->fit_graph.graph);
   m->fit_graph.graph = nullptr;
   for (auto& kv : m->targets) {
-    for (auto& p : kv.second.plans) {
-      for (auto& g : p.second->graphs)
-        if (g.exec) hipGraphExecDestroy(g.exec);
-      for (auto& rg : p.second->row_groups)
-        if (rg->partial) hipFree(rg->partial);
-      if (p.second->arena) hipFree(p.second->arena);
-    }
+    for (auto& p : kv.second.plans) release_plan(*p.second);
     if (kv.second.bucket_owned && kv.second.bucket) hipFree(kv.second.bucket);
   }
   for (auto& p : m->params)

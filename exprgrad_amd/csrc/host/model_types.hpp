@@ -200,6 +200,7 @@ struct Plan {
     long epoch = 0;
   };
   Captured graphs[6];  // 0 whole call, 1 backward part, 2 update part; data-parallel split: 3 head, 4 side lane, 5 tail
+  long epoch = 0;      // Model.epoch the plan was made under (part of the key when the program has epoch_in_setup)
   int dp_agreed = 0;   // data-parallel exchange plan compared across the ranks: 0 not yet, 1 the same everywhere (split allowed), 2 differs (one bucket)
   int dp_agreed_for = 0;  // the split setting (1 allowed, 2 forbidden) the agreement was made under
 };
@@ -216,6 +217,7 @@ struct TargetState {
   float* bucket = nullptr;
   bool bucket_owned = false;
   uint64_t last_stamp = ~0ull;  // eg_model::inputs_gen for which `last` was looked up
+  long last_epoch = -1;         // ... and Model.epoch (compared when the program computes host values from epoch())
 };
 
 struct BoundInput {
@@ -324,6 +326,7 @@ bool full_cover(const Kernel& k, const KernelInfo& info, const std::vector<long>
 void note_vec4(Launch& L, long total);
 int fill_params(eg_model* m, const Kernel& k, const KernelInfo& info, const Shapes& shapes, const GenericSource& src, bool accumulate, long total, long rtotal, long chunk, std::vector<long>& out);
 std::string shape_key(eg_model* m);
+void release_plan(Plan& plan);
 bool copy_can_alias(eg_model* m, TargetState& ts, const Kernel& k, const KernelInfo& info, const Shapes& shapes, int p);
 int make_plan(eg_model* m, TargetState& ts, Plan& plan);
 int get_plan(eg_model* m, const char* target, TargetState** ts_out, Plan** plan_out);

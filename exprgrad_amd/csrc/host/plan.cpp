@@ -181,6 +181,20 @@ int fill_params(eg_model* m, const Kernel& k, const KernelInfo& info, const Shap
   return EG_OK;
 }
 
+// Device resources of a plan (graphs, row-group partials, the arena).  The caller has waited for the stream.
+void release_plan(Plan& plan) {
+  for (auto& g : plan.graphs) {
+    if (g.exec) hipGraphExecDestroy(g.exec);
+    g.exec = nullptr;
+  }
+  for (auto& rg : plan.row_groups) {
+    if (rg->partial) hipFree(rg->partial);
+    rg->partial = nullptr;
+  }
+  if (plan.arena) hipFree(plan.arena);
+  plan.arena = nullptr;
+}
+
 std::string shape_key(eg_model* m) {
   std::ostringstream os;
   for (auto& in : m->inputs) {
@@ -189,7 +203,7 @@ std::string shape_key(eg_model* m) {
     for (long s : in.second.shape) os << s << ",";
     os << ";";
   }
-  os << "e" << 0;
+  os << "e" << (m->prog.epoch_in_setup ? m->epoch : 0);  // host values computed from epoch() are fixed per plan (kd.hpp)
   if (m->keep_values) os << "v";
   return os.str();
 }
@@ -596,7 +610,8 @@ int get_plan(eg_model* m, const char* target, TargetState** ts_out, Plan** plan_
   // model.nim:395-396
   EG_REQUIRE(it != m->targets.end(), EG_ERR_RUNTIME, "%s is not a target of the model", target);
   TargetState& ts = it->second;
-  if (ts.last && ts.last_stamp == m->inputs_gen) {  // same bindings as the last lookup: same shapes, same plan
+  const bool per_epoch = m->prog.epoch_in_setup;
+  if (ts.last && ts.last_stamp == m->inputs_gen && (!per_epoch || ts.last_epoch == m->epoch)) {  // same bindings as the last lookup: same shapes, same plan
     *ts_out = &ts;
     *plan_out = ts.last;
     return EG_OK;
@@ -604,8 +619,27 @@ int get_plan(eg_model* m, const char* target, TargetState** ts_out, Plan** plan_
   const std::string key = shape_key(m);
   auto p = ts.plans.find(key);
   if (p == ts.plans.end()) {
+    if (per_epoch) {
+      // Plans of other epochs will not be asked for again (the epoch only grows): release them instead of keeping one
+      // arena per epoch.  Their launches may still be queued, hence the wait.
+      bool stale = false;
+      for (auto& old : ts.plans) stale = stale || old.second->epoch != m->epoch;
+      if (stale) {
+        EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
+        for (auto it = ts.plans.begin(); it != ts.plans.end();) {
+          if (it->second->epoch != m->epoch) {
+            release_plan(*it->second);
+            it = ts.plans.erase(it);
+          } else {
+            ++it;
+          }
+        }
+        ts.last = nullptr;
+      }
+    }
     std::unique_ptr<Plan> plan(new Plan());
     plan->key = key;
+    plan->epoch = m->epoch;
     int rc = make_plan(m, ts, *plan);
     if (rc) {
       if (plan->arena) hipFree(plan->arena);
@@ -615,6 +649,7 @@ int get_plan(eg_model* m, const char* target, TargetState** ts_out, Plan** plan_
   }
   ts.last = p->second.get();
   ts.last_stamp = m->inputs_gen;
+  ts.last_epoch = m->epoch;
   *ts_out = &ts;
   *plan_out = p->second.get();
   return EG_OK;

@@ -56,9 +56,14 @@ def rel_err(got, want):
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     denom = np.max(np.abs(want))
-    if denom == 0:
-        return float(np.max(np.abs(got)))
-    return float(np.max(np.abs(got - want)) / denom)
+    err = float(np.max(np.abs(got))) if denom == 0 else float(np.max(np.abs(got - want)) / denom)
+    record = os.environ.get("EG_PARITY_RECORD")
+    if record:   # survey mode (tools/parity_survey.py): every direct two-way comparison of a GPU test is logged as well
+        import json
+        with open(record, "a") as f:
+            f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", ""), "what": "direct comparison (rel_err)",
+                                "direct": err, "size": int(want.size)}) + "\n")
+    return err
 
 
 # float32 parity tolerance stated by BASELINE.json north_star: 1e-5 relative.

@@ -87,10 +87,15 @@ class Trio:
         e_gpu = float(np.max(np.abs(np.asarray(got, np.float64) - exact))) / scale if np.size(exact) else 0.0
         e_ref = float(np.max(np.abs(np.asarray(ref32, np.float64) - exact))) / scale if np.size(exact) else 0.0
         record = os.environ.get("EG_PARITY_RECORD")
-        if record:      # survey mode: log both distances instead of asserting (profiles/parity_survey_r02.json)
+        if record:      # survey mode: log the distances instead of asserting (profiles/parity_survey_r02.json)
+            # e_go: the comparison as BASELINE.json words it — backend against the reference CPU path (the oracle)
+            # directly, relative to max|oracle| (round 5; the two distances above are each against the float64 shadow)
+            ref64 = np.asarray(ref32, np.float64)
+            oscale = max(float(np.max(np.abs(ref64))) if ref64.size else 0.0, 1e-30)
+            e_go = float(np.max(np.abs(np.asarray(got, np.float64) - ref64))) / oscale if ref64.size else 0.0
             with open(record, "a") as f:
                 f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", ""), "what": what, "n": n,
-                                    "e_gpu": e_gpu, "e_ref": e_ref, "size": int(np.size(exact))}) + "\n")
+                                    "e_gpu": e_gpu, "e_ref": e_ref, "e_go": e_go, "size": int(np.size(exact))}) + "\n")
             return
         assert np.all(np.isfinite(np.asarray(got))) == np.all(np.isfinite(exact)), (what, "finiteness differs")
         if not np.all(np.isfinite(exact)):
@@ -123,9 +128,10 @@ class Trio:
         e_ref = float(np.max(np.abs(np.asarray(ref32, np.float64) - exact) / scale)) if exact.size else 0.0
         record = os.environ.get("EG_PARITY_RECORD")
         if record:
+            e_go = float(np.max(np.abs(got64 - np.asarray(ref32, np.float64)) / scale)) if exact.size else 0.0   # same scale
             with open(record, "a") as f:
                 f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", ""), "what": what + " (vs sum of |terms|)", "n": n,
-                                    "e_gpu": e_gpu, "e_ref": e_ref, "size": int(exact.size)}) + "\n")
+                                    "e_gpu": e_gpu, "e_ref": e_ref, "e_go": e_go, "size": int(exact.size)}) + "\n")
             return
         assert np.all(np.isfinite(got64)) == np.all(np.isfinite(exact)), (what, "finiteness differs")
         if np.all(np.isfinite(exact)):

@@ -176,6 +176,41 @@ def test_shape_changes_between_calls(gpu_ctx):
     model.close()
 
 
+def test_epoch_inside_a_computed_index_follows_the_epoch(gpu_ctx):
+    """`row{i} ++= x[epoch() mod shape, i]`: epoch() inside a tensor index is a host value, evaluated when a plan is made
+    (kd.cpp hoist_host_indices).  A plan made at epoch 1 must not serve epoch 2 (it did, and returned row 1
+    again): the program is flagged (kd::Program::epoch_in_setup) and plans are then keyed by the epoch.  Checked over
+    several epochs against the oracle, which re-evaluates the value on every call, and against the rows themselves;
+    written both as `setup` (what dsl.py emits) and as `idx` (what another producer may emit)."""
+    from oracle import kd
+    from exprgrad_amd import dsl
+    from exprgrad_amd.dsl import Fun, iters
+
+    def graphs():
+        x = dsl.input("x")
+        i = iters("i")
+        r = Fun()
+        r[i] += x[dsl.epoch() % x.shape[0], i] * 2.0
+        r.with_shape(x.shape[1])
+        return [r.target("row")]
+
+    text = refcases.program_text(graphs())
+    assert "epoch" in text
+    variants = [text]
+    if "  setup " in text:
+        variants.append(text.replace("  setup ", "  idx "))
+    xs = np.arange(5 * 7, dtype=np.float32).reshape(5, 7)
+    for t in variants:
+        gpu = egm.Model(egm._LoadedProgram(t), gpu_ctx)
+        ref = kd.Model(t)
+        for epoch in (1, 2, 2, 7, 3, 11):
+            gpu.epoch = ref.epoch = epoch
+            got = gpu.call("row", {"x": xs})
+            assert np.array_equal(got, ref.call("row", {"x": xs})), epoch
+            assert np.array_equal(got, xs[epoch % 5] * 2.0), epoch
+        gpu.close()
+
+
 def test_device_inputs_are_borrowed(gpu_ctx):
     model = egm.compile(*refcases.matmul(), gpu=gpu_ctx)
     a = np.arange(6, dtype=np.float32).reshape(2, 3)
