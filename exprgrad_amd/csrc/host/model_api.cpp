@@ -17,6 +17,7 @@
 // (passes.nim:1386-1436).
 #include <random>
 #include "model_types.hpp"
+#include "dp_schedule.hpp"
 
 using namespace eg::kd;
 using namespace eg::model;
@@ -46,48 +47,37 @@ int model_backward_with_exchange(eg_model* m, const char* target, const GradExch
     }
     return (int)EG_OK;
   };
-  // The split is a per-rank decision (plan.overlaps depends on this rank's shapes and environment); every rank must
-  // make the SAME one.  Once per plan the piece list is compared across the ranks; where it differs, every rank
-  // exchanges the whole bucket in one call (and if even the bucket sizes differ, the step is refused).
-  bool split = gx.split && ex.big >= 0 && !plan->pipe.active;
-  // (agreed once per plan AND per split setting: eg_dp_set_split after an agreement makes the ranks agree again — every
-  // rank changes the setting together, that is the contract of eg_dp_set_split.  What this cannot see is ONE rank
-  // arriving with a new plan while the others replay an agreed one — unequal shards in one step only: ranks must
-  // change their input shapes in the same step, INTEGRATION.md "data parallel".)
-  const int want_agreed_for = gx.split ? 1 : 2;
-  if (gx.agree && (plan->dp_agreed == 0 || plan->dp_agreed_for != want_agreed_for)) {
-    plan->dp_agreed = 0;
-    plan->dp_agreed_for = want_agreed_for;
-    // fixed length whatever the piece count, so ranks with different piece lists still meet in one collective: the
-    // bucket size, the decision, the two piece counts and a 128-bit hash of the complete piece list (no truncation)
-    uint64_t h1 = 1469598103934665603ull, h2 = 0x9e3779b97f4a7c15ull;
-    auto mix = [&](int64_t v) {
-      for (int b = 0; b < 8; ++b) {
-        const unsigned char c = (unsigned char)((uint64_t)v >> (8 * b));
-        h1 = (h1 ^ c) * 1099511628211ull;
-        h2 = (h2 + c + 0x9e3779b97f4a7c15ull) * 0xbf58476d1ce4e5b9ull;
-        h2 ^= h2 >> 29;
-      }
-    };
-    if (split) {
-      for (auto& seg : ex.early) { mix(seg.first); mix(seg.second); }
-      mix(-1);
-      for (auto& seg : ex.late) { mix(seg.first); mix(seg.second); }
-    }
-    std::vector<int64_t> finger = {(int64_t)ts->bucket_floats, split ? 1 : 0, split ? (int64_t)ex.early.size() : 0,
-                                   split ? (int64_t)ex.late.size() : 0, (int64_t)(h1 >> 1), (int64_t)(h2 >> 1)};
-    int same = 0, same_bucket = 0;
-    rc = gx.agree(gx.user, finger.data(), (int)finger.size(), &same);
-    if (rc) return rc;
-    if (!same) {
-      rc = gx.agree(gx.user, finger.data(), 1, &same_bucket);
-      if (rc) return rc;
-      EG_REQUIRE(same_bucket, EG_ERR_INVALID,
-                 "data-parallel step: the ranks hold gradient buckets of different sizes (different models or targets)");
-    }
-    plan->dp_agreed = same ? 1 : 2;
+  // WHICH all-reduce calls this step issues is the (group, target)'s exchange schedule, not this plan's own cut
+  // (host/dp_schedule.hpp): negotiated at step counts every rank reaches together, served by whatever plan a rank
+  // currently holds — overlapped when the plan proposes the agreed cut, behind its whole backward range otherwise.
+  eg::dp::Proposal mine;
+  mine.bucket_floats = ts->bucket_floats;
+  mine.split = ex.big >= 0 && !plan->pipe.active;
+  mine.early = ex.early;
+  mine.late = ex.late;
+  static const long reagree_every = [] {
+    const char* e = getenv("EG_DP_REAGREE_STEPS");
+    return e ? atol(e) : 256L;
+  }();
+  eg::dp::Schedule& sched = ts->dp_schedules[gx.user];
+  eg::dp::How how = eg::dp::How::Whole;
+  std::string why;
+  rc = eg::dp::step_decision(sched, mine, gx.split, gx.agree, gx.user, reagree_every, &how, &why);
+  if (rc == -1) {
+    set_error("%s", why.c_str());
+    return EG_ERR_INVALID;
   }
-  if (plan->dp_agreed == 2) split = false;
+  if (rc) return rc;
+  const bool split = how == eg::dp::How::Overlapped;
+  if (how == eg::dp::How::Sequential) {
+    // the agreed cut, without the overlap this plan cannot give: same calls, same order as on the other ranks
+    rc = run_range(m, *ts, *plan, 0, plan->n_backward, true, 1);
+    if (rc) return rc;
+    rc = reduce(sched.early);
+    if (!rc) rc = reduce(sched.late);
+    if (pieces) *pieces = issued;
+    return rc;
+  }
   if (!split) {
     // nothing to overlap with: the captured backward range, then one all-reduce of the whole bucket
     rc = run_range(m, *ts, *plan, 0, plan->n_backward, true, 1);

@@ -21,10 +21,12 @@
 #include <vector>
 
 #include "../eg_internal.hpp"
+#include "dp_schedule.hpp"
 #include "../kernels/gemm_fused.hpp"
 #include "codegen.hpp"
 #include "epilogue.hpp"
 #include "kd.hpp"
+#include "dp_schedule.hpp"
 #include "rowfuse.hpp"
 
 namespace eg {
@@ -201,8 +203,6 @@ struct Plan {
   };
   Captured graphs[6];  // 0 whole call, 1 backward part, 2 update part; data-parallel split: 3 head, 4 side lane, 5 tail
   long epoch = 0;      // Model.epoch the plan was made under (part of the key when the program has epoch_in_setup)
-  int dp_agreed = 0;   // data-parallel exchange plan compared across the ranks: 0 not yet, 1 the same everywhere (split allowed), 2 differs (one bucket)
-  int dp_agreed_for = 0;  // the split setting (1 allowed, 2 forbidden) the agreement was made under
 };
 
 struct TargetState {
@@ -217,6 +217,8 @@ struct TargetState {
   float* bucket = nullptr;
   bool bucket_owned = false;
   uint64_t last_stamp = ~0ull;  // eg_model::inputs_gen for which `last` was looked up
+  // exchange schedule of the data-parallel step per group (GradExchange::user): host/dp_schedule.hpp
+  std::map<void*, eg::dp::Schedule> dp_schedules;
   long last_epoch = -1;         // ... and Model.epoch (compared when the program computes host values from epoch())
 };
 

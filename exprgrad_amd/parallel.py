@@ -58,8 +58,12 @@ class GpuEngine:
         # seed every shard would draw the SAME mask for its rows; fold the rank into the seed
         model.set_seed(0x5EED5EED + 7919 * int(rank))
         _, count = model.grad_bucket(target)
-        # gradients live in a torch tensor so torch.distributed can reduce them in place
-        self.bucket = torch.zeros(max(count, 1), dtype=torch.float32, device="cuda")
+        # gradients live in a torch tensor so torch.distributed can reduce them in place; behind them one float per rank
+        # that travels in the SAME all-reduce: the rows of every rank's shard (DataParallel's check of equal shards)
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        self.exchange = torch.zeros(max(count, 1) + world, dtype=torch.float32, device="cuda")
+        self.bucket = self.exchange[:max(count, 1)]
+        self.trailer = self.exchange[max(count, 1):]
         if count > 0:
             model.bind_grad_bucket(target, self.bucket)
 
@@ -74,24 +78,80 @@ class GpuEngine:
 
 
 class DataParallel:
-    def __init__(self, engine, reduction="mean", group=None, always_reduce=False):
+    def __init__(self, engine, reduction="mean", group=None, always_reduce=False, check_shards=None):
         """always_reduce: issue the all-reduce on a one-rank group too (exercises the RCCL path on a
-        one-GPU box; a sum over one rank leaves the bucket unchanged)."""
+        one-GPU box; a sum over one rank leaves the bucket unchanged).
+        check_shards (default: on for "mean"): every step carries the row count of each rank's shard in the step's ONE
+        all-reduce (engines that expose `exchange` / `trailer`, one float per rank behind the bucket: no extra
+        collective, and the call has the same shape on every rank whatever the shards look like — a rank that changes
+        its shard one step before the others cannot pair mismatched collectives).  With a batch-mean loss every shard is
+        weighted 1 / world, which is the full-batch step only for EQUAL shards: unequal ones raise RuntimeError —
+        checked without stalling the stream, i.e. at a later step or at finish()."""
         if reduction not in ("mean", "sum"):
             raise ValueError("reduction must be 'mean' (loss divides by the batch) or 'sum'")
         self.engine, self.reduction, self.group = engine, reduction, group
         self.always_reduce = always_reduce and dist.is_initialized()
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if check_shards is None:
+            check_shards = reduction == "mean"
+        self.check_shards = bool(check_shards) and self.world > 1 and hasattr(engine, "trailer") and \
+            engine.trailer.numel() == self.world
+        self.steps = 0
+        self._rows_src, self._rows = None, None
+        self._pending = []     # (step, host copy of the trailer, event or None)
+
+    def _raise_if_unequal(self, step, rows):
+        rows = [int(round(float(v))) for v in rows]
+        if len(set(rows)) > 1:
+            raise RuntimeError(f"data-parallel step {step}: the ranks ran shards of {rows} rows; a batch-mean loss weights "
+                               "every shard 1 / world, which equals the full-batch step only for equal shards")
+
+    def _poll(self, block=False):
+        while self._pending:
+            step, host, event = self._pending[0]
+            if event is not None and not block and not event.query():
+                return
+            if event is not None:
+                event.synchronize()
+            self._pending.pop(0)
+            self._raise_if_unequal(step, host.tolist())
+
+    def finish(self):
+        """Wait for the steps queued so far and report a shard mismatch of any of them."""
+        self._poll(block=True)
 
     def step(self, local_args):
         """One training step on this rank's shard.  Asynchronous on GPUs."""
         e = self.engine
+        if self.check_shards:
+            self._poll()
+            items = local_args.items() if isinstance(local_args, dict) else local_args
+            rows = int(next(iter(items))[1].shape[0])
+            if rows != self._rows:      # (device-side constant, rewritten only when the shard changes)
+                src = torch.zeros(self.world, dtype=torch.float32)
+                src[self.rank] = float(rows)
+                self._rows_src, self._rows = src.to(e.trailer.device), rows
         e.set_grad_scale(1.0 / self.world if self.reduction == "mean" else 1.0)
         e.run_backward(local_args)
         if self.world > 1 or self.always_reduce:
-            dist.all_reduce(e.bucket, op=dist.ReduceOp.SUM, group=self.group)
+            if self.check_shards:
+                e.trailer.copy_(self._rows_src)
+                dist.all_reduce(e.exchange, op=dist.ReduceOp.SUM, group=self.group)
+                if e.trailer.is_cuda:
+                    host = torch.empty(self.world, dtype=torch.float32, pin_memory=True)
+                    host.copy_(e.trailer, non_blocking=True)
+                    event = torch.cuda.Event()
+                    event.record()
+                    self._pending.append((self.steps, host, event))
+                else:
+                    self._pending.append((self.steps, e.trailer.clone(), None))
+            else:
+                dist.all_reduce(e.bucket, op=dist.ReduceOp.SUM, group=self.group)
         e.run_update()
+        self.steps += 1
+        if self.check_shards and not e.trailer.is_cuda:
+            self._poll()
 
 
 class RcclGroup:

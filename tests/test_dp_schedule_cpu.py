@@ -1,0 +1,20 @@
+"""The exchange schedule of the data-parallel step (exprgrad_amd/csrc/host/dp_schedule.hpp) on the CPU: the header the
+library compiles, driven by W simulated ranks over a transport that flags every slot in which two ranks issue different
+collectives (tests/dp_schedule_sim.cpp).  The scenario VERDICT r4 named the likeliest first-contact bug of an N > 1 run —
+one rank arriving with a new plan one step before the others — must produce no mismatched slot, and the round-4 policy
+(agreement per plan) must be SEEN to produce one, so that the simulation is known to be able to catch it."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exchange_schedule_scenarios(tmp_path):
+    exe = str(tmp_path / "dp_schedule_sim")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-pthread", os.path.join(ROOT, "tests", "dp_schedule_sim.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    lines = out.stdout.strip().splitlines()
+    assert out.returncode == 0 and lines[-1] == "ALL PASS", out.stdout + out.stderr
+    names = [l.split()[1].rstrip(":") for l in lines[:-1]]
+    assert names == ["steady", "early_replan", "early_replan_new_cut", "lone_replan", "toggle", "buckets", "legacy_policy_is_caught"]
+    assert all(l.startswith("PASS") for l in lines[:-1])

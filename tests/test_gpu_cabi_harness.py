@@ -62,6 +62,18 @@ def test_runtime_group_from_c(tmp_path):
     assert "run-time compiler: hiprtc" in done.stdout, done.stdout
 
 
+@pytest.mark.gpu
+def test_the_references_own_lowered_kernels_through_the_jit_stub_calls(tmp_path):
+    """Level 1 of INTEGRATION.md end to end: four kernels the reference's pipeline lowers for its GPU target
+    (tests/cache/{matmul_basic, matmul_schedule_tiled16, relu_basic, conv1_basic}.ir), as the HIP text the clgen.nim
+    patch of nim/PATCHES.md section 5 emits, compiled by eg_kernel_compile and driven with the calls the JIT launch stub
+    makes (set tensor, set index, run with groups = ceil(global / local)); results equal the host loops the
+    reference's tests compare with (VERDICT r4 next #9)."""
+    done = subprocess.run([build_harness(tmp_path), "jit"], capture_output=True, text=True)
+    assert done.returncode == 0, done.stdout + done.stderr
+    assert "4 reference kernels" in done.stdout
+
+
 with open(os.path.join(HERE, "golden", "handwritten.json")) as _f:
     CASES = json.load(_f)
 
