@@ -260,11 +260,14 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
       case StepKind::RowFused: {
         const PlanRowGroup& pg = *plan.row_groups[L.row_group];
         os << "row-fused " << pg.g.kernel_index.size() << " kernels";
+        if (pg.g.in_kernel_finalize) os << " | partial rows folded by the last block to arrive";
+        if (L.tail_launch >= 0) os << " | which goes on with launch " << L.tail_launch << " when a range holds both";
         break;
       }
       case StepKind::SmallFused: {
         const PlanSmallGroup& sg = *plan.small_groups[L.row_group];
         os << (sg.g.blocks > 1 ? "map-fused " : "small-fused ") << sg.g.kernel_index.size() << " kernels";
+        if (L.tail_of >= 0) os << " (run by the last block of launch " << L.tail_of << " when a range holds both)";
         break;
       }
     }

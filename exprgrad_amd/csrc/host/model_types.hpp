@@ -106,6 +106,11 @@ struct Launch {
   int vec_slot = -1;                        // GenericA: index of the Slot::Vec4 argument, if the kernel has one
   bool vec_ok = false;                      //   the shapes allow four elements per thread (pointers are checked per launch)
   long total_items = 0;                     //   independent iterations (grid = items or items / 4)
+  // Row tail (plan_groups.cpp fuse_row_tails): a small / map group that directly follows a multi-block row group runs in
+  // that group's last block.  Both launches stay in the list; when a range holds both, the row launch gets MODE 2 and the
+  // tail launch is skipped; when a range ends between them (backward | update of the data-parallel step) both run.
+  int tail_launch = -1;                     // RowFused: index of the launch its last block can run
+  int tail_of = -1;                         // SmallFused: index of the RowFused launch that can run it
 };
 
 // A run of per-sample kernels fused into one generated kernel (rowfuse.hpp), built per plan.
@@ -115,6 +120,8 @@ struct PlanRowGroup {
   float* partial = nullptr;  // [nblocks][g.red_total]
   int nblocks = 0;
   std::vector<int> red_tensors;  // reduction destinations, in segment order
+  unsigned* counter = nullptr;   // in_kernel_finalize: arrival tickets of the blocks (zero between launches)
+  int tail_group = -1;           // index into Plan::small_groups of the group the last block runs (MODE 2), or -1
 };
 
 // A run of small-tensor kernels (optimizer updates) fused into one single-block kernel.
@@ -202,6 +209,7 @@ struct Plan {
     long epoch = 0;
   };
   Captured graphs[6];  // 0 whole call, 1 backward part, 2 update part; data-parallel split: 3 head, 4 side lane, 5 tail
+  int active_begin = 0, active_end = 0;  // the launch range being issued (run_range_eager): decides MODE of a row group with a tail
   long epoch = 0;      // Model.epoch the plan was made under (part of the key when the program has epoch_in_setup)
 };
 
@@ -315,6 +323,8 @@ int build_pending(eg_model* m);
 void describe(eg_model* m);
 // plan_groups.cpp
 int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos, const std::map<int, int>& first_writer, std::vector<int>& group_of);
+int fuse_row_tails(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos);
+bool row_tail_active(const Plan& plan, const Launch& row_launch);
 // plan_overlap.cpp
 int ensure_side_lane(eg_ctx* ctx);
 bool launch_tensors(const Plan& plan, const Launch& L, std::set<int>& reads, std::set<int>& writes);

@@ -190,6 +190,8 @@ void release_plan(Plan& plan) {
   for (auto& rg : plan.row_groups) {
     if (rg->partial) hipFree(rg->partial);
     rg->partial = nullptr;
+    if (rg->counter) hipFree(rg->counter);
+    rg->counter = nullptr;
   }
   if (plan.arena) hipFree(plan.arena);
   plan.arena = nullptr;
@@ -560,6 +562,10 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
 
   plan_overlap(m, ts, plan);
   plan_pipeline(m, ts, plan);
+  {
+    int rc = fuse_row_tails(m, ts, plan, infos);
+    if (rc) return rc;
+  }
   {
     int rc = build_plan_kernels(m, plan);
     if (rc) return rc;

@@ -13,6 +13,73 @@ bool row_fusion_enabled() {
   return on;
 }
 
+bool row_tails_enabled() {  // (read when a plan is made: a test builds one model each way)
+  const char* e = getenv("EG_NO_ROW_TAIL");
+  return !(e && e[0] && e[0] != '0');
+}
+
+// Is the tail of this RowFused launch part of the range being issued?  (run.cpp: MODE 2 and the tail launch skipped.)
+bool row_tail_active(const Plan& plan, const Launch& L) {
+  return L.kind == StepKind::RowFused && L.tail_launch >= 0 && L.tail_launch < plan.active_end && L.tail_launch >= plan.active_begin;
+}
+
+// A small / map group (the optimizer updates of a small net) that DIRECTLY follows a multi-block row group whose last
+// block folds the partial rows: that block goes on with the group's kernels — everything they read is complete by then
+// (every block has arrived), they are small (is_small_kernel: tensors of at most 4096 elements), and one 256-thread
+// block runs them exactly as a small group's kernel would.  The XOR step (rows + finalize + update: three dependent
+// launches of ~5 us each) becomes ONE launch.  Not across an overlap group or under the batch pipeline.
+int fuse_row_tails(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos) {
+  if (!row_tails_enabled() || plan.pipe.active) return EG_OK;
+  Target& t = *ts.target;
+  auto in_overlap = [&](int i) {
+    for (auto& ov : plan.overlaps)
+      if (i >= ov.first && i <= ov.big) return true;
+    return false;
+  };
+  for (int i = 0; i + 1 < (int)plan.launches.size(); ++i) {
+    Launch& R = plan.launches[i];
+    Launch& S = plan.launches[i + 1];
+    if (R.kind != StepKind::RowFused || S.kind != StepKind::SmallFused) continue;
+    PlanRowGroup& pg = *plan.row_groups[R.row_group];
+    if (!pg.g.in_kernel_finalize || pg.tail_group >= 0 || in_overlap(i) || in_overlap(i + 1)) continue;
+    PlanSmallGroup& sg = *plan.small_groups[S.row_group];
+    long work = 0;
+    bool ok = true;
+    for (int ki : sg.g.kernel_index) {
+      const Kernel& k = t.all[ki];
+      ok = ok && is_small_kernel(m->prog, k, infos[ki], plan.shapes);
+      long w = 1;
+      for (size_t l = 0; l < k.loops.size() && ok; ++l) w *= std::max(0L, infos[ki].bounds[l].second - infos[ki].bounds[l].first);
+      work += w;
+    }
+    if (!ok || work > 16384) continue;
+    pg.g.tail_kernels = sg.g.kernel_index;
+    int rc = generate_row_group(m->prog, t.all, infos, plan.shapes, pg.g);
+    if (rc) return rc;
+    bool replaced = false;
+    for (auto& pk : plan.pending)
+      if (pk.slot == &pg.handle) {
+        pk.source = pg.g.source;
+        replaced = true;
+      }
+    if (!replaced) {  // (cannot happen: the group's kernel is built with the plan)
+      pg.g.tail_kernels.clear();
+      return generate_row_group(m->prog, t.all, infos, plan.shapes, pg.g);
+    }
+    pg.tail_group = S.row_group;
+    R.tail_launch = i + 1;
+    S.tail_of = i;
+    // A launch-bound step: fewer, longer blocks (the kernel walks its samples with a grid stride) — 64 arrivals at the
+    // ticket counter instead of 256 (a fan-in of 255 costs ~3.3 us, MI355X_MICROARCH.md price list) and 64 partial rows
+    // for the last block; 786 KB of input do not need 256 CUs.  Per-thread totals then span several samples: the sums
+    // change their order (not their terms) against the one-sample-per-thread launch.
+    long cap = 64;
+    if (const char* e = getenv("EG_ROW_TAIL_BLOCKS")) cap = std::max(1L, atol(e));
+    if (pg.nblocks > cap) pg.nblocks = (int)cap;
+  }
+  return EG_OK;
+}
+
 // Partition the live kernel list into row groups (rowfuse.hpp) and build their kernels.
 // group_of[p] = index into plan.row_groups, or -1 for kernels that keep their own launch.
 int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos,
@@ -208,13 +275,20 @@ int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<
     char name[64];
     snprintf(name, sizeof(name), "eg_rows%d", m->kernel_serial++);
     g.name = name;
+    pg->nblocks = (int)((B + 255) / 256);
+    // several blocks: the last one to arrive folds the partial rows itself (rowfuse.hpp) — every thread of it keeps one
+    // accumulator per total in registers (at most 64 totals), rows in strides of 256
+    g.in_kernel_finalize = row_tails_enabled() && g.red_total > 0 && g.red_total <= 64 && pg->nblocks > 1 && pg->nblocks <= 4096;
     int rc = generate_row_group(m->prog, t.all, infos, shapes, g);
     if (rc) return rc;
     plan.pending.push_back({g.name, g.source, &pg->handle});
-    pg->nblocks = (int)((B + 255) / 256);
     if (g.red_total > 0) {
       EG_HIP_CHECK(hipSetDevice(m->ctx->device));
       EG_HIP_CHECK(hipMalloc((void**)&pg->partial, (size_t)pg->nblocks * g.red_total * sizeof(float)));
+      if (g.in_kernel_finalize) {
+        EG_HIP_CHECK(hipMalloc((void**)&pg->counter, 64));
+        EG_HIP_CHECK(hipMemsetAsync(pg->counter, 0, 64, m->ctx->stream));  // (the context's stream: ordered against the launches)
+      }
     }
     const int gi = (int)plan.row_groups.size();
     for (int s = p; s < q; ++s) group_of[s] = gi;

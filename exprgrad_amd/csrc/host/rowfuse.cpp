@@ -244,9 +244,13 @@ struct GroupEmitter {
 
 }  // namespace
 
+static std::string small_kernel_body(const Kernel& k, const KernelInfo& info, const Shapes& shapes, const std::string& prefix,
+                                     int serial, bool barrier = true);
+
 int generate_row_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
                        const Shapes& shapes, RowGroup& g) {
   GroupEmitter em{prog, shapes, g, {}};
+  em.code.clear();
   // pointer arguments: every tensor that touches memory
   g.ptr_args.clear();
   for (auto& kv : g.tensors) {
@@ -274,26 +278,49 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
   // dependent launch costs ~4.5 us whatever it does, and row_finalize of one partial row does nothing but copy
   // (p + 0 + 0 + 0 in its tree: the same value).
   g.single_block = g.B <= 256 && g.red_total > 0 && getenv("EG_NO_ROW_DIRECT") == nullptr;
-  if (g.single_block)
+  if (g.single_block) g.in_kernel_finalize = false;
+  if (g.red_total <= 0) g.in_kernel_finalize = false;
+  if (!g.in_kernel_finalize) g.tail_kernels.clear();
+  if (g.single_block || g.in_kernel_finalize)
     for (auto& kv : g.tensors)
       if (kv.second.role == RowGroupTensor::Reduction) sig += ", float* d" + std::to_string(kv.first);
+  g.tail_ptr_args.clear();
+  if (g.in_kernel_finalize) {
+    sig += ", unsigned* counter, long MODE";
+    std::set<int> touched;
+    for (int ki : g.tail_kernels) {
+      touched.insert(all[ki].write.tensor);
+      for (auto& rd : all[ki].reads) touched.insert(rd.tensor);
+    }
+    g.tail_ptr_args.assign(touched.begin(), touched.end());
+    for (int t : g.tail_ptr_args) sig += ", float* __restrict__ u" + std::to_string(t);  // (one name per tensor: no aliases)
+  }
   sig += ")";
 
   std::string& c = em.code;
-  c += "  const long y = (long)blockIdx.x * 256 + threadIdx.x;\n  const bool active = y < B;\n";
+  // in_kernel_finalize: the samples are walked with a grid stride, so that a launch may use FEWER blocks than B / 256 (a
+  // row group with a tail: 64 blocks — fewer arrivals at the ticket counter, fewer partial rows for the last block);
+  // with ceil(B / 256) blocks the loop runs once and every value is what the one-sample-per-thread form computes.
+  const bool strided = g.in_kernel_finalize;
+  if (!strided) c += "  const long y = (long)blockIdx.x * 256 + threadIdx.x;\n  const bool active = y < B;\n";
+  std::string init;  // per-sample state: (re)initialised for every sample
   for (auto& kv : g.tensors) {
     const RowGroupTensor& t = kv.second;
     const std::string id = std::to_string(kv.first);
     if (t.role == RowGroupTensor::RowLocal) {
       c += "  float L" + id + "[" + std::to_string(t.inner) + "];\n";
-      c += "  _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) L" + id + "[j] = ";
-      c += t.load_first ? "active ? t" + id + "[y * " + std::to_string(t.inner) + "L + j] : 0.0f;\n" : "0.0f;\n";
+      init += "  _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) L" + id + "[j] = ";
+      init += t.load_first ? "active ? t" + id + "[y * " + std::to_string(t.inner) + "L + j] : 0.0f;\n" : "0.0f;\n";
     } else if (t.role == RowGroupTensor::SmallLocal || t.role == RowGroupTensor::Reduction) {
       const char* p = t.role == RowGroupTensor::SmallLocal ? "S" : "R";
       c += std::string("  float ") + p + id + "[" + std::to_string(t.inner) + "];\n";
-      c += "  _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) " + p + id + "[j] = 0.0f;\n";
+      std::string z = "  _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) " + p + id + "[j] = 0.0f;\n";
+      if (t.role == RowGroupTensor::Reduction) c += z;  // batch totals: once
+      else init += z;
     }
   }
+  if (strided) c += "  for (long y = (long)blockIdx.x * 256 + threadIdx.x; y < B; y += (long)gridDim.x * 256) {\n  const bool active = true;\n";
+  c += init;
   for (size_t i = 0; i < g.kernel_index.size(); ++i)
     em.emit_kernel(all[g.kernel_index[i]], infos[g.kernel_index[i]], g.infos[i], (int)i);
   // rows that are needed after the group
@@ -304,6 +331,7 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
     c += "  if (active) { _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) t" + id + "[y * " +
          std::to_string(t.inner) + "L + j] = L" + id + "[j]; }\n";
   }
+  if (strided) c += "  }\n";
   // batch reductions: wave shuffles, then the four wave totals through LDS, one partial row per block
   if (g.red_total > 0) {
     const std::string E = std::to_string(g.red_total);
@@ -330,9 +358,72 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
         c += std::string("    d") + id + "[j] = " + (t.accumulate ? "d" + id + "[j] + s" : std::string("s")) + ";\n  }\n";
       }
     } else {
-      c += "  for (int e = threadIdx.x; e < " + E + "; e += 256)\n";
-      c += "    partial[(long)blockIdx.x * " + E + " + e] = (red[e] + red[" + E + " + e]) + (red[2 * " + E + " + e] + red[3 * " +
-           E + " + e]);\n";
+      c += "  for (int e = threadIdx.x; e < " + E + "; e += 256) {\n";
+      c += "    const float total = (red[e] + red[" + E + " + e]) + (red[2 * " + E + " + e] + red[3 * " + E + " + e]);\n";
+      if (g.in_kernel_finalize)
+        c += "    __hip_atomic_store(partial + (long)blockIdx.x * " + E + " + e, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);\n  }\n";
+      else
+        c += "    partial[(long)blockIdx.x * " + E + " + e] = total;\n  }\n";
+      if (g.in_kernel_finalize) {
+        // The last block to arrive folds the partial rows.  No agent-scope fences (each costs ~1.7 us on MI355X, and
+        // every block would pay one): the partial rows go out as write-through stores (system scope: sc0 sc1) and are
+        // read back with loads of the same scope, which bypass the non-coherent caches on both sides
+        // (MI355X_MICROARCH.md, "Workgroup dispatch ... inter-workgroup visibility": sc0 sc1 stores and loads on both
+        // sides are a valid hand-off; the stores are drained — vmcnt(0) — before the block takes its ticket).
+        // Sums in the order of row_finalize_kernel (reduce.hip): thread t of 256 adds rows t, t + 256, ...; xor-shuffle
+        // tree per wave; ((w0 + w1) + w2) + w3 — the same value to the bit for the same number of blocks.
+        c += "  if (MODE != 0) {\n";
+        c += "    __shared__ int s_last;\n";
+        c += "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n";
+        c += "    __syncthreads();\n";
+        c += "    if (threadIdx.x == 0) {\n";
+        c += "      const unsigned ticket = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n";
+        c += "      s_last = ticket == gridDim.x - 1 ? 1 : 0;\n";
+        c += "      if (s_last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch\n";
+        c += "    }\n";
+        c += "    __syncthreads();\n";
+        c += "    if (s_last) {\n";
+        c += "      const int NB = (int)gridDim.x;\n";
+        c += "      float acc[" + E + "];\n";
+        c += "      _Pragma(\"unroll\") for (int e = 0; e < " + E + "; ++e) acc[e] = 0.0f;\n";
+        c += "      for (int b = threadIdx.x; b < NB; b += 256) {\n";
+        c += "        _Pragma(\"unroll\") for (int e = 0; e < " + E + "; ++e)\n";
+        c += "          acc[e] += __hip_atomic_load(partial + (long)b * " + E + " + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);\n      }\n";
+        c += "      _Pragma(\"unroll\") for (int e = 0; e < " + E + "; ++e) {\n";
+        c += "        float v = acc[e];\n";
+        c += "        _Pragma(\"unroll\") for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);\n";
+        c += "        if (lane == 0) red[wave * " + E + " + e] = v;\n      }\n";
+        c += "      __syncthreads();\n";
+        for (auto& kv : g.tensors) {
+          const RowGroupTensor& t = kv.second;
+          if (t.role != RowGroupTensor::Reduction) continue;
+          const std::string id = std::to_string(kv.first), off = std::to_string(t.red_offset);
+          c += "      for (int j = threadIdx.x; j < " + std::to_string(t.inner) + "; j += 256) {\n";
+          c += "        const int e = " + off + " + j;\n";
+          c += "        const float s = ((red[e] + red[" + E + " + e]) + red[2 * " + E + " + e]) + red[3 * " + E + " + e];\n";
+          c += std::string("        d") + id + "[j] = " + (t.accumulate ? "d" + id + "[j] + s" : std::string("s")) + ";\n      }\n";
+        }
+        if (!g.tail_kernels.empty()) {
+          c += "      if (MODE == 2) {  // the kernels that follow the group, on the totals just written\n";
+          c += "      __syncthreads();\n";
+          // Kernels none of which touches what another one writes (one gradientDescent kernel per parameter,
+          // base.nim:37-38) need no barrier between them: a thread's loads of all of them can be in flight together —
+          // one memory round trip for the tail instead of one per kernel.
+          bool independent = true;
+          for (size_t i = 0; i < g.tail_kernels.size() && independent; ++i)
+            for (size_t j = 0; j < g.tail_kernels.size() && independent; ++j) {
+              if (i == j) continue;
+              const Kernel &a = all[g.tail_kernels[i]], &b = all[g.tail_kernels[j]];
+              if (a.write.tensor == b.write.tensor) independent = false;
+              for (auto& rd : b.reads)
+                if (rd.tensor == a.write.tensor) independent = false;
+            }
+          for (size_t i = 0; i < g.tail_kernels.size(); ++i)
+            c += small_kernel_body(all[g.tail_kernels[i]], infos[g.tail_kernels[i]], shapes, "u", (int)i, !independent);
+          c += "      }\n";
+        }
+        c += "    }\n  }\n";
+      }
     }
   }
   g.source = sig + " {\n" + c + "}\n";
@@ -360,27 +451,14 @@ bool is_small_kernel(const Program& prog, const Kernel& k, const KernelInfo& inf
   return !scatter;
 }
 
-int generate_small_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
-                         const Shapes& shapes, SmallGroup& g) {
-  (void)prog;
-  std::set<int> written, touched;
-  for (int ki : g.kernel_index) {
-    written.insert(all[ki].write.tensor);
-    touched.insert(all[ki].write.tensor);
-    for (auto& rd : all[ki].reads) touched.insert(rd.tensor);
-  }
-  g.ptr_args.assign(touched.begin(), touched.end());
-  std::string sig = "extern \"C\" __global__ void __launch_bounds__(256) " + g.name + "(";
-  for (size_t i = 0; i < g.ptr_args.size(); ++i) {
-    const int t = g.ptr_args[i];
-    sig += (i ? ", " : "") + std::string(written.count(t) ? "float* t" : "const float* t") + std::to_string(t);
-  }
-  sig += std::string(g.ptr_args.empty() ? "" : ", ") + "float GS, long EP)";
+// One small kernel as a loop of a single 256-thread block over its independent iterations, reductions serial per
+// thread, `__syncthreads()` behind it: the body of a small group, and of the tail a row group's last block runs
+// (pointer names <prefix><tensor id>).
+static std::string small_kernel_body(const Kernel& k, const KernelInfo& info, const Shapes& shapes, const std::string& prefix,
+                                     int serial, bool barrier) {
   std::string c;
   const std::map<int, std::string> no_subst;
-  for (size_t gi = 0; gi < g.kernel_index.size(); ++gi) {
-    const Kernel& k = all[g.kernel_index[gi]];
-    const KernelInfo& info = infos[g.kernel_index[gi]];
+  {
     const std::vector<Ty> ty = infer_types(k);
     std::vector<int> indep, red;
     bool scatter;
@@ -400,9 +478,9 @@ int generate_small_group(const Program& prog, const std::vector<Kernel>& all, co
           stride *= shp[d];
         }
       }
-      return "t" + std::to_string(op.tensor) + "[" + idx + "]";
+      return prefix + std::to_string(op.tensor) + "[" + idx + "]";
     };
-    c += "  // kernel " + std::to_string(gi) + ": " + to_text(k).substr(0, 90) + "\n";
+    c += "  // kernel " + std::to_string(serial) + ": " + to_text(k).substr(0, 90) + "\n";
     c += "  for (long idx = threadIdx.x; idx < " + std::to_string(total) + "L; idx += 256) {\n";
     for (auto& s : k.setup) c += "    const long r" + std::to_string(s.res) + " = " + std::to_string(info.vals.at(s.res)) + "L;\n";
     c += "    long rem = idx;\n";
@@ -443,8 +521,31 @@ int generate_small_group(const Program& prog, const std::vector<Kernel>& all, co
     c += "      acc = acc + r" + std::to_string(k.result) + ";\n";
     for (size_t i = 0; i < red.size(); ++i) c += "    }\n";
     const std::string w = element(k.write);
-    c += "    " + w + " = " + w + " + acc;\n  }\n  __syncthreads();\n";
+    c += "    " + w + " = " + w + " + acc;\n  }\n";
+    if (barrier) c += "  __syncthreads();\n";
   }
+  return c;
+}
+
+int generate_small_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
+                         const Shapes& shapes, SmallGroup& g) {
+  (void)prog;
+  std::set<int> written, touched;
+  for (int ki : g.kernel_index) {
+    written.insert(all[ki].write.tensor);
+    touched.insert(all[ki].write.tensor);
+    for (auto& rd : all[ki].reads) touched.insert(rd.tensor);
+  }
+  g.ptr_args.assign(touched.begin(), touched.end());
+  std::string sig = "extern \"C\" __global__ void __launch_bounds__(256) " + g.name + "(";
+  for (size_t i = 0; i < g.ptr_args.size(); ++i) {
+    const int t = g.ptr_args[i];
+    sig += (i ? ", " : "") + std::string(written.count(t) ? "float* t" : "const float* t") + std::to_string(t);
+  }
+  sig += std::string(g.ptr_args.empty() ? "" : ", ") + "float GS, long EP)";
+  std::string c;
+  for (size_t gi = 0; gi < g.kernel_index.size(); ++gi)
+    c += small_kernel_body(all[g.kernel_index[gi]], infos[g.kernel_index[gi]], shapes, "t", (int)gi);
   g.source = sig + " {\n" + c + "}\n";
   return EG_OK;
 }

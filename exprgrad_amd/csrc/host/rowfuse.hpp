@@ -62,10 +62,19 @@ struct RowGroup {
   // B <= 256: the one block adds its totals to their destinations itself (arguments d<id> behind `epoch`, one per
   // reduction in segment order) — no second launch; EG_NO_ROW_DIRECT=1: partial row + row_finalize as for many blocks
   bool single_block = false;
+  // More than one block (round 5): the LAST block to arrive (a ticket counter) folds the partial rows itself, in the order
+  // of row_finalize_kernel, instead of a second launch doing it; and it can go on with a run of small kernels that
+  // directly follows the group — the optimizer updates of a small net (the whole XOR step becomes ONE launch).
+  // Arguments behind `epoch`: d<id> per reduction, unsigned* counter, long MODE (0: partial rows only, the caller
+  // launches row_finalize; 1: fold in the kernel; 2: fold, then the tail), u<id> per tail tensor.
+  bool in_kernel_finalize = false;
+  std::vector<int> tail_kernels;   // indices into target.all, in execution order
+  std::vector<int> tail_ptr_args;  // tensor ids of the tail kernels, in pointer-argument order
 };
 
 // Emit the fused kernel.  Arguments of the generated kernel:
-//   (float* partial, float* / const float* t<ids>..., long B, float grad_scale, long epoch[, float* d<ids>...: single_block])
+//   (float* partial, float* / const float* t<ids>..., long B, float grad_scale, long epoch[, float* d<ids>...: single_block
+//    or in_kernel_finalize][, unsigned* counter, long MODE, float* u<ids>...: in_kernel_finalize])
 int generate_row_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
                        const Shapes& shapes, RowGroup& group);
 

@@ -136,14 +136,26 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       args.push_back(&GS);
       args.push_back(&EP);
       std::vector<float*> dsts;
-      if (pg.g.single_block) {  // the one block adds its totals to their destinations itself (rowfuse.hpp)
-        dsts.reserve(pg.red_tensors.size());
+      if (pg.g.single_block || pg.g.in_kernel_finalize) {  // totals go to their destinations from inside the kernel (rowfuse.hpp)
+        dsts.reserve(pg.red_tensors.size() + pg.g.tail_ptr_args.size());
         for (int tid : pg.red_tensors) dsts.push_back(tensor_ptr(m, ts, plan, tid));
         for (auto& p : dsts) args.push_back(&p);
       }
+      // several blocks: the last one to arrive folds the partial rows (MODE 1) and, when the range being issued
+      // holds the small group behind this launch as well, runs it (MODE 2; run_range_eager skips that launch)
+      long MODE = 0;
+      unsigned* counter = pg.counter;
+      if (pg.g.in_kernel_finalize) {
+        MODE = row_tail_active(plan, L) ? 2 : 1;
+        args.push_back(&counter);
+        args.push_back(&MODE);
+        const size_t first_tail = dsts.size();
+        for (int tid : pg.g.tail_ptr_args) dsts.push_back(tensor_ptr(m, ts, plan, tid));
+        for (size_t a = first_tail; a < dsts.size(); ++a) args.push_back(&dsts[a]);
+      }
       int rc = eg::kernel_launch_raw(pg.handle, (unsigned)pg.nblocks, 1, 1, 256, args.data());
       if (rc) return rc;
-      if (pg.g.red_total > 0 && !pg.g.single_block) {
+      if (pg.g.red_total > 0 && !pg.g.single_block && MODE == 0) {
         eg::RowFinalizeArgs fa = {};
         fa.nseg = (int)pg.red_tensors.size();
         for (int s = 0; s < fa.nseg; ++s) {
@@ -256,8 +268,12 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
     if (rc) return rc;
     begin = plan.n_backward;
   }
+  plan.active_begin = begin;
+  plan.active_end = end;
   size_t next_overlap = 0;
   for (int i = begin; i < end; ++i) {
+    // a small group that the last block of the row group in front of it has run already (fuse_row_tails)
+    if (plan.launches[i].tail_of >= begin && row_tail_active(plan, plan.launches[plan.launches[i].tail_of])) continue;
     while (next_overlap < plan.overlaps.size() && plan.overlaps[next_overlap].first < i) ++next_overlap;
     if (next_overlap < plan.overlaps.size() && plan.overlaps[next_overlap].first == i &&
         plan.overlaps[next_overlap].big < end) {
@@ -341,7 +357,14 @@ int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool
   int rc = eg::set_device(m->ctx);
   if (rc) return rc;
   Plan::Captured& cap = plan.graphs[slot];
-  if (!graphs_enabled() || end - begin < 2) return run_range_eager(m, ts, plan, begin, end, zero);
+  // (a range that comes down to ONE kernel — a row group whose last block runs the small group behind it — gains nothing
+  //  from a graph: replaying a one-node graph measured 19 us per XOR step against 13.7 us for the plain launch)
+  int launches = 0;
+  for (int i = begin; i < end; ++i) {
+    const int of = plan.launches[i].tail_of;
+    if (!(of >= begin && plan.launches[of].tail_launch == i)) ++launches;
+  }
+  if (!graphs_enabled() || launches < 2) return run_range_eager(m, ts, plan, begin, end, zero);
   // every pointer / scalar that ends up in a kernel argument: as plain words first (a replay formats no string)
   const void* now[5] = {m->ctx->workspace, m->ctx->aux, m->ctx->side_workspace, m->ctx->side_aux, ts.bucket};
   if (cap.exec && cap.stamp == m->inputs_gen && cap.grad_scale == m->grad_scale && cap.epoch == m->epoch &&
@@ -490,6 +513,19 @@ int run_launch_sliced(eg_model* m, TargetState& ts, Plan& plan, Launch& L, const
       if (pg.g.single_block) {
         set_error("batch pipeline: a single-block row group cannot be cut");
         return EG_ERR_RUNTIME;
+      }
+      // (a half batch is folded by row_finalize, which can add the second half to the first: MODE 0)
+      std::vector<float*> extra;
+      long MODE = 0;
+      unsigned* counter = pg.counter;
+      if (pg.g.in_kernel_finalize) {
+        extra.reserve(pg.red_tensors.size() + pg.g.tail_ptr_args.size());
+        for (int tid : pg.red_tensors) extra.push_back(tensor_ptr(m, ts, plan, tid));
+        for (int tid : pg.g.tail_ptr_args) extra.push_back(tensor_ptr(m, ts, plan, tid));
+        for (size_t a = 0; a < pg.red_tensors.size(); ++a) args.push_back(&extra[a]);
+        args.push_back(&counter);
+        args.push_back(&MODE);
+        for (size_t a = pg.red_tensors.size(); a < extra.size(); ++a) args.push_back(&extra[a]);
       }
       int rc = eg::kernel_launch_raw(pg.handle, (unsigned)nblocks, 1, 1, 256, args.data());
       if (rc) return rc;

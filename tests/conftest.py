@@ -51,8 +51,9 @@ def gpu_ctx():
     ctx.sync()
 
 
-def rel_err(got, want):
-    """max|got - want| / max|want| — the comparison SURVEY.md §7 budgets at 1e-5 for float32."""
+def rel_err(got, want, what="direct comparison (rel_err)"):
+    """max|got - want| / max|want| — the comparison SURVEY.md §7 budgets at 1e-5 for float32.
+    `what` labels the line the parity survey logs for it (tools/parity_survey.py)."""
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     denom = np.max(np.abs(want))
@@ -61,7 +62,7 @@ def rel_err(got, want):
     if record:   # survey mode (tools/parity_survey.py): every direct two-way comparison of a GPU test is logged as well
         import json
         with open(record, "a") as f:
-            f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", ""), "what": "direct comparison (rel_err)",
+            f.write(json.dumps({"test": os.environ.get("PYTEST_CURRENT_TEST", ""), "what": what,
                                 "direct": err, "size": int(want.size)}) + "\n")
     return err
 

@@ -117,8 +117,10 @@ def test_cfg3_xor_train_step_batch_65536(gpu_ctx):
             exact[t] += count * (one.params[t].astype(np.float64) - before[t])
     for tid in sorted(ref.params):
         du_gpu, du_ref = gpu.params[tid] - before[tid], ref.params[tid] - before[tid]
-        assert rel_err(du_gpu, exact[tid]) <= TOL, tid
-        assert rel_err(du_ref, exact[tid]) <= batch * 6e-8 / 2, tid
+        assert rel_err(du_gpu, exact[tid], what=f"update of parameter {tid}: backend vs exact") <= TOL, tid
+        assert rel_err(du_ref, exact[tid], what=f"update of parameter {tid}: ORACLE vs exact (its own 65 536-term drift)") <= batch * 6e-8 / 2, tid
+        # the comparison in BASELINE.json's words (backend against the reference CPU path): bounded by the oracle's own drift
+        assert rel_err(du_gpu, du_ref, what=f"update of parameter {tid}: backend vs oracle") <= batch * 6e-8 / 2 + TOL, tid
     for tid in sorted(ref.params):
         assert np.all(np.isfinite(ref.params[tid])) and np.all(np.isfinite(gpu.params[tid]))
     gpu.close()
