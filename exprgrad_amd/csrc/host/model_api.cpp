@@ -264,6 +264,12 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
         if (L.tail_launch >= 0) os << " | which goes on with launch " << L.tail_launch << " when a range holds both";
         break;
       }
+      case StepKind::SampleFused: {
+        const PlanSampleGroup& sg = *plan.sample_group;
+        os << "sample-fused " << sg.g.kernel_index.size() << " kernels, one block per sample (" << sg.g.B << " blocks)";
+        if (sg.g.slab_floats > 0) os << " | " << sg.sum_tensors.size() << " batch sums folded by one slab pass";
+        break;
+      }
       case StepKind::SmallFused: {
         const PlanSmallGroup& sg = *plan.small_groups[L.row_group];
         os << (sg.g.blocks > 1 ? "map-fused " : "small-fused ") << sg.g.kernel_index.size() << " kernels";

@@ -48,7 +48,7 @@ struct ConvMatch {
   enum Role { Forward, GradImage, GradFilter } role = Forward;
 };
 
-enum class StepKind { Gemm, Conv, ConvGradImage, ConvGradFilter, Seed, GenericA, GenericB, RowFused, SmallFused, GemmFused };
+enum class StepKind { Gemm, Conv, ConvGradImage, ConvGradFilter, Seed, GenericA, GenericB, RowFused, SmallFused, GemmFused, SampleFused };
 
 struct Generic {
   GenericSource src;
@@ -124,6 +124,16 @@ struct PlanRowGroup {
   int tail_group = -1;           // index into Plan::small_groups of the group the last block runs (MODE 2), or -1
 };
 
+// A run of per-sample kernels as one generated kernel with one block per sample (rowfuse.hpp "sample groups"), per plan.
+struct PlanSampleGroup {
+  SampleGroup g;
+  eg_kernel* handle = nullptr;
+  float* slab = nullptr;          // [B][g.slab_floats]: every sample's contribution to the tensors summed over the batch
+  long bucket_base = 0;           // the slab rows mirror bucket floats [bucket_base, bucket_base + g.slab_floats)
+  std::vector<int> positions;     // live positions of the member kernels, in order
+  std::vector<int> sum_tensors;   // tensors summed over the batch (gradient bucket members)
+};
+
 // A run of small-tensor kernels (optimizer updates) fused into one single-block kernel.
 struct PlanSmallGroup {
   SmallGroup g;
@@ -177,6 +187,7 @@ struct Plan {
   // launch-latency bound (19 kernels for the XOR step), a replay costs one submission.
   std::vector<std::unique_ptr<PlanRowGroup>> row_groups;
   std::vector<std::unique_ptr<PlanSmallGroup>> small_groups;
+  std::unique_ptr<PlanSampleGroup> sample_group;  // at most one per plan
   std::vector<std::unique_ptr<PlanEpilogue>> epilogues;
   // generated kernels of this plan waiting for the one hiprtc program make_plan builds at its end
   struct PendingKernel {
@@ -323,6 +334,9 @@ int build_pending(eg_model* m);
 void describe(eg_model* m);
 // plan_groups.cpp
 int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos, const std::map<int, int>& first_writer, std::vector<int>& group_of);
+constexpr int SAMPLE_GROUP_CODE = -1000000;  // group_of[] entry of a sample group's kernels
+int form_sample_group(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos, const std::map<int, int>& first_writer,
+                      std::vector<int>& group_of, std::set<int>& needs_zero);
 int fuse_row_tails(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos);
 bool row_tail_active(const Plan& plan, const Launch& row_launch);
 // plan_overlap.cpp

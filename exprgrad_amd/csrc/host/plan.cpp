@@ -193,6 +193,10 @@ void release_plan(Plan& plan) {
     if (rg->counter) hipFree(rg->counter);
     rg->counter = nullptr;
   }
+  if (plan.sample_group && plan.sample_group->slab) {
+    hipFree(plan.sample_group->slab);
+    plan.sample_group->slab = nullptr;
+  }
   if (plan.arena) hipFree(plan.arena);
   plan.arena = nullptr;
 }
@@ -322,17 +326,32 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   // ---- row fusion (rowfuse.hpp): runs of per-sample kernels become one generated kernel each
   std::vector<int> group_of(t.live.size(), -1);
   plan.row_groups.clear();
+  // decide overwrite vs accumulate per launch; collect tensors that must be zeroed
+  std::set<int> needs_zero;
+  plan.sample_group.reset();
+  {
+    int rc = form_sample_group(m, ts, plan, infos, first_writer, group_of, needs_zero);
+    if (rc) return rc;
+  }
   int rc_groups = form_row_groups(m, ts, plan, infos, first_writer, group_of);
   if (rc_groups) return rc_groups;
 
-  // decide overwrite vs accumulate per launch; collect tensors that must be zeroed
-  std::set<int> needs_zero;
   plan.launches.clear();
   plan.n_backward = -1;
   std::set<int> folded;  // consumers that run inside the kernel before them
   for (size_t p = 0; p < t.live.size(); ++p) {
     if ((int)p == t.first_update) plan.n_backward = (int)plan.launches.size();
     if (folded.count((int)p)) continue;
+    if (group_of[p] == SAMPLE_GROUP_CODE) {
+      if (!plan.sample_group->positions.empty() && plan.sample_group->positions[0] == (int)p) {
+        Launch L;
+        L.lowered = (int)p;
+        L.kind = StepKind::SampleFused;
+        L.accumulate = false;
+        plan.launches.push_back(L);
+      }
+      continue;
+    }
     if (group_of[p] <= -2) {
       const int wt = t.all[t.live[p]].write.tensor;  // small groups always accumulate
       if (m->prog.tensors[wt].kind == TK::Result && first_writer[wt] == (int)p) needs_zero.insert(wt);

@@ -111,6 +111,22 @@ void launch_io(eg_model* m, TargetState& ts, const Plan& plan, const Launch& L, 
       }
       break;
     }
+    case StepKind::SampleFused: {
+      const PlanSampleGroup& sg = *plan.sample_group;
+      std::set<int> inside;
+      for (size_t i = 0; i < sg.g.kernel_index.size(); ++i) {
+        const Kernel& k = t.all[sg.g.kernel_index[i]];
+        for (auto& r : k.reads)
+          if (!inside.count(root(plan, r.tensor))) rd(r.tensor);
+        const int w = root(plan, k.write.tensor);
+        io.writes.insert(w);
+        // a summed tensor is written whole by the fold behind the kernel; a plain store needs nothing before it
+        // (a tensor that lives in the block's LDS starts from zero there)
+        if (!sg.g.infos[i].reduced && !sg.g.overwrite[i] && !inside.count(w) && !sg.g.lds.count(k.write.tensor)) io.needs_prior.insert(w);
+        inside.insert(w);
+      }
+      break;
+    }
     case StepKind::SmallFused: {
       const PlanSmallGroup& sg = *plan.small_groups[L.row_group];
       // every kernel of a small / map group accumulates; a tensor written earlier in the group
@@ -168,6 +184,9 @@ int check_plan(eg_model* m, TargetState& ts, Plan& plan) {
           break;
         case StepKind::SmallFused:
           for (int ki : plan.small_groups[L.row_group]->g.kernel_index) mark(pos_of_all.count(ki) ? pos_of_all[ki] : -1);
+          break;
+        case StepKind::SampleFused:
+          for (int pos : plan.sample_group->positions) mark(pos);
           break;
         case StepKind::GemmFused:
           mark(L.lowered);

@@ -130,7 +130,7 @@ int fuse_epilogues(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
     bool found = false;
     for (; j < plan.launches.size() && j <= i + 4; ++j) {
       const Launch& X = plan.launches[j];
-      if (X.kind == StepKind::RowFused || X.kind == StepKind::SmallFused || X.kind == StepKind::GemmFused) break;
+      if (X.kind == StepKind::RowFused || X.kind == StepKind::SmallFused || X.kind == StepKind::GemmFused || X.kind == StepKind::SampleFused) break;
       const Kernel& kx = t.all[ts.lowered[X.lowered].all_index];
       bool reads_c = false;
       for (auto& rd : kx.reads)
@@ -322,7 +322,7 @@ int fold_bias_gradients(eg_model* m, TargetState& ts, Plan& plan, const std::vec
       bool legal = true;
       for (size_t j = lo + 1; j < hi && legal; ++j) {
         const Launch& X = plan.launches[j];
-        if (X.kind == StepKind::RowFused || X.kind == StepKind::SmallFused || X.kind == StepKind::GemmFused) {
+        if (X.kind == StepKind::RowFused || X.kind == StepKind::SmallFused || X.kind == StepKind::GemmFused || X.kind == StepKind::SampleFused) {
           legal = false;  // (their tensor sets are not worth analysing here: adjacent launches are the case that matters)
           break;
         }

@@ -80,6 +80,247 @@ int fuse_row_tails(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
   return EG_OK;
 }
 
+
+// A run of per-sample kernels of the backward range as ONE kernel with one block per sample (rowfuse.hpp, "sample
+// groups"): for small batches, where every launch of the step sits at the floor of a dependent launch.  At most one group
+// per plan: the longest run of consecutive live kernels each of which
+//   * walks the samples with one loop that indexes dimension 0 of every [B, ...] tensor it touches (or is a raw map over
+//     B * inner elements, or the gradLoss seed), and
+//   * reads nothing that an earlier member sums over the batch (a block sees its own sample only), and
+//   * if it sums over the batch itself, writes a member of the gradient bucket without scatter (its per-sample
+//     contributions go to the slab; one slab_sum launch behind the kernel folds them, in a fixed order).
+// Switches: EG_NO_SAMPLE_FUSE=1, EG_SAMPLE_FUSE_MAX_BATCH (default 2048), EG_SAMPLE_THREADS (512), EG_SAMPLE_NO_LDS.
+int form_sample_group(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos, const std::map<int, int>& first_writer,
+                      std::vector<int>& group_of, std::set<int>& needs_zero) {
+  {
+    const char* e = getenv("EG_NO_SAMPLE_FUSE");
+    if ((e && e[0] && e[0] != '0') || !row_fusion_enabled()) return EG_OK;
+  }
+  Target& t = *ts.target;
+  const Shapes& shapes = plan.shapes;
+  long B = 0;
+  for (auto& in : m->inputs)
+    if (in.second.bound && !in.second.shape.empty()) {
+      B = in.second.shape[0];
+      break;
+    }
+  long max_batch = 2048;  // (fashion_mnist step, one box: 43.7 vs 76.5 us at batch 32, 58 vs 180 at 256, 313 vs 381 at 2048; even at ~4096)
+  if (const char* e = getenv("EG_SAMPLE_FUSE_MAX_BATCH")) max_batch = atol(e);
+  if (B < 2 || B > max_batch) return EG_OK;
+  const int n = (int)t.live.size();
+  const int limit = t.first_update >= 0 ? t.first_update : n;
+  std::vector<SampleKernelInfo> ski((size_t)n);
+  for (int p = 0; p < limit; ++p) {
+    const Lowered& lo = ts.lowered[p];
+    if (lo.absorbed && lo.inlined) continue;
+    const Kernel& k = t.all[t.live[p]];
+    ski[p] = analyse_sample_kernel(m->prog, k, infos[t.live[p]], shapes, B);
+    std::vector<int> indep, red;
+    bool scatter = false;
+    split_loops(k, indep, red, scatter);
+    ConvMatch cm;
+    if (ski[p].ok && match_conv(k, cm) && cm.role == ConvMatch::GradImage && cm.batched) {
+      ski[p].gather = true;
+      ski[p].g_img = k.write.tensor;
+      ski[p].g_out = k.reads[cm.out_op].tensor;
+      ski[p].g_flt = k.reads[cm.flt_op].tensor;
+      if (shapes.at(ski[p].g_img).size() != 4 || shapes.at(ski[p].g_out).size() != 4 || shapes.at(ski[p].g_flt).size() != 4) ski[p].ok = false;
+    } else if (ski[p].ok && scatter && ski[p].reduced) {
+      ski[p].ok = false;  // (the slab row would have to start from zero)
+    }
+    if (ski[p].ok && ski[p].reduced && !ts.bucket_offset.count(k.write.tensor)) ski[p].ok = false;
+    if (ski[p].ok && plan.alias.count(k.write.tensor)) ski[p].ok = false;
+    // What belongs on the matrix cores stays there: a contraction whose two other extents are both >= 32 (a hidden layer of
+    // 64 x 64 and up: at batch 2048 the MFMA tiles finish it in ~10 us, 2048 scalar blocks in ~150), a convolution with
+    // >= 16 channels AND >= 16 filters (the halo / implicit-GEMM kernels).  The run ends at such a kernel.
+    if (ski[p].ok && ski[p].batch_loop >= 0) {
+      GemmMatch gm;
+      if (match_gemm(k, gm)) {
+        long lo_ext = -1;
+        for (size_t l = 0; l < k.loops.size(); ++l) {
+          if ((int)l == ski[p].batch_loop) continue;
+          const long e = infos[t.live[p]].bounds[l].second - infos[t.live[p]].bounds[l].first;
+          lo_ext = lo_ext < 0 ? e : std::min(lo_ext, e);
+        }
+        if (lo_ext >= 32) ski[p].ok = false;
+      } else if (match_conv(k, cm) && cm.batched) {
+        const int ft = cm.flt_op < 0 ? k.write.tensor : k.reads[cm.flt_op].tensor;
+        const std::vector<long>& fs = shapes.at(ft);
+        if (fs.size() == 4 && fs[0] >= 16 && fs[3] >= 16) ski[p].ok = false;
+      }
+    }
+  }
+  static const bool debug = getenv("EG_DEBUG_SAMPLE") != nullptr;
+  if (debug)
+    for (int p = 0; p < limit; ++p)
+      fprintf(stderr, "[eg] sample: live %d ok %d loop %d raw %d reduced %d seed %d gather %d work %ld absorbed %d inlined %d | %s\n", p, (int)ski[p].ok,
+              ski[p].batch_loop, (int)ski[p].raw, (int)ski[p].reduced, (int)ski[p].seed, (int)ski[p].gather, ski[p].work,
+              (int)ts.lowered[p].absorbed, (int)ts.lowered[p].inlined, to_text(t.all[t.live[p]]).substr(0, 110).c_str());
+  // longest run
+  int best_p = 0, best_q = 0, best_members = 0;
+  for (int p = 0; p < limit;) {
+    if (!(ski[p].ok || (ts.lowered[p].absorbed && ts.lowered[p].inlined))) {
+      ++p;
+      continue;
+    }
+    std::set<int> local, summed;
+    int q = p, members = 0, last_member = -1;
+    long work = 0;
+    for (; q < limit; ++q) {
+      const Lowered& lo = ts.lowered[q];
+      if (lo.absorbed && lo.inlined) continue;  // recomputed inside its readers: nothing to run
+      if (!ski[q].ok) break;
+      // a bias folded into the contraction in front of it is part of THAT launch: a member only next to its contraction
+      if (lo.absorbed && last_member != q - 1) break;
+      // ... and a contraction does not leave its folded bias behind
+      if (q + 1 < n && ts.lowered[q + 1].absorbed && !ts.lowered[q + 1].inlined && (q + 1 >= limit || !ski[q + 1].ok)) break;
+      const Kernel& k = t.all[t.live[q]];
+      const int yreg = ski[q].batch_loop >= 0 ? k.loops[ski[q].batch_loop].reg : 0;
+      auto by_sample = [&](const Op& op) {
+        if (!yreg) return false;
+        for (auto& d : op.dims)
+          if (d.factor_of(yreg)) return true;
+        return false;
+      };
+      bool ok = true;
+      for (auto& rd : k.reads) {
+        if (summed.count(rd.tensor)) ok = false;
+        if (local.count(rd.tensor) && !by_sample(rd)) ok = false;
+      }
+      if (ski[q].reduced) {
+        if (local.count(k.write.tensor)) ok = false;
+      } else if (ski[q].seed) {
+        if (summed.count(k.write.tensor) || local.count(k.write.tensor)) ok = false;
+      } else {
+        if (summed.count(k.write.tensor)) ok = false;
+      }
+      if (!ok) break;
+      if (ski[q].reduced) summed.insert(k.write.tensor);
+      else if (!ski[q].seed) local.insert(k.write.tensor);
+      work += ski[q].work;
+      ++members;
+      last_member = q;
+    }
+    // the run must not end between a contraction and the bias folded into it
+    if (q < n && ts.lowered[q].absorbed && !ts.lowered[q].inlined && last_member == q - 1) {
+      p = std::max(q, p + 1);
+      continue;
+    }
+    if (work >= 4096 && work <= (1L << 20) && members > best_members) {  // (per sample; a 784 x 512 layer belongs on the matrix cores at any batch)
+      best_p = p;
+      best_q = q;
+      best_members = members;
+    }
+    p = std::max(q, p + 1);
+  }
+  if (debug) fprintf(stderr, "[eg] sample: best run [%d, %d) with %d members\n", best_p, best_q, best_members);
+  if (best_members < 4) return EG_OK;
+  std::unique_ptr<PlanSampleGroup> sg(new PlanSampleGroup());
+  SampleGroup& g = sg->g;
+  g.B = B;
+  std::set<int> sums;
+  std::vector<int> zero_these;
+  for (int q = best_p; q < best_q; ++q) {
+    const Lowered& lo = ts.lowered[q];
+    if (lo.absorbed && lo.inlined) continue;
+    const Kernel& k = t.all[t.live[q]];
+    const KernelInfo& info = infos[t.live[q]];
+    const int wt = k.write.tensor;
+    std::vector<int> indep, red;
+    bool scatter = false;
+    split_loops(k, indep, red, scatter);
+    char over = 0;
+    if (ski[q].reduced) {
+      sums.insert(wt);
+    } else {
+      const bool is_result = m->prog.tensors[wt].kind == TK::Result;
+      auto fw = first_writer.find(wt);
+      const bool first = is_result && fw != first_writer.end() && fw->second == q;
+      const bool whole = ski[q].gather || (!scatter && full_cover(k, info, shapes.at(wt)));
+      over = first && whole && !ts.bucket_offset.count(wt) ? 1 : 0;
+      if (ski[q].seed && !over) return EG_OK;  // every block would add its own 1
+      if (first && !over) zero_these.push_back(wt);
+    }
+    g.kernel_index.push_back(t.live[q]);
+    g.infos.push_back(ski[q]);
+    g.overwrite.push_back(over);
+    sg->positions.push_back(q);
+  }
+  // the summed tensors: written by members only, one contiguous range of the bucket
+  if (!sums.empty()) {
+    for (int p = 0; p < n; ++p) {
+      const bool member = std::find(sg->positions.begin(), sg->positions.end(), p) != sg->positions.end();
+      if (!member && !(ts.lowered[p].absorbed && ts.lowered[p].inlined) && sums.count(t.all[t.live[p]].write.tensor)) return EG_OK;
+    }
+    long base = -1, end = 0;
+    for (int tid : sums) {
+      const long off = ts.bucket_offset.at(tid);
+      if (base < 0 || off < base) base = off;
+      end = std::max(end, off + align4(prod(shapes.at(tid))));
+    }
+    for (auto& b : ts.bucket_offset)
+      if (b.second >= base && b.second < end && !sums.count(b.first)) return EG_OK;
+    sg->bucket_base = base;
+    g.slab_floats = end - base;
+    for (int tid : sums) {
+      g.slab_offset[tid] = ts.bucket_offset.at(tid) - base;
+      sg->sum_tensors.push_back(tid);
+    }
+  }
+  // Tensors that live inside the group only stay in the block's LDS (rowfuse.hpp): written by members, every access
+  // by sample, nobody outside the run touches them, not the target's output, and the model does not keep values.
+  {
+    long thr = 512;  // (measured on the fashion_mnist step at batch 32: 256 / 512 / 1024 threads -> 51.9 / 43.9 / 49.8 us per batch)
+    if (const char* e = getenv("EG_SAMPLE_THREADS")) thr = atol(e);
+    g.threads = (int)std::min(1024L, std::max(64L, thr / 64 * 64));
+    std::map<int, bool> first_plain;  // candidate -> its first member write is a plain store
+    std::set<int> candidates;
+    for (size_t i = 0; i < g.kernel_index.size(); ++i) {
+      const Kernel& k = t.all[g.kernel_index[i]];
+      if (g.infos[i].reduced || g.infos[i].seed) continue;
+      const int wt = k.write.tensor;
+      if (m->prog.tensors[wt].kind != TK::Result || ts.bucket_offset.count(wt) || wt == t.output) continue;
+      if (!candidates.count(wt)) first_plain[wt] = g.overwrite[i] != 0;
+      candidates.insert(wt);
+    }
+    for (int p = 0; p < n; ++p) {
+      const bool member = std::find(sg->positions.begin(), sg->positions.end(), p) != sg->positions.end();
+      if (member || (ts.lowered[p].absorbed && ts.lowered[p].inlined)) continue;
+      const Kernel& k = t.all[t.live[p]];
+      candidates.erase(k.write.tensor);
+      for (auto& rd : k.reads) candidates.erase(rd.tensor);
+    }
+    static const bool no_lds = getenv("EG_SAMPLE_NO_LDS") != nullptr;
+    long budget = 36L * 1024;  // floats (144 KB of the 160 KB a block may own)
+    if (!m->keep_values && !no_lds)
+      for (int tid : candidates) {
+        const long inner = prod(shapes.at(tid)) / B;
+        if (inner <= 0 || inner > budget) continue;
+        budget -= inner;
+        g.lds[tid] = inner;
+        if (!first_plain[tid]) g.lds_zero.insert(tid);
+      }
+    // (what starts from zero in LDS needs no zeroed global storage)
+    zero_these.erase(std::remove_if(zero_these.begin(), zero_these.end(), [&](int tid) { return g.lds.count(tid) != 0; }), zero_these.end());
+  }
+  char name[64];
+  snprintf(name, sizeof(name), "eg_samples%d", m->kernel_serial++);
+  g.name = name;
+  int rc = generate_sample_group(m->prog, t.all, infos, shapes, g);
+  if (rc) return rc;
+  if (g.slab_floats > 0) {
+    EG_HIP_CHECK(hipSetDevice(m->ctx->device));
+    EG_HIP_CHECK(hipMalloc((void**)&sg->slab, (size_t)B * g.slab_floats * sizeof(float)));
+    // (padding floats between the tensors of a row are never written by a block: zero once, so that the fold writes zeros there)
+    EG_HIP_CHECK(hipMemsetAsync(sg->slab, 0, (size_t)B * g.slab_floats * sizeof(float), m->ctx->stream));
+  }
+  plan.pending.push_back({g.name, g.source, &sg->handle});
+  for (int wt : zero_these) needs_zero.insert(wt);
+  for (int q = best_p; q < best_q; ++q) group_of[q] = SAMPLE_GROUP_CODE;
+  plan.sample_group = std::move(sg);
+  return EG_OK;
+}
+
 // Partition the live kernel list into row groups (rowfuse.hpp) and build their kernels.
 // group_of[p] = index into plan.row_groups, or -1 for kernels that keep their own launch.
 int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos,
@@ -96,7 +337,8 @@ int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<
   if (B <= 0) return EG_OK;
   const int n = (int)t.live.size();
   std::vector<RowKernelInfo> rki(n);
-  for (int p = 0; p < n; ++p) rki[p] = analyse_row_kernel(m->prog, t.all[t.live[p]], infos[t.live[p]], shapes, B);
+  for (int p = 0; p < n; ++p)
+    if (group_of[p] == -1) rki[p] = analyse_row_kernel(m->prog, t.all[t.live[p]], infos[t.live[p]], shapes, B);
   // a bias folded into a library contraction is not available on its own
   for (int p = 1; p < n; ++p)
     if (ts.lowered[p].absorbed && !rki[p - 1].ok) rki[p].ok = false;

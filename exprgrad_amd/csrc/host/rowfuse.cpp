@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <regex>
 #include <set>
 
 #include "../eg_internal.hpp"
@@ -639,6 +640,334 @@ int generate_map_group(const Program& prog, const std::vector<Kernel>& all, cons
     first_block += nblocks;
   }
   g.blocks = first_block;
+  g.source = sig + " {\n" + c + "}\n";
+  return EG_OK;
+}
+
+
+// ---------------------------------------------------------------------------------- sample groups
+
+SampleKernelInfo analyse_sample_kernel(const Program& prog, const Kernel& k, const KernelInfo& info, const Shapes& shapes, long B) {
+  (void)prog;
+  SampleKernelInfo r;
+  if (!info.ok || B <= 0 || k.gen != Gen::None) return r;
+  std::vector<const Op*> ops;
+  for (auto& rd : k.reads) ops.push_back(&rd);
+  ops.push_back(&k.write);
+  for (const Op* op : ops)
+    if (!shapes.count(op->tensor)) return r;
+  long all_work = 1;
+  for (size_t l = 0; l < k.loops.size(); ++l) all_work *= std::max(0L, info.bounds[l].second - info.bounds[l].first);
+  if (k.is_seed) {
+    if (all_work > 4096 || !k.index_instrs.empty()) return r;
+    r.ok = true;
+    r.seed = true;
+    r.work = all_work;
+    return r;
+  }
+  auto used_as_value = [&](int y) {
+    for (auto& ins : k.instrs)
+      for (int a : ins.args)
+        if (a == y) return true;
+    for (auto& ins : k.index_instrs)
+      for (int a : ins.args)
+        if (a == y) return true;
+    return false;
+  };
+  for (size_t l = 0; l < k.loops.size(); ++l) {
+    const int y = k.loops[l].reg;
+    const long lo = info.bounds[l].first, hi = info.bounds[l].second;
+    if (lo != 0 || used_as_value(y)) continue;
+    bool any_raw = false, any = false, ok = true;
+    for (const Op* op : ops)
+      if (op_has(*op, y) && op->raw) any_raw = true;
+    bool raw = false;
+    long inner = 0;
+    if (hi == B && !any_raw) {
+      for (const Op* op : ops) {
+        if (!op_has(*op, y)) continue;
+        any = true;
+        const std::vector<long>& shp = shapes.at(op->tensor);
+        if (op->raw || shp.empty() || shp[0] != B || op->dims.empty() || op->dims[0].only_register() != y) ok = false;
+        for (size_t d = 1; ok && d < op->dims.size(); ++d)
+          if (lin_has(op->dims[d], y)) ok = false;
+      }
+    } else if (any_raw && hi >= B && hi % B == 0) {
+      raw = true;
+      inner = hi / B;
+      for (const Op* op : ops) {
+        if (!op_has(*op, y)) continue;
+        any = true;
+        const std::vector<long>& shp = shapes.at(op->tensor);
+        if (!op->raw || op->dims.size() != 1 || op->dims[0].only_register() != y || shp.empty() || shp[0] != B || prodv(shp) != hi)
+          ok = false;
+      }
+      if (!op_has(k.write, y)) ok = false;
+    } else {
+      continue;
+    }
+    if (!ok || !any) continue;
+    r.ok = true;
+    r.batch_loop = (int)l;
+    r.raw = raw;
+    r.inner = inner;
+    r.reduced = !op_has(k.write, y);
+    r.work = raw ? inner : all_work / B;
+    return r;
+  }
+  return r;
+}
+
+namespace {
+
+// literal element offset of a tensor op (extents are literals in a per-plan kernel)
+std::string literal_element(const Op& op, const Shapes& shapes, const std::string& name, long local_inner = 0) {
+  const std::vector<long>& shp = shapes.at(op.tensor);
+  const std::map<int, std::string> no_subst;
+  std::string idx;
+  if (op.raw) {
+    idx = lin_text(op.dims[0], no_subst);
+  } else {
+    long stride = 1;
+    idx = "0L";
+    for (size_t d = shp.size(); d-- > 0;) {
+      idx += " + " + std::to_string(stride) + "L * " + lin_text(op.dims[d], no_subst);
+      stride *= shp[d];
+    }
+  }
+  // a block's own slice of a [B, ...] tensor (kept in LDS): the same element, counted from the start of sample n
+  if (local_inner > 0) idx = "(" + idx + ") - n * " + std::to_string(local_inner) + "L";
+  return name + "[" + idx + "]";
+}
+
+std::string sample_instr(const Kernel& k, const Instr& ins, const std::vector<Ty>& ty, const Shapes& shapes) {
+  const Ty t = ty[ins.res];
+  const char* ctype = t == Ty::Scalar ? "float" : (t == Ty::Index ? "long" : "bool");
+  std::string special;
+  if (ins.kind == IK::Epoch) {
+    special = "EP";
+  } else if (ins.kind == IK::Shape || ins.kind == IK::Len || ins.kind == IK::ShapeLen) {
+    const std::vector<long>& shp = shapes.at(ins.tensor);
+    long v = 0;
+    if (ins.kind == IK::Len) v = prodv(shp);
+    else if (ins.kind == IK::ShapeLen) v = (long)shp.size();
+    else {
+      int d = ins.dim < 0 ? ins.dim + (int)shp.size() : ins.dim;
+      v = (d >= 0 && d < (int)shp.size()) ? shp[d] : 0;
+    }
+    special = std::to_string(v) + "L";
+  }
+  std::string e = instr_expression(ins, special, "r");
+  if (k.is_seed && ins.kind == IK::Scalar) e = "GS";
+  return std::string("        const ") + ctype + " r" + std::to_string(ins.res) + " = " + e + ";\n";
+}
+
+}  // namespace
+
+int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
+                          const Shapes& shapes, SampleGroup& g) {
+  (void)prog;
+  std::set<int> touched, written;
+  for (size_t i = 0; i < g.kernel_index.size(); ++i) {
+    const Kernel& k = all[g.kernel_index[i]];
+    for (auto& rd : k.reads) touched.insert(rd.tensor);
+    if (!g.infos[i].reduced) {
+      touched.insert(k.write.tensor);
+      written.insert(k.write.tensor);
+    }
+  }
+  g.ptr_args.clear();
+  for (int t : touched)
+    if (!g.lds.count(t)) g.ptr_args.push_back(t);
+  const std::string NT = std::to_string(g.threads);
+  std::string sig = "extern \"C\" __global__ void __launch_bounds__(" + NT + ") " + g.name + "(float* __restrict__ slab";
+  for (int t : g.ptr_args) sig += std::string(written.count(t) ? ", float* t" : ", const float* t") + std::to_string(t);
+  sig += ", float GS, long EP)";
+  std::string c = "  const long n = blockIdx.x;  // this block's sample\n";
+  for (auto& kv : g.lds) c += "  __shared__ float t" + std::to_string(kv.first) + "[" + std::to_string(kv.second) + "];\n";
+  for (int t : g.lds_zero)
+    c += "  for (int i = threadIdx.x; i < " + std::to_string(g.lds.at(t)) + "; i += " + NT + ") t" + std::to_string(t) + "[i] = 0.0f;\n";
+  if (!g.lds_zero.empty()) c += "  __syncthreads();\n";
+  auto local = [&](int tensor) -> long {
+    auto it = g.lds.find(tensor);
+    return it == g.lds.end() ? 0 : it->second;
+  };
+  if (g.slab_floats > 0) c += "  float* const row = slab + n * " + std::to_string(g.slab_floats) + "L;\n";
+  std::set<int> slab_seen;
+  bool uses_scratch = false;
+  // EG_SAMPLE_STOP=<k> (measurement aid): the kernel ends behind member k — the time of the first k + 1 members
+  const char* stop_env = getenv("EG_SAMPLE_STOP");
+  const long stop = stop_env ? atol(stop_env) : -1;
+  for (size_t gi = 0; gi < g.kernel_index.size(); ++gi) {
+    if (stop >= 0 && (long)gi > stop) break;
+    const Kernel& k = all[g.kernel_index[gi]];
+    const KernelInfo& info = infos[g.kernel_index[gi]];
+    const SampleKernelInfo& si = g.infos[gi];
+    const std::vector<Ty> ty = infer_types(k);
+    c += "  {  // kernel " + std::to_string(gi) + ": " + to_text(k).substr(0, 100) + "\n";
+    if (si.gather) {
+      // gimg[n, Y, X, c] = sum over (dy, dx, f) of gout[n, Y - dy, X - dx, f] * flt[f, dy, dx, c] where the output pixel exists
+      const std::vector<long>&gi_s = shapes.at(si.g_img), &go_s = shapes.at(si.g_out), &fl_s = shapes.at(si.g_flt);
+      const long H = gi_s[1], W = gi_s[2], C = gi_s[3], Ho = go_s[1], Wo = go_s[2], F = go_s[3], FH = fl_s[1], FW = fl_s[2];
+      auto L = [](long v) { return std::to_string(v) + "L"; };
+      const std::string img = "t" + std::to_string(si.g_img), out = "t" + std::to_string(si.g_out), flt = "t" + std::to_string(si.g_flt);
+      c += "    for (long idx = threadIdx.x; idx < " + L(H * W * C) + "; idx += " + NT + ") {\n";
+      c += "      const long ch = idx % " + L(C) + ", X = (idx / " + L(C) + ") % " + L(W) + ", Y = idx / " + L(C * W) + ";\n";
+      c += "      float acc = 0.0f;\n";
+      c += "      for (long dy = 0; dy < " + L(FH) + "; ++dy) {\n        const long y = Y - dy;\n        if (y < 0 || y >= " + L(Ho) + ") continue;\n";
+      c += "        for (long dx = 0; dx < " + L(FW) + "; ++dx) {\n          const long x = X - dx;\n          if (x < 0 || x >= " + L(Wo) + ") continue;\n";
+      c += "          const float* go = " + out + " + ((" + (local(si.g_out) ? std::string("0L") : std::string("n")) + " * " + L(Ho) + " + y) * " + L(Wo) + " + x) * " + L(F) + ";\n";
+      c += "          const float* fl = " + flt + " + (dy * " + L(FW) + " + dx) * " + L(C) + " + ch;\n";
+      c += "          for (long f = 0; f < " + L(F) + "; ++f) acc = acc + go[f] * fl[f * " + L(FH * FW * C) + "];\n        }\n      }\n";
+      const std::string w = img + "[" + (local(si.g_img) ? std::string("0L") : std::string("n")) + " * " + L(H * W * C) + " + idx]";
+      c += "      " + w + " = " + (g.overwrite[gi] ? std::string("0.0f") : w) + " + acc;\n    }\n  }\n  __syncthreads();\n";
+      continue;
+    }
+    std::vector<int> indep, red;
+    bool scatter;
+    split_loops(k, indep, red, scatter);
+    auto drop = [&](std::vector<int>& v, int l) { v.erase(std::remove(v.begin(), v.end(), l), v.end()); };
+    long total = 1;
+    std::string fix;  // the batch iterator of this block
+    if (si.seed) {
+      // every block writes the same values: no batch loop
+    } else if (si.raw) {
+      drop(indep, si.batch_loop);
+      drop(red, si.batch_loop);
+      total = si.inner;
+      fix = "      const long r" + std::to_string(k.loops[si.batch_loop].reg) + " = n * " + std::to_string(si.inner) + "L + idx;\n";
+    } else {
+      drop(indep, si.batch_loop);
+      drop(red, si.batch_loop);
+      fix = "      const long r" + std::to_string(k.loops[si.batch_loop].reg) + " = n;\n";
+    }
+    if (!si.raw)
+      for (int l : indep) total *= std::max(0L, info.bounds[l].second - info.bounds[l].first);
+    if (si.raw && !indep.empty()) {
+      set_error("internal: raw sample kernel with further independent loops");
+      return EG_ERR_INVALID;
+    }
+    // where the value goes
+    std::string w;
+    bool plain = g.overwrite[gi] != 0;
+    if (si.reduced) {
+      const long off = g.slab_offset.at(k.write.tensor);
+      const std::string e = literal_element(k.write, shapes, "row");
+      w = e.substr(0, 4) + std::to_string(off) + "L + " + e.substr(4);   // row[<off> + index]
+      plain = slab_seen.count(k.write.tensor) == 0;  // the first contribution of this block to that tensor
+    } else {
+      w = literal_element(k.write, shapes, "t" + std::to_string(k.write.tensor), local(k.write.tensor));
+    }
+    long rtotal = 1;
+    for (int l : red) rtotal *= std::max(0L, info.bounds[l].second - info.bounds[l].first);
+    auto decode_indep = [&](const std::string& from, const std::string& ind) {
+      std::string d;
+      for (auto& s : k.setup) d += ind + "const long r" + std::to_string(s.res) + " = " + std::to_string(info.vals.at(s.res)) + "L;\n";
+      if (si.raw) {
+        d += ind + "const long r" + std::to_string(k.loops[si.batch_loop].reg) + " = n * " + std::to_string(si.inner) + "L + " + from + ";\n";
+        return d;
+      }
+      if (!si.seed) d += ind + "const long r" + std::to_string(k.loops[si.batch_loop].reg) + " = n;\n";
+      d += ind + "long rem = " + from + ";\n";
+      for (size_t i = indep.size(); i-- > 0;) {
+        const int l = indep[i];
+        const long ext = info.bounds[l].second - info.bounds[l].first;
+        d += ind + "const long r" + std::to_string(k.loops[l].reg) + " = " + std::to_string(info.bounds[l].first) + "L + rem % " +
+             std::to_string(ext) + "L; rem /= " + std::to_string(ext) + "L;\n";
+      }
+      d += ind + "(void)rem;\n";
+      return d;
+    };
+    auto term = [&](const std::string& ind) {  // loads + expression of one point of the loop nest
+      std::string d;
+      for (auto& ins : k.index_instrs) d += ind + "const long r" + std::to_string(ins.res) + " = " + instr_expression(ins, "0L", "r") + ";\n";
+      for (auto& rd : k.reads)
+        d += ind + "const float r" + std::to_string(rd.reg) + " = " + literal_element(rd, shapes, "t" + std::to_string(rd.tensor), local(rd.tensor)) + ";\n";
+      for (auto& ins : k.instrs) d += sample_instr(k, ins, ty, shapes);
+      return d;
+    };
+    // Few outputs, long reductions (a dense layer's 10 outputs of 400 terms each, a first-layer filter gradient's 200
+    // outputs of 576): one thread per output would leave most of the block idle for hundreds of serial iterations.
+    // T threads share an output: thread `part` takes the points part, part + T, ... of the flattened reduction space,
+    // the T partial sums meet in LDS and are added in the order of `part` (fixed: run-to-run identical).
+    long T = 1;
+    const long outer_ext = red.empty() ? 0 : std::max(0L, info.bounds[red[0]].second - info.bounds[red[0]].first);
+    if (!scatter && !si.raw && total > 0 && total * 2 <= g.threads && rtotal >= 16 && outer_ext >= 2) {
+      T = std::min<long>(g.threads / total, std::min<long>(outer_ext, 64));
+      if (T < 2) T = 1;
+    }
+    auto inner_loops = [&](size_t from, const std::string& ind) {  // reduction loops red[from ...], innermost unrolled
+      std::string d;
+      for (size_t i = from; i < red.size(); ++i) {
+        const int l = red[i];
+        const long ext = info.bounds[l].second - info.bounds[l].first;
+        const std::string r = "r" + std::to_string(k.loops[l].reg);
+        if (i + 1 == red.size()) d += ind + (ext <= 32 ? "_Pragma(\"unroll\")\n" : "_Pragma(\"unroll 4\")\n");  // loads of several iterations in flight
+        d += ind + "for (long " + r + " = " + std::to_string(info.bounds[l].first) + "L; " + r + " < " + std::to_string(info.bounds[l].second) +
+             "L; ++" + r + ") {\n";
+      }
+      return d;
+    };
+    if (T > 1) {
+      const std::string TS = std::to_string(T);
+      c += "    {\n      const long out = threadIdx.x / " + TS + "L, part = threadIdx.x % " + TS + "L;\n      float acc = 0.0f;\n";
+      c += "      if (out < " + std::to_string(total) + "L) {\n";
+      c += decode_indep("out", "        ");
+      {
+        const int l = red[0];
+        const std::string r = "r" + std::to_string(k.loops[l].reg);
+        c += "        for (long " + r + " = " + std::to_string(info.bounds[l].first) + "L + part; " + r + " < " + std::to_string(info.bounds[l].second) +
+             "L; " + r + " += " + TS + "L) {\n";
+      }
+      c += inner_loops(1, "          ");
+      c += term("          ");
+      c += "          acc = acc + r" + std::to_string(k.result) + ";\n";
+      for (size_t i = 1; i < red.size(); ++i) c += "          }\n";
+      c += "        }\n      }\n";
+      c += "      scratch[threadIdx.x] = acc;\n      __syncthreads();\n";
+      c += "      if (out < " + std::to_string(total) + "L && part == 0) {\n";
+      c += decode_indep("out", "        ");
+      c += "        float sum = 0.0f;\n        for (int q = 0; q < " + TS + "; ++q) sum = sum + scratch[out * " + TS + "L + q];\n";
+      c += "        " + w + " = " + (plain ? std::string("0.0f") : w) + " + sum;\n      }\n    }\n  }\n  __syncthreads();\n";
+      uses_scratch = true;
+      if (si.reduced) slab_seen.insert(k.write.tensor);
+      continue;
+    }
+    c += "    for (long idx = threadIdx.x; idx < " + std::to_string(total) + "L; idx += " + NT + ") {\n";
+    c += decode_indep("idx", "      ");
+    c += "      float acc = 0.0f;\n";
+    c += inner_loops(0, "      ");
+    c += term("        ");
+    if (scatter) {
+      // the element depends on the reduction iterators: add term by term (the destination starts from zero)
+      c += "        " + w + " = " + w + " + r" + std::to_string(k.result) + ";\n";
+    } else {
+      c += "        acc = acc + r" + std::to_string(k.result) + ";\n";
+    }
+    for (size_t i = 0; i < red.size(); ++i) c += "      }\n";
+    if (!scatter) c += "      " + w + " = " + (plain ? std::string("0.0f") : w) + " + acc;\n";
+    c += "    }\n  }\n  __syncthreads();\n";
+    if (si.reduced) slab_seen.insert(k.write.tensor);
+  }
+  // 32-bit index arithmetic where it is exact: every tensor (and the slab) has fewer than 2^31 elements and no member
+  // computes with Index VALUES (`toScalar(i * 100000)`: only addressing is known to fit — the rule of Slot::Narrow,
+  // codegen.hpp).  64-bit divisions and multiply-adds per element were most of a convolution member's time.
+  if (uses_scratch) c = "  __shared__ float scratch[" + NT + "];\n" + c;
+  bool narrow = getenv("EG_NO_NARROW_INDEX") == nullptr && g.B * std::max(1L, g.slab_floats) < (1L << 31);
+  for (int t : touched) narrow = narrow && prodv(shapes.at(t)) < (1L << 31);
+  for (int ki : g.kernel_index) {
+    const Kernel& k = all[ki];
+    const std::vector<Ty> ty = infer_types(k);
+    for (auto& ins : k.instrs) {
+      const bool index_typed = ins.res > 0 && ins.res < (int)ty.size() && ty[ins.res] == Ty::Index;
+      const bool derived = ins.kind != IK::Shape && ins.kind != IK::Len && ins.kind != IK::ShapeLen && ins.kind != IK::Epoch;
+      if (index_typed && derived) narrow = false;
+    }
+  }
+  if (narrow) {
+    c = std::regex_replace(c, std::regex("\\blong\\b"), "int");
+    c = std::regex_replace(c, std::regex("\\b([0-9]+)L\\b"), "$1");
+  }
   g.source = sig + " {\n" + c + "}\n";
   return EG_OK;
 }

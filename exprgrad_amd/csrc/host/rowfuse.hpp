@@ -108,5 +108,53 @@ bool is_map_kernel(const Program& prog, const Kernel& k, const KernelInfo& info,
 int generate_map_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
                        const Shapes& shapes, SmallGroup& group);
 
+// ---- sample groups (round 5) -----------------------------------------------------------------------------
+// A whole training step at a SMALL batch is a chain of dependent launches, each at the ~4.5 us floor of a dependent
+// kernel whatever it computes (Model.fit at the reference's default batch of 32, model.nim:413-454 with the network of
+// examples/fashion_mnist/fashion_mnist.nim:39-57: 16 launches, 70 us).  But every kernel of the forward and backward
+// pass works sample by sample — only the parameter gradients add over the batch.  A sample group runs a run of such
+// kernels as ONE generated kernel with ONE BLOCK PER SAMPLE: the block walks the kernel list in order, its 256 threads
+// share the independent iterations of a kernel restricted to the block's sample (reductions serial per thread,
+// `__syncthreads()` between kernels; the tensors stay where they are, in L2-resident global memory), and a kernel that
+// reduces over the batch writes its sample's contribution into row `sample` of a slab, which one deterministic
+// slab_sum launch folds into the gradient bucket afterwards.  The reference fuses loops for its CPU target only
+// (fuseLoops, passes.nim:1929-2004); its GPU target launches every kernel (llvmgen.nim:455-500).
+struct SampleKernelInfo {
+  bool ok = false;
+  int batch_loop = -1;   // index into k.loops of the loop that walks the samples (-1: the seed, no such loop)
+  bool raw = false;      // that loop is a raw iterator over B * inner elements (it = sample * inner + j)
+  long inner = 0;
+  bool reduced = false;  // the write is not indexed by the batch loop: a sum over the samples (parameter gradients)
+  bool seed = false;     // gradLoss{i} = 1 (passes.nim:575-606): every block writes the same value
+  long work = 0;         // loop iterations per sample
+  // conv2's image gradient — a scatter in the derived loop nest (gimg[n, y + dy, x + dx, c] += ...) — as a gather over
+  // the image gradient's own elements (tensor ids; filled in by the planner from match_conv)
+  bool gather = false;
+  int g_img = 0, g_out = 0, g_flt = 0;
+};
+
+SampleKernelInfo analyse_sample_kernel(const Program& prog, const Kernel& k, const KernelInfo& info, const Shapes& shapes, long B);
+
+struct SampleGroup {
+  std::vector<int> kernel_index;  // indices into target.all, in execution order
+  std::vector<SampleKernelInfo> infos;
+  std::vector<char> overwrite;    // per member: the write is a plain store (first writer, whole tensor) instead of +=
+  long B = 0;
+  std::map<int, long> slab_offset;  // tensors summed over the batch -> float offset inside a slab row
+  long slab_floats = 0;             // length of a slab row (a multiple of 4)
+  std::string name, source;
+  std::vector<int> ptr_args;        // tensor ids in pointer-argument order (behind `slab`)
+  // Tensors that exist inside the group only (written and read by members, sample by sample): a block keeps its sample's
+  // slice in LDS instead of global memory — an L2 round trip (~0.5 - 1 us) at the head of every one of the ~25 kernels of
+  // a step is what the first version of this kernel spent most of its 85 us on.  tensor id -> floats per sample.
+  std::map<int, long> lds;
+  std::set<int> lds_zero;           // of those: accumulated into before being written whole (start from zero)
+  int threads = 256;                // block size (a multiple of 64)
+};
+
+// Arguments of the generated kernel: (float* slab, float* t<ids>..., float grad_scale, long epoch); grid = B blocks of `threads`.
+int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, const std::vector<KernelInfo>& infos,
+                          const Shapes& shapes, SampleGroup& group);
+
 }  // namespace kd
 }  // namespace eg

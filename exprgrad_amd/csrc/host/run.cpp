@@ -123,6 +123,29 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       args.push_back(&EP);
       return eg::kernel_launch_raw(sg.handle, (unsigned)sg.g.blocks, 1, 1, 256, args.data());
     }
+    case StepKind::SampleFused: {
+      PlanSampleGroup& sg = *plan.sample_group;
+      std::vector<float*> ptrs;
+      ptrs.push_back(sg.slab);
+      for (int tid : sg.g.ptr_args) {
+        float* p = tensor_ptr(m, ts, plan, tid);
+        if (!p && prod(plan.shapes.at(tid)) > 0) {
+          set_error("tensor %d has no device storage", tid);
+          return EG_ERR_INVALID;
+        }
+        ptrs.push_back(p);
+      }
+      std::vector<void*> args;
+      for (auto& p : ptrs) args.push_back(&p);
+      float GS = m->grad_scale;
+      long EP = m->epoch;
+      args.push_back(&GS);
+      args.push_back(&EP);
+      int rc = eg::kernel_launch_raw(sg.handle, (unsigned)sg.g.B, 1, 1, (unsigned)sg.g.threads, args.data());
+      if (rc || sg.g.slab_floats <= 0) return rc;
+      // every sample's contribution to the parameter gradients -> the gradient bucket, in a fixed order
+      return eg::slab_sum(ctx, sg.g.B, sg.g.slab_floats, sg.slab, ts.bucket + sg.bucket_base, 0);
+    }
     case StepKind::RowFused: {
       PlanRowGroup& pg = *plan.row_groups[L.row_group];
       std::vector<float*> ptrs;
@@ -635,6 +658,9 @@ int plan_exchange(eg_model* m, TargetState& ts, Plan& plan, ExchangePlan& ex) {
         break;
       case StepKind::SmallFused:
         for (int ki : plan.small_groups[L.row_group]->g.kernel_index) note(t.all[ki].write.tensor, i);
+        break;
+      case StepKind::SampleFused:
+        for (int ki : plan.sample_group->g.kernel_index) note(t.all[ki].write.tensor, i);
         break;
       case StepKind::GemmFused:
         note(L.c_tensor, i);

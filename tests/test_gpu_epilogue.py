@@ -13,6 +13,13 @@ from parity import Trio
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def no_sample_groups(monkeypatch):
+    """These tests are about the plans of LARGE layers, exercised at small sizes (EG_EPILOGUE_MIN_ELEMS etc.): the
+    small-batch sample groups of round 5 (tests/test_gpu_sample_fuse.py) would take the narrow layers first."""
+    monkeypatch.setenv("EG_NO_SAMPLE_FUSE", "1")
+
 ACTS = {"relu": layers.relu, "leaky_relu": layers.leaky_relu, "sigmoid": layers.sigmoid, "tanh": layers.tanh}
 
 

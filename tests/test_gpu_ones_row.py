@@ -12,6 +12,13 @@ from parity import Trio
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def no_sample_groups(monkeypatch):
+    """These tests are about the plans of LARGE layers, exercised at small sizes (EG_EPILOGUE_MIN_ELEMS etc.): the
+    small-batch sample groups of round 5 (tests/test_gpu_sample_fuse.py) would take the narrow layers first."""
+    monkeypatch.setenv("EG_NO_SAMPLE_FUSE", "1")
+
+
 def net(n_in, n_hidden, n_out=4):
     def build():
         x = layers.dense(dsl.input("x"), n_in, n_hidden)

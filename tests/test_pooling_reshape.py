@@ -118,11 +118,12 @@ def test_gpu_activation_is_inlined_into_the_pooling_kernels(gpu_ctx, kind):
 
 
 @pytest.mark.gpu
-def test_gpu_activation_gradient_is_applied_inside_the_pooling_gradient(gpu_ctx):
+def test_gpu_activation_gradient_is_applied_inside_the_pooling_gradient(gpu_ctx, monkeypatch):
     """Backward pass of leakyRelu -> maxpool2 (the reference's fashion_mnist network): maxpool2's
     hand-written gradient kernel applies the activation's gradient to every value before storing it
     (consumer inlining), so the pooled gradient is never stored."""
     from exprgrad_amd import model as egm
+    monkeypatch.setenv("EG_NO_SAMPLE_FUSE", "1")   # (the launch chain is what this test looks at; sample groups: test_gpu_sample_fuse.py)
 
     def graphs():
         img = dsl.input("img")
