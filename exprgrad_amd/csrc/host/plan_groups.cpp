@@ -291,7 +291,7 @@ int form_sample_group(eg_model* m, TargetState& ts, Plan& plan, const std::vecto
       for (auto& rd : k.reads) candidates.erase(rd.tensor);
     }
     static const bool no_lds = getenv("EG_SAMPLE_NO_LDS") != nullptr;
-    long budget = 36L * 1024;  // floats (144 KB of the 160 KB a block may own)
+    long budget = 34L * 1024;  // floats (136 KB of the 160 KB a block may own; up to 16 KB more for the split reductions)
     if (!m->keep_values && !no_lds)
       for (int tid : candidates) {
         const long inner = prod(shapes.at(tid)) / B;

@@ -794,12 +794,15 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
   };
   if (g.slab_floats > 0) c += "  float* const row = slab + n * " + std::to_string(g.slab_floats) + "L;\n";
   std::set<int> slab_seen;
-  bool uses_scratch = false;
+  long scratch_floats = 0;
   // EG_SAMPLE_STOP=<k> (measurement aid): the kernel ends behind member k — the time of the first k + 1 members
   const char* stop_env = getenv("EG_SAMPLE_STOP");
   const long stop = stop_env ? atol(stop_env) : -1;
+  const char* skip_env = getenv("EG_SAMPLE_SKIP");  // (measurement aid: member <k> left out — wrong numbers, the time it costs)
+  const long skip = skip_env ? atol(skip_env) : -1;
   for (size_t gi = 0; gi < g.kernel_index.size(); ++gi) {
     if (stop >= 0 && (long)gi > stop) break;
+    if (skip >= 0 && (long)gi == skip) continue;
     const Kernel& k = all[g.kernel_index[gi]];
     const KernelInfo& info = infos[g.kernel_index[gi]];
     const SampleKernelInfo& si = g.infos[gi];
@@ -860,6 +863,37 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
     }
     long rtotal = 1;
     for (int l : red) rtotal *= std::max(0L, info.bounds[l].second - info.bounds[l].first);
+    // Register blocking.  A convolution member spends its time in LDS reads — two per multiply-add, 921 KB per sample for
+    // 115 K multiply-adds against 128 B per clock and CU — not in arithmetic.  A thread therefore owns R consecutive
+    // values of the fastest independent iterator (R <= 8 dividing its extent) and walks the reduction once for all of
+    // them: the unrolled copies share every load that does not depend on that iterator (the compiler merges them).
+    int blk = -1;
+    long R = 1;
+    static const bool no_block = getenv("EG_SAMPLE_NO_BLOCK") != nullptr;
+    if (!no_block && !scatter && !si.raw && !si.seed && !red.empty() && rtotal >= 4) {
+      // NOT the fastest iterator: consecutive lanes walk that one, so that a wave's LDS reads fall into consecutive banks
+      // (blocking it measured 47 us against 32 for the whole kernel: eight-way bank conflicts); the next one up —
+      // `x` of out[n, y, x, f], `dx` of gflt[f, dy, dx, c] — is where the window operand and the other operand repeat.
+      bool lane_seen = false;
+      for (size_t i = indep.size(); i-- > 0 && blk < 0;) {
+        const long ext = info.bounds[indep[i]].second - info.bounds[indep[i]].first;
+        if (ext < 2) continue;
+        if (!lane_seen) {
+          lane_seen = true;
+          continue;
+        }
+        for (long r = std::min<long>(ext, 8); r >= 2; --r)
+          if (ext % r == 0) {
+            blk = (int)i;
+            R = r;
+            break;
+          }
+        break;
+      }
+    }
+    const long items = total / R;
+    const std::string RS = std::to_string(R);
+    const std::string breg = blk >= 0 ? "r" + std::to_string(k.loops[indep[blk]].reg) : "";
     auto decode_indep = [&](const std::string& from, const std::string& ind) {
       std::string d;
       for (auto& s : k.setup) d += ind + "const long r" + std::to_string(s.res) + " = " + std::to_string(info.vals.at(s.res)) + "L;\n";
@@ -872,8 +906,14 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
       for (size_t i = indep.size(); i-- > 0;) {
         const int l = indep[i];
         const long ext = info.bounds[l].second - info.bounds[l].first;
-        d += ind + "const long r" + std::to_string(k.loops[l].reg) + " = " + std::to_string(info.bounds[l].first) + "L + rem % " +
-             std::to_string(ext) + "L; rem /= " + std::to_string(ext) + "L;\n";
+        const std::string lo = std::to_string(info.bounds[l].first) + "L";
+        if ((int)i == blk) {
+          d += ind + "const long " + breg + "_0 = " + lo + " + (rem % " + std::to_string(ext / R) + "L) * " + RS + "L; rem /= " +
+               std::to_string(ext / R) + "L;\n";
+        } else {
+          d += ind + "const long r" + std::to_string(k.loops[l].reg) + " = " + lo + " + rem % " + std::to_string(ext) + "L; rem /= " +
+               std::to_string(ext) + "L;\n";
+        }
       }
       d += ind + "(void)rem;\n";
       return d;
@@ -886,14 +926,38 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
       for (auto& ins : k.instrs) d += sample_instr(k, ins, ty, shapes);
       return d;
     };
+    // one point of the reduction for the thread's R values: acc[u] += term(u)
+    auto accumulate = [&](const std::string& ind) {
+      std::string d;
+      if (blk < 0) {
+        d += term(ind);
+        d += ind + "acc[0] = acc[0] + r" + std::to_string(k.result) + ";\n";
+        return d;
+      }
+      d += ind + "_Pragma(\"unroll\")\n" + ind + "for (int u = 0; u < " + RS + "; ++u) {\n";
+      d += ind + "  const long " + breg + " = " + breg + "_0 + u;\n";
+      d += term(ind + "  ");
+      d += ind + "  acc[u] = acc[u] + r" + std::to_string(k.result) + ";\n" + ind + "}\n";
+      return d;
+    };
+    // store acc[u] for the thread's R values
+    auto store = [&](const std::string& ind) {
+      std::string d;
+      if (blk < 0) return ind + w + " = " + (plain ? std::string("0.0f") : w) + " + acc[0];\n";
+      d += ind + "_Pragma(\"unroll\")\n" + ind + "for (int u = 0; u < " + RS + "; ++u) {\n";
+      d += ind + "  const long " + breg + " = " + breg + "_0 + u;\n";
+      d += ind + "  " + w + " = " + (plain ? std::string("0.0f") : w) + " + acc[u];\n" + ind + "}\n";
+      return d;
+    };
     // Few outputs, long reductions (a dense layer's 10 outputs of 400 terms each, a first-layer filter gradient's 200
     // outputs of 576): one thread per output would leave most of the block idle for hundreds of serial iterations.
-    // T threads share an output: thread `part` takes the points part, part + T, ... of the flattened reduction space,
-    // the T partial sums meet in LDS and are added in the order of `part` (fixed: run-to-run identical).
+    // T threads share an item: thread `part` takes the values part, part + T, ... of the OUTERMOST reduction iterator
+    // (the inner ones stay plain nested loops), the T partial sums meet in LDS and are added in the order of `part`
+    // (fixed: run-to-run identical).
     long T = 1;
     const long outer_ext = red.empty() ? 0 : std::max(0L, info.bounds[red[0]].second - info.bounds[red[0]].first);
-    if (!scatter && !si.raw && total > 0 && total * 2 <= g.threads && rtotal >= 16 && outer_ext >= 2) {
-      T = std::min<long>(g.threads / total, std::min<long>(outer_ext, 64));
+    if (!scatter && !si.raw && items > 0 && items * 2 <= g.threads && rtotal >= 16 && outer_ext >= 2) {
+      T = std::min<long>(g.threads / items, std::min<long>(outer_ext, 64));
       if (T < 2) T = 1;
     }
     auto inner_loops = [&](size_t from, const std::string& ind) {  // reduction loops red[from ...], innermost unrolled
@@ -902,16 +966,17 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
         const int l = red[i];
         const long ext = info.bounds[l].second - info.bounds[l].first;
         const std::string r = "r" + std::to_string(k.loops[l].reg);
-        if (i + 1 == red.size()) d += ind + (ext <= 32 ? "_Pragma(\"unroll\")\n" : "_Pragma(\"unroll 4\")\n");  // loads of several iterations in flight
+        if (i + 1 == red.size()) d += ind + (ext * R <= 64 ? "_Pragma(\"unroll\")\n" : "_Pragma(\"unroll 4\")\n");  // loads of several iterations in flight
         d += ind + "for (long " + r + " = " + std::to_string(info.bounds[l].first) + "L; " + r + " < " + std::to_string(info.bounds[l].second) +
              "L; ++" + r + ") {\n";
       }
       return d;
     };
+    const std::string zero_acc = "      float acc[" + RS + "];\n      _Pragma(\"unroll\") for (int u = 0; u < " + RS + "; ++u) acc[u] = 0.0f;\n";
     if (T > 1) {
       const std::string TS = std::to_string(T);
-      c += "    {\n      const long out = threadIdx.x / " + TS + "L, part = threadIdx.x % " + TS + "L;\n      float acc = 0.0f;\n";
-      c += "      if (out < " + std::to_string(total) + "L) {\n";
+      c += "    {\n      const long out = threadIdx.x / " + TS + "L, part = threadIdx.x % " + TS + "L;\n" + zero_acc;
+      c += "      if (out < " + std::to_string(items) + "L) {\n";
       c += decode_indep("out", "        ");
       {
         const int l = red[0];
@@ -920,39 +985,42 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
              "L; " + r + " += " + TS + "L) {\n";
       }
       c += inner_loops(1, "          ");
-      c += term("          ");
-      c += "          acc = acc + r" + std::to_string(k.result) + ";\n";
+      c += accumulate("          ");
       for (size_t i = 1; i < red.size(); ++i) c += "          }\n";
       c += "        }\n      }\n";
-      c += "      scratch[threadIdx.x] = acc;\n      __syncthreads();\n";
-      c += "      if (out < " + std::to_string(total) + "L && part == 0) {\n";
+      c += "      _Pragma(\"unroll\") for (int u = 0; u < " + RS + "; ++u) scratch[u * " + NT + " + threadIdx.x] = acc[u];\n      __syncthreads();\n";
+      c += "      if (out < " + std::to_string(items) + "L && part == 0) {\n";
       c += decode_indep("out", "        ");
-      c += "        float sum = 0.0f;\n        for (int q = 0; q < " + TS + "; ++q) sum = sum + scratch[out * " + TS + "L + q];\n";
-      c += "        " + w + " = " + (plain ? std::string("0.0f") : w) + " + sum;\n      }\n    }\n  }\n  __syncthreads();\n";
-      uses_scratch = true;
+      c += "        _Pragma(\"unroll\") for (int u = 0; u < " + RS + "; ++u) {\n          float sum = 0.0f;\n";
+      c += "          for (int q = 0; q < " + TS + "; ++q) sum = sum + scratch[u * " + NT + " + out * " + TS + "L + q];\n          acc[u] = sum;\n        }\n";
+      c += store("        ");
+      c += "      }\n    }\n  }\n  __syncthreads();\n";
+      scratch_floats = std::max(scratch_floats, (long)g.threads * R);
       if (si.reduced) slab_seen.insert(k.write.tensor);
       continue;
     }
-    c += "    for (long idx = threadIdx.x; idx < " + std::to_string(total) + "L; idx += " + NT + ") {\n";
+    c += "    for (long idx = threadIdx.x; idx < " + std::to_string(items) + "L; idx += " + NT + ") {\n";
     c += decode_indep("idx", "      ");
-    c += "      float acc = 0.0f;\n";
-    c += inner_loops(0, "      ");
-    c += term("        ");
     if (scatter) {
       // the element depends on the reduction iterators: add term by term (the destination starts from zero)
+      c += inner_loops(0, "      ");
+      c += term("        ");
       c += "        " + w + " = " + w + " + r" + std::to_string(k.result) + ";\n";
+      for (size_t i = 0; i < red.size(); ++i) c += "      }\n";
     } else {
-      c += "        acc = acc + r" + std::to_string(k.result) + ";\n";
+      c += zero_acc;
+      c += inner_loops(0, "      ");
+      c += accumulate("        ");
+      for (size_t i = 0; i < red.size(); ++i) c += "      }\n";
+      c += store("      ");
     }
-    for (size_t i = 0; i < red.size(); ++i) c += "      }\n";
-    if (!scatter) c += "      " + w + " = " + (plain ? std::string("0.0f") : w) + " + acc;\n";
     c += "    }\n  }\n  __syncthreads();\n";
     if (si.reduced) slab_seen.insert(k.write.tensor);
   }
   // 32-bit index arithmetic where it is exact: every tensor (and the slab) has fewer than 2^31 elements and no member
   // computes with Index VALUES (`toScalar(i * 100000)`: only addressing is known to fit — the rule of Slot::Narrow,
   // codegen.hpp).  64-bit divisions and multiply-adds per element were most of a convolution member's time.
-  if (uses_scratch) c = "  __shared__ float scratch[" + NT + "];\n" + c;
+  if (scratch_floats > 0) c = "  __shared__ float scratch[" + std::to_string(scratch_floats) + "];\n" + c;
   bool narrow = getenv("EG_NO_NARROW_INDEX") == nullptr && g.B * std::max(1L, g.slab_floats) < (1L << 31);
   for (int t : touched) narrow = narrow && prodv(shapes.at(t)) < (1L << 31);
   for (int ki : g.kernel_index) {

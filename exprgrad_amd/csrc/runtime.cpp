@@ -134,6 +134,10 @@ int kernels_compile_batch(eg_ctx* ctx, const char* label, const char* source, co
       fwrite(code.data(), 1, code.size(), fp);
       fclose(fp);
     }
+    if (FILE* fp = fopen((std::string(dump) + "/" + label + ".hip").c_str(), "wb")) {  // ... and the text it was built from
+      fwrite(source, 1, strlen(source), fp);
+      fclose(fp);
+    }
   }
 
   std::shared_ptr<eg_module> mod(new eg_module());
