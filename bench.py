@@ -961,7 +961,8 @@ def run_fashion_fit(args, env):
 
 def cpu_baseline_fit(budget_s=5.0):
     """Model.fit of the fashion_mnist network on the host: the oracle's kernel list run batch by batch the way
-    model.nim:413-454 does (epoch += 1 per batch, results zeroed per call), batch 32.  No kernel of a 32-sample batch
+    model.nim:413-454 does (Model.epoch bumped ONCE per fit call, model.nim:436 — not per batch; results zeroed per batch,
+    model.nim:447-449), batch 32; a pass over the 8 batches of the sample is one fit call.  No kernel of a 32-sample batch
     reaches the reference's 2^24 work-per-thread threshold: one thread is its policy."""
     import numpy as np
     from exprgrad_amd import dsl, examples
@@ -976,7 +977,8 @@ def cpu_baseline_fit(budget_s=5.0):
     t0, n = time.perf_counter(), 0
     while time.perf_counter() - t0 < budget_s or n < 2:
         i = (n % 8) * batch
-        m.epoch += 1
+        if i == 0:
+            m.epoch += 1      # a new pass over the data = a new fit call (what fit.cpp does on the device)
         m.apply("fit", {"x": x[i:i + batch], "y": y[i:i + batch]})
         n += 1
     dt = (time.perf_counter() - t0) / n

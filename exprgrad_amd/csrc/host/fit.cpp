@@ -33,12 +33,18 @@ int launch_group(eg_model* m, TargetState& ts, Plan& plan, long group, long b, R
   std::ostringstream k;
   k << capture_key(m, ts) << "|plan" << (const void*)&plan << "|g" << group << "|n" << plan.launches.size();
   const std::string key = k.str();
+  bool fresh = false;
   if (!fg.exec || fg.key != key) {
+    fresh = true;
     if (fg.exec) {
       EG_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // (an older group may still be running)
       hipGraphExecDestroy(fg.exec);
       fg.exec = nullptr;
     }
+    if (fg.exec2) hipGraphExecDestroy(fg.exec2);
+    fg.exec2 = nullptr;
+    fg.launched[0] = fg.launched[1] = false;
+    fg.turn = 0;
     if (fg.graph) hipGraphDestroy(fg.graph);
     fg.graph = nullptr;
     fg.copies.clear();
@@ -90,26 +96,41 @@ int launch_group(eg_model* m, TargetState& ts, Plan& plan, long group, long b, R
       fg.exec = nullptr;
       return EG_OK;
     }
+    if (hipGraphInstantiate(&fg.exec2, graph, nullptr, nullptr, 0) != hipSuccess) {  // (one executable then: its event is waited for before every update)
+      (void)hipGetLastError();
+      fg.exec2 = nullptr;
+    }
+    for (int i = 0; i < 2; ++i)
+      if (!fg.done[i]) EG_HIP_CHECK(hipEventCreateWithFlags(&fg.done[i], hipEventDisableTiming));
     fg.graph = graph;
     fg.copies.swap(copies);
     fg.key = key;
-  } else {
+  }
+  const int t = fg.exec2 ? fg.turn : 0;
+  hipGraphExec_t exec = t ? fg.exec2 : fg.exec;
+  if (!fresh || t == 1) {
+    if (fg.launched[t]) EG_HIP_CHECK(hipEventSynchronize(fg.done[t]));  // this executable's previous launch has run
     for (long j = 0; j < group; ++j) {
       const eg::CopySegments cs = rows_of(b + j);
       hipKernelNodeParams p;
       void* arg[1];
       if (!eg::copy_segments_node_params(ctx, cs, &p, arg) ||
-          hipGraphExecKernelNodeSetParams(fg.exec, fg.copies[(size_t)j], &p) != hipSuccess) {
+          hipGraphExecKernelNodeSetParams(exec, fg.copies[(size_t)j], &p) != hipSuccess) {
         if (getenv("EG_DEBUG_GRAPH")) fprintf(stderr, "[eg] fit group: hipGraphExecKernelNodeSetParams refused: %s\n", hipGetErrorString(hipGetLastError()));
         (void)hipGetLastError();
         EG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         hipGraphExecDestroy(fg.exec);
         fg.exec = nullptr;
+        if (fg.exec2) hipGraphExecDestroy(fg.exec2);
+        fg.exec2 = nullptr;
         return EG_OK;
       }
     }
   }
-  EG_HIP_CHECK(hipGraphLaunch(fg.exec, ctx->stream));
+  EG_HIP_CHECK(hipGraphLaunch(exec, ctx->stream));
+  EG_HIP_CHECK(hipEventRecord(fg.done[t], ctx->stream));
+  fg.launched[t] = true;
+  fg.turn = fg.exec2 ? 1 - t : 0;
   *done = true;
   return EG_OK;
 }

@@ -193,6 +193,10 @@ int eg_model_free(eg_model* m) try {
   hipStreamSynchronize(m->ctx->stream);
   if (m->fit_graph.exec) hipGraphExecDestroy(m->fit_graph.exec);
   m->fit_graph.exec = nullptr;
+  if (m->fit_graph.exec2) hipGraphExecDestroy(m->fit_graph.exec2);
+  m->fit_graph.exec2 = nullptr;
+  for (auto& ev : m->fit_graph.done)
+    if (ev) hipEventDestroy(ev);
   if (m->fit_graph.graph) hipGraphDestroy(m->fit_graph.graph);
   m->fit_graph.graph = nullptr;
   for (auto& kv : m->targets) {
@@ -267,7 +271,7 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
       case StepKind::SampleFused: {
         const PlanSampleGroup& sg = *plan.sample_group;
         os << "sample-fused " << sg.g.kernel_index.size() << " kernels, one block per sample (" << sg.g.B << " blocks)";
-        if (sg.g.slab_floats > 0) os << " | " << sg.sum_tensors.size() << " batch sums folded by one slab pass";
+        if (sg.g.slab_floats > 0) os << " | " << sg.sum_tensors.size() << " batch sums " << (L.fold_launch >= 0 ? "folded by launch " + std::to_string(L.fold_launch) + " (one slab pass when a range ends between them)" : std::string("folded by one slab pass"));
         break;
       }
       case StepKind::SmallFused: {

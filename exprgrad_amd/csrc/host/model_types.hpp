@@ -111,6 +111,9 @@ struct Launch {
   // tail launch is skipped; when a range ends between them (backward | update of the data-parallel step) both run.
   int tail_launch = -1;                     // RowFused: index of the launch its last block can run
   int tail_of = -1;                         // SmallFused: index of the RowFused launch that can run it
+  // Slab fold (plan_groups.cpp fuse_slab_fold): the map group behind a sample group adds up the slab rows itself
+  int fold_launch = -1;                     // SampleFused: index of the map group that folds its slab when a range holds both
+  int fold_of = -1;                         // SmallFused: index of that sample group's launch
 };
 
 // A run of per-sample kernels fused into one generated kernel (rowfuse.hpp), built per plan.
@@ -280,6 +283,13 @@ struct eg_model {
   // ~8 us: a group pays that once.
   struct FitGraph {
     hipGraphExec_t exec = nullptr;
+    // A second executable of the same graph: a group's copy nodes are re-pointed with hipGraphExecKernelNodeSetParams, and
+    // HIP does not say that a launch still queued keeps the arguments it was launched with — so the executable being
+    // updated is never the one launched last (A / B in turns), and its own previous launch has completed (an event).
+    hipGraphExec_t exec2 = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    bool launched[2] = {false, false};
+    int turn = 0;
     hipGraph_t graph = nullptr;          // kept: the copy nodes are addressed through it
     std::vector<hipGraphNode_t> copies;  // the group's segment-copy nodes, in batch order
     std::string key;                     // everything baked into the captured kernel arguments
@@ -339,6 +349,8 @@ int form_sample_group(eg_model* m, TargetState& ts, Plan& plan, const std::vecto
                       std::vector<int>& group_of, std::set<int>& needs_zero);
 int fuse_row_tails(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos);
 bool row_tail_active(const Plan& plan, const Launch& row_launch);
+int fuse_slab_fold(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos);
+bool slab_fold_active(const Plan& plan, const Launch& sample_launch);
 // plan_overlap.cpp
 int ensure_side_lane(eg_ctx* ctx);
 bool launch_tensors(const Plan& plan, const Launch& L, std::set<int>& reads, std::set<int>& writes);

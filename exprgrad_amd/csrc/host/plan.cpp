@@ -584,6 +584,8 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   {
     int rc = fuse_row_tails(m, ts, plan, infos);
     if (rc) return rc;
+    rc = fuse_slab_fold(m, ts, plan, infos);
+    if (rc) return rc;
   }
   {
     int rc = build_plan_kernels(m, plan);

@@ -81,6 +81,62 @@ int fuse_row_tails(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
 }
 
 
+bool slab_fold_active(const Plan& plan, const Launch& L) {
+  return L.kind == StepKind::SampleFused && L.fold_launch >= 0 && L.fold_launch >= plan.active_begin && L.fold_launch < plan.active_end;
+}
+
+// The optimizer's map group directly behind a sample group adds up the slab rows itself (rowfuse.hpp, SmallGroup::fold_*):
+// the slab_sum launch between the two disappears when a range holds both (Model.apply / fit; the data-parallel step
+// ends its backward range between them and keeps the launch, because the exchange needs the totals in the bucket).
+// Every summed tensor must be read by the group as a raw map of its own size; EG_NO_SLAB_FOLD=1 off.
+int fuse_slab_fold(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos) {
+  {
+    const char* e = getenv("EG_NO_SLAB_FOLD");
+    if (e && e[0] && e[0] != '0') return EG_OK;
+  }
+  if (!plan.sample_group || plan.sample_group->g.slab_floats <= 0 || plan.pipe.active) return EG_OK;
+  Target& t = *ts.target;
+  for (int i = 0; i + 1 < (int)plan.launches.size(); ++i) {
+    Launch& S = plan.launches[i];
+    Launch& M = plan.launches[i + 1];
+    if (S.kind != StepKind::SampleFused || M.kind != StepKind::SmallFused) continue;
+    PlanSampleGroup& sg = *plan.sample_group;
+    PlanSmallGroup& mg = *plan.small_groups[M.row_group];
+    if (mg.g.blocks <= 1 || M.tail_of >= 0) return EG_OK;  // (a map group: one block per 256 elements)
+    std::set<int> read_as_map;
+    for (int ki : mg.g.kernel_index) {
+      const Kernel& k = t.all[ki];
+      long count = 0;
+      if (!is_map_kernel(m->prog, k, infos[ki], plan.shapes, count)) return EG_OK;
+      for (auto& rd : k.reads)
+        if (prod(plan.shapes.at(rd.tensor)) == count) read_as_map.insert(rd.tensor);
+    }
+    for (int tid : sg.sum_tensors)
+      if (!read_as_map.count(tid)) return EG_OK;
+    for (int ki : mg.g.kernel_index)  // nobody in the group writes a summed tensor (the fold stores into it first)
+      if (std::find(sg.sum_tensors.begin(), sg.sum_tensors.end(), t.all[ki].write.tensor) != sg.sum_tensors.end()) return EG_OK;
+    mg.g.fold_offset = sg.g.slab_offset;
+    mg.g.fold_rows = sg.g.B;
+    mg.g.fold_row_floats = sg.g.slab_floats;
+    int rc = generate_map_group(m->prog, t.all, infos, plan.shapes, mg.g);
+    if (rc) return rc;
+    bool replaced = false;
+    for (auto& pk : plan.pending)
+      if (pk.slot == &mg.handle) {
+        pk.source = mg.g.source;
+        replaced = true;
+      }
+    if (!replaced) {
+      mg.g.fold_offset.clear();
+      return generate_map_group(m->prog, t.all, infos, plan.shapes, mg.g);
+    }
+    S.fold_launch = i + 1;
+    M.fold_of = i;
+    return EG_OK;
+  }
+  return EG_OK;
+}
+
 // A run of per-sample kernels of the backward range as ONE kernel with one block per sample (rowfuse.hpp, "sample
 // groups"): for small batches, where every launch of the step sits at the floor of a dependent launch.  At most one group
 // per plan: the longest run of consecutive live kernels each of which

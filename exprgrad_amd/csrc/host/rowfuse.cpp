@@ -588,13 +588,16 @@ int generate_map_group(const Program& prog, const std::vector<Kernel>& all, cons
     touched.insert(all[ki].write.tensor);
     for (auto& rd : all[ki].reads) touched.insert(rd.tensor);
   }
+  for (auto& f : g.fold_offset) written.insert(f.first);  // (the folded total is stored where the gradient lives)
   g.ptr_args.assign(touched.begin(), touched.end());
   std::string sig = "extern \"C\" __global__ void __launch_bounds__(256) " + g.name + "(";
   for (size_t i = 0; i < g.ptr_args.size(); ++i) {
     const int t = g.ptr_args[i];
     sig += (i ? ", " : "") + std::string(written.count(t) ? "float* t" : "const float* t") + std::to_string(t);
   }
-  sig += std::string(g.ptr_args.empty() ? "" : ", ") + "float GS, long EP)";
+  sig += std::string(g.ptr_args.empty() ? "" : ", ") + "float GS, long EP";
+  if (!g.fold_offset.empty()) sig += ", const float* __restrict__ slab, long FOLD";
+  sig += ")";
   std::string c = "  const long block = blockIdx.x;\n";
   long first_block = 0;
   for (size_t seg = 0; seg < counts.size(); ++seg) {
@@ -603,6 +606,19 @@ int generate_map_group(const Program& prog, const std::vector<Kernel>& all, cons
          std::to_string(n) + " elements\n";
     c += "    const long idx = (block - " + std::to_string(first_block) + "L) * 256 + threadIdx.x;\n";
     c += "    if (idx < " + std::to_string(n) + "L) {\n";
+    for (auto& f : g.fold_offset) {
+      if (prodv(shapes.at(f.first)) != n || !touched.count(f.first)) continue;
+      bool in_segment = false;
+      for (size_t gi = 0; gi < g.kernel_index.size(); ++gi)
+        if (of_kernel[gi] == n)
+          for (auto& rd : all[g.kernel_index[gi]].reads) in_segment = in_segment || rd.tensor == f.first;
+      if (!in_segment) continue;
+      c += "      if (FOLD) {  // this element's sum over the batch: the samples' contributions in sample order\n";
+      c += "        float total = 0.0f;\n";
+      c += "        for (long s = 0; s < " + std::to_string(g.fold_rows) + "L; ++s) total = total + slab[s * " + std::to_string(g.fold_row_floats) +
+           "L + " + std::to_string(f.second) + "L + idx];\n";
+      c += "        t" + std::to_string(f.first) + "[idx] = total;\n      }\n";
+    }
     for (size_t gi = 0; gi < g.kernel_index.size(); ++gi) {
       if (of_kernel[gi] != n) continue;
       const Kernel& k = all[g.kernel_index[gi]];

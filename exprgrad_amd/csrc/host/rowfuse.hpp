@@ -90,6 +90,12 @@ struct SmallGroup {
   std::string name, source;
   std::vector<int> ptr_args;      // tensor ids in pointer-argument order
   long blocks = 1;                // grid size (1 for a small group, sum over the segments of a map group)
+  // Map groups only (round 5): gradient tensors whose sum over the batch the group takes from a sample group's slab
+  // itself — thread idx adds rows 0 .. fold_rows - 1 of its element in that order, stores the total where the gradient
+  // lives (other readers find it there) and goes on with its kernels: the slab_sum launch between the sample kernel and
+  // the optimizer disappears.  Arguments behind `epoch`: const float* slab, long FOLD (0: the gradients are in place).
+  std::map<int, long> fold_offset;  // tensor -> float offset inside a slab row
+  long fold_rows = 0, fold_row_floats = 0;
 };
 
 // Arguments of the generated kernel: (float* / const float* t<ids>..., float grad_scale, long epoch).

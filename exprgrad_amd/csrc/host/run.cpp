@@ -121,6 +121,14 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       long EP = m->epoch;
       args.push_back(&GS);
       args.push_back(&EP);
+      const float* slab = nullptr;
+      long FOLD = 0;
+      if (!sg.g.fold_offset.empty()) {  // the group can add up a sample group's slab rows itself (fuse_slab_fold)
+        slab = plan.sample_group ? plan.sample_group->slab : nullptr;
+        FOLD = (L.fold_of >= 0 && slab && slab_fold_active(plan, plan.launches[L.fold_of])) ? 1 : 0;
+        args.push_back(&slab);
+        args.push_back(&FOLD);
+      }
       return eg::kernel_launch_raw(sg.handle, (unsigned)sg.g.blocks, 1, 1, 256, args.data());
     }
     case StepKind::SampleFused: {
@@ -143,6 +151,7 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       args.push_back(&EP);
       int rc = eg::kernel_launch_raw(sg.handle, (unsigned)sg.g.B, 1, 1, (unsigned)sg.g.threads, args.data());
       if (rc || sg.g.slab_floats <= 0) return rc;
+      if (slab_fold_active(plan, L)) return EG_OK;  // the optimizer's map group behind this launch adds the rows up itself
       // every sample's contribution to the parameter gradients -> the gradient bucket, in a fixed order
       return eg::slab_sum(ctx, sg.g.B, sg.g.slab_floats, sg.slab, ts.bucket + sg.bucket_base, 0);
     }

@@ -207,7 +207,9 @@ bool read_file(const std::string& path, std::vector<char>& out) {
          sum == content_hash(out.data(), (size_t)length);
     if (ok) out.resize((size_t)length);
   }
-  if (!ok) unlink(path.c_str());  // never serve it again; the caller compiles and rewrites the entry
+  // An entry that does not validate is simply not served: the caller compiles and write_file_atomic's rename replaces it.
+  // (Unlinking it here could remove a VALID entry another process renamed into place between this read and the unlink —
+  // several ranks starting together would then recompile in turns)
   return ok;
 }
 

@@ -5,14 +5,15 @@ import pytest
 
 import refcases
 from conftest import TOL, rel_err
-from exprgrad_amd import dsl, examples
+import extra_examples
+from exprgrad_amd import dsl
 
 DIMS = dict(seed_dim=8, h1=12, h2=16, pixels=20)
 
 
 def oracle_model():
     from oracle import kd
-    return kd.Model(refcases.program_text(examples.gan(**DIMS)), threads=2)
+    return kd.Model(refcases.program_text(extra_examples.gan(**DIMS)), threads=2)
 
 
 def data(rng, n=6):
@@ -23,7 +24,7 @@ def data(rng, n=6):
 
 
 def test_cond_selects_the_branch_of_the_target():
-    text = refcases.program_text(examples.gan(**DIMS))
+    text = refcases.program_text(extra_examples.gan(**DIMS))
     m = oracle_model()
     rng = np.random.default_rng(0)
     for tid in m.params:
@@ -50,7 +51,7 @@ def test_cond_selects_the_branch_of_the_target():
 @pytest.mark.gpu
 def test_gpu_gan_matches_the_oracle(gpu_ctx):
     from parity import Trio
-    t = Trio(gpu_ctx, lambda: examples.gan(**DIMS))
+    t = Trio(gpu_ctx, lambda: extra_examples.gan(**DIMS))
     rng = np.random.default_rng(1)
     t.init_params(rng, -0.2, 0.2)
     seed, real, labels = data(rng)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import refcases
-from exprgrad_amd import examples
+import extra_examples
 
 RED, BLUE = np.array([1, 0, 0], np.float32), np.array([0, 0, 1], np.float32)
 
@@ -18,8 +18,8 @@ def oracle(graphs, threads=8):
 
 
 def target_image(size):
-    scene = examples.inverse_rendering_scene()
-    ref = oracle(examples.inverse_rendering(size=size, trainable_colors=False))
+    scene = extra_examples.inverse_rendering_scene()
+    ref = oracle(extra_examples.inverse_rendering(size=size, trainable_colors=False))
     img = ref.call("render", {**scene, "sphere0.color": RED, "sphere1.color": BLUE})
     return scene, ref, np.clip(img, 0, 1)          # renderTargetImage clamps (inverse_rendering.nim:133)
 
@@ -27,7 +27,7 @@ def target_image(size):
 def test_oracle_recovers_the_sphere_colours():
     scene, _, target = target_image(32)
     assert (target[:, :, 0] > 0.6).sum() > 5 and (target[:, :, 2] > 0.6).sum() > 5      # both spheres are visible
-    ref = oracle(examples.inverse_rendering(size=32, rate=0.5))
+    ref = oracle(extra_examples.inverse_rendering(size=32, rate=0.5))
     for tid in ref.params:
         ref.params[tid][...] = 0.5
     first = float(ref.call("loss", {**scene, "target": target})[0])
@@ -43,7 +43,7 @@ def test_gpu_render_matches_the_oracle(gpu_ctx):
     from exprgrad_amd import model as egm
     size = 96
     scene, ref, _ = target_image(size)
-    gpu = egm.compile(*examples.inverse_rendering(size=size, trainable_colors=False), gpu=gpu_ctx)
+    gpu = egm.compile(*extra_examples.inverse_rendering(size=size, trainable_colors=False), gpu=gpu_ctx)
     args = {**scene, "sphere0.color": RED, "sphere1.color": BLUE}
     got, want = gpu.call("render", args), ref.call("render", args)
     assert got.shape == want.shape == (size, size, 3)
@@ -61,7 +61,7 @@ def test_gpu_training_matches_the_oracle(gpu_ctx):
     from parity import Trio
     size = 64
     scene, _, target = target_image(size)
-    t = Trio(gpu_ctx, lambda: examples.inverse_rendering(size=size, rate=0.25))
+    t = Trio(gpu_ctx, lambda: extra_examples.inverse_rendering(size=size, rate=0.25))
     for tid in sorted(t.ref.params):
         t.set_param(tid, np.full(t.ref.params[tid].shape, 0.5, dtype=np.float32))
     args = {**scene, "target": target}

@@ -8,6 +8,9 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# (no device-clock probe under the profiler: a --pmc pass may serialise dispatches across queues, and the probe wave waits for
+#  markers on the main stream; it would only give up after its 8 s guard)
+export EG_BENCH_NO_DEVICE_CLOCK=1
 CMD="python $REPO/bench.py --no-cpu-baseline --no-end-to-end $*"
 # what the byte counts describe: bench.py flags roofline.traffic as stale when the sources differ from these
 (cd $REPO && python -c "import bench; print(bench.source_fingerprint())") > $OUT/source_fingerprint.txt
