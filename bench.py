@@ -937,13 +937,14 @@ def run_fashion_fit(args, env):
             "library_calls_per_batch": len(plan) + 1, "dependent_launch_floor_us": round((len(plan) + 1) * DEPENDENT_LAUNCH_US, 1),
             "algorithmic_mb_per_batch": round(2 * tensor_bytes / 1e6, 2),
             "hbm_floor_us": round(2 * tensor_bytes / (HBM_PEAK_GBS * 1e9) * 1e6, 2),
-            "kernels_per_batch": 16 if batch <= 256 else None,
+            "kernels_per_batch": len(plan) + 1,
+            "sample_group": any("sample-fused" in ln for ln in plan),
             "measured_us_per_dependent_kernel": 4.5,
-            "measured_note": "rocprofv3 --kernel-trace with the graphs left on (profiles/r04_fit_timeline.txt): the 16 kernels of a "
-                             "batch-32 step each end 4.4 - 8.0 us after their predecessor, including those that move a few KB "
-                             "(dispatch, first load from memory, last store and completion are serial), and 8 us pass between two "
-                             "launches of the captured sequence (paid once per 16 batches: eg_model::FitGraph).  The floor above "
-                             "uses the guide's 1.5 us; 16 kernels at what is measured here are 72 us.",
+            "measured_note": "round 5: the forward + backward pass of a step is ONE kernel with one block per sample (DESIGN.md §3 "
+                             "'Round 5', profiles/r05_fit_timeline.txt: copy_segments 4.7 + eg_samples 31 + eg_maps 4.3 us at batch "
+                             "32; the launch chain it replaces, EG_NO_SAMPLE_FUSE=1: 16 kernels of 4.1 - 8.0 us each, 72 us).  A "
+                             "dependent kernel ends >= 4.5 us after its predecessor here whatever it does; the floor above uses the "
+                             "guide's 1.5 us per boundary.",
             "note": "calls = launches of the plan + the segment copy of the batch's rows; some calls are two kernels (a "
                     "k-sliced contraction and its fixed-order sum).  Bytes: every activation / gradient of the network "
                     "written once and read once, float32.  At batch 32 the step is launch-bound, at 4096 "
@@ -953,8 +954,10 @@ def run_fashion_fit(args, env):
                        "peak": out["batch_32"]["bound"]["dependent_launch_floor_us"],
                        "frac": round(out["batch_32"]["bound"]["dependent_launch_floor_us"] / out["batch_32"]["us_per_batch"], 3),
                        "traffic": None,
-                       "note": "floor / achieved: the batch-32 step against its dependent-launch floor (no kernel of it is "
-                               "bandwidth- or matrix-bound: 25 K-element tensors)"}
+                       "note": "floor / achieved: the batch-32 step against its dependent-launch floor.  Since round 5 the step is "
+                               "three launches and its time is the sample kernel's (31 of 38 us), which is bound by LDS "
+                               "instructions (two reads per multiply-add), not by launches: the fraction says how far the step is "
+                               "from a chain of three empty kernels"}
     model.close()
     return out
 

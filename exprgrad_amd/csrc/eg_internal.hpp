@@ -88,6 +88,7 @@ struct eg_buf {
 namespace eg {
 // Ensure ctx->workspace holds at least `bytes`; synchronises the stream if it has to grow.
 int ensure_workspace(eg_ctx* ctx, size_t bytes);
+void* kernel_function(eg_kernel* kernel);  // what a captured kernel node of it carries as `func`
 int ensure_aux(eg_ctx* ctx, size_t bytes);
 // Blocking copies between a host array and device memory, ordered on ctx->stream (host_copy.cpp): large
 // pageable arrays go through pinned staging buffers filled by several threads, the rest is a plain copy.

@@ -22,14 +22,54 @@ long fit_group_size(long batch_size) {
   return batch_size <= 256 ? 16 : 1;   // (measured at batch 32: 4 -> 78.4 us, 8 -> 78.1, 16 -> 76.8, 32 -> 79.0, 64 -> 82.2; every batch by itself 82.1)
 }
 
+// Is the sample group's kernel the only launch of the plan that reads an input tensor?  (Then a batch's rows can be read
+// where they lie.)  Conservative: any launch kind whose operands are not enumerated here counts as a reader.
+bool inputs_read_by_sample_kernel_only(eg_model* m, TargetState& ts, Plan& plan) {
+  if (!plan.sample_group || getenv("EG_FIT_NO_DIRECT")) return false;
+  const Target& t = *ts.target;
+  auto is_input = [&](int tid) { return tid > 0 && m->prog.tensors[tid].kind == TK::Input; };
+  bool sample_reads = false;
+  for (int tid : plan.sample_group->g.ptr_args) sample_reads = sample_reads || is_input(tid);
+  if (!sample_reads) return false;
+  for (const Launch& L : plan.launches) {
+    switch (L.kind) {
+      case StepKind::SampleFused: break;
+      case StepKind::Seed: break;
+      case StepKind::SmallFused:
+        for (int ki : plan.small_groups[L.row_group]->g.kernel_index)
+          for (auto& rd : t.all[ki].reads)
+            if (is_input(rd.tensor)) return false;
+        break;
+      case StepKind::Gemm:
+      case StepKind::Conv:
+      case StepKind::ConvGradImage:
+      case StepKind::ConvGradFilter:
+        if (is_input(L.a_tensor) || is_input(L.b_tensor) || is_input(L.bias_tensor)) return false;
+        break;
+      default: return false;
+    }
+  }
+  return true;
+}
+
 // One graph launch for the batches [b, b + group): the graph holds `group` times (segment copy, launch sequence); its copy
 // nodes are re-pointed at the rows of these batches first.  *done = false: not available here (capture refused, node
 // parameters not updatable) — the caller goes on batch by batch.
+// (Round 5: when the sample group's kernel is the only reader of the inputs, the batches are captured without their copies
+// and the kernel nodes' input arguments are re-pointed instead — FitGraph::direct.)
 template <class RowsOf>
-int launch_group(eg_model* m, TargetState& ts, Plan& plan, long group, long b, RowsOf rows_of, bool* done) {
+int launch_group(eg_model* m, TargetState& ts, Plan& plan, long group, long b, RowsOf rows_of, const std::vector<BoundInput*>& col_inputs,
+                 const std::vector<int>& col_tids, bool* done) {
   *done = false;
   eg_ctx* ctx = m->ctx;
   eg_model::FitGraph& fg = m->fit_graph;
+  const bool want_direct = inputs_read_by_sample_kernel_only(m, ts, plan);
+  // argument index of every column's tensor in the sample kernel: (slab, t<ptr_args>..., GS, EP)
+  std::vector<int> arg_of(col_tids.size(), -1);
+  if (want_direct)
+    for (size_t i = 0; i < col_tids.size(); ++i)
+      for (size_t a = 0; a < plan.sample_group->g.ptr_args.size(); ++a)
+        if (plan.sample_group->g.ptr_args[a] == col_tids[i]) arg_of[i] = 1 + (int)a;
   std::ostringstream k;
   k << capture_key(m, ts) << "|plan" << (const void*)&plan << "|g" << group << "|n" << plan.launches.size();
   const std::string key = k.str();
@@ -55,9 +95,16 @@ int launch_group(eg_model* m, TargetState& ts, Plan& plan, long group, long b, R
     }
     int rc = EG_OK;
     for (long j = 0; j < group && !rc; ++j) {
-      rc = eg::copy_segments(ctx, rows_of(b + j));
+      if (want_direct) {  // the kernels read the batch's rows in place
+        const eg::CopySegments cs = rows_of(b + j);
+        for (size_t i = 0; i < col_inputs.size(); ++i) col_inputs[i]->device = cs.src[i];
+      } else {
+        rc = eg::copy_segments(ctx, rows_of(b + j));
+      }
       if (!rc) rc = run_range_eager(m, ts, plan, 0, (int)plan.launches.size(), true);
     }
+    if (want_direct)
+      for (BoundInput* in : col_inputs) in->device = in->owned;  // (the staging buffers stay what single batches use)
     const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
     if (rc) {
       if (graph) hipGraphDestroy(graph);
@@ -76,17 +123,30 @@ int launch_group(eg_model* m, TargetState& ts, Plan& plan, long group, long b, R
       ok = hipGraphGetNodes(graph, nodes.data(), &count) == hipSuccess;
     }
     std::vector<hipGraphNode_t> copies((size_t)group, nullptr);
+    void* const reader_fn = want_direct ? eg::kernel_function(plan.sample_group->handle) : nullptr;
+    int first_col = -1;
+    for (size_t i = 0; i < arg_of.size() && first_col < 0; ++i)
+      if (arg_of[i] >= 0) first_col = (int)i;
+    if (want_direct && (first_col < 0 || !reader_fn)) ok = false;
     for (size_t i = 0; ok && i < count; ++i) {
       hipGraphNodeType type;
       if (hipGraphNodeGetType(nodes[i], &type) != hipSuccess || type != hipGraphNodeTypeKernel) continue;
       hipKernelNodeParams p = {};
       if (hipGraphKernelNodeGetParams(nodes[i], &p) != hipSuccess) continue;
+      if (want_direct) {  // the sample kernel's node whose first input argument is batch b + j's rows
+        if (p.func != reader_fn || !p.kernelParams || !p.kernelParams[arg_of[(size_t)first_col]]) continue;
+        const float* have = *static_cast<const float* const*>(p.kernelParams[arg_of[(size_t)first_col]]);
+        for (long j = 0; j < group; ++j)
+          if (have == rows_of(b + j).src[first_col]) copies[(size_t)j] = nodes[i];
+        continue;
+      }
       if (p.func != eg::copy_segments_function() || !p.kernelParams || !p.kernelParams[0]) continue;
       const eg::CopySegments* cs = static_cast<const eg::CopySegments*>(p.kernelParams[0]);
       for (long j = 0; j < group; ++j)
         if (cs->src[0] == rows_of(b + j).src[0]) copies[(size_t)j] = nodes[i];
     }
     for (hipGraphNode_t n : copies) ok = ok && n != nullptr;
+    fg.direct = want_direct;
     static const bool debug = getenv("EG_DEBUG_GRAPH") != nullptr;
     if (debug) fprintf(stderr, "[eg] fit group of %ld batches: %zu nodes captured, copy nodes %s\n", group, count, ok ? "found" : "NOT found");
     if (ok) ok = hipGraphInstantiate(&fg.exec, graph, nullptr, nullptr, 0) == hipSuccess;
@@ -114,8 +174,28 @@ int launch_group(eg_model* m, TargetState& ts, Plan& plan, long group, long b, R
       const eg::CopySegments cs = rows_of(b + j);
       hipKernelNodeParams p;
       void* arg[1];
-      if (!eg::copy_segments_node_params(ctx, cs, &p, arg) ||
-          hipGraphExecKernelNodeSetParams(exec, fg.copies[(size_t)j], &p) != hipSuccess) {
+      bool set = false;
+      if (fg.direct) {
+        // the node's own argument list with the input pointers replaced (the other entries keep pointing at what the
+        // capture stored: slab, parameters, arena tensors, scale, epoch)
+        hipKernelNodeParams q = {};
+        const float* rows[8];
+        std::vector<void*> argv;
+        if (hipGraphKernelNodeGetParams(fg.copies[(size_t)j], &q) == hipSuccess && q.kernelParams) {
+          const size_t nargs = plan.sample_group->g.ptr_args.size() + 3;
+          argv.assign(q.kernelParams, q.kernelParams + nargs);
+          for (size_t i = 0; i < arg_of.size() && i < 8; ++i)
+            if (arg_of[i] >= 0) {
+              rows[i] = cs.src[i];
+              argv[(size_t)arg_of[i]] = &rows[i];
+            }
+          q.kernelParams = argv.data();
+          set = hipGraphExecKernelNodeSetParams(exec, fg.copies[(size_t)j], &q) == hipSuccess;
+        }
+      } else {
+        set = eg::copy_segments_node_params(ctx, cs, &p, arg) && hipGraphExecKernelNodeSetParams(exec, fg.copies[(size_t)j], &p) == hipSuccess;
+      }
+      if (!set) {
         if (getenv("EG_DEBUG_GRAPH")) fprintf(stderr, "[eg] fit group: hipGraphExecKernelNodeSetParams refused: %s\n", hipGetErrorString(hipGetLastError()));
         (void)hipGetLastError();
         EG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -250,6 +330,12 @@ int eg_model_fit(eg_model* m, const char* target, int n_inputs, const char* cons
 
   TargetState* ts = nullptr;
   Plan* plan = nullptr;
+  std::vector<BoundInput*> col_inputs;
+  std::vector<int> col_tids;
+  for (int i = 0; i < n_inputs; ++i) {
+    col_inputs.push_back(cols[(size_t)i].in);
+    col_tids.push_back(m->prog.inputs.find(names[i])->second);
+  }
   long group = fit_group_size(batch_size), single_batches = 0;
   for (long seg = 0; seg < batch_count; seg += seg_batches) {
     const long seg_end = std::min(batch_count, seg + seg_batches);
@@ -293,7 +379,7 @@ int eg_model_fit(eg_model* m, const char* target, int n_inputs, const char* cons
         // grown, its own graph captured)
         if (group > 1 && single_batches >= 2 && piece_end - b >= group && plan) {
           bool done = false;
-          rc = launch_group(m, *ts, *plan, group, b, rows_of, &done);
+          rc = launch_group(m, *ts, *plan, group, b, rows_of, col_inputs, col_tids, &done);
           if (rc) return rc;
           if (done) {
             b += group;

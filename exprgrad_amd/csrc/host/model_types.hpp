@@ -292,6 +292,11 @@ struct eg_model {
     int turn = 0;
     hipGraph_t graph = nullptr;          // kept: the copy nodes are addressed through it
     std::vector<hipGraphNode_t> copies;  // the group's segment-copy nodes, in batch order
+    // Inputs read in place (round 5): when the step's only reader of the inputs is a sample group's kernel, a group's
+    // batches are captured WITHOUT their segment copies — the kernel nodes read the batch's rows where they lie, and a
+    // launch re-points those nodes' input arguments instead of the copy nodes (one launch less per batch).
+    bool direct = false;
+    std::vector<hipGraphNode_t> readers;  // direct: the group's sample-kernel nodes, in batch order
     std::string key;                     // everything baked into the captured kernel arguments
   } fit_graph;
 };

@@ -109,6 +109,8 @@ struct eg_kernel {
 };
 
 namespace eg {
+void* kernel_function(eg_kernel* kernel) { return kernel ? reinterpret_cast<void*>(kernel->fn) : nullptr; }
+
 int kernel_launch_raw(eg_kernel* kernel, unsigned gx, unsigned gy, unsigned gz, unsigned block, void** args) {
   EG_REQUIRE(kernel, EG_ERR_INVALID, "kernel_launch_raw: kernel is NULL");
   if (gx == 0 || gy == 0 || gz == 0) return EG_OK;

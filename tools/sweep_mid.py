@@ -29,8 +29,8 @@ def timed(M, N, K, A, B, C):
     return best
 
 configs = [("auto", {})]
-for t in ("64,64", "128,128", "256,256"):
-    for sp in (1, 2, 4, 8, 16):
+for t in ("64,64", "128,64", "128,128", "256,64", "256,256"):
+    for sp in (1, 2, 3, 4, 6, 8, 16):
         configs.append((f"{t}/s{sp}", {"EG_GEMM_FORCE_TILE": t, "EG_GEMM_FORCE_SPLITS": str(sp)}))
         if t == "64,64":
             configs.append((f"{t}/s{sp}/k32", {"EG_GEMM_FORCE_TILE": t, "EG_GEMM_FORCE_SPLITS": str(sp), "EG_GEMM_SMALL_BK32": "1"}))
