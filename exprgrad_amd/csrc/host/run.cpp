@@ -125,7 +125,9 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       long FOLD = 0;
       if (!sg.g.fold_offset.empty()) {  // the group can add up a sample group's slab rows itself (fuse_slab_fold)
         slab = plan.sample_group ? plan.sample_group->slab : nullptr;
-        FOLD = (L.fold_of >= 0 && slab && slab_fold_active(plan, plan.launches[L.fold_of])) ? 1 : 0;
+        // only when the sample kernel ran in THIS range: behind a backward | exchange | update split the bucket holds the
+        // all-reduced totals and the slab only this rank's rows
+        FOLD = (L.fold_of >= plan.active_begin && L.fold_of < plan.active_end && slab && slab_fold_active(plan, plan.launches[L.fold_of])) ? 1 : 0;
         args.push_back(&slab);
         args.push_back(&FOLD);
       }

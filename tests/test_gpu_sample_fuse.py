@@ -98,3 +98,35 @@ def test_dense_net_small_batch(gpu_ctx, monkeypatch):
     for _ in range(3):
         t.step("train", args, n=16)
     t.close()
+
+
+def test_backward_update_split_takes_the_slab_pass(gpu_ctx, monkeypatch):
+    """What the data-parallel step does: the backward range alone (the exchange needs the batch totals in the gradient
+    bucket, so the sample kernel is followed by its slab_sum launch), then the update range — against Model.apply, where
+    the optimizer's map group adds the slab rows up itself.  Two orders of the same 8 terms per element: 1e-6 of the
+    gradient; and the bucket must hold the totals after the backward range."""
+    from oracle import kd
+    monkeypatch.delenv("EG_NO_SAMPLE_FUSE", raising=False)
+    args = data(8, 21)
+    whole = build(gpu_ctx, examples.fashion_mnist_net, monkeypatch, True)
+    split = build(gpu_ctx, examples.fashion_mnist_net, monkeypatch, True)
+    pairs = kd.Model(refcases.program_text(examples.fashion_mnist_net())).param_grads("fit")
+    for step in range(1, 5):
+        whole.epoch = split.epoch = step
+        whole.apply("fit", args)
+        split.run_backward("fit", args)
+        grads = {gt: split.read_tensor("fit", gt) for _, gt in pairs}          # complete BEFORE the update range runs
+        split.run_update("fit")
+        for _, gt in pairs:
+            gw = whole.read_tensor("fit", gt)
+            assert np.all(np.isfinite(gw))
+            assert np.max(np.abs(gw - grads[gt])) <= 1e-6 * max(np.max(np.abs(gw)), 1e-30), (step, gt)
+            assert np.array_equal(split.read_tensor("fit", gt), grads[gt])       # the update range leaves them alone
+        for tid in whole.params.ids():
+            split.params[tid] = whole.params[tid]
+        for cid in whole.caches.ids():
+            split.caches[cid] = whole.caches[cid]
+    if not debug_toggles_active():
+        assert "folded by launch" in whole.launch_plan("fit")
+    whole.close()
+    split.close()
