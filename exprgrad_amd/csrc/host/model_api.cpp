@@ -502,6 +502,9 @@ static int read_tensor(eg_model* m, TargetState& ts, int tid, float* host, int64
   if (n == 0) return EG_OK;
   EG_REQUIRE(!ts.last->predicated.count(tid), EG_ERR_INVALID,
              "tensor %d exists only as predicate bits in the last run's plan (eg_model_keep_values(model, 1) makes the plans keep values)", tid);
+  EG_REQUIRE(!(ts.last->sample_group && ts.last->sample_group->g.lds.count(tid)), EG_ERR_INVALID,
+             "tensor %d lived in the LDS of a sample group's blocks in the last run's plan: its values were never stored "
+             "(eg_model_keep_values(model, 1) makes the plans keep values)", tid);
   float* p = tensor_ptr(m, ts, *ts.last, tid);
   EG_REQUIRE(p, EG_ERR_INVALID, "tensor %d was not materialised by the last run", tid);
   return eg::copy_d2h(m->ctx, host, p, (size_t)n * sizeof(float));

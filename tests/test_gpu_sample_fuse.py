@@ -130,3 +130,38 @@ def test_backward_update_split_takes_the_slab_pass(gpu_ctx, monkeypatch):
         assert "folded by launch" in whole.launch_plan("fit")
     whole.close()
     split.close()
+
+
+def test_intermediates_of_a_sample_group_are_refused_unless_values_are_kept(gpu_ctx, monkeypatch):
+    """A tensor that lives in the blocks' LDS was never stored: read_tensor says so instead of returning stale arena
+    memory; eg_model_keep_values(model, 1) re-plans with every value in memory, and the two plans agree on it."""
+    from exprgrad_amd._lib import GpuError
+    from oracle import kd
+    monkeypatch.delenv("EG_NO_SAMPLE_FUSE", raising=False)
+    args = data(8, 2)
+    m = build(gpu_ctx, examples.fashion_mnist_net, monkeypatch, True)
+    ref = kd.Model(refcases.program_text(examples.fashion_mnist_net()))
+    for tid in m.params.ids():
+        ref.params[tid][...] = m.params[tid]
+    m.epoch = ref.epoch = 1
+    m.apply("fit", args)
+    if debug_toggles_active():
+        m.close()
+        return
+    conv1_out = 14                      # t14 = conv2(reshape(x), filters) of the first layer (the program text numbers it)
+    with pytest.raises(GpuError, match="eg_model_keep_values"):
+        m.read_tensor("fit", conv1_out)
+    m.keep_values(True)
+    for tid in m.params.ids():
+        m.params[tid] = ref.params[tid]          # the same step again, from the same state
+    for cid in m.caches.ids():
+        m.caches[cid] = np.zeros_like(m.caches[cid])
+    m.apply("fit", args)
+    got = m.read_tensor("fit", conv1_out)
+    x = args["x"].reshape(8, 28, 28, 1)
+    flt = ref.params[1]
+    from parity import exact_conv2
+    want = exact_conv2(x, flt)
+    assert got.shape == want.shape or got.size == want.size
+    assert np.max(np.abs(got.reshape(want.shape) - want)) <= 1e-5 * np.max(np.abs(want))
+    m.close()
