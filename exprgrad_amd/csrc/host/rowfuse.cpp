@@ -890,20 +890,37 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
       // NOT the fastest iterator: consecutive lanes walk that one, so that a wave's LDS reads fall into consecutive banks
       // (blocking it measured 47 us against 32 for the whole kernel: eight-way bank conflicts); the next one up —
       // `x` of out[n, y, x, f], `dx` of gflt[f, dy, dx, c] — is where the window operand and the other operand repeat.
-      bool lane_seen = false;
+      // EG_SAMPLE_BLOCK_POS (tuning aid): which iterator, counted from the fastest one that has an extent (0), is blocked
+      static const long block_pos = getenv("EG_SAMPLE_BLOCK_POS") ? atol(getenv("EG_SAMPLE_BLOCK_POS")) : 1;
+      long seen = 0;
       for (size_t i = indep.size(); i-- > 0 && blk < 0;) {
         const long ext = info.bounds[indep[i]].second - info.bounds[indep[i]].first;
         if (ext < 2) continue;
-        if (!lane_seen) {
-          lane_seen = true;
-          continue;
-        }
-        for (long r = std::min<long>(ext, 8); r >= 2; --r)
-          if (ext % r == 0) {
-            blk = (int)i;
-            R = r;
-            break;
+        if (seen++ < block_pos) continue;
+        // R by what a thread ends up doing, not "as large as divides": the threads run ceil(items / threads) rounds of R
+        // multiply-adds with R loads of every read that moves with the iterator and one of every read that does not
+        // (4 608 outputs on 512 threads: R = 8 is 2 rounds of 17 with 7 of 8 waves idle in the second, R = 3 is 3 of 7);
+        // with few items the outermost reduction iterator is split over T threads instead (below).
+        const int breg_c = k.loops[indep[i]].reg;
+        long nd = 0, ns = 0;
+        for (auto& rd : k.reads) (op_has(rd, breg_c) ? nd : ns) += 1;
+        const long outer = red.empty() ? 1 : std::max(1L, info.bounds[red[0]].second - info.bounds[red[0]].first);
+        double best_cost = 1e30;
+        for (long r = 1; r <= std::min<long>(ext, 8); ++r) {
+          if (ext % r != 0) continue;
+          const long it = total / r;
+          double rounds = (double)((it + g.threads - 1) / g.threads);
+          if (it * 2 <= g.threads && rtotal >= 16 && outer >= 2) {  // the split-reduction path
+            const long t = std::max(1L, std::min<long>(g.threads / it, std::min<long>(outer, 64)));
+            rounds = (double)((outer + t - 1) / t) / (double)outer;
           }
+          const double cost = rounds * (double)(r * (1 + nd) + ns);
+          if (cost < best_cost - 1e-9) {
+            best_cost = cost;
+            R = r;
+          }
+        }
+        if (R > 1) blk = (int)i;
         break;
       }
     }
@@ -982,7 +999,13 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
         const int l = red[i];
         const long ext = info.bounds[l].second - info.bounds[l].first;
         const std::string r = "r" + std::to_string(k.loops[l].reg);
-        if (i + 1 == red.size()) d += ind + (ext * R <= 64 ? "_Pragma(\"unroll\")\n" : "_Pragma(\"unroll 4\")\n");  // loads of several iterations in flight
+        // loads of several iterations in flight; EG_SAMPLE_UNROLL_MACS (tuning aid): outer reduction loops are unrolled too
+        // while the unrolled body stays below that many multiply-adds (copies that read the same element merge)
+        static const long unroll_macs = getenv("EG_SAMPLE_UNROLL_MACS") ? atol(getenv("EG_SAMPLE_UNROLL_MACS")) : 0;
+        long inner = R;
+        for (size_t j = i; j < red.size(); ++j) inner *= std::max(1L, info.bounds[red[j]].second - info.bounds[red[j]].first);
+        if (i + 1 == red.size()) d += ind + (ext * R <= 64 ? "_Pragma(\"unroll\")\n" : "_Pragma(\"unroll 4\")\n");
+        else if (unroll_macs > 0 && inner <= unroll_macs) d += ind + "_Pragma(\"unroll\")\n";
         d += ind + "for (long " + r + " = " + std::to_string(info.bounds[l].first) + "L; " + r + " < " + std::to_string(info.bounds[l].second) +
              "L; ++" + r + ") {\n";
       }
