@@ -128,10 +128,24 @@ _SIGS = {
     "eg_model_save": (c_int, [c_void_p, c_char_p]),
     "eg_model_load": (c_int, [c_void_p, c_char_p, P(c_void_p)]),
     "eg_model_source_text": (c_char_p, [c_void_p]),
+    "eg_dgemm": (c_int, [c_void_p, c_int, c_int, c_i64, c_i64, c_i64, c_void_p, c_i64, c_void_p, c_i64,
+                         c_void_p, c_i64, c_int, c_void_p]),
+    "eg_colsum_f64": (c_int, [c_void_p, c_i64, c_i64, c_void_p, c_void_p, c_int]),
+    "eg_fill_f64": (c_int, [c_void_p, c_i64, c_f64, c_void_p]),
+    "eg_fill_uniform_f64": (c_int, [c_void_p, c_i64, c_f64, c_f64, c_void_p, ctypes.c_uint64, c_void_p]),
+    "eg_model_scalar_bytes": (c_int, [c_void_p]),
+    "eg_model_param_write_f64": (c_int, [c_void_p, c_int, c_void_p, c_i64]),
+    "eg_model_param_read_f64": (c_int, [c_void_p, c_int, c_void_p, c_i64]),
+    "eg_model_set_input_host_f64": (c_int, [c_void_p, c_char_p, c_void_p, c_int, P(c_i64)]),
+    "eg_model_set_input_device_f64": (c_int, [c_void_p, c_char_p, c_void_p, c_int, P(c_i64)]),
+    "eg_model_read_output_f64": (c_int, [c_void_p, c_char_p, c_void_p, c_i64]),
+    "eg_model_read_tensor_f64": (c_int, [c_void_p, c_char_p, c_int, c_void_p, c_i64]),
+    "eg_model_fit_f64": (c_int, [c_void_p, c_char_p, c_int, P(c_char_p), P(c_void_p), P(c_int), P(c_int), P(c_i64), c_i64]),
+    "eg_dp_allreduce_sum_f64": (c_int, [c_void_p, c_void_p, c_i64]),
 }
 
 # functions whose int return value is not a status code
-_NOT_STATUS = {"eg_version", "eg_ctx_device", "eg_model_kernel_count", "eg_model_tensor_count", "eg_dp_rank",
+_NOT_STATUS = {"eg_version", "eg_model_scalar_bytes", "eg_ctx_device", "eg_model_kernel_count", "eg_model_tensor_count", "eg_dp_rank",
                "eg_dp_world", "eg_dp_last_pieces", "eg_dp_rccl_count", "eg_dp_rccl_rank"}
 
 

@@ -212,6 +212,18 @@ int eg_dp_allreduce_sum_f32(eg_dp* dp, float* device_buf, int64_t count) {
   return EG_OK;
 }
 
+int eg_dp_allreduce_sum_f64(eg_dp* dp, double* device_buf, int64_t count) {
+  EG_REQUIRE(dp && dp->comm, EG_ERR_INVALID, "eg_dp_allreduce_sum_f64: NULL communicator");
+  EG_REQUIRE(count >= 0, EG_ERR_INVALID, "eg_dp_allreduce_sum_f64: negative count");
+  if (count == 0) return EG_OK;
+  EG_REQUIRE(device_buf, EG_ERR_INVALID, "eg_dp_allreduce_sum_f64: NULL buffer");
+  int rc = eg::set_device(dp->ctx);
+  if (rc) return rc;
+  EG_RCCL_CHECK(rccl().AllReduce(device_buf, device_buf, (size_t)count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, dp->comm,
+                                 dp->ctx->stream));
+  return EG_OK;
+}
+
 // One data-parallel training step on this rank's shard (the inputs are bound already):
 //   [forward + backward kernels] | all-reduce of the gradient bucket | [optimizer kernels]
 // with the bucket split where the plan allows it: the gradients that are complete before the last
@@ -236,6 +248,10 @@ int eg_model_step_dp(eg_model* model, const char* target, eg_dp* dp, int mean) {
   gx.allreduce = [](void* user, float* buf, long count) {
     return eg_dp_allreduce_sum_f32(static_cast<eg_dp*>(user), buf, (int64_t)count);
   };
+  if (eg_model_scalar_bytes(model) == 8)  // a float64 model's bucket: the segments are counted in 4-byte units (host/model_types.hpp)
+    gx.allreduce = [](void* user, float* buf, long count) {
+      return eg_dp_allreduce_sum_f64(static_cast<eg_dp*>(user), reinterpret_cast<double*>(buf), (int64_t)(count / 2));
+    };
   if (multi)
     gx.agree = [](void* user, const int64_t* values, int n, int* same) {
       // MAX over the ranks of [v, -v]: all ranks hold the same v  <=>  max(v) == -max(-v) element by element

@@ -123,6 +123,8 @@ bool slab_sum_supported(long total, const float* slab, const float* out);
 int slab_sum(eg_ctx* ctx, long slabs, long total, const float* slab, float* out, int accumulate);
 int colsum_with_scratch(eg_ctx* ctx, long rows, long cols, const float* in, float* out, int accumulate,
                         float* scratch);
+// float64 twin (kernels/gemm_f64_mfma.hip): same geometry, scratch of colsum_scratch_floats(...) DOUBLES
+int colsum_f64_with_scratch(eg_ctx* ctx, long rows, long cols, const double* in, double* out, int accumulate, double* scratch);
 // Second stage of a row-fused kernel's batch reductions (host/rowfuse.hpp): partial is
 // [nblocks][E]; column e belongs to segment s with offset[s] <= e < offset[s+1] and is summed over
 // the blocks (fixed tree order) into dst[s][e - offset[s]].

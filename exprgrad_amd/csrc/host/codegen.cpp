@@ -31,6 +31,7 @@ struct Emitter {
     slots.push_back(s);
     return (int)slots.size() - 1;
   }
+  const char* S() const { return k.f64 ? "double" : "float"; }  // the program's scalar type (model.nim:253-260)
   std::string p(int i) const { return "p" + std::to_string(i); }
   std::string reg(int r) const { return "r" + std::to_string(r); }
 
@@ -63,11 +64,11 @@ struct Emitter {
 
   int emit_instr(const Instr& ins, int index, std::string& out) {
     const Ty t = ty[ins.res];
-    const char* ctype = t == Ty::Scalar ? "float" : (t == Ty::Index ? "long" : "bool");
+    const char* ctype = t == Ty::Scalar ? S() : (t == Ty::Index ? "long" : "bool");
     std::string special;
     if (ins.kind == IK::Shape || ins.kind == IK::Len || ins.kind == IK::ShapeLen || ins.kind == IK::Epoch)
       special = p(slot(Slot::InstrVal, index));
-    out += std::string("      const ") + ctype + " " + reg(ins.res) + " = " + instr_expression(ins, special, "r") + ";\n";
+    out += std::string("      const ") + ctype + " " + reg(ins.res) + " = " + instr_expression(ins, special, "r", k.f64) + ";\n";
     return EG_OK;
   }
 
@@ -75,7 +76,7 @@ struct Emitter {
   void emit_body(std::string& out) {
     emit_indices(out);
     for (size_t i = 0; i < k.reads.size(); ++i)
-      out += "      const float " + reg(k.reads[i].reg) + " = t" + std::to_string(k.reads[i].tensor) + "[x" + std::to_string(i) + "];\n";
+      out += std::string("      const ") + S() + " " + reg(k.reads[i].reg) + " = t" + std::to_string(k.reads[i].tensor) + "[x" + std::to_string(i) + "];\n";
     for (size_t i = 0; i < k.instrs.size(); ++i) emit_instr(k.instrs[i], (int)i, out);
   }
 
@@ -154,10 +155,38 @@ std::string f32_literal(double v) {
   return s;
 }
 
+// const_real(double type, v) (llvmgen.nim:215-216 with Scalar64): the literal itself, 17 significant digits.
+std::string f64_literal(double v) {
+  if (std::isinf(v)) return v > 0 ? "__builtin_inf()" : "(-__builtin_inf())";
+  if (std::isnan(v)) return "__builtin_nan(\"\")";
+  char buf[64];
+  snprintf(buf, sizeof(buf), "%.17g", v);
+  std::string s = buf;
+  if (s.find('.') == std::string::npos && s.find('e') == std::string::npos) s += ".0";
+  return s;
+}
+
 // One scalar instruction as a C expression over variables `<prefix><register>`; llvmgen.nim:212-276.
-std::string instr_expression(const Instr& ins, const std::string& special, const std::string& prefix) {
+// f64: the program's scalar type is float64 — literals keep their double value, the math functions are the double ones.
+std::string instr_expression(const Instr& ins, const std::string& special, const std::string& prefix, bool f64) {
   auto a = [&](int i) { return prefix + std::to_string(ins.args[i]); };
   std::string e;
+  if (f64) {
+    switch (ins.kind) {
+      case IK::Scalar: return f64_literal(ins.lit);
+      case IK::Sin: return "sin(" + a(0) + ")";
+      case IK::Cos: return "cos(" + a(0) + ")";
+      case IK::Exp: return "exp(" + a(0) + ")";
+      case IK::Pow: return "pow(" + a(0) + ", " + a(1) + ")";
+      case IK::Sqrt: return "sqrt(" + a(0) + ")";
+      case IK::Log: return "log(" + a(0) + ") / log(" + a(1) + ")";
+      case IK::Log10: return "log10(" + a(0) + ")";
+      case IK::Log2: return "log2(" + a(0) + ")";
+      case IK::Ln: return "log(" + a(0) + ")";
+      case IK::ToScalar: return "(double)" + a(0);
+      default: break;
+    }
+  }
   switch (ins.kind) {
       case IK::Scalar: e = f32_literal(ins.lit); break;
       case IK::Index: e = std::to_string((long)ins.lit) + "L"; break;
@@ -209,18 +238,18 @@ std::vector<int> distinct_tensors(const Kernel& k, bool include_write) {
 }
 
 std::string signature(const std::string& name, const std::vector<int>& tensors, int write_tensor, bool partial_first,
-                      size_t nslots) {
+                      size_t nslots, const std::string& S) {
   std::string s = "extern \"C\" __global__ void __launch_bounds__(256) " + name + "(";
   bool first = true;
   if (partial_first) {
-    s += "float* __restrict__ partial";
+    s += S + "* __restrict__ partial";
     first = false;
   }
   for (int t : tensors) {
     s += first ? "" : ", ";
     first = false;
     // the written tensor may also be read (optimizer kernels read their own parameter): no restrict
-    s += (t == write_tensor && !partial_first ? "float* t" : "const float* t") + std::to_string(t);
+    s += (t == write_tensor && !partial_first ? S + "* t" : "const " + S + "* t") + std::to_string(t);
   }
   for (size_t i = 0; i < nslots; ++i) {
     s += first ? "" : ", ";
@@ -302,7 +331,8 @@ int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out
   // Four elements per thread (Slot::Vec4, decided per launch): possible when every operand ends in
   // the bare fastest iterator and nothing else depends on it — then the four elements are adjacent
   // in every operand, the index arithmetic is shared and loads / stores are 16 bytes wide.
-  bool vec = out.red.empty() && !out.scatter && !out.indep.empty() && k.reads.size() <= 12;
+  // (float32 only: a float64 kernel moves 8 bytes per element and lane already)
+  bool vec = !k.f64 && out.red.empty() && !out.scatter && !out.indep.empty() && k.reads.size() <= 12;
   int rc = 0;
   if (vec) {
     const Loop& fast = k.loops[out.indep.back()];
@@ -380,7 +410,7 @@ int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out
     std::string idx, loads, instrs;
     em.emit_indices(idx);
     for (size_t i = 0; i < k.reads.size(); ++i)
-      loads += "      const float " + em.reg(k.reads[i].reg) + " = t" + std::to_string(k.reads[i].tensor) + "[x" + std::to_string(i) + "];\n";
+      loads += std::string("      const ") + em.S() + " " + em.reg(k.reads[i].reg) + " = t" + std::to_string(k.reads[i].tensor) + "[x" + std::to_string(i) + "];\n";
     for (size_t i = 0; i < k.instrs.size(); ++i) em.emit_instr(k.instrs[i], (int)i, instrs);
     code += "    {\n" + idx + em.index_decl("w", k.write, write_index, (int)k.reads.size());
     if (vec) {
@@ -401,7 +431,7 @@ int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out
     if (vec) code += "      }\n";
     code += "    }\n";
   } else {
-    code += "  float acc = 0.0f;\n";
+    code += std::string("  ") + em.S() + (k.f64 ? " acc = 0.0;\n" : " acc = 0.0f;\n");
     for (int l : out.red) {
       const std::string r = em.reg(k.loops[l].reg);
       code += "  for (long " + r + " = " + em.p(em.slot(Slot::LoopStart, l)) + "; " + r + " < " +
@@ -431,7 +461,7 @@ int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out
     qdecl += "    const int q" + std::to_string(i) + " = (int)p" + std::to_string(i) + ";\n";
   out.slots = em.slots;
   out.source = std::string("typedef float eg_f4 __attribute__((ext_vector_type(4)));\n") +
-               signature(name, out.tensor_args, k.write.tensor, false, out.slots.size()) + " {\n" + head + "  if (" +
+               signature(name, out.tensor_args, k.write.tensor, false, out.slots.size(), em.S()) + " {\n" + head + "  if (" +
                em.p(s_narrow) + ") {\n" + qdecl + narrow + "  } else {\n" + wide + "  }\n}\n";
   return EG_OK;
 }
@@ -451,13 +481,14 @@ int generate_mode_b(const Kernel& k, const std::string& name, int tx, GenericSou
   const int s_rtotal = em.slot(Slot::RTotal);
   const int s_chunk = em.slot(Slot::Chunk);
   std::string code;
-  code += "  __shared__ float red[256];\n";
+  const std::string S = em.S(), Z = k.f64 ? "0.0" : "0.0f";
+  code += "  __shared__ " + S + " red[256];\n";
   code += "  const int tx = threadIdx.x % " + std::to_string(tx) + ", ty = threadIdx.x / " + std::to_string(tx) + ";\n";
   code += "  long ii = (long)blockIdx.y * " + std::to_string(tx) + " + tx;\n";
   code += "  const bool active = ii < " + em.p(s_total) + ";\n";
   code += "  const long flat_out = ii;\n";
   code += em.setup_decls();
-  code += "  float acc = 0.0f;\n";
+  code += "  " + S + " acc = " + Z + ";\n";
   code += "  if (active) {\n";
   for (size_t i = out.indep.size(); i-- > 0;) {
     const int l = out.indep[i];
@@ -472,7 +503,7 @@ int generate_mode_b(const Kernel& k, const std::string& name, int tx, GenericSou
   // the element evaluation as a lambda so the loop can be unrolled 4x with independent partial
   // sums: four loads in flight per lane instead of one (bias-gradient sums are HBM bound)
   const std::string TY = std::to_string(out.ty);
-  code += "  auto term = [&](long rr) -> float {\n";
+  code += "  auto term = [&](long rr) -> " + S + " {\n";
   code += "    long rem = rr;\n";
   for (size_t i = out.red.size(); i-- > 0;) {  // innermost reduction loop varies fastest
     const int l = out.red[i];
@@ -485,21 +516,21 @@ int generate_mode_b(const Kernel& k, const std::string& name, int tx, GenericSou
   std::string inner;
   em.emit_body(inner);
   code += inner + "    return " + em.reg(k.result) + ";\n  };\n";
-  code += "  float acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;\n";
+  code += "  " + S + " acc1 = " + Z + ", acc2 = " + Z + ", acc3 = " + Z + ";\n";
   code += "  long rr = r_begin + ty;\n";
   code += "  for (; rr + 3 * " + TY + " < r_end; rr += 4 * " + TY + ") {\n";
-  code += "    const float v0 = term(rr), v1 = term(rr + " + TY + "), v2 = term(rr + 2 * " + TY + "), v3 = term(rr + 3 * " + TY + ");\n";
+  code += "    const " + S + " v0 = term(rr), v1 = term(rr + " + TY + "), v2 = term(rr + 2 * " + TY + "), v3 = term(rr + 3 * " + TY + ");\n";
   code += "    acc = acc + v0; acc1 = acc1 + v1; acc2 = acc2 + v2; acc3 = acc3 + v3;\n  }\n";
   code += "  for (; rr < r_end; rr += " + TY + ") acc = acc + term(rr);\n";
   code += "  acc = (acc + acc1) + (acc2 + acc3);\n";
   code += "  }\n";
   code += "  red[threadIdx.x] = acc;\n  __syncthreads();\n";
-  code += "  if (ty == 0 && active) {\n    float s = 0.0f;\n";
+  code += "  if (ty == 0 && active) {\n    " + S + " s = " + Z + ";\n";
   code += "    for (int t = 0; t < " + std::to_string(out.ty) + "; ++t) s = s + red[t * " + std::to_string(tx) + " + tx];\n";
   code += "    partial[(long)blockIdx.x * " + em.p(s_total) + " + flat_out] = s;\n  }\n";
   out.tensor_args = distinct_tensors(k, false);
   out.slots = em.slots;
-  out.source = signature(name, out.tensor_args, k.write.tensor, true, out.slots.size()) + " {\n" + code + "}\n";
+  out.source = signature(name, out.tensor_args, k.write.tensor, true, out.slots.size(), S) + " {\n" + code + "}\n";
   return EG_OK;
 }
 

@@ -53,7 +53,7 @@ bool split_reduction_capable(const Kernel& k);
 std::string f32_literal(double v);
 // One scalar instruction as a C expression over variables `<prefix><register id>`; `special`
 // is the text used for the host-evaluated builtins (shape / len / shapelen / epoch).
-std::string instr_expression(const Instr& ins, const std::string& special, const std::string& prefix);
+std::string instr_expression(const Instr& ins, const std::string& special, const std::string& prefix, bool f64 = false);
 
 int generate_mode_a(const Kernel& k, const std::string& name, GenericSource& out);
 int generate_mode_b(const Kernel& k, const std::string& name, int tx, GenericSource& out);

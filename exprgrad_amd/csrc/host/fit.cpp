@@ -225,9 +225,11 @@ extern "C" {
 // while the batches of piece k run, and every batch is one segment-copy launch (the batch's rows
 // of every input -> that input's fixed staging buffer, so the captured launch sequence replays
 // unchanged) plus one graph launch.  Nothing in the loop waits for the device.
-int eg_model_fit(eg_model* m, const char* target, int n_inputs, const char* const* names, const float* const* data,
-                 const int* on_device, const int* ranks, const int64_t* shapes8, int64_t batch_size) try {
+static int model_fit(eg_model* m, const char* target, int n_inputs, const char* const* names, const float* const* data,
+                     const int* on_device, const int* ranks, const int64_t* shapes8, int64_t batch_size, bool f64) {
   EG_REQUIRE(m && target, EG_ERR_INVALID, "NULL model or target");
+  EG_REQUIRE(m->f64 == f64, EG_ERR_INVALID, "eg_model_fit%s: the model computes in %s (the T of compile[T])", f64 ? "_f64" : "",
+             m->f64 ? "float64" : "float32");
   // model.nim:417-421
   EG_REQUIRE(n_inputs > 0, EG_ERR_RUNTIME,
              "Model.fit requires at least one input tensor. Use Model.apply instead if the target has zero inputs.");
@@ -261,6 +263,7 @@ int eg_model_fit(eg_model* m, const char* target, int n_inputs, const char* cons
       c.row_floats *= shapes8[i * 8 + d];
       c.batch_shape.push_back(shapes8[i * 8 + d]);
     }
+    c.row_floats *= m->esz;  // 4-byte units per row: a float64 model's rows are twice as long (host/model_types.hpp)
     EG_REQUIRE(c.data || c.rows * c.row_floats == 0, EG_ERR_INVALID, "NULL data for input %s", names[i]);
   }
   const long batch_count = cols[0].rows / batch_size;  // model.nim:434: the ragged tail is dropped
@@ -278,13 +281,14 @@ int eg_model_fit(eg_model* m, const char* target, int n_inputs, const char* cons
   for (auto& c : cols) {
     BoundInput& b = *c.in;
     const long count = batch_size * c.row_floats;
-    if (b.owned_count < count || !b.owned) {
+    const long elems = count / m->esz;  // (owned_count is in elements, as bind_input keeps it)
+    if (b.owned_count < elems || !b.owned) {
       EG_HIP_CHECK(hipStreamSynchronize(stream));
       if (b.owned) EG_HIP_CHECK(hipFree(b.owned));
       b.owned = nullptr;
       b.owned_count = 0;
       EG_HIP_CHECK(hipMalloc((void**)&b.owned, (size_t)(count > 0 ? count : 1) * sizeof(float)));
-      b.owned_count = count;
+      b.owned_count = elems;
     }
     b.device = b.owned;
     b.shape = c.batch_shape;
@@ -404,6 +408,18 @@ int eg_model_fit(eg_model* m, const char* target, int n_inputs, const char* cons
   if (host_row_bytes > 0) EG_HIP_CHECK(hipStreamSynchronize(m->copy_stream));
   return EG_OK;
 }
+
+int eg_model_fit(eg_model* m, const char* target, int n_inputs, const char* const* names, const float* const* data,
+                 const int* on_device, const int* ranks, const int64_t* shapes8, int64_t batch_size) try {
+  return model_fit(m, target, n_inputs, names, data, on_device, ranks, shapes8, batch_size, false);
+}
 EG_CATCH_ALL
+
+int eg_model_fit_f64(eg_model* m, const char* target, int n_inputs, const char* const* names, const double* const* data,
+                     const int* on_device, const int* ranks, const int64_t* shapes8, int64_t batch_size) try {
+  return model_fit(m, target, n_inputs, names, reinterpret_cast<const float* const*>(data), on_device, ranks, shapes8, batch_size, true);
+}
+EG_CATCH_ALL
+
 
 }  // extern "C"

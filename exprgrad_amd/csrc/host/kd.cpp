@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <set>
 #include <sstream>
 
@@ -189,7 +190,10 @@ int parse(const char* text, Program& prog) {
     if (tk.t.empty() || tk.t[0][0] == '#') continue;
     const std::string kw = tk.next();
     if (kw == "kd") {
-      if (tk.next() != "1" || tk.next() != "f32") P_FAIL("kd line %d: unsupported version/scalar type", lineno);
+      if (tk.next() != "1") P_FAIL("kd line %d: unsupported version/scalar type", lineno);
+      const std::string scalar = tk.next();
+      if (scalar != "f32" && scalar != "f64") P_FAIL("kd line %d: unsupported version/scalar type", lineno);
+      prog.f64 = scalar == "f64";
       header = true;
     } else if (kw == "tensor") {
       long id, rank;
@@ -759,6 +763,16 @@ int compile_program(Program& prog) {
   }
   // grad tensors allocated by one target enlarge prog.tensors: eliminate after all are generated
   for (auto& t : prog.targets) dead_kernel_elim(prog, t);
+  if (prog.f64) {
+    std::function<void(Kernel&)> mark = [&](Kernel& k) {
+      k.f64 = true;
+      for (auto& c : k.custom_grad) mark(c);
+    };
+    for (auto& t : prog.targets) {
+      for (auto& k : t.source) mark(k);
+      for (auto& k : t.all) mark(k);
+    }
+  }
   return EG_OK;
 }
 

@@ -79,6 +79,7 @@ struct Kernel {
   int gen_tensor = 0;  // Backwards: the loss; Gradient: differentiate with respect to this tensor
   int gen_dest = 0;    // Gradient: tensor that receives the gradient
   bool is_seed = false;  // the gradLoss{i} = 1 kernel (passes.nim:575-606)
+  bool f64 = false;      // the program computes in float64 (compile[float64], model.nim:253-260): set on every kernel by compile_program
   int alloc() { return ++nregs; }
 };
 
@@ -112,6 +113,9 @@ struct Program {
   // fixed when a plan is made (loop bounds, kernel arguments, literals of generated code), so plans are keyed by the
   // epoch as well as by the input shapes (plan.cpp shape_key) — `x[epoch() mod n]` reads another row every epoch.
   bool epoch_in_setup = false;
+  // Scalar type of the program, from the header line (`kd 1 f32` / `kd 1 f64`): the T of compile[T] (model.nim:253-260,
+  // toScalarType -> Scalar32 / Scalar64).  Every tensor of a program has it.
+  bool f64 = false;
   Target* find_target(const std::string& name);
   int alloc_tensor(TK kind, const std::string& name);
 };

@@ -35,7 +35,7 @@ void inline_producers(eg_model* m, TargetState& ts) {
   auto is_library = [&](const Kernel& k) {
     GemmMatch g;
     ConvMatch c;
-    return k.is_seed || match_gemm(k, g) || match_conv(k, c);
+    return k.is_seed || match_gemm(k, g) || (!prog.f64 && match_conv(k, c));
   };
   for (size_t p = 0; p < t.live.size(); ++p) {
     if (ts.lowered[p].absorbed || (int)p == t.first_update) continue;
@@ -250,7 +250,8 @@ int lower_target(eg_model* m, TargetState& ts) {
       }
       continue;
     }
-    if (match_conv(k, lo.conv)) {
+    // (float64: no library convolution yet — conv2 and its gradients run as generated kernels over `double`)
+    if (!m->prog.f64 && match_conv(k, lo.conv)) {
       lo.kind = lo.conv.role == ConvMatch::Forward     ? StepKind::Conv
                 : lo.conv.role == ConvMatch::GradImage ? StepKind::ConvGradImage
                                                        : StepKind::ConvGradFilter;

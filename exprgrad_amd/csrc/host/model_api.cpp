@@ -138,6 +138,8 @@ int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out) try 
   if (rc) return rc;
   rc = compile_program(m->prog);
   if (rc) return rc;
+  m->f64 = m->prog.f64;
+  m->esz = m->f64 ? 2 : 1;
   rc = eg::set_device(ctx);
   if (rc) return rc;
   // parameters: uniform in initRange (model.nim:241-247); deterministic here, tests overwrite them
@@ -149,7 +151,13 @@ int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out) try 
     DevTensor dt;
     dt.shape = d.shape;
     dt.count = prod(d.shape);
-    if (dt.count > 0) {
+    if (dt.count > 0 && m->f64) {  // newRandTensor[float64] (model.nim:241-247)
+      EG_HIP_CHECK(hipMalloc((void**)&dt.ptr, (size_t)dt.count * sizeof(double)));
+      std::vector<double> host(dt.count);
+      std::uniform_real_distribution<double> dist(d.lo, d.hi);
+      for (auto& v : host) v = d.kind == TK::Cache ? 0.0 : (d.hi > d.lo ? dist(rng) : d.lo);
+      EG_HIP_CHECK(hipMemcpy(dt.ptr, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+    } else if (dt.count > 0) {
       EG_HIP_CHECK(hipMalloc((void**)&dt.ptr, (size_t)dt.count * sizeof(float)));
       std::vector<float> host(dt.count);
       std::uniform_real_distribution<float> dist((float)d.lo, (float)d.hi);
@@ -168,7 +176,7 @@ int eg_model_compile(eg_ctx* ctx, const char* program_text, eg_model** out) try 
           !ts.bucket_offset.count(k.gen_dest)) {
         ts.grad_tensors.push_back(k.gen_dest);
         ts.bucket_offset[k.gen_dest] = off;
-        off += align4(prod(m->prog.tensors[k.gen_tensor].shape));
+        off += align4(prod(m->prog.tensors[k.gen_tensor].shape) * m->esz);
       }
     ts.bucket_floats = off;
     if (off > 0) {
@@ -315,8 +323,49 @@ int eg_model_param_info(eg_model* m, int tensor_id, int* kind, int* rank, int64_
 }
 EG_CATCH_ALL
 
+// The float32-typed entry points refuse a float64 model and the other way round: a Tensor[float32] handed to a
+// Model[float64] does not compile in the reference either (model.nim:357-376 are generic over the model's T).
+#define EG_REQUIRE_SCALAR(m, want64, fn)                                                                         \
+  EG_REQUIRE((m)->f64 == (want64), EG_ERR_INVALID, "%s: the model computes in %s (the T of compile[T]); call the %s", fn, \
+             (m)->f64 ? "float64" : "float32", (m)->f64 ? "_f64 entry points" : "entry points without _f64")
+
+static int param_write(eg_model* m, int tensor_id, const void* host, int64_t count, bool f64, const char* fn) {
+  EG_REQUIRE(m && host, EG_ERR_INVALID, "%s: NULL argument", fn);
+  EG_REQUIRE_SCALAR(m, f64, fn);
+  auto it = m->params.find(tensor_id);
+  EG_REQUIRE(it != m->params.end(), EG_ERR_INVALID, "tensor %d is not a parameter", tensor_id);
+  EG_REQUIRE(count == it->second.count, EG_ERR_SIZE, "parameter %d has %ld elements, got %ld", tensor_id,
+             it->second.count, (long)count);
+  if (count == 0) return EG_OK;
+  return eg::copy_h2d(m->ctx, it->second.ptr, host, (size_t)count * sizeof(float) * m->esz);
+}
+
+static int param_read(eg_model* m, int tensor_id, void* host, int64_t count, bool f64, const char* fn) {
+  EG_REQUIRE(m && host, EG_ERR_INVALID, "%s: NULL argument", fn);
+  EG_REQUIRE_SCALAR(m, f64, fn);
+  auto it = m->params.find(tensor_id);
+  EG_REQUIRE(it != m->params.end(), EG_ERR_INVALID, "tensor %d is not a parameter", tensor_id);
+  EG_REQUIRE(count == it->second.count, EG_ERR_SIZE, "parameter %d has %ld elements, got %ld", tensor_id,
+             it->second.count, (long)count);
+  if (count == 0) return EG_OK;
+  return eg::copy_d2h(m->ctx, host, it->second.ptr, (size_t)count * sizeof(float) * m->esz);
+}
+
+int eg_model_scalar_bytes(eg_model* m) { return m ? 4 * m->esz : 0; }
+
+int eg_model_param_write_f64(eg_model* m, int tensor_id, const double* host, int64_t count) try {
+  return param_write(m, tensor_id, host, count, true, "eg_model_param_write_f64");
+}
+EG_CATCH_ALL
+
+int eg_model_param_read_f64(eg_model* m, int tensor_id, double* host, int64_t count) try {
+  return param_read(m, tensor_id, host, count, true, "eg_model_param_read_f64");
+}
+EG_CATCH_ALL
+
 int eg_model_param_write(eg_model* m, int tensor_id, const float* host, int64_t count) try {
   EG_REQUIRE(m && host, EG_ERR_INVALID, "eg_model_param_write: NULL argument");
+  EG_REQUIRE_SCALAR(m, false, "eg_model_param_write");
   auto it = m->params.find(tensor_id);
   EG_REQUIRE(it != m->params.end(), EG_ERR_INVALID, "tensor %d is not a parameter", tensor_id);
   EG_REQUIRE(count == it->second.count, EG_ERR_SIZE, "parameter %d has %ld elements, got %ld", tensor_id,
@@ -328,6 +377,7 @@ EG_CATCH_ALL
 
 int eg_model_param_read(eg_model* m, int tensor_id, float* host, int64_t count) try {
   EG_REQUIRE(m && host, EG_ERR_INVALID, "eg_model_param_read: NULL argument");
+  EG_REQUIRE_SCALAR(m, false, "eg_model_param_read");
   auto it = m->params.find(tensor_id);
   EG_REQUIRE(it != m->params.end(), EG_ERR_INVALID, "tensor %d is not a parameter", tensor_id);
   EG_REQUIRE(count == it->second.count, EG_ERR_SIZE, "parameter %d has %ld elements, got %ld", tensor_id,
@@ -352,7 +402,7 @@ int eg_model_grad_bucket(eg_model* m, const char* target, float** device_ptr, in
   auto it = m->targets.find(target);
   EG_REQUIRE(it != m->targets.end(), EG_ERR_RUNTIME, "%s is not a target of the model", target);
   if (device_ptr) *device_ptr = it->second.bucket;
-  if (count) *count = it->second.bucket_floats;
+  if (count) *count = it->second.bucket_floats / m->esz;  // elements (doubles of a float64 model)
   return EG_OK;
 }
 EG_CATCH_ALL
@@ -362,7 +412,7 @@ int eg_model_bind_grad_bucket(eg_model* m, const char* target, float* device_ptr
   auto it = m->targets.find(target);
   EG_REQUIRE(it != m->targets.end(), EG_ERR_RUNTIME, "%s is not a target of the model", target);
   TargetState& ts = it->second;
-  EG_REQUIRE(count >= ts.bucket_floats, EG_ERR_SIZE, "gradient bucket needs %ld floats, got %ld", ts.bucket_floats,
+  EG_REQUIRE(count * m->esz >= ts.bucket_floats, EG_ERR_SIZE, "gradient bucket needs %ld elements, got %ld", ts.bucket_floats / m->esz,
              (long)count);
   EG_HIP_CHECK(hipSetDevice(m->ctx->device));
   EG_HIP_CHECK(hipStreamSynchronize(m->ctx->stream));
@@ -374,8 +424,9 @@ int eg_model_bind_grad_bucket(eg_model* m, const char* target, float* device_ptr
 EG_CATCH_ALL
 
 static int bind_input(eg_model* m, const char* name, const float* device, const float* host, int rank,
-                      const int64_t* shape) {
+                      const int64_t* shape, bool f64 = false) {
   EG_REQUIRE(m && name, EG_ERR_INVALID, "NULL argument");
+  EG_REQUIRE_SCALAR(m, f64, f64 ? "eg_model_set_input_*_f64" : "eg_model_set_input_*");
   auto it = m->prog.inputs.find(name);
   // model.nim:358-359
   EG_REQUIRE(it != m->prog.inputs.end(), EG_ERR_RUNTIME, "%s is not an input to the model", name);
@@ -392,12 +443,12 @@ static int bind_input(eg_model* m, const char* name, const float* device, const 
       if (b.owned) EG_HIP_CHECK(hipFree(b.owned));
       b.owned = nullptr;
       b.owned_count = 0;
-      EG_HIP_CHECK(hipMalloc((void**)&b.owned, (size_t)(count > 0 ? count : 1) * sizeof(float)));
+      EG_HIP_CHECK(hipMalloc((void**)&b.owned, (size_t)(count > 0 ? count : 1) * sizeof(float) * m->esz));
       b.owned_count = count;
     }
     if (count > 0) {
       // blocking H2D on every call, as the reference does (model.nim:364-368 -> cl.nim:111-116)
-      int rc = eg::copy_h2d(m->ctx, b.owned, host, (size_t)count * sizeof(float));
+      int rc = eg::copy_h2d(m->ctx, b.owned, host, (size_t)count * sizeof(float) * m->esz);
       if (rc) return rc;
     }
     b.device = b.owned;
@@ -417,6 +468,18 @@ EG_CATCH_ALL
 
 int eg_model_set_input_device(eg_model* m, const char* name, const float* device_ptr, int rank, const int64_t* shape) try {
   return bind_input(m, name, device_ptr, nullptr, rank, shape);
+}
+EG_CATCH_ALL
+
+int eg_model_set_input_host_f64(eg_model* m, const char* name, const double* host, int rank, const int64_t* shape) try {
+  EG_REQUIRE(host || rank == 0, EG_ERR_INVALID, "NULL host pointer");
+  static const double dummy = 0;
+  return bind_input(m, name, nullptr, reinterpret_cast<const float*>(host ? host : &dummy), rank, shape, true);
+}
+EG_CATCH_ALL
+
+int eg_model_set_input_device_f64(eg_model* m, const char* name, const double* device_ptr, int rank, const int64_t* shape) try {
+  return bind_input(m, name, reinterpret_cast<const float*>(device_ptr), nullptr, rank, shape, true);
 }
 EG_CATCH_ALL
 
@@ -493,8 +556,9 @@ static int tensor_shape(eg_model* m, TargetState& ts, int tid, int* rank, int64_
   return EG_OK;
 }
 
-static int read_tensor(eg_model* m, TargetState& ts, int tid, float* host, int64_t count) {
+static int read_tensor(eg_model* m, TargetState& ts, int tid, void* host, int64_t count, bool f64 = false) {
   EG_REQUIRE(ts.last && host, EG_ERR_INVALID, "nothing to read");
+  EG_REQUIRE_SCALAR(m, f64, f64 ? "eg_model_read_*_f64" : "eg_model_read_*");
   auto s = ts.last->shapes.find(tid);
   EG_REQUIRE(s != ts.last->shapes.end(), EG_ERR_INVALID, "tensor %d has no shape in the last run", tid);
   const long n = prod(s->second);
@@ -507,7 +571,7 @@ static int read_tensor(eg_model* m, TargetState& ts, int tid, float* host, int64
              "(eg_model_keep_values(model, 1) makes the plans keep values)", tid);
   float* p = tensor_ptr(m, ts, *ts.last, tid);
   EG_REQUIRE(p, EG_ERR_INVALID, "tensor %d was not materialised by the last run", tid);
-  return eg::copy_d2h(m->ctx, host, p, (size_t)n * sizeof(float));
+  return eg::copy_d2h(m->ctx, host, p, (size_t)n * sizeof(float) * m->esz);
 }
 
 int eg_model_output_shape(eg_model* m, const char* target, int* rank, int64_t* shape8) try {
@@ -530,6 +594,16 @@ int eg_model_read_output(eg_model* m, const char* target, float* host, int64_t c
 }
 EG_CATCH_ALL
 
+int eg_model_read_output_f64(eg_model* m, const char* target, double* host, int64_t count) try {
+  EG_REQUIRE(m && target, EG_ERR_INVALID, "NULL argument");
+  int tid;
+  TargetState* ts;
+  int rc = find_tensor(m, target, &tid, &ts);
+  if (rc) return rc;
+  return read_tensor(m, *ts, tid, host, count, true);
+}
+EG_CATCH_ALL
+
 static TargetState* last_target(eg_model* m, const char* target) {
   auto it = m->targets.find(target ? target : "");
   return it == m->targets.end() ? nullptr : &it->second;
@@ -548,6 +622,14 @@ int eg_model_read_tensor(eg_model* m, const char* target, int tensor_id, float* 
   TargetState* ts = last_target(m, target);
   EG_REQUIRE(ts, EG_ERR_RUNTIME, "%s is not a target of the model", target ? target : "(null)");
   return read_tensor(m, *ts, tensor_id, host, count);
+}
+EG_CATCH_ALL
+
+int eg_model_read_tensor_f64(eg_model* m, const char* target, int tensor_id, double* host, int64_t count) try {
+  EG_REQUIRE(m, EG_ERR_INVALID, "NULL model");
+  TargetState* ts = last_target(m, target);
+  EG_REQUIRE(ts, EG_ERR_RUNTIME, "%s is not a target of the model", target ? target : "(null)");
+  return read_tensor(m, *ts, tensor_id, host, count, true);
 }
 EG_CATCH_ALL
 

@@ -167,6 +167,7 @@ struct DevTensor {
 
 struct Plan {
   std::string key;
+  int esz = 1;  // 4-byte units per element (eg_model::esz)
   Shapes shapes;
   std::vector<Launch> launches;
   int n_backward = 0;  // launches before the first parameter update
@@ -261,6 +262,11 @@ struct eg_model {
   std::map<std::string, eg::model::TargetState> targets;
   std::map<int, eg::model::DevTensor> params;  // device-resident parameters (model.params)
   std::map<int, eg::model::BoundInput> inputs;
+  // compile[float64] (model.nim:253-260): every tensor of the model holds doubles.  The planner's bookkeeping stays in
+  // units of 4 bytes ("floats": arena and bucket offsets, zero ranges, `float*` handles): an element of such a model
+  // occupies esz = 2 of them, and the handles are only ever cast (host/run.cpp), never indexed by element.
+  bool f64 = false;
+  int esz = 1;
   bool keep_values = false;  // eg_model_keep_values: plans keep result values where they would keep predicate bits
   uint64_t inputs_gen = 0;  // bumped by every change of `inputs` (bind, clear, fit): caches keyed on the bindings compare it
   float grad_scale = 1.0f;
@@ -315,7 +321,7 @@ inline long align4(long n) { return (n + 3) & ~3L; }
 // floats of arena storage a result tensor occupies in this plan
 inline long storage_floats(const Plan& plan, int tid) {
   const long n = prod(plan.shapes.at(tid));
-  return plan.predicated.count(tid) ? (n + 31) / 32 : n;
+  return plan.predicated.count(tid) ? (n + 31) / 32 : n * plan.esz;
 }
 
 

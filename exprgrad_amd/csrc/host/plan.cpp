@@ -244,6 +244,11 @@ bool copy_can_alias(eg_model* m, TargetState& ts, const Kernel& k, const KernelI
 int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   Target& t = *ts.target;
   Shapes& shapes = plan.shapes;
+  plan.esz = m->esz;
+  // A float64 program (compile[float64], model.nim:253-260) runs as the plain launch list: library contractions in
+  // float64 (eg_dgemm), everything else as generated kernels over `double`; the float32 fusion passes (row / sample /
+  // map groups, contraction epilogues, predicate bits, side lanes) generate float32 code and stay out of it.
+  const bool fuse = !m->f64;
   for (auto& in : m->inputs) {
     if (!in.second.bound) continue;
     const TensorDef& d = m->prog.tensors[in.first];
@@ -329,11 +334,11 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   // decide overwrite vs accumulate per launch; collect tensors that must be zeroed
   std::set<int> needs_zero;
   plan.sample_group.reset();
-  {
+  if (fuse) {
     int rc = form_sample_group(m, ts, plan, infos, first_writer, group_of, needs_zero);
     if (rc) return rc;
   }
-  int rc_groups = form_row_groups(m, ts, plan, infos, first_writer, group_of);
+  int rc_groups = fuse ? form_row_groups(m, ts, plan, infos, first_writer, group_of) : EG_OK;
   if (rc_groups) return rc_groups;
 
   plan.launches.clear();
@@ -566,22 +571,22 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
   }
   if (plan.n_backward < 0) plan.n_backward = (int)plan.launches.size();
   if (t.output && m->prog.tensors[t.output].kind == TK::Result && !first_writer.count(t.output)) needs_zero.insert(t.output);
-  {
+  if (fuse) {
     int rc = fuse_epilogues(m, ts, plan, infos);
     if (rc) return rc;
   }
-  {
+  if (fuse) {
     int rc = fold_bias_gradients(m, ts, plan, infos);
     if (rc) return rc;
   }
-  {
+  if (fuse) {
     int rc = fold_row_products(m, ts, plan);
     if (rc) return rc;
   }
 
-  plan_overlap(m, ts, plan);
-  plan_pipeline(m, ts, plan);
-  {
+  if (fuse) plan_overlap(m, ts, plan);
+  if (fuse) plan_pipeline(m, ts, plan);
+  if (fuse) {
     int rc = fuse_row_tails(m, ts, plan, infos);
     if (rc) return rc;
     rc = fuse_slab_fold(m, ts, plan, infos);
@@ -616,7 +621,7 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
     for (auto& rd : t.all[p].reads)
       if (m->prog.tensors[rd.tensor].kind == TK::Random && !plan.arena_offset.count(rd.tensor)) {
         plan.arena_offset[rd.tensor] = off;
-        off += align4(prod(shapes.at(rd.tensor)));
+        off += align4(prod(shapes.at(rd.tensor)) * plan.esz);
         plan.random_tensors.push_back(rd.tensor);
       }
   if (!plan.random_tensors.empty()) {

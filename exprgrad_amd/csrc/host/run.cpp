@@ -26,8 +26,14 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
   eg_ctx* ctx = m->ctx;
   switch (L.kind) {
     case StepKind::Seed:
+      if (m->f64) return eg_fill_f64(ctx, L.count, (double)m->grad_scale, reinterpret_cast<double*>(tensor_ptr(m, ts, plan, L.c_tensor)));
       return eg_fill_f32(ctx, L.count, m->grad_scale, tensor_ptr(m, ts, plan, L.c_tensor));
     case StepKind::Gemm:
+      if (m->f64) {
+        auto dp = [&](int t) { return reinterpret_cast<double*>(tensor_ptr(m, ts, plan, t)); };
+        return eg_dgemm(ctx, L.trans_a, L.trans_b, L.M, L.N, L.K, dp(L.a_tensor), L.lda, dp(L.b_tensor), L.ldb, dp(L.c_tensor), L.ldc,
+                        L.accumulate, L.bias_tensor ? dp(L.bias_tensor) : nullptr);
+      }
       if (L.ones_tensor) {
         // weight gradient + bias gradient in one contraction; when the operands of this run do not
         // qualify (alignment of a caller-owned input), the two reductions run separately
@@ -213,8 +219,8 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       float* partial = nullptr;
       float* scratch = nullptr;
       if (L.kind == StepKind::GenericB) {
-        const long pfloats = (L.partial_rows * L.partial_cols + 3) & ~3L;
-        const long sfloats = eg::colsum_scratch_floats(ctx, L.partial_rows, L.partial_cols);
+        const long pfloats = ((L.partial_rows * L.partial_cols + 3) & ~3L) * m->esz;
+        const long sfloats = eg::colsum_scratch_floats(ctx, L.partial_rows, L.partial_cols) * m->esz;
         int rc = eg::ensure_workspace(ctx, (size_t)(pfloats + sfloats) * sizeof(float));
         if (rc) return rc;
         partial = static_cast<float*>(ctx->workspace);
@@ -242,6 +248,10 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       }
       int rc = eg::kernel_launch_raw(L.generic->handle, (unsigned)blocks_x, (unsigned)L.blocks_y, 1, 256, args.data());
       if (rc) return rc;
+      if (L.kind == StepKind::GenericB && m->f64)
+        return eg::colsum_f64_with_scratch(ctx, L.partial_rows, L.partial_cols, reinterpret_cast<const double*>(partial),
+                                           reinterpret_cast<double*>(tensor_ptr(m, ts, plan, L.c_tensor)), L.accumulate,
+                                           reinterpret_cast<double*>(scratch));
       if (L.kind == StepKind::GenericB)
         return eg::colsum_with_scratch(ctx, L.partial_rows, L.partial_cols, partial,
                                        tensor_ptr(m, ts, plan, L.c_tensor), L.accumulate, scratch);
@@ -259,7 +269,7 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
       if (plan.zero_floats > 0) ranges.emplace_back(plan.arena, plan.zero_floats);
       for (int tid : plan.bucket_zero) {
         float* p = ts.bucket + ts.bucket_offset[tid];
-        const long n = prod(plan.shapes.at(tid));
+        const long n = prod(plan.shapes.at(tid)) * m->esz;
         // neighbours in the bucket (a layer's weights and bias) are one range
         if (!ranges.empty() && ranges.back().first + ranges.back().second == p)
           ranges.back().second += n;
@@ -277,7 +287,7 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
       std::set<int> zeroed(plan.bucket_zero.begin(), plan.bucket_zero.end());
       for (auto& b : ts.bucket_offset)
         if (!zeroed.count(b.first) && plan.shapes.count(b.first))
-          EG_HIP_CHECK(hipMemsetAsync(ts.bucket + b.second, 0xFF, (size_t)prod(plan.shapes.at(b.first)) * sizeof(float),
+          EG_HIP_CHECK(hipMemsetAsync(ts.bucket + b.second, 0xFF, (size_t)prod(plan.shapes.at(b.first)) * m->esz * sizeof(float),
                                       m->ctx->stream));
       for (auto& rg : plan.row_groups)
         if (rg->partial)
@@ -288,7 +298,9 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
     for (size_t r = 0; r < plan.random_tensors.size(); ++r) {
       const int tid = plan.random_tensors[r];
       const TensorDef& d = m->prog.tensors[tid];
-      int rc = eg_fill_uniform(m->ctx, prod(plan.shapes.at(tid)), (float)d.lo, (float)d.hi, m->rng_state, (uint64_t)tid,
+      int rc = m->f64 ? eg_fill_uniform_f64(m->ctx, prod(plan.shapes.at(tid)), d.lo, d.hi, m->rng_state, (uint64_t)tid,
+                                            reinterpret_cast<double*>(plan.arena + plan.arena_offset[tid]))
+                      : eg_fill_uniform(m->ctx, prod(plan.shapes.at(tid)), (float)d.lo, (float)d.hi, m->rng_state, (uint64_t)tid,
                                plan.arena + plan.arena_offset[tid]);
       if (rc) return rc;
     }
@@ -338,7 +350,7 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
     // Two independent tiny contractions next to each other (a dense layer's two gradients at a small batch): one launch
     // (EG_NO_SMALL_PAIR=1: two).  Independence is checked on the storage: neither writes what the other touches.
     const bool pair_off = getenv("EG_NO_SMALL_PAIR") != nullptr;   // (read per launch sequence: a test builds one model each way)
-    if (!pair_off && i + 1 < end && i + 1 != plan.n_backward &&
+    if (!pair_off && !m->f64 && i + 1 < end && i + 1 != plan.n_backward &&
         !(next_overlap < plan.overlaps.size() && plan.overlaps[next_overlap].first == i + 1)) {
       const Launch &A = plan.launches[i], &B = plan.launches[i + 1];
       if (A.kind == StepKind::Gemm && B.kind == StepKind::Gemm && !A.ones_tensor && !B.ones_tensor &&

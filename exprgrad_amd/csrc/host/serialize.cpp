@@ -88,12 +88,14 @@ int store_table(eg_model* m, TK kind, Writer& w) {
     w.i64((int64_t)p.second.shape.size());  // seq[int] shape
     for (long d : p.second.shape) w.i64(d);
     if (!w.out) {
-      w.n += (size_t)p.second.count * 4;
+      w.n += (size_t)p.second.count * 4 * m->esz;
       continue;
     }
-    host.resize((size_t)p.second.count);
+    // (a float64 model's elements are 8 bytes, little endian like everything else — serialize.nim:35 — i.e. two of the
+    //  32-bit words this loop writes, low word first)
+    host.resize((size_t)p.second.count * m->esz);
     if (p.second.count > 0) {
-      int rc = eg_model_param_read(m, p.first, host.data(), p.second.count);  // D2H on the context's stream + sync
+      int rc = eg::copy_d2h(m->ctx, host.data(), p.second.ptr, host.size() * sizeof(float));  // D2H on the context's stream + sync
       if (rc) return rc;
     }
     for (float f : host) {
@@ -127,7 +129,7 @@ int load_table(eg_model* m, TK kind, Reader& r, const char* what) {
     for (int64_t d = 0; d < rank; ++d) shape.push_back((long)r.i64());
     EG_REQUIRE(r.ok, EG_ERR_INVALID, "model state: truncated shape of tensor %ld", (long)tid);
     EG_REQUIRE(shape == it->second.shape, EG_ERR_SHAPE, "model state: tensor %ld has another shape than the model's", (long)tid);
-    const long n = it->second.count;
+    const long n = it->second.count * m->esz;  // 32-bit words
     EG_REQUIRE(r.pos + (size_t)n * 4 <= r.n, EG_ERR_INVALID, "model state: truncated data of tensor %ld", (long)tid);
     host.resize((size_t)n);
     for (long i = 0; i < n; ++i) {
@@ -135,7 +137,7 @@ int load_table(eg_model* m, TK kind, Reader& r, const char* what) {
       memcpy(&host[(size_t)i], &bits, 4);
     }
     if (n > 0) {
-      int rc = eg_model_param_write(m, (int)tid, host.data(), n);
+      int rc = eg::copy_h2d(m->ctx, it->second.ptr, host.data(), (size_t)n * sizeof(float));
       if (rc) return rc;
     }
   }

@@ -714,6 +714,7 @@ class Program:
         self.tensors = []   # dicts: kind, name, shape, range
         self.inputs = {}
         self.targets = {}
+        self.scalar = "f32"  # the T of compile[T] (model.nim:253-260): "f32" or "f64"
 
     def alloc_tensor(self, **kw):
         self.tensors.append(kw)
@@ -721,7 +722,7 @@ class Program:
 
     # ---- kernel-description text (grammar: DESIGN.md) --------------------------------------
     def to_text(self):
-        out = ["kd 1 f32"]
+        out = ["kd 1 " + self.scalar]
         for i, t in enumerate(self.tensors, 1):
             name = t.get("name") or "-"
             line = ["tensor", str(i), t["kind"], name.replace(" ", "_")]

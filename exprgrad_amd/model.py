@@ -19,13 +19,13 @@ from ._lib import call, GpuError, RuntimeErrorEG  # noqa: F401
 from .runtime import GpuContext
 
 
-def _check_device_tensor(name, tensor, ctx):
+def _check_device_tensor(name, tensor, ctx, want="float32"):
     """Only the address and the shape of a borrowed device tensor cross the C ABI: anything that is not
     packed float32 on the context's device would be read as if it were (a transposed view, a float64
     or half tensor), silently.  Refuse it instead."""
     dtype = getattr(tensor, "dtype", None)
-    if dtype is not None and str(dtype) not in ("torch.float32", "float32"):
-        raise GpuError(f"input {name}: device tensors must be float32, got {dtype}")
+    if dtype is not None and str(dtype) not in ("torch." + want, want):
+        raise GpuError(f"input {name}: device tensors must be {want}, got {dtype}")
     if hasattr(tensor, "is_contiguous") and not tensor.is_contiguous():
         raise GpuError(f"input {name}: device tensors must be contiguous (row-major, packed); call .contiguous()")
     dev = getattr(tensor, "device", None)
@@ -43,6 +43,8 @@ class _Params:
     def __init__(self, model, shapes=None):
         self._m = model
         self._shapes = model._param_shapes if shapes is None else shapes
+        self._dtype = model.dtype
+        self._sfx = model._sfx
 
     def ids(self):
         return list(self._shapes)
@@ -55,16 +57,16 @@ class _Params:
 
     def __getitem__(self, tid):
         shape = self._shapes[tid]
-        out = np.empty(shape, dtype=np.float32)
-        call("eg_model_param_read", self._m.handle, int(tid), out.ctypes.data_as(ctypes.c_void_p), out.size)
+        out = np.empty(shape, dtype=self._dtype)
+        call("eg_model_param_read" + self._sfx, self._m.handle, int(tid), out.ctypes.data_as(ctypes.c_void_p), out.size)
         return out
 
     def __setitem__(self, tid, value):
         shape = self._shapes[tid]
-        arr = np.ascontiguousarray(value, dtype=np.float32)
+        arr = np.ascontiguousarray(value, dtype=self._dtype)
         if list(arr.shape) != list(shape):
             raise GpuError(f"parameter {tid} has shape {list(shape)}, got {list(arr.shape)}")
-        call("eg_model_param_write", self._m.handle, int(tid), arr.ctypes.data_as(ctypes.c_void_p), arr.size)
+        call("eg_model_param_write" + self._sfx, self._m.handle, int(tid), arr.ctypes.data_as(ctypes.c_void_p), arr.size)
 
     def items(self):
         return [(t, self[t]) for t in self.ids()]
@@ -81,6 +83,9 @@ class Model:
             handle = ctypes.c_void_p()
             call("eg_model_compile", ctx.handle, self.source_text.encode(), ctypes.byref(handle))
         self.handle = handle
+        # Model[T] (model.nim:21-43): float32, or float64 for a program whose header says `kd 1 f64`
+        self.dtype = np.float64 if call("eg_model_scalar_bytes", handle) == 8 else np.float32
+        self._sfx = "_f64" if self.dtype == np.float64 else ""
         self._param_shapes = {}
         self._cache_shapes = {}
         for tid, t in enumerate(program.tensors, 1):
@@ -130,15 +135,15 @@ class Model:
     # ---- inputs ------------------------------------------------------------------------------
     def _bind(self, name, tensor):
         if hasattr(tensor, "data_ptr"):  # device tensor: borrow
-            _check_device_tensor(name, tensor, self.ctx)
+            _check_device_tensor(name, tensor, self.ctx, np.dtype(self.dtype).name)
             shape = [int(s) for s in tensor.shape]
             arr = (ctypes.c_int64 * max(len(shape), 1))(*shape)
             self._keep[name] = tensor
-            call("eg_model_set_input_device", self.handle, name.encode(), ctypes.c_void_p(tensor.data_ptr()), len(shape), arr)
+            call("eg_model_set_input_device" + self._sfx, self.handle, name.encode(), ctypes.c_void_p(tensor.data_ptr()), len(shape), arr)
         else:
-            a = np.ascontiguousarray(tensor, dtype=np.float32)
+            a = np.ascontiguousarray(tensor, dtype=self.dtype)
             arr = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
-            call("eg_model_set_input_host", self.handle, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.ndim, arr)
+            call("eg_model_set_input_host" + self._sfx, self.handle, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.ndim, arr)
 
     def _bind_all(self, args):
         items = list(args.items() if isinstance(args, dict) else args)
@@ -177,16 +182,19 @@ class Model:
         shape = (ctypes.c_int64 * 8)()
         call("eg_model_output_shape", self.handle, target.encode(), ctypes.byref(rank), shape)
         from .runtime import pinned_pool
-        out = pinned_pool.empty([shape[i] for i in range(rank.value)])   # fresh array, recycled pinned block when large
-        call("eg_model_read_output", self.handle, target.encode(), out.ctypes.data_as(ctypes.c_void_p), out.size)
+        if self.dtype == np.float64:
+            out = np.empty([shape[i] for i in range(rank.value)], dtype=np.float64)
+        else:
+            out = pinned_pool.empty([shape[i] for i in range(rank.value)])   # fresh array, recycled pinned block when large
+        call("eg_model_read_output" + self._sfx, self.handle, target.encode(), out.ctypes.data_as(ctypes.c_void_p), out.size)
         return out
 
     def read_tensor(self, target, tensor_id):
         rank = ctypes.c_int(0)
         shape = (ctypes.c_int64 * 8)()
         call("eg_model_tensor_shape", self.handle, target.encode(), int(tensor_id), ctypes.byref(rank), shape)
-        out = np.empty([shape[i] for i in range(rank.value)], dtype=np.float32)
-        call("eg_model_read_tensor", self.handle, target.encode(), int(tensor_id), out.ctypes.data_as(ctypes.c_void_p),
+        out = np.empty([shape[i] for i in range(rank.value)], dtype=self.dtype)
+        call("eg_model_read_tensor" + self._sfx, self.handle, target.encode(), int(tensor_id), out.ctypes.data_as(ctypes.c_void_p),
              out.size)
         return out
 
@@ -209,10 +217,10 @@ class Model:
             if hasattr(tensor, "data_ptr"):      # device tensor: read in place
                 if hasattr(tensor, "is_contiguous") and not tensor.is_contiguous():
                     tensor = tensor.contiguous()
-                _check_device_tensor(items[i][0], tensor, self.ctx)
+                _check_device_tensor(items[i][0], tensor, self.ctx, np.dtype(self.dtype).name)
                 data[i], on_device[i], shape = tensor.data_ptr(), 1, [int(s) for s in tensor.shape]
             else:
-                tensor = np.ascontiguousarray(tensor, dtype=np.float32)
+                tensor = np.ascontiguousarray(tensor, dtype=self.dtype)
                 data[i], on_device[i], shape = tensor.ctypes.data, 0, list(tensor.shape)
             keep.append(tensor)
             if len(shape) > 8:
@@ -221,7 +229,7 @@ class Model:
             shapes[8 * i:8 * i + len(shape)] = shape
         self._keep = {"fit": keep}
         self._bound_sig = None   # the library binds batch slices of its own during the epoch
-        call("eg_model_fit", self.handle, target.encode(), n, names, data, on_device, ranks, shapes, int(batch_size))
+        call("eg_model_fit" + self._sfx, self.handle, target.encode(), n, names, data, on_device, ranks, shapes, int(batch_size))
 
     # ---- data-parallel hooks ---------------------------------------------------
     def grad_bucket(self, target):
@@ -314,8 +322,13 @@ def load_model(path, gpu=None):
 loadModel = load_model
 
 
-def compile(*graphs, gpu=None):  # noqa: A001 - mirrors compile[T](graphs, gpu) model.nim:270-273
+def compile(*graphs, gpu=None, dtype=np.float32):  # noqa: A001 - mirrors compile[T](graphs, gpu) model.nim:270-273
+    """dtype: the T of compile[T] — np.float32 or np.float64 (model.nim:253-260: any other type raises ValueError)."""
     if len(graphs) == 1 and isinstance(graphs[0], (list, tuple)):
         graphs = tuple(graphs[0])
+    dt = np.dtype(dtype)
+    if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise ValueError(f"{dt} is not a valid scalar type")   # model.nim:259
     program = dsl.to_program(*graphs)
+    program.scalar = "f64" if dt == np.dtype(np.float64) else "f32"
     return Model(program, gpu)

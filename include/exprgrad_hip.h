@@ -202,6 +202,16 @@ int eg_conv2_nhwc_grad_filter(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int6
 int eg_conv2_nhwc_grad_image(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64_t C, int64_t F, int64_t FH,
                              int64_t FW, const float* flt, const float* gout, float* gimg, int accumulate);
 
+/* float64 forms of the library kernels — what a `compile[float64]` model (model.nim:253-260: every kernel of the
+ * program instantiated over Scalar64) runs on; same conventions as their float32 namesakes above.
+ *   eg_dgemm: `v_mfma_f64_16x16x4_f64` tiles (exact float64 multiply-adds in k order; sliced products are summed in a
+ *   fixed order), eg_colsum_f64 / eg_fill_f64 / eg_fill_uniform_f64: as eg_colsum / eg_fill_f32 / eg_fill_uniform. */
+int eg_dgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+             const double* B, int64_t ldb, double* C, int64_t ldc, int accumulate, const double* bias);
+int eg_colsum_f64(eg_ctx* ctx, int64_t rows, int64_t cols, const double* in, double* out, int accumulate);
+int eg_fill_f64(eg_ctx* ctx, int64_t n, double value, double* out);
+int eg_fill_uniform_f64(eg_ctx* ctx, int64_t n, double lo, double hi, const uint64_t* state, uint64_t stream, double* out);
+
 /* ------------------------------------------------------------------ group 3: model ---- */
 /* A program is the text form of exprgrad's `Program` (ir.nim:247-270) before `generate`:
  * tensors, targets, and per target the ordered list of `++=` kernel descriptions
@@ -319,6 +329,27 @@ int eg_model_load(eg_ctx* ctx, const char* path, eg_model** out);
 /* The kernel-description text the model was compiled from. */
 const char* eg_model_source_text(eg_model* model);
 
+/* compile[float64] (model.nim:253-260: toScalarType(T) -> Scalar64, every tensor a Tensor[float64]).  The scalar type
+ * of a program is in its header line (`kd 1 f32` / `kd 1 f64`).  A float64 model runs its contractions on the float64
+ * matrix cores (eg_dgemm) and everything else as generated kernels over `double`; the float32 fusion passes stay out of
+ * it.  The entry points above that carry `float*` arrays refuse a float64 model (EG_ERR_INVALID) — a Tensor[float32]
+ * does not type-check against a Model[float64] in the reference either — and these, their twins, refuse a float32 one.
+ * Entry points that only hand out device pointers (eg_model_param_ptr, eg_model_tensor_ptr, eg_model_grad_bucket /
+ * eg_model_bind_grad_bucket) return / take the address of DOUBLES for such a model, typed `float*`; their counts are
+ * elements.  eg_model_save / eg_model_load / *_state store 8-byte elements (serialize.nim:35).  eg_model_step_dp
+ * all-reduces the bucket as float64. */
+int eg_model_scalar_bytes(eg_model* model); /* 4 or 8 */
+int eg_model_param_write_f64(eg_model* model, int tensor_id, const double* host, int64_t count);
+int eg_model_param_read_f64(eg_model* model, int tensor_id, double* host, int64_t count);
+int eg_model_set_input_host_f64(eg_model* model, const char* name, const double* host, int rank, const int64_t* shape);
+int eg_model_set_input_device_f64(eg_model* model, const char* name, const double* device_ptr, int rank,
+                                  const int64_t* shape);
+int eg_model_read_output_f64(eg_model* model, const char* target, double* host, int64_t count);
+int eg_model_read_tensor_f64(eg_model* model, const char* target, int tensor_id, double* host, int64_t count);
+int eg_model_fit_f64(eg_model* model, const char* target, int n_inputs, const char* const* names,
+                     const double* const* data, const int* on_device, const int* ranks, const int64_t* shapes8,
+                     int64_t batch_size);
+
 /* ---------------------------------------------------------------------------------------------
  * Group 4 — data-parallel exchange (BASELINE.json north_star: "training-step batches
  * shard data-parallel across the 8 GPUs of one node with an RCCL all-reduce of parameter gradients
@@ -344,6 +375,7 @@ int eg_dp_rccl_rank(const eg_dp* dp);
 int eg_dp_set_split(eg_dp* dp, int enabled);
 /* In-place SUM over the ranks of `count` floats at `device_buf`; asynchronous on the stream. */
 int eg_dp_allreduce_sum_f32(eg_dp* dp, float* device_buf, int64_t count);
+int eg_dp_allreduce_sum_f64(eg_dp* dp, double* device_buf, int64_t count);
 /* One training step on this rank's shard of the batch (inputs bound with eg_model_set_input_*):
  * eg_model_run_backward | all-reduce of the gradient bucket | eg_model_run_update.  mean != 0 for
  * losses that divide by the batch (mse, crossEntropy; base.nim:57-67): the seed gradient is scaled

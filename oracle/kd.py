@@ -152,7 +152,8 @@ def parse(text):
             continue
         t = toks[0]
         if t == "kd":
-            assert toks[1] == "1" and toks[2] == "f32"
+            assert toks[1] == "1" and toks[2] in ("f32", "f64")
+            prog.scalar = toks[2]
         elif t == "tensor":
             tid, kind, name, rank = int(toks[1]), toks[2], toks[3], int(toks[4])
             d = {"kind": kind, "name": "" if name == "-" else name, "shape": None}
@@ -782,7 +783,7 @@ def _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch, f64=False):
     """Kernels with computed (non-affine) indices: flat index of an operand = constant +
     sum(coefficient * register) over iterator AND index-instruction registers (ref_interp_kernel2)."""
     lib = refcpu.lib()
-    interp = lib.ref_interp_kernel2_f64 if f64 else lib.ref_interp_kernel2
+    interp = {False: lib.ref_interp_kernel2, True: lib.ref_interp_kernel2_f64, "c64": lib.ref_interp_kernel2_c64}[f64]
     interp.restype = ctypes.c_int
     typ = infer_types(k, vals)
     c_i64, c_i32 = ctypes.c_int64, ctypes.c_int32
@@ -835,14 +836,15 @@ def _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch, f64=False):
 
 
 def run_kernel(k, bounds, vals, shapes, tensors, epoch=0, f64=False, abs_into=None):
-    """f64: the float64 shadow of the kernel (oracle/refinterp_body.h) on float64 tensors.
+    """f64: True = the float64 shadow of the kernel (oracle/refinterp_body.h) on float64 tensors; "c64" = the kernel of a
+    compile[float64] program (float64 arithmetic AND float64 constants: the reference's own path for T = float64).
     abs_into: instead of the written tensor, add the MAGNITUDE of every term to this array (affine kernels only)."""
     if k.index_instrs:
         if abs_into is not None:
             raise NotImplementedError("term magnitudes of a kernel with computed indices")
         return _run_kernel_indexed(k, bounds, vals, shapes, tensors, epoch, f64)
     lib = refcpu.lib()
-    interp = lib.ref_interp_kernel_f64 if f64 else lib.ref_interp_kernel
+    interp = {False: lib.ref_interp_kernel, True: lib.ref_interp_kernel_f64, "c64": lib.ref_interp_kernel_c64}[f64]
     interp.restype = ctypes.c_int
     nl = len(k.loops)
     loop_index = {lp.reg: i for i, lp in enumerate(k.loops)}
@@ -954,7 +956,10 @@ class Model:
         the reference computes in float32.  Tests hold the GPU to 1e-5 of it and the float32 oracle to
         its own sequential-summation bound, instead of widening a GPU-vs-oracle tolerance."""
         self.prog = parse(text)
-        self.dtype = np.float64 if shadow else np.float32
+        # compile[float64] (model.nim:253-260; header `kd 1 f64`): the reference instantiates every kernel over float64 —
+        # double tensors, double constants, libm's double functions, the same loop nests (refinterp.c "_c64").
+        self.c64 = getattr(self.prog, "scalar", "f32") == "f64"
+        self.dtype = np.float64 if (shadow or self.c64) else np.float32
         self.compiled = {name: compile_target(self.prog, name) for name in list(self.prog.targets)}
         self.params = {}
         self.epoch = 0
@@ -1004,13 +1009,16 @@ class Model:
     def _run_one(self, k, infos, shapes, tensors, grad_scale):
         bounds, vals = infos[id(k)]
         wt = k.write.tensor
-        shadow = self.dtype == np.float64
+        shadow = "c64" if self.c64 else self.dtype == np.float64
         if wt not in tensors:
             tensors[wt] = np.zeros(shapes[wt], dtype=self.dtype)
         pat = contraction_pattern(k) if self.fast else None
         if k.is_seed:
             # gradLoss{i} = 1 (passes.nim:594-596), times B_local/B_global under data parallelism
             tensors[wt] += self.dtype(np.float32(grad_scale))
+        elif pat is not None and self.c64:
+            a_op, b_op, ta, tb = pat
+            refcpu.dgemm64(tensors[a_op.tensor], tensors[b_op.tensor], ta, tb, out=tensors[wt])
         elif pat is not None and shadow:
             a_op, b_op, ta, tb = pat
             a, b = tensors[a_op.tensor], tensors[b_op.tensor]
@@ -1045,7 +1053,9 @@ class Model:
             if name not in self.prog.inputs:
                 raise KeyError(name + " is not an input to the model")    # model.nim:358-359
             tid = self.prog.inputs[name]
-            arr = np.ascontiguousarray(np.ascontiguousarray(arr, dtype=np.float32), dtype=self.dtype)
+            if not self.c64:
+                arr = np.ascontiguousarray(arr, dtype=np.float32)
+            arr = np.ascontiguousarray(arr, dtype=self.dtype)
             static = self.prog.tensors[tid]["shape"]
             if static:
                 if len(static) != arr.ndim or any(s >= 0 and s != a for s, a in zip(static, arr.shape)):

@@ -137,6 +137,33 @@ EXPORT void ref_sgemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
   free(jobs);
 }
 
+/* compile[float64] (model.nim:253-260): the same four loop nests over double — C (+)= op(A) op(B), every output element
+ * summed sequentially in the reference's loop order (y, it, x; passes.nim:700-745), no FMA contraction. */
+EXPORT void ref_dgemm(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const double* A, int64_t lda,
+                      const double* B, int64_t ldb, double* C, int64_t ldc) {
+  if (!trans_a && !trans_b) {          /* c[y,x] += a[y,it] * b[it,x]: y, it, x */
+    for (int64_t y = 0; y < M; ++y)
+      for (int64_t it = 0; it < K; ++it) {
+        const double a = A[y * lda + it];
+        for (int64_t x = 0; x < N; ++x) C[y * ldc + x] += a * B[it * ldb + x];
+      }
+  } else if (!trans_a && trans_b) {    /* gradA[y,it] += g[y,x] * b[it,x]: y, it, x (x the reduction) */
+    for (int64_t y = 0; y < M; ++y)
+      for (int64_t it = 0; it < N; ++it)
+        for (int64_t x = 0; x < K; ++x) C[y * ldc + it] += A[y * lda + x] * B[it * ldb + x];
+  } else if (trans_a && !trans_b) {    /* gradB[it,x] += a[y,it] * g[y,x]: y (the reduction) outermost */
+    for (int64_t y = 0; y < K; ++y)
+      for (int64_t it = 0; it < M; ++it) {
+        const double a = A[y * lda + it];
+        for (int64_t x = 0; x < N; ++x) C[it * ldc + x] += a * B[y * ldb + x];
+      }
+  } else {
+    for (int64_t y = 0; y < M; ++y)
+      for (int64_t x = 0; x < N; ++x)
+        for (int64_t it = 0; it < K; ++it) C[y * ldc + x] += A[it * lda + y] * B[x * ldb + it];
+  }
+}
+
 /* The thread count the reference would use for a loop of `size` iterations whose body costs
  * `work_per_iter` units: minSize = 2^24 / work; threads = clamp(size / minSize, 1, pool)
  * (passes.nim:2415-2437 MIN_WORK_PER_THREAD; model.nim:116-119). */

@@ -55,6 +55,8 @@ def lib():
         _lib.ref_conv2_nhwc_grad_filter.argtypes = [i64] * 7 + [f32p, f32p, f32p]
         _lib.ref_conv2_nhwc_grad_image.argtypes = [i64] * 7 + [f32p, f32p, f32p]
         _lib.ref_dgemm_from_f32.argtypes = [cint, cint, i64, i64, i64, f32p, i64, f32p, i64, f64p, i64]
+        _lib.ref_dgemm.argtypes = [cint, cint, i64, i64, i64, f64p, i64, f64p, i64, f64p, i64]
+        _lib.ref_dgemm.restype = None
         for name in ("ref_sgemm", "ref_bias_add", "ref_colsum", "ref_rowsum", "ref_sum",
                      "ref_gradient_descent", "ref_axpy", "ref_map", "ref_map_grad",
                      "ref_conv2_nhwc", "ref_conv2_nhwc_grad_filter", "ref_conv2_nhwc_grad_image", "ref_dgemm_from_f32"):
@@ -82,6 +84,21 @@ def sgemm(a, b, trans_a=False, trans_b=False, out=None, threads=1):
     assert out.dtype == np.float32 and out.flags.c_contiguous and out.shape == (M, N)
     lib().ref_sgemm(int(trans_a), int(trans_b), M, N, K, _p(a), a.shape[1], _p(b), b.shape[1],
                     _p(out), N, threads)
+    return out
+
+
+def dgemm64(a, b, trans_a=False, trans_b=False, out=None):
+    """compile[float64]: out (+)= op(a) @ op(b) over float64 in the reference's loop order (ref_dgemm)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    N = b.shape[0] if trans_b else b.shape[1]
+    assert (b.shape[1] if trans_b else b.shape[0]) == K
+    if out is None:
+        out = np.zeros((M, N), dtype=np.float64)
+    assert out.dtype == np.float64 and out.flags.c_contiguous and out.shape == (M, N)
+    pd = lambda x: x.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    lib().ref_dgemm(int(trans_a), int(trans_b), M, N, K, pd(a), a.shape[1], pd(b), b.shape[1], pd(out), N)
     return out
 
 

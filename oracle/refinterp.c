@@ -37,19 +37,39 @@ enum {
 #define REG_T reg_f32_t
 #define FN(name) name
 #define M(fn) fn##f
+#define LITERAL(x) ((float)(x))
 #include "refinterp_body.h"
 #undef REAL
 #undef REG_T
 #undef FN
 #undef M
+#undef LITERAL
 
 /* float64 shadow of the same kernels (exported with the suffix _f64) */
 #define REAL double
 #define REG_T reg_f64_t
 #define FN(name) name##_f64
 #define M(fn) fn
+#define LITERAL(x) ((double)(float)(x)) /* the float32 program's constants */
 #include "refinterp_body.h"
 #undef REAL
 #undef REG_T
 #undef FN
 #undef M
+#undef LITERAL
+
+/* compile[float64] (model.nim:253-260: toScalarType(float64) = Scalar64): the reference's arithmetic for a program
+ * instantiated over float64 — double registers, libm's double functions, constants as const_real(double type, v)
+ * leaves them (llvmgen.nim:215-216: the literal itself).  Same loop nests, same sequential sums.  Exported with
+ * the suffix _c64. */
+#define REAL double
+#define REG_T reg_c64_t
+#define FN(name) name##_c64
+#define M(fn) fn
+#define LITERAL(x) ((double)(x))
+#include "refinterp_body.h"
+#undef REAL
+#undef REG_T
+#undef FN
+#undef M
+#undef LITERAL

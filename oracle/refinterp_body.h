@@ -19,7 +19,7 @@ static inline int FN(exec_instrs)(REG_T* regs, int ninstr, const int32_t* instr,
     REG_T* d = &regs[in[1]];
     const REG_T a = regs[in[2]], b = regs[in[3]], c = regs[in[4]];
     switch (in[0]) {
-      case OP_SCALAR_LIT: d->f = (REAL)(float)instr_lit[k]; break; /* const_real(float, double) llvmgen.nim:215-216 */
+      case OP_SCALAR_LIT: d->f = LITERAL(instr_lit[k]); break; /* const_real(scalar type, double) llvmgen.nim:215-216 */
       case OP_INDEX_LIT: d->i = (int64_t)instr_lit[k]; break;
       case OP_BOOL_LIT: d->i = instr_lit[k] != 0.0; break;
       case OP_ADD_F: d->f = a.f + b.f; break;
