@@ -29,6 +29,7 @@ with open(os.path.join(ROOT, "roofline_constants.json")) as _f:
     ROOFLINE = json.load(_f)
 F32_MFMA_PEAK_TFLOPS = ROOFLINE["f32_mfma_peak_tflops"]
 HBM_PEAK_GBS = ROOFLINE["hbm_peak_gbs"]
+F64_MFMA_PEAK_TFLOPS = ROOFLINE["f64_mfma_peak_tflops"]
 
 DENSE = dict(n_in=784, n_hidden=512, n_out=10, rate=0.01, batch=65536)
 # algorithmic GEMM FLOPs per sample of the dense-net train step (SURVEY.md §8d cfg 5):
@@ -625,6 +626,75 @@ def run_matmul_sizes(args, env):
                          "traffic": None}}
 
 
+def run_float64(args, env):
+    """compile[float64] (model.nim:253-260), the scalar type of several of the reference's own tests and of its conv2
+    benchmark: eg_dgemm at three sizes against the float64 matrix peak (v_mfma_f64_16x16x4_f64: 32 FLOP / clk / SIMD,
+    measured ceiling 77.8 TFLOP/s, tools/mfma_ceiling_f64.hip), and the reference's conv2 benchmark program in its own type
+    and shape (benchmarks/conv2/conv2.nim:128-138, 330-364: image 960 x 1280 x 8, 8 filters of 3 x 3 x 8, float64) through
+    eg_model_run on device-resident inputs — a generated kernel over double, HBM-bound (157 MB per call)."""
+    import ctypes
+    import numpy as np
+    from exprgrad_amd import _lib, examples
+    from exprgrad_amd import model as egm
+    torch, ctx, timer = env["torch"], env["ctx"], env["timer"]
+    steps = max(args.steps, 20)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    rows = {}
+    for n in (1024, 2048, 4096):
+        a = torch.rand((n, n), device="cuda", dtype=torch.float64, generator=gen) - 0.5
+        b = torch.rand((n, n), device="cuda", dtype=torch.float64, generator=gen) - 0.5
+        c = torch.empty((n, n), device="cuda", dtype=torch.float64)
+
+        def step():
+            _lib.call("eg_dgemm", ctx.handle, 0, 0, n, n, n, ctypes.c_void_p(a.data_ptr()), n, ctypes.c_void_p(b.data_ptr()), n,
+                      ctypes.c_void_p(c.data_ptr()), n, 0, None)
+        elapsed, ev_avg, _ = timer.run(step, steps, args.warmup)
+        tflops = 2.0 * n * n * n * steps / elapsed / 1e12
+        rows[str(n)] = {"us_per_launch": round(elapsed / steps * 1e6, 2), "tflops": round(tflops, 2),
+                        "frac_of_f64_mfma_peak": round(tflops / F64_MFMA_PEAK_TFLOPS, 4), "kernel_us_by_events": round(ev_avg * 1e3, 2)}
+    out = {"metric": "TFLOP/s of C = A*B, M = N = K, float64, through eg_dgemm", "unit": "TFLOP/s", "sizes": rows, "timed_steps": steps,
+           "roofline": {"bound": "mfma", "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "achieved": rows["4096"]["tflops"],
+                        "frac": rows["4096"]["frac_of_f64_mfma_peak"], "traffic": None,
+                        "kernel": "dgemm_kernel<128,128,2,4,...> (eight waves of 64 x 32 per tile, two blocks per CU)"}}
+    H, W, C, F = 960, 1280, 8, 8
+    model = egm.compile(*examples.conv2_3d(), gpu=ctx, dtype=np.float64)
+    image = torch.rand((H, W, C), device="cuda", dtype=torch.float64, generator=gen)
+    filters = torch.rand((F, 3, 3, C), device="cuda", dtype=torch.float64, generator=gen) * 4 - 2
+    feed = {"image": image, "filters": filters}
+    elapsed, ev_avg, _ = timer.run(lambda: model.apply("conv2", feed), steps, args.warmup)
+    flops = 2.0 * (H - 2) * (W - 2) * F * 9 * C
+    nbytes = 8.0 * (H * W * C + (H - 2) * (W - 2) * F + F * 9 * C)
+    out["conv2_benchmark"] = {
+        "workload": "benchmarks/conv2/conv2.nim:330-364: 960 x 1280 x 8 image, 8 filters 3 x 3 x 8, float64, compile[float64] + call",
+        "ms_per_call": round(elapsed / steps * 1e3, 4), "gflops": round(flops * steps / elapsed / 1e9, 1),
+        "algorithmic_gbs": round(nbytes * steps / elapsed / 1e9, 1), "frac_of_hbm_peak": round(nbytes * steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+        "launches": model.launch_plan("conv2").strip().splitlines()}
+    model.close()
+    return out
+
+
+def cpu_baseline_float64(budget_s=4.0):
+    """The oracle's compile[float64] form of the reference's conv2 benchmark program on a crop of its image (one core)."""
+    import numpy as np
+    from exprgrad_amd import dsl, examples
+    from oracle import kd
+    prog = dsl.to_program(*examples.conv2_3d())
+    prog.scalar = "f64"
+    m = kd.Model(prog.to_text())
+    rng = np.random.default_rng(0)
+    H, W = 96, 1280
+    image, filters = rng.random((H, W, 8)), rng.random((8, 3, 3, 8)) * 4 - 2
+    t0, calls = time.perf_counter(), 0
+    while calls < 1 or time.perf_counter() - t0 < budget_s:
+        m.call("conv2", {"image": image, "filters": filters})
+        calls += 1
+    dt = (time.perf_counter() - t0) / calls
+    flops = 2.0 * (H - 2) * (W - 2) * 8 * 72
+    return {"value": round(flops / dt / 1e9, 3), "unit": "GFLOP/s", "cores": 1, "kind": "port",
+            "sample": f"conv2 benchmark program, float64, a 96 x 1280 x 8 crop of the 960 x 1280 x 8 image, {calls} call(s) of the oracle's interpreter"}
+
+
 def build_dense(env, batch):
     from exprgrad_amd import examples as refcases
     from exprgrad_amd import model as egm
@@ -1135,6 +1205,7 @@ def main():
             guarded("conv2", lambda: run_conv2(small, env))
             guarded("fashion_mnist_fit", lambda: run_fashion_fit(small, env))
             guarded("matmul_sizes", lambda: run_matmul_sizes(small, env))
+            guarded("float64", lambda: run_float64(small, env))
             guarded("compile_latency", compile_latency)
             line["extra"] = extra
             if not args.no_cpu_baseline:
@@ -1151,6 +1222,7 @@ def main():
                 baseline("conv2", cpu_baseline_conv2)
                 baseline("fashion_mnist_fit", cpu_baseline_fit)
                 baseline("matmul_sizes", lambda: cpu_baseline_matmul(1024, budget_s=2.0))
+                baseline("float64", cpu_baseline_float64)
             if "error" not in extra["train"]:
                 # the --gpus N > 1 invocations report the data-parallel train step; its 1-GPU point:
                 line["scaling_series_n1"] = {"metric": extra["train"]["metric"], "value": extra["train"]["value"],

@@ -12,11 +12,15 @@
 // fall into different bank halves).  All four storage orders go through one loader (strides), ragged
 // tiles are zero filled, K is cut into slices with a fixed-order second pass when the tiles alone
 // cannot fill the chip (deterministic: no atomics).
+#include <cstdlib>
+#include <cstring>
+
 #include "../eg_internal.hpp"
 
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 16;
 constexpr int PAD = 16;
@@ -27,7 +31,7 @@ struct DgemmArgs {
   double* C;        // destination, or the slab block when splits > 1
   const double* bias;
   long M, N, K;
-  long a_sm, a_sk, b_sk, b_sn, ldc;
+  long lda, ldb, ldc;
   int accumulate;
   int splits;       // k-slices (grid.y)
   long k_per_split; // multiple of BK
@@ -35,54 +39,77 @@ struct DgemmArgs {
   int remap;        // tiles % 8 == 0: contiguous tile ranges per XCD
 };
 
-// Tile loader: ELEMS doubles per thread of a [BK][BMN] tile whose (mn, k) element lives at base[mn * s_mn + k * s_k].
-// k-contiguous operands walk k with the lanes (16 lanes = one 128-byte row piece), mn-contiguous ones walk mn.
-template <int BMN>
+// Tile loader.  A k-contiguous operand ((mn, k) at base[mn * ld + k]) is staged as [mn][LDK = 18] rows, an mn-contiguous one
+// ((mn, k) at base[k * ld + mn]) as [k][BMN + 16] rows; either way a thread moves 16-byte pieces (two doubles that are
+// neighbours in memory AND in LDS: one global_load_dwordx4, one ds_write_b128) and consecutive lanes walk consecutive
+// memory.  Both row strides put the two half-waves of a fragment read (ds_read_b64) on disjoint bank sets.
+// VEC = false (an odd leading dimension or a base that is not 16-byte aligned): the same pieces as two 8-byte loads.
+constexpr int LDK = BK + 2;
+
+template <int BMN, int NT, bool KC, bool VEC>
 struct TileLoader {
-  static constexpr int ELEMS = BMN * BK / 256;
-  double v[ELEMS];
-  __device__ __forceinline__ void load(const double* __restrict__ base, long s_mn, long s_k, long mn0, long k0, long MN, long Kend,
-                                       bool kc, int tid) {
+  static constexpr int PIECES = BMN * (BK / 2) / NT;
+  static constexpr int LDM = BMN + PAD;
+  static constexpr int LDS_DOUBLES = KC ? BMN * LDK : BK * LDM;
+  double v[PIECES][2];
+  // piece -> (mn, k) of its first element
+  static __device__ __forceinline__ void where(int p, int& mn, int& k) {
+    if (KC) {
+      mn = p / (BK / 2);
+      k = (p % (BK / 2)) * 2;
+    } else {
+      k = p / (BMN / 2);
+      mn = (p % (BMN / 2)) * 2;
+    }
+  }
+  __device__ __forceinline__ void load(const double* __restrict__ base, long ld, long mn0, long k0, long MN, long Kend, int tid) {
 #pragma unroll
-    for (int j = 0; j < ELEMS; ++j) {
+    for (int j = 0; j < PIECES; ++j) {
       int mn, k;
-      if (kc) {
-        k = tid & 15;
-        mn = (tid >> 4) + 16 * j;
-      } else {
-        mn = tid % BMN;
-        k = tid / BMN + (256 / BMN) * j;
-      }
+      where(tid + NT * j, mn, k);
       const long gm = mn0 + mn, gk = k0 + k;
-      v[j] = (gm < MN && gk < Kend) ? base[gm * s_mn + gk * s_k] : 0.0;
-    }
-  }
-  __device__ __forceinline__ void store(double* lds, bool kc, int tid) const {
-#pragma unroll
-    for (int j = 0; j < ELEMS; ++j) {
-      int mn, k;
-      if (kc) {
-        k = tid & 15;
-        mn = (tid >> 4) + 16 * j;
+      const double* src = KC ? base + gm * ld + gk : base + gk * ld + gm;
+      const bool in0 = gm < MN && gk < Kend;
+      const bool in1 = KC ? (gm < MN && gk + 1 < Kend) : (gm + 1 < MN && gk < Kend);
+      if (VEC && in1) {  // (in1 implies in0)
+        const d2 t = *reinterpret_cast<const d2*>(src);
+        v[j][0] = t[0];
+        v[j][1] = t[1];
       } else {
-        mn = tid % BMN;
-        k = tid / BMN + (256 / BMN) * j;
+        v[j][0] = in0 ? src[0] : 0.0;
+        v[j][1] = in1 ? src[1] : 0.0;
       }
-      lds[k * (BMN + PAD) + mn] = v[j];
     }
   }
+  __device__ __forceinline__ void store(double* lds, int tid) const {
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      int mn, k;
+      where(tid + NT * j, mn, k);
+      double* dst = KC ? lds + mn * LDK + k : lds + k * LDM + mn;
+      *reinterpret_cast<d2*>(dst) = d2{v[j][0], v[j][1]};
+    }
+  }
+  // fragment element (mn, k) of the staged tile
+  static __device__ __forceinline__ double at(const double* lds, int mn, int k) { return KC ? lds[mn * LDK + k] : lds[k * LDM + mn]; }
 };
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void dgemm_kernel(DgemmArgs a) {
-  constexpr int WM = BM / 2, WN = BN / 2;  // 2 x 2 waves
+// One wave alone issues a float64 MFMA every ~146 cycles, two waves of a SIMD together one every 64 (tools/mfma_ceiling_f64.hip:
+// 34 against 77.8 TFLOP/s) — the matrix pipe needs several waves per SIMD that are multiplying at the same time.  So a tile
+// is shared by WR x WC waves with small sub-tiles (128 x 128: eight waves of 64 x 32; 64 x 64: four of 32 x 32) and
+// blocks are small enough in LDS for two (three) of them per CU, which meet their barriers at different times.
+template <int BM, int BN, int WR, int WC, bool AKC, bool BKC, bool VEC>
+__global__ __launch_bounds__(WR* WC * 64, 4) void dgemm_kernel(DgemmArgs a) {
+  constexpr int NT = WR * WC * 64;
+  constexpr int WM = BM / WR, WN = BN / WC;
   constexpr int FM = WM / 16, FN = WN / 16;
-  constexpr int LDA = BM + PAD, LDB = BN + PAD;
-  extern __shared__ double lds[];
-  double* As = lds;                      // [2][BK][LDA]
-  double* Bs = lds + 2 * BK * LDA;       // [2][BK][LDB]
+  using LA = TileLoader<BM, NT, AKC, VEC>;
+  using LB = TileLoader<BN, NT, BKC, VEC>;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* As = lds;                             // [2][LA::LDS_DOUBLES]
+  double* Bs = lds + 2 * LA::LDS_DOUBLES;       // [2][LB::LDS_DOUBLES]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+  const int wm = (wave / WC) * WM, wn = (wave % WC) * WN;
   long tile = blockIdx.x;
   if (a.remap) {
     const long per = (long)gridDim.x >> 3;
@@ -92,7 +119,6 @@ __global__ __launch_bounds__(256) void dgemm_kernel(DgemmArgs a) {
   const long m0 = tm * BM, n0 = tn * BN;
   const long kbeg = (long)blockIdx.y * a.k_per_split;
   const long kend = min(a.K, kbeg + a.k_per_split);
-  const bool a_kc = a.a_sk == 1, b_kc = a.b_sk == 1;
 
   d4 acc[FM][FN];
 #pragma unroll
@@ -100,14 +126,14 @@ __global__ __launch_bounds__(256) void dgemm_kernel(DgemmArgs a) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
-  TileLoader<BM> la;
-  TileLoader<BN> lb;
+  LA la;
+  LB lb;
   const long ktiles = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
   if (ktiles > 0) {
-    la.load(a.A, a.a_sm, a.a_sk, m0, kbeg, a.M, kend, a_kc, tid);
-    lb.load(a.B, a.b_sn, a.b_sk, n0, kbeg, a.N, kend, b_kc, tid);
-    la.store(As, a_kc, tid);
-    lb.store(Bs, b_kc, tid);
+    la.load(a.A, a.lda, m0, kbeg, a.M, kend, tid);
+    lb.load(a.B, a.ldb, n0, kbeg, a.N, kend, tid);
+    la.store(As, tid);
+    lb.store(Bs, tid);
   }
   __syncthreads();
   const int fr = lane & 15, fk = lane >> 4;
@@ -115,26 +141,26 @@ __global__ __launch_bounds__(256) void dgemm_kernel(DgemmArgs a) {
     const int cur = (int)(kt & 1);
     const bool more = kt + 1 < ktiles;
     if (more) {
-      la.load(a.A, a.a_sm, a.a_sk, m0, kbeg + (kt + 1) * BK, a.M, kend, a_kc, tid);
-      lb.load(a.B, a.b_sn, a.b_sk, n0, kbeg + (kt + 1) * BK, a.N, kend, b_kc, tid);
+      la.load(a.A, a.lda, m0, kbeg + (kt + 1) * BK, a.M, kend, tid);
+      lb.load(a.B, a.ldb, n0, kbeg + (kt + 1) * BK, a.N, kend, tid);
     }
-    const double* Ac = As + cur * BK * LDA;
-    const double* Bc = Bs + cur * BK * LDB;
+    const double* Ac = As + cur * LA::LDS_DOUBLES;
+    const double* Bc = Bs + cur * LB::LDS_DOUBLES;
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s) {
       double af[FM], bf[FN];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = Ac[(4 * s + fk) * LDA + wm + 16 * i + fr];
+      for (int i = 0; i < FM; ++i) af[i] = LA::at(Ac, wm + 16 * i + fr, 4 * s + fk);
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bf[j] = Bc[(4 * s + fk) * LDB + wn + 16 * j + fr];
+      for (int j = 0; j < FN; ++j) bf[j] = LB::at(Bc, wn + 16 * j + fr, 4 * s + fk);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
-      la.store(As + (cur ^ 1) * BK * LDA, a_kc, tid);
-      lb.store(Bs + (cur ^ 1) * BK * LDB, b_kc, tid);
+      la.store(As + (cur ^ 1) * LA::LDS_DOUBLES, tid);
+      lb.store(Bs + (cur ^ 1) * LB::LDS_DOUBLES, tid);
     }
     __syncthreads();
   }
@@ -229,21 +255,40 @@ __global__ __launch_bounds__(256) void fill_uniform_f64_kernel(double* __restric
   }
 }
 
-template <int BM, int BN>
-int launch_dgemm(eg_ctx* ctx, DgemmArgs& a) {
-  constexpr size_t lds = (size_t)2 * BK * ((BM + PAD) + (BN + PAD)) * sizeof(double);
+template <int BM, int BN, int WR, int WC, bool AKC, bool BKC, bool VEC>
+int launch_one(eg_ctx* ctx, DgemmArgs& a) {
+  using LA = TileLoader<BM, WR * WC * 64, AKC, VEC>;
+  using LB = TileLoader<BN, WR * WC * 64, BKC, VEC>;
+  constexpr size_t lds = (size_t)2 * (LA::LDS_DOUBLES + LB::LDS_DOUBLES) * sizeof(double);
   static bool attr_set = false;
   if (!attr_set) {
-    EG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dgemm_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    EG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&dgemm_kernel<BM, BN, WR, WC, AKC, BKC, VEC>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   a.tiles_m = (int)((a.M + BM - 1) / BM);
   a.tiles_n = (int)((a.N + BN - 1) / BN);
   const long tiles = (long)a.tiles_m * a.tiles_n;
   a.remap = tiles % 8 == 0 && tiles >= 16;
-  hipLaunchKernelGGL((dgemm_kernel<BM, BN>), dim3((unsigned)tiles, (unsigned)a.splits), dim3(256), lds, ctx->stream, a);
+  hipLaunchKernelGGL((dgemm_kernel<BM, BN, WR, WC, AKC, BKC, VEC>), dim3((unsigned)tiles, (unsigned)a.splits), dim3(WR * WC * 64), lds, ctx->stream, a);
   EG_HIP_CHECK(hipGetLastError());
   return EG_OK;
+}
+
+template <int BM, int BN, int WR, int WC>
+int launch_dgemm(eg_ctx* ctx, DgemmArgs& a, bool akc, bool bkc, bool vec) {
+#define EG_DGEMM_CASE(AK, BK_, V) \
+  if (akc == AK && bkc == BK_ && vec == V) return launch_one<BM, BN, WR, WC, AK, BK_, V>(ctx, a);
+  EG_DGEMM_CASE(true, true, true)
+  EG_DGEMM_CASE(true, false, true)
+  EG_DGEMM_CASE(false, true, true)
+  EG_DGEMM_CASE(false, false, true)
+  EG_DGEMM_CASE(true, true, false)
+  EG_DGEMM_CASE(true, false, false)
+  EG_DGEMM_CASE(false, true, false)
+  EG_DGEMM_CASE(false, false, false)
+#undef EG_DGEMM_CASE
+  return EG_ERR_INVALID;
 }
 
 }  // namespace
@@ -296,38 +341,72 @@ extern "C" int eg_dgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_
   a.M = M;
   a.N = N;
   a.K = K;
-  a.a_sm = trans_a ? 1 : lda;
-  a.a_sk = trans_a ? lda : 1;
-  a.b_sk = trans_b ? 1 : ldb;
-  a.b_sn = trans_b ? ldb : 1;
-  // (an operand with a single column / row has stride 1 both ways: treat it as k-contiguous only if it really is)
+  a.lda = lda;
+  a.ldb = ldb;
   a.ldc = ldc;
+  // A(m, k): [M, K] rows are k-contiguous unless transposed; B(k, n): [K, N] rows are n-contiguous unless transposed
+  const bool akc = !trans_a, bkc = trans_b != 0;
+  const bool vec = lda % 2 == 0 && ldb % 2 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
   a.accumulate = accumulate;
   a.splits = 1;
   a.k_per_split = ((K + BK - 1) / BK) * BK;
   if (a.k_per_split == 0) a.k_per_split = BK;
+  // Tile shape by a small time model.  What a SIMD's matrix pipe delivers depends on how many waves multiply on it at the
+  // same time (tools/mfma_ceiling_f64.hip: one wave 0.44 of peak, two 0.99 in a bare loop), so a launch is priced as
+  // rounds of resident blocks, each round at the rate of the waves it puts on a SIMD:
+  //   config        waves  blocks / CU (LDS)   relative loop efficiency
+  //   128 x 128     8      2 (74 KB)           1.00
+  //   128 x  64     8      2 (55 KB)           0.97
+  //    64 x  64     8      4 (37 KB)           0.92
   const long cus = ctx->compute_units;
-  const long tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
-  const bool big = tiles128 >= 2 * cus;
-  const long tiles = big ? tiles128 : ((M + 63) / 64) * ((N + 63) / 64);
-  if (!big && tiles < cus && K >= 1024) {
-    long splits = (2 * cus + tiles - 1) / tiles;
-    const long max_splits = K / 256;
-    if (splits > max_splits) splits = max_splits;
-    if (splits > 1) {
-      long per = (K + splits - 1) / splits;
-      per = ((per + BK - 1) / BK) * BK;
-      splits = (K + per - 1) / per;
-      if (splits > 1) {
-        rc = eg::ensure_workspace(ctx, (size_t)splits * M * N * sizeof(double));
-        if (rc) return rc;
-        a.splits = (int)splits;
-        a.k_per_split = per;
-        a.C = static_cast<double*>(ctx->workspace);
+  struct Cfg { int bm, bn, cap; double eff; };
+  static const Cfg cfgs[3] = {{128, 128, 2, 1.0}, {128, 64, 2, 0.97}, {64, 64, 4, 0.92}};
+  auto rate = [](long waves_per_simd) { return waves_per_simd <= 1 ? 0.44 : waves_per_simd == 2 ? 0.80 : waves_per_simd == 3 ? 0.88 : 0.92; };
+  auto cost = [&](const Cfg& c, long splits) {
+    const long tiles = ((M + c.bm - 1) / c.bm) * ((N + c.bn - 1) / c.bn) * splits;
+    const double t_tile = (double)c.bm * c.bn * ((double)K / splits) / c.eff;  // matrix work of one block at the pipe's full rate
+    const long slots = cus * c.cap;
+    const long full = tiles / slots, rem = tiles % slots;
+    double t = (double)full * c.cap * t_tile / rate(2L * c.cap);  // 8-wave blocks: two waves per SIMD each
+    if (rem > 0) {
+      const long per_cu = (rem + cus - 1) / cus;
+      t += (double)per_cu * t_tile / rate(2L * per_cu);
+    }
+    // slabs out and back (16 bytes per element and slice at ~3 TB/s, in units of a CU's 64 multiply-adds per clock) and a second launch (~5 us)
+    if (splits > 1) t += (double)M * N * splits * 1.0 + 8.0e5;
+    return t;
+  };
+  int best = 0;
+  long best_splits = 1;
+  double best_t = 1e300;
+  for (int c = 0; c < 3; ++c)
+    for (long splits = 1; splits <= 64 && (splits == 1 || K / splits >= 256); splits *= 2) {
+      const double t = cost(cfgs[c], splits);
+      if (t < best_t) {
+        best_t = t;
+        best = c;
+        best_splits = splits;
       }
     }
+  if (const char* e = getenv("EG_DGEMM_TILE")) {  // measurement aid: "<config>[,<splits>]"
+    best = atoi(e) % 3;
+    if (const char* comma = strchr(e, ',')) best_splits = atol(comma + 1) > 0 ? atol(comma + 1) : 1;
   }
-  rc = big ? launch_dgemm<128, 128>(ctx, a) : launch_dgemm<64, 64>(ctx, a);
+  if (best_splits > 1) {
+    long per = (K + best_splits - 1) / best_splits;
+    per = ((per + BK - 1) / BK) * BK;
+    const long splits = (K + per - 1) / per;
+    if (splits > 1) {
+      rc = eg::ensure_workspace(ctx, (size_t)splits * M * N * sizeof(double));
+      if (rc) return rc;
+      a.splits = (int)splits;
+      a.k_per_split = per;
+      a.C = static_cast<double*>(ctx->workspace);
+    }
+  }
+  rc = best == 0   ? launch_dgemm<128, 128, 2, 4>(ctx, a, akc, bkc, vec)
+       : best == 1 ? launch_dgemm<128, 64, 4, 2>(ctx, a, akc, bkc, vec)
+                   : launch_dgemm<64, 64, 2, 4>(ctx, a, akc, bkc, vec);
   if (rc) return rc;
   if (a.splits > 1) {
     hipLaunchKernelGGL(dgemm_reduce_kernel, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, ctx->stream, static_cast<const double*>(ctx->workspace), C,
