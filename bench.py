@@ -631,7 +631,8 @@ def run_float64(args, env):
     benchmark: eg_dgemm at three sizes against the float64 matrix peak (v_mfma_f64_16x16x4_f64: 32 FLOP / clk / SIMD,
     measured ceiling 77.8 TFLOP/s, tools/mfma_ceiling_f64.hip), and the reference's conv2 benchmark program in its own type
     and shape (benchmarks/conv2/conv2.nim:128-138, 330-364: image 960 x 1280 x 8, 8 filters of 3 x 3 x 8, float64) through
-    eg_model_run on device-resident inputs — a generated kernel over double, HBM-bound (157 MB per call)."""
+    eg_model_run on device-resident inputs — the direct float64 convolution (kernels/conv2_direct.cpp: 16 pixels x 4 taps x
+    16 filter columns per matrix instruction, input rows staged in LDS), 157 MB per call against 1.4 GFLOP."""
     import ctypes
     import numpy as np
     from exprgrad_amd import _lib, examples
@@ -669,6 +670,9 @@ def run_float64(args, env):
         "workload": "benchmarks/conv2/conv2.nim:330-364: 960 x 1280 x 8 image, 8 filters 3 x 3 x 8, float64, compile[float64] + call",
         "ms_per_call": round(elapsed / steps * 1e3, 4), "gflops": round(flops * steps / elapsed / 1e9, 1),
         "algorithmic_gbs": round(nbytes * steps / elapsed / 1e9, 1), "frac_of_hbm_peak": round(nbytes * steps / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+        # 18 matrix instructions per 16 pixels whatever F <= 16 is: the instruction-bound time of this shape is 36 us
+        "matrix_instruction_bound_ms": round((H - 2) * (W - 2) / 16.0 * 18 * 64 / (1024 * 2.4e9) * 1e3, 4),
+        "kernel": "eg_conv_mfma64_c8_f8_3x3 (v_mfma_f64_16x16x4_f64, a ring of 4 input row segments in LDS per 128-pixel column strip)",
         "launches": model.launch_plan("conv2").strip().splitlines()}
     model.close()
     return out

@@ -138,6 +138,8 @@ int row_finalize(eg_ctx* ctx, const float* partial, int nblocks, int E, const Ro
 // Direct per-pixel kernels for few input channels (kernels/conv2_direct.cpp), same convention.
 int conv2_direct_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
                      const float* flt, float* out, int accumulate, bool* launched);
+int conv2_direct_f64_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const double* img, const double* flt,
+                         double* out, int accumulate, bool* launched);
 int conv2_direct_grad_filter_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
                                  const float* gout, float* gflt, int accumulate, bool* launched);
 // LDS-halo convolution (kernels/conv2_halo.hip); *launched = false when the problem does not suit it.

@@ -558,6 +558,28 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
         int rc = fill_params(m, k, info, shapes, lo.mode_a.src, !overwrite, total, rtotal, 0, L.params);
         if (rc) return rc;
         note_vec4(L, total);
+        ConvMatch cm;
+        if (m->f64 && match_conv(k, cm) && cm.role == ConvMatch::Forward) {
+          // (operands of a matched forward convolution: image = reads[img_op], filters = reads[flt_op], the result is written)
+          const std::vector<long>& is = shapes.at(k.reads[cm.img_op].tensor);
+          const std::vector<long>& fs = shapes.at(k.reads[cm.flt_op].tensor);
+          const int o = cm.batched ? 1 : 0;
+          const bool valid = fs.size() == 4 && is.size() == (size_t)(3 + o) && wshape.size() == is.size() && fs[3] == is[o + 2] &&
+                             wshape[o] == is[o] - fs[1] + 1 && wshape[o + 1] == is[o + 1] - fs[2] + 1 && wshape[o + 2] == fs[0] &&
+                             (!cm.batched || wshape[0] == is[0]) && full_cover(k, info, wshape);
+          if (valid) {
+            L.conv_direct64 = true;
+            L.cN = cm.batched ? is[0] : 1;
+            L.cH = is[o];
+            L.cW = is[o + 1];
+            L.cC = is[o + 2];
+            L.cF = fs[0];
+            L.cFH = fs[1];
+            L.cFW = fs[2];
+            L.a_tensor = k.reads[cm.img_op].tensor;
+            L.b_tensor = k.reads[cm.flt_op].tensor;
+          }
+        }
       }
       for (size_t si = 0; si < L.generic->src.slots.size(); ++si) {
         const Slot& sl = L.generic->src.slots[si];

@@ -212,6 +212,13 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
     case StepKind::GenericA:
     case StepKind::GenericB: {
       if (L.blocks_x <= 0 || L.blocks_y <= 0) return EG_OK;
+      if (L.conv_direct64) {
+        bool launched = false;
+        auto dp = [&](int t) { return reinterpret_cast<double*>(tensor_ptr(m, ts, plan, t)); };
+        int rc = eg::conv2_direct_f64_try(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, dp(L.a_tensor), dp(L.b_tensor), dp(L.c_tensor),
+                                          L.accumulate, &launched);
+        if (rc || launched) return rc;
+      }
       const GenericSource& src = L.generic->src;
       std::vector<void*> args;
       std::vector<float*> ptrs;

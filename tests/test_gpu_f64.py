@@ -38,18 +38,22 @@ def text64(graphs):
 
 # ---- group 2: eg_dgemm -------------------------------------------------------------------------------------------------
 def dgemm(ctx, a, b, ta, tb, M, N, K, c0=None, bias=None):
-    import torch
-    dev = torch.device("cuda", ctx.device)
-    A = torch.from_numpy(a).to(dev)
-    B = torch.from_numpy(b).to(dev)
-    C = torch.from_numpy(c0.copy()).to(dev) if c0 is not None else torch.full((M, N), float("nan"), dtype=torch.float64, device=dev)
-    bias_t = torch.from_numpy(bias).to(dev) if bias is not None else None
-    torch.cuda.synchronize()
-    _lib.call("eg_dgemm", ctx.handle, int(ta), int(tb), M, N, K, ctypes.c_void_p(A.data_ptr()), a.shape[1],
-              ctypes.c_void_p(B.data_ptr()), b.shape[1], ctypes.c_void_p(C.data_ptr()), N, 1 if c0 is not None else 0,
-              ctypes.c_void_p(bias_t.data_ptr()) if bias is not None else None)
-    ctx.sync()
-    return C.cpu().numpy()
+    """eg_dgemm on the library's own buffers (group 1 of the C ABI: allocBuffer / write / readInto)."""
+    def put(x):
+        buf = ctx.allocBuffer(x.nbytes)
+        buf.write(np.ascontiguousarray(x, dtype=np.float64))
+        return buf
+    A, B = put(a), put(b)
+    C = put(c0 if c0 is not None else np.full((M, N), np.nan))
+    bias_b = put(bias) if bias is not None else None
+    _lib.call("eg_dgemm", ctx.handle, int(ta), int(tb), M, N, K, ctypes.c_void_p(A.ptr), a.shape[1], ctypes.c_void_p(B.ptr), b.shape[1],
+              ctypes.c_void_p(C.ptr), N, 1 if c0 is not None else 0, ctypes.c_void_p(bias_b.ptr) if bias is not None else None)
+    out = np.empty((M, N), dtype=np.float64)
+    C.readInto(out)
+    for buf in (A, B, C, bias_b):
+        if buf is not None:
+            buf.dealloc()
+    return out
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
@@ -277,4 +281,64 @@ def test_matmul_program_f64_full_tiles(gpu_ctx):
     rng = np.random.default_rng(4)
     a, b = rng.random((512, 512)) - 0.5, rng.random((512, 512)) - 0.5
     assert rel(gpu.call("c", {"a": a, "b": b}), ref.call("c", {"a": a, "b": b})) <= 1e-13
+    gpu.close()
+
+
+def conv_numpy(image, filters):
+    """out[n, y, x, f] = sum_{dy, dx, c} image[n, y + dy, x + dx, c] * filters[f, dy, dx, c] as FH * FW small matrix products."""
+    F, FH, FW, C = filters.shape
+    Ho, Wo = image.shape[-3] - FH + 1, image.shape[-2] - FW + 1
+    out = np.zeros(image.shape[:-3] + (Ho, Wo, F))
+    for dy in range(FH):
+        for dx in range(FW):
+            out += image[..., dy:dy + Ho, dx:dx + Wo, :] @ filters[:, dy, dx, :].T
+    return out
+
+
+@pytest.mark.parametrize("H,W,C,F,FH", [(130, 90, 8, 8, 3), (100, 120, 8, 16, 3), (200, 200, 1, 1, 3), (96, 100, 3, 5, 5)])
+def test_direct_convolution_f64(gpu_ctx, H, W, C, F, FH):
+    """The shapes of the reference's conv2 benchmark targets (conv2.nim:134-138: 8 -> 8, 8 -> 16, 1 -> 1 filters of 3 x 3) with
+    enough pixels for the direct per-pixel kernel over double (kernels/conv2_direct.cpp), against the oracle."""
+    from oracle import kd
+    gpu = egm.compile(*examples.conv2_3d(), gpu=gpu_ctx, dtype=np.float64)
+    ref = kd.Model(text64(examples.conv2_3d()))
+    rng = np.random.default_rng(H + C)
+    image, filters = rng.random((H, W, C)), rng.random((F, FH, FH, C)) * 4 - 2
+    got = gpu.call("conv2", {"image": image, "filters": filters})
+    want = ref.call("conv2", {"image": image, "filters": filters})
+    assert rel(got, want) <= TOL64
+    assert rel(got, conv_numpy(image, filters)) <= TOL64
+    gpu.close()
+
+
+def test_conv2_benchmark_full_size_f64(gpu_ctx):
+    """benchmarks/conv2/conv2.nim:330-364 at its own size (960 x 1280 x 8 image, 8 filters of 3 x 3 x 8, float64): 1.2 M
+    pixels, against nine float64 matrix products per tap on the host; and linear in the filter bank (a size-independent
+    property: conv(a, f + g) = conv(a, f) + conv(a, g) to rounding)."""
+    gpu = egm.compile(*examples.conv2_3d(), gpu=gpu_ctx, dtype=np.float64)
+    rng = np.random.default_rng(9)
+    image = rng.random((960, 1280, 8))
+    f, g = rng.random((8, 3, 3, 8)) * 4 - 2, rng.random((8, 3, 3, 8)) * 4 - 2
+    out_f = gpu.call("conv2", {"image": image, "filters": f})
+    assert out_f.shape == (958, 1278, 8)
+    assert rel(out_f, conv_numpy(image, f)) <= 1e-13
+    out_g = gpu.call("conv2", {"image": image, "filters": g})
+    out_fg = gpu.call("conv2", {"image": image, "filters": f + g})
+    assert rel(out_fg, out_f + out_g) <= 1e-13
+    gpu.close()
+
+
+def test_batched_convolution_layer_f64(gpu_ctx):
+    """layers.conv2 (dnn.nim:45-49, four-dimensional images) in float64 with its two gradients (generated kernels) in a
+    training step: conv2 -> mse -> gradientDescent against the oracle."""
+    def net():
+        out = layers.conv2(dsl.input("x"), 4, 3, 3, 6).target("predict")
+        return [layers.mse(out, dsl.input("y")).target("loss").backprop(layers.gradient_descent(0.05)).target("train")]
+    gpu, ref, rng = step_pair(gpu_ctx, net, 21)
+    x, y = rng.random((12, 30, 34, 4)), rng.random((12, 28, 32, 6))
+    assert rel(gpu.call("predict", {"x": x}), ref.call("predict", {"x": x})) <= TOL64
+    for step in range(2):
+        gpu.apply("train", {"x": x, "y": y})
+        ref.apply("train", {"x": x, "y": y})
+        compare_state(gpu, ref, 1e-11, f"step {step}")
     gpu.close()
