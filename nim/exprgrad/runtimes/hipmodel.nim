@@ -41,7 +41,28 @@ proc eg_model_state_bytes(model: ptr EgModel, bytes: ptr csize_t): cint
 proc eg_model_store_state(model: ptr EgModel, buf: pointer, cap: csize_t, written: ptr csize_t): cint
 proc eg_model_load_state(model: ptr EgModel, buf: pointer, bytes: csize_t, consumed: ptr csize_t): cint
 proc eg_last_error(): cstring
+# compile[float64] (model.nim:253-260): the float64 twins of the typed entry points (include/exprgrad_hip.h)
+proc eg_model_set_input_host_f64(model: ptr EgModel, name: cstring, host: ptr float64, rank: cint, shape: ptr int64): cint
+proc eg_model_fit_f64(model: ptr EgModel, target: cstring, nInputs: cint, names: ptr cstring, data: ptr ptr float64,
+                      onDevice: ptr cint, ranks: ptr cint, shapes8: ptr int64, batchSize: int64): cint
+proc eg_model_read_output_f64(model: ptr EgModel, target: cstring, host: ptr float64, count: int64): cint
+proc eg_model_param_write_f64(model: ptr EgModel, tensor: cint, host: ptr float64, count: int64): cint
+proc eg_model_param_read_f64(model: ptr EgModel, tensor: cint, host: ptr float64, count: int64): cint
 {.pop.}
+
+# The typed calls by the model's T (float32 / float64: toScalarType, model.nim:253-260)
+template setInputHost[T](model: ptr EgModel, name: cstring, host: ptr T, rank: cint, shape: ptr int64): cint =
+  when T is float64: eg_model_set_input_host_f64(model, name, host, rank, shape)
+  else: eg_model_set_input_host(model, name, host, rank, shape)
+template readOutput[T](model: ptr EgModel, target: cstring, host: ptr T, count: int64): cint =
+  when T is float64: eg_model_read_output_f64(model, target, host, count)
+  else: eg_model_read_output(model, target, host, count)
+template paramWrite[T](model: ptr EgModel, tensor: cint, host: ptr T, count: int64): cint =
+  when T is float64: eg_model_param_write_f64(model, tensor, host, count)
+  else: eg_model_param_write(model, tensor, host, count)
+template paramRead[T](model: ptr EgModel, tensor: cint, host: ptr T, count: int64): cint =
+  when T is float64: eg_model_param_read_f64(model, tensor, host, count)
+  else: eg_model_param_read(model, tensor, host, count)
 
 # Status codes of include/exprgrad_hip.h that map onto exceptions of their own (tests/test_errors.nim expects them).
 const
@@ -373,8 +394,8 @@ proc toKd*(source: Program): string =
   ## Kernel-description text of a Program as `toProgram` built it (parser.nim:404-417), i.e. model.source
   ## (model.nim:232-236).  The passes that only normalise — makeTensorLookups, deadCodeElim, foldLinearIndices,
   ## deduplicateReads (model.nim:47-50) — run here on a clone; generate and everything after it is the library's job.
-  if source.scalarType != Scalar32:
-    raise GeneratorError(msg: "the HIP backend computes in float32 (compile[float32]); float64 models keep the LLVM path")
+  # the scalar type (Scalar32 / Scalar64, ir.nim; set by compile[T] through toScalarType, model.nim:253-260) is the header's
+  # third word: a float64 program runs on eg_dgemm + generated kernels over double
   let program = source.clone()
   program.makeTensorLookups()
   program.deadCodeElim()
@@ -410,7 +431,7 @@ proc toKd*(source: Program): string =
     for constr in target.shapes:
       constr.emitShapeConstraint(shapeLines, shaped)
 
-  var lines = @["kd 1 f32"]
+  var lines = @[if source.scalarType == Scalar64: "kd 1 f64" else: "kd 1 f32"]
   for it, def in program.tensors:
     # tensor <id> input|param|result|cache|random <name|-> <rank|-1> <dims...> [<lo> <hi>]
     var
@@ -454,14 +475,14 @@ type
 proc newHipModel*[T](source: Program, ctx: GpuContext, params, caches: Table[TensorId, Tensor[T]]): HipModel[T] =
   ## newModel for the GPU side (model.nim:215-251): compile, then upload the parameter values the host drew
   ## (parser.nim:714 initRange through newRandTensor, model.nim:241-249) so that host and device start identical.
-  when T isnot float32:
-    {.error: "the HIP backend is float32 only".}
+  when T isnot float32 and T isnot float64:
+    {.error: "not a valid scalar type".}   # model.nim:259
   result = HipModel[T](ctx: ctx, program: source)
   check eg_model_compile(ctx.rawHandle(), source.toKd().cstring, result.handle.addr)
   for id, tensor in params:
-    check eg_model_param_write(result.handle, cint(int(id)), tensor.data[0].addr, int64(tensor.len))
+    check paramWrite[T](result.handle, cint(int(id)), tensor.data[0].addr, int64(tensor.len))
   for id, tensor in caches:
-    check eg_model_param_write(result.handle, cint(int(id)), tensor.data[0].addr, int64(tensor.len))
+    check paramWrite[T](result.handle, cint(int(id)), tensor.data[0].addr, int64(tensor.len))
 
 proc close*[T](model: HipModel[T]) =
   if not model.handle.isNil:
@@ -476,7 +497,7 @@ proc bindInputs[T](model: HipModel[T], args: openArray[(string, Tensor[T])]) =
     var shape = newSeq[int64](max(tensor.shape.len, 1))
     for it, size in tensor.shape:
       shape[it] = int64(size)
-    check eg_model_set_input_host(model.handle, name.cstring, tensor.data[0].addr, cint(tensor.shape.len), shape[0].addr)
+    check setInputHost[T](model.handle, name.cstring, tensor.data[0].addr, cint(tensor.shape.len), shape[0].addr)
 
 proc call*[T](model: HipModel[T], target: string, args: openArray[(string, Tensor[T])] = []): Tensor[T] =
   ## Model.call (model.nim:392-406): writeInput per argument, inferShapes + allocShapes + the kernel list
@@ -495,7 +516,7 @@ proc call*[T](model: HipModel[T], target: string, args: openArray[(string, Tenso
       shape[it] = int(shape8[it])
     result = newTensor[T](shape)
     if result.len > 0:
-      check eg_model_read_output(model.handle, target.cstring, result.data[0].addr, int64(result.len))
+      check readOutput[T](model.handle, target.cstring, result.data[0].addr, int64(result.len))
 
 proc apply*[T](model: HipModel[T], target: string, args: openArray[(string, Tensor[T])] = []) =
   ## Model.apply (model.nim:408-411) — without reading an output back
@@ -510,7 +531,7 @@ proc fit*[T](model: HipModel[T], target: string, args: openArray[(string, Tensor
     raise RuntimeError(msg: "Model.fit requires at least one input tensor. Use Model.apply instead if the target has zero inputs.")
   var
     names = newSeq[cstring](args.len)
-    data = newSeq[ptr float32](args.len)
+    data = newSeq[ptr T](args.len)
     onDevice = newSeq[cint](args.len)
     ranks = newSeq[cint](args.len)
     shapes8 = newSeq[int64](8 * args.len)
@@ -520,16 +541,20 @@ proc fit*[T](model: HipModel[T], target: string, args: openArray[(string, Tensor
     ranks[it] = cint(tensor.shape.len)
     for dim, size in tensor.shape:
       shapes8[8 * it + dim] = int64(size)
-  check eg_model_fit(model.handle, target.cstring, cint(args.len), names[0].addr, data[0].addr, onDevice[0].addr,
-                     ranks[0].addr, shapes8[0].addr, int64(batchSize))
+  when T is float64:
+    check eg_model_fit_f64(model.handle, target.cstring, cint(args.len), names[0].addr, data[0].addr, onDevice[0].addr,
+                           ranks[0].addr, shapes8[0].addr, int64(batchSize))
+  else:
+    check eg_model_fit(model.handle, target.cstring, cint(args.len), names[0].addr, data[0].addr, onDevice[0].addr,
+                       ranks[0].addr, shapes8[0].addr, int64(batchSize))
 
 proc readParam*[T](model: HipModel[T], id: TensorId, into: Tensor[T]) =
   ## The device copy is the truth once a GPU target has run (the reference never copies GPU-side updates back:
   ## stateLocation only grows, model.nim:326-345)
-  check eg_model_param_read(model.handle, cint(int(id)), into.data[0].addr, int64(into.len))
+  check paramRead[T](model.handle, cint(int(id)), into.data[0].addr, int64(into.len))
 
 proc writeParam*[T](model: HipModel[T], id: TensorId, value: Tensor[T]) =
-  check eg_model_param_write(model.handle, cint(int(id)), value.data[0].addr, int64(value.len))
+  check paramWrite[T](model.handle, cint(int(id)), value.data[0].addr, int64(value.len))
 
 proc epoch*[T](model: HipModel[T]): int = int(eg_model_epoch(model.handle))
 proc `epoch=`*[T](model: HipModel[T], value: int) = check eg_model_set_epoch(model.handle, int64(value))
