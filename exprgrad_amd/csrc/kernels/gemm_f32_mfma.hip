@@ -445,6 +445,36 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
       return EG_OK;
     }
   }
+  // 96 x 96 tiles (round 5): an output that is ONE round of them — 1536^2 = 256 tiles on 256 CUs — is 2.25 rounds of 64 x 64
+  // tiles (576 blocks: three on some CUs, two on others: 0.59 of peak) and a quarter of a round of 256 x 256.  Same kernel as
+  // the wave pairs (gemm_f32_pair.hpp), three 96 x 32 sub-tiles per block, each shared by FOUR waves that split every
+  // 64-deep k-tile (12 waves = three per SIMD, 24 matrix instructions per wave and k-tile).  EG_GEMM_NO_PAIR=1 keeps 64 x 64.
+  {
+    const long t96 = (M / 96) * (N / 96);
+    const bool on = getenv("EG_GEMM_NO_PAIR") == nullptr && getenv("EG_GEMM_NO_T96") == nullptr && getenv("EG_GEMM_FORCE_TILE") == nullptr &&
+                    getenv("EG_GEMM_FORCE_SPLITS") == nullptr;
+    if (on && !conv && vec_ok && !a_vec_only && !args.ones_row && M % 96 == 0 && N % 96 == 0 && K % 64 == 0 && K >= 512 &&
+        t96 <= ctx->compute_units && 4 * t96 > 3L * ctx->compute_units && args.ldc % 4 == 0 && aligned16(args.C) &&
+        (args.bias == nullptr || aligned16(args.bias))) {
+      args.tiles_m = (int)(M / 96);
+      args.tiles_n = (int)(N / 96);
+      args.partial = nullptr;
+      args.splits = 1;
+      args.k_per_split = K;
+      args.prio = side_priority(ctx);
+      args.nt_store = nt_store_enabled();
+      args.no_skew = getenv("EG_GEMM_NO_SKEW") != nullptr;
+      dim3 grid((unsigned)t96), block(768);
+#define EG_T96(AKC, BKC) hipLaunchKernelGGL((gemm_pair_kernel<96, 96, 96, 32, AKC, BKC, 0, 2, 64, false, 4>), grid, block, 0, ctx->stream, args)
+      if (a_kc && !b_kc) EG_T96(true, false);
+      else if (a_kc && b_kc) EG_T96(true, true);
+      else if (!a_kc && !b_kc) EG_T96(false, false);
+      else EG_T96(false, true);
+#undef EG_T96
+      EG_HIP_CHECK(hipGetLastError());
+      return EG_OK;
+    }
+  }
   // A few rows / columns beyond whole 256 x 256 tiles of a large output (4100 = 16 x 256 + 4): the ragged
   // tile row and column stage whole operand tiles for 1/64 of the matrix work and push the launch into another
   // round of blocks (4100 x 4096 x 4096: +76 us, 4096 x 4100 x 4096: +154 us over 969 us).  As contractions
@@ -684,6 +714,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   if (pair_on && BM == 64 && BN == 64 && vec && !conv && splits <= 1 && args.tail_tiles == 0 && args.edge_splits == 0 &&
       args.wide_store && !args.ones_row && (long)args.tiles_m * args.tiles_n <= ctx->compute_units) {
     const bool ragged = edge || K % 64 != 0;
+    // (four waves per sub-tile, 16 per block, 128-deep k-tiles: 1024^3 21.9 us either way, 1024 x 1024 x 4096 76.1 against 77.2 — not taken)
     dim3 grid((unsigned)((long)args.tiles_m * args.tiles_n)), block(512);
 #define EG_PAIR(AKC, BKC)                                                                                                  \
   do {                                                                                                                     \

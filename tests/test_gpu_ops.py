@@ -365,6 +365,9 @@ def test_tail_tiles_are_cut_along_k(gpu_ctx, case):
     # whole 256 x 256 tiles + remainder rows + remainder columns as contractions of their own, K ending inside a k-tile
     (4100, 4100, 260, False, False, True, True), (4104, 4096, 100, True, False, False, False),
     (4096, 4128, 72, False, True, True, False), (4100, 4100, 260, True, True, False, True),
+    # one round of 96 x 96 tiles, four waves per 96 x 32 sub-tile (round 5): every layout, accumulate and bias, 193 .. 256 tiles
+    (1536, 1536, 1536, False, False, False, False), (1536, 1536, 640, True, False, True, True), (1440, 1536, 512, False, True, False, True),
+    (1536, 1248, 1024, True, True, True, False), (1344, 1440, 576, False, False, True, True),
     # skinny outputs next to the wide-tile model's boundary
     (8192, 128, 512, False, False, False, False), (100, 8192, 512, False, False, True, True), (65, 65, 5000, True, False, False, False)])
 def test_mid_size_and_remainder_contractions(gpu_ctx, case):
