@@ -475,6 +475,8 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
       return EG_OK;
     }
   }
+  // (the same design on one round of 128 x 128 tiles — four 64 x 64 sub-tiles x four waves — measured equal to what the model
+  //  picks: 2048^3 129.1 against 130.7 us, 1792^3 113.1 / 113.9, 2048 x 2048 x 512 40.8 / 39.2: the gain above is the whole round, not the wave count)
   // A few rows / columns beyond whole 256 x 256 tiles of a large output (4100 = 16 x 256 + 4): the ragged
   // tile row and column stage whole operand tiles for 1/64 of the matrix work and push the launch into another
   // round of blocks (4100 x 4096 x 4096: +76 us, 4096 x 4100 x 4096: +154 us over 969 us).  As contractions
