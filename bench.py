@@ -654,6 +654,10 @@ def run_float64(args, env):
         tflops = 2.0 * n * n * n * steps / elapsed / 1e12
         rows[str(n)] = {"us_per_launch": round(elapsed / steps * 1e6, 2), "tflops": round(tflops, 2),
                         "frac_of_f64_mfma_peak": round(tflops / F64_MFMA_PEAK_TFLOPS, 4), "kernel_us_by_events": round(ev_avg * 1e3, 2)}
+        clock = timer.last_clock
+        if clock and clock.get("mhz"):   # the float64 matrix rate at the clock the timed launches ran at: 32 FLOP / clk / SIMD x 1024
+            at_clock = clock["mhz"] * 1e6 * 32768 / 1e12
+            rows[str(n)].update({"effective_clock_mhz": clock["mhz"], "frac_of_rate_at_effective_clock": round(tflops / at_clock, 4)})
     out = {"metric": "TFLOP/s of C = A*B, M = N = K, float64, through eg_dgemm", "unit": "TFLOP/s", "sizes": rows, "timed_steps": steps,
            "roofline": {"bound": "mfma", "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "achieved": rows["4096"]["tflops"],
                         "frac": rows["4096"]["frac_of_f64_mfma_peak"], "traffic": None,
