@@ -54,6 +54,19 @@ static int close_enough(const float* got, const double* want, long n, double tol
   return ok;
 }
 
+static int close_enough_f64(const double* got, const double* want, long n, double tol, const char* what) {
+  double scale = 1e-30, worst = 0;
+  for (long i = 0; i < n; ++i)
+    if (fabs(want[i]) > scale) scale = fabs(want[i]);
+  for (long i = 0; i < n; ++i) {
+    const double d = fabs(got[i] - want[i]);
+    if (!(d <= worst)) worst = d;
+  }
+  const int ok = tol == 0.0 ? worst == 0.0 : worst <= tol * scale;
+  if (!ok) fprintf(stderr, "FAILED: %s: max |got - want| = %.3e, allowed %.3e\n", what, worst, tol * scale);
+  return ok;
+}
+
 /* ---------------------------------------------------------------------------------------- group 1 */
 static const char* kSource =
     "extern \"C\" __global__ void scale_shift(float* x, long n, float a, float b) {\n"
@@ -313,6 +326,7 @@ struct input {
   int rank;
   int64_t shape[8];
   float* data;
+  double* data64; /* the same values as read (a float64 model's input) */
   long count;
 };
 
@@ -332,6 +346,8 @@ static int run_model(const char* kd_path, const char* case_path) {
   eg_model* model = NULL;
   CHECK(eg_ctx_create(0, &ctx));
   CHECK(eg_model_compile(ctx, text, &model));
+  /* compile[float64] (header line `kd 1 f64`): the same walk through the _f64 twins of the typed entry points */
+  const int f64 = eg_model_scalar_bytes(model) == 8;
   FILE* fp = fopen(case_path, "r");
   if (!fp) {
     fprintf(stderr, "cannot open %s\n", case_path);
@@ -355,14 +371,23 @@ static int run_model(const char* kd_path, const char* case_path) {
       if (fscanf(fp, "%d %ld", &id, &count) != 2) return 2;
       double* v = read_doubles(fp, count);
       float* f = (float*)malloc(sizeof(float) * (size_t)(count > 0 ? count : 1));
-      if (is_param) {
+      if (is_param && f64) {
+        CHECK(eg_model_param_write_f64(model, id, v, count));
+      } else if (is_param) {
         for (long i = 0; i < count; ++i) f[i] = (float)v[i];
         CHECK(eg_model_param_write(model, id, f, count));
       } else {
         char what[96];
-        CHECK(eg_model_param_read(model, id, f, count));
         snprintf(what, sizeof what, "tensor %d after the step", id);
-        if (!close_enough(f, v, count, tol, what)) ++failures;
+        if (f64) {
+          double* d = (double*)malloc(sizeof(double) * (size_t)(count > 0 ? count : 1));
+          CHECK(eg_model_param_read_f64(model, id, d, count));
+          if (!close_enough_f64(d, v, count, tol, what)) ++failures;
+          free(d);
+        } else {
+          CHECK(eg_model_param_read(model, id, f, count));
+          if (!close_enough(f, v, count, tol, what)) ++failures;
+        }
       }
       free(f);
       free(v);
@@ -380,7 +405,7 @@ static int run_model(const char* kd_path, const char* case_path) {
       double* v = read_doubles(fp, in->count);
       in->data = (float*)malloc(sizeof(float) * (size_t)(in->count > 0 ? in->count : 1));
       for (long i = 0; i < in->count; ++i) in->data[i] = (float)v[i];
-      free(v);
+      in->data64 = v;
     } else if (!strcmp(word, "call") || !strcmp(word, "apply")) {
       const int is_call = word[0] == 'c';
       char target[64];
@@ -398,8 +423,10 @@ static int run_model(const char* kd_path, const char* case_path) {
       }
       for (int i = 0; i < n_names; ++i)
         for (int j = 0; j < n_inputs; ++j)
-          if (!strcmp(names[i], inputs[j].name))
-            CHECK(eg_model_set_input_host(model, inputs[j].name, inputs[j].data, inputs[j].rank, inputs[j].shape));
+          if (!strcmp(names[i], inputs[j].name)) {
+            if (f64) CHECK(eg_model_set_input_host_f64(model, inputs[j].name, inputs[j].data64, inputs[j].rank, inputs[j].shape));
+            else CHECK(eg_model_set_input_host(model, inputs[j].name, inputs[j].data, inputs[j].rank, inputs[j].shape));
+          }
       CHECK(eg_model_run(model, target));
       if (is_call) {
         long count;
@@ -415,6 +442,11 @@ static int run_model(const char* kd_path, const char* case_path) {
         if (have != count) {
           fprintf(stderr, "FAILED: %s has %ld elements, %ld expected\n", what, have, count);
           ++failures;
+        } else if (f64) {
+          double* got = (double*)malloc(sizeof(double) * (size_t)(count > 0 ? count : 1));
+          CHECK(eg_model_read_output_f64(model, target, got, count));
+          if (!close_enough_f64(got, want, count, tol, what)) ++failures;
+          free(got);
         } else {
           float* got = (float*)malloc(sizeof(float) * (size_t)(count > 0 ? count : 1));
           CHECK(eg_model_read_output(model, target, got, count));

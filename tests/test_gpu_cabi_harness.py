@@ -86,3 +86,26 @@ def test_model_group_from_c(tmp_path, name):
     case_file(CASES[name], path)
     done = subprocess.run([exe, "model", os.path.join(HERE, "golden", "handwritten", name + ".kd"), path], capture_output=True, text=True)
     assert done.returncode == 0, done.stdout + done.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_model_group_from_c_in_float64(tmp_path, name):
+    """The same hand-derived programs with the header line `kd 1 f64` (compile[float64], model.nim:253-260) through the
+    _f64 twins of the typed entry points, from plain C.  The closed-form answers were derived for the float32 program,
+    whose constants are float32(0.1), float32(0.001) ...: the float64 program differs from them by those roundings (1e-7
+    class), so the bound is the float32 case's, never looser than 1e-6; what this shows is that the double-typed walk
+    (param_write_f64 -> set_input_host_f64 -> run -> read_output_f64 / param_read_f64) is wired through."""
+    exe = build_harness(tmp_path)
+    case = dict(CASES[name])
+    case["tol"] = max(case["tol"], 1e-6)
+    path = os.path.join(str(tmp_path), name + ".case")
+    case_file(case, path)
+    with open(os.path.join(HERE, "golden", "handwritten", name + ".kd")) as f:
+        text = f.read()
+    assert text.count("\nkd 1 f32\n") + text.startswith("kd 1 f32\n") == 1
+    kd64 = os.path.join(str(tmp_path), name + "_f64.kd")
+    with open(kd64, "w") as f:
+        f.write(text.replace("kd 1 f32", "kd 1 f64", 1))
+    done = subprocess.run([exe, "model", kd64, path], capture_output=True, text=True)
+    assert done.returncode == 0, done.stdout + done.stderr

@@ -342,3 +342,28 @@ def test_batched_convolution_layer_f64(gpu_ctx):
         ref.apply("train", {"x": x, "y": y})
         compare_state(gpu, ref, 1e-11, f"step {step}")
     gpu.close()
+
+
+def test_native_data_parallel_step_f64(gpu_ctx):
+    """eg_model_step_dp on a float64 model: the gradient bucket goes through RCCL as float64 (eg_dp_allreduce_sum_f64;
+    one rank here, a sum over one rank is the identity), so the step equals apply() bit for bit; and the bucket the C ABI
+    hands out is counted in elements (doubles)."""
+    from exprgrad_amd.parallel import NativeDataParallel, RcclGroup
+    group = RcclGroup(gpu_ctx, RcclGroup.unique_id(), rank=0, world=1)
+    whole = egm.compile(*examples.dense_softmax_net(24, 16, 4, rate=0.1), gpu=gpu_ctx, dtype=np.float64)
+    split = egm.compile(*examples.dense_softmax_net(24, 16, 4, rate=0.1), gpu=gpu_ctx, dtype=np.float64)
+    for tid in whole.params:
+        split.params[tid] = whole.params[tid]
+    rng = np.random.default_rng(6)
+    x, y = rng.standard_normal((50, 24)), np.eye(4)[rng.integers(0, 4, 50)]
+    dp = NativeDataParallel(split, "train", group, reduction="mean")
+    for _ in range(3):
+        whole.apply("train", {"x": x, "y": y})
+        dp.step({"x": x, "y": y})
+    for tid in whole.params:
+        assert np.array_equal(whole.params[tid], split.params[tid]), tid
+    _, count = split.grad_bucket("train")
+    assert count >= 24 * 16 + 16 + 16 * 4 + 4 and count < 2 * (24 * 16 + 16 + 16 * 4 + 4)
+    whole.close()
+    split.close()
+    group.close()
