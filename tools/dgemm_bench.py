@@ -19,7 +19,7 @@ def main():
         a = torch.rand((n, n), dtype=torch.float64, device=dev) - 0.5
         b = torch.rand((n, n), dtype=torch.float64, device=dev) - 0.5
         c = torch.empty((n, n), dtype=torch.float64, device=dev)
-        for ta, tb in ((0, 0), (1, 0), (0, 1)):
+        for ta, tb in ((0, 0), (1, 0), (0, 1), (0, 0)):
             def run():
                 _lib.call("eg_dgemm", ctx.handle, ta, tb, n, n, n, ctypes.c_void_p(a.data_ptr()), n, ctypes.c_void_p(b.data_ptr()), n,
                           ctypes.c_void_p(c.data_ptr()), n, 0, None)
