@@ -61,7 +61,10 @@ class GpuEngine:
         # gradients live in a torch tensor so torch.distributed can reduce them in place; behind them one float per rank
         # that travels in the SAME all-reduce: the rows of every rank's shard (DataParallel's check of equal shards)
         world = dist.get_world_size() if dist.is_initialized() else 1
-        self.exchange = torch.zeros(max(count, 1) + world, dtype=torch.float32, device="cuda")
+        # (a compile[float64] model's bucket holds doubles: eg_model_grad_bucket counts elements)
+        import numpy as _np
+        dtype = torch.float64 if getattr(model, "dtype", _np.float32) == _np.float64 else torch.float32
+        self.exchange = torch.zeros(max(count, 1) + world, dtype=dtype, device="cuda")
         self.bucket = self.exchange[:max(count, 1)]
         self.trailer = self.exchange[max(count, 1):]
         if count > 0:

@@ -367,3 +367,33 @@ def test_native_data_parallel_step_f64(gpu_ctx):
     whole.close()
     split.close()
     group.close()
+
+
+def test_split_step_with_a_caller_owned_bucket_f64(gpu_ctx):
+    """The torch.distributed form of the data-parallel step (parallel.GpuEngine + DataParallel: run_backward | all-reduce of a
+    caller-owned bucket tensor | run_update) on a float64 model: the bucket is a float64 torch tensor bound with
+    eg_model_bind_grad_bucket (counts in elements), one rank, equal to apply() bit for bit."""
+    torch = pytest.importorskip("torch")
+    import exprgrad_amd as eg
+    from exprgrad_amd.parallel import DataParallel, GpuEngine
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        ctx = eg.newGpuContext(0, stream=stream.cuda_stream)
+        whole = egm.compile(*examples.dense_softmax_net(12, 8, 3, rate=0.1), gpu=ctx, dtype=np.float64)
+        split = egm.compile(*examples.dense_softmax_net(12, 8, 3, rate=0.1), gpu=ctx, dtype=np.float64)
+        for tid in whole.params:
+            split.params[tid] = whole.params[tid]
+        engine = GpuEngine(split, "train")
+        assert engine.bucket.dtype == torch.float64
+        dp = DataParallel(engine, reduction="mean")
+        rng = np.random.default_rng(1)
+        x, y = rng.standard_normal((20, 12)), np.eye(3)[rng.integers(0, 3, 20)]
+        for _ in range(3):
+            whole.apply("train", {"x": x, "y": y})
+            dp.step({"x": x, "y": y})
+        stream.synchronize()
+        assert float(engine.bucket.abs().sum()) > 0.0          # the gradients really live in the caller's tensor
+        for tid in whole.params:
+            assert np.array_equal(whole.params[tid], split.params[tid]), tid
+        whole.close()
+        split.close()
