@@ -650,14 +650,25 @@ def run_float64(args, env):
         def step():
             _lib.call("eg_dgemm", ctx.handle, 0, 0, n, n, n, ctypes.c_void_p(a.data_ptr()), n, ctypes.c_void_p(b.data_ptr()), n,
                       ctypes.c_void_p(c.data_ptr()), n, 0, None)
-        elapsed, ev_avg, _ = timer.run(step, steps, args.warmup)
+        # The clock probe's resident wave (DeviceClock: 16 registers of one SIMD) takes the slot of a 128-register wave with it:
+        # eg_dgemm's blocks fill the register files exactly (four waves per SIMD), the probe's CU then holds one block instead
+        # of two and 1024 tiles need a third round — 4096^3 runs 2.48 instead of 2.25 ms next to the probe
+        # (tools/f64_only.py).  So the rows are timed WITHOUT the probe; a second pass with it only reads the clock.
+        probe, timer.clock = timer.clock, None
+        try:
+            elapsed, ev_avg, _ = timer.run(step, steps, args.warmup)
+        finally:
+            timer.clock = probe
         tflops = 2.0 * n * n * n * steps / elapsed / 1e12
         rows[str(n)] = {"us_per_launch": round(elapsed / steps * 1e6, 2), "tflops": round(tflops, 2),
                         "frac_of_f64_mfma_peak": round(tflops / F64_MFMA_PEAK_TFLOPS, 4), "kernel_us_by_events": round(ev_avg * 1e3, 2)}
-        clock = timer.last_clock
-        if clock and clock.get("mhz"):   # the float64 matrix rate at the clock the timed launches ran at: 32 FLOP / clk / SIMD x 1024
-            at_clock = clock["mhz"] * 1e6 * 32768 / 1e12
-            rows[str(n)].update({"effective_clock_mhz": clock["mhz"], "frac_of_rate_at_effective_clock": round(tflops / at_clock, 4)})
+        if probe is not None and n == 4096:
+            timer.run(step, steps, args.warmup)
+            clock = timer.last_clock
+            if clock and clock.get("mhz"):   # the float64 matrix rate at that clock: 32 FLOP / clk / SIMD x 1024 SIMDs
+                at_clock = clock["mhz"] * 1e6 * 32768 / 1e12
+                rows[str(n)].update({"effective_clock_mhz_separate_pass": clock["mhz"],
+                                     "frac_of_rate_at_effective_clock": round(tflops / at_clock, 4)})
     out = {"metric": "TFLOP/s of C = A*B, M = N = K, float64, through eg_dgemm", "unit": "TFLOP/s", "sizes": rows, "timed_steps": steps,
            "roofline": {"bound": "mfma", "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "achieved": rows["4096"]["tflops"],
                         "frac": rows["4096"]["frac_of_f64_mfma_peak"], "traffic": None,

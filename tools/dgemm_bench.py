@@ -28,7 +28,7 @@ def main():
             ctx.sync()
             stream = torch.cuda.ExternalStream(ctx.stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 10
+            reps = int(__import__('os').environ.get('REPS', '10'))
             e0.record(stream)
             for _ in range(reps):
                 run()

@@ -35,7 +35,7 @@ def short(name):
 
 def ours(name):
     return (name.startswith("eg") or "eg::" in name or "eg_" in name or
-            any(k in name for k in ("colsum", "rowsum", "conv2_halo", "conv2_gradf", "grad_image_operands", "copy_segments")))
+            any(k in name for k in ("colsum", "rowsum", "conv2_halo", "conv2_gradf", "grad_image_operands", "copy_segments", "dgemm_")))
 
 
 def main():
