@@ -6,6 +6,7 @@ TAG=${1:-r05}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $REPO
 mkdir -p gpurun_out/summ
+[ -f gpurun_out/summ/traffic.json ] || cp profiles/traffic.json gpurun_out/summ/traffic.json   # (entries of the other workloads stay)
 export PYTHONPATH=$REPO
 run() {  # <name> <kernel substring> <command...>
   name=$1; kern=$2; shift 2
