@@ -138,6 +138,13 @@ int row_finalize(eg_ctx* ctx, const float* partial, int nblocks, int E, const Ro
 // Direct per-pixel kernels for few input channels (kernels/conv2_direct.cpp), same convention.
 int conv2_direct_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
                      const float* flt, float* out, int accumulate, bool* launched);
+// kernels/conv2_band.cpp: convolutions with at most 16 channels and 16 filters on 16 x 16 x 4 matrix instructions, float32 and float64
+int conv2_band_forward_try(eg_ctx* ctx, bool f64, long N, long H, long W, long C, long F, long FH, long FW, const void* img, const void* flt, void* out,
+                           int accumulate, bool* launched);
+int conv2_band_grad_image_try(eg_ctx* ctx, bool f64, long N, long H, long W, long C, long F, long FH, long FW, const void* flt, const void* gout, void* gimg,
+                              int accumulate, bool* launched);
+int conv2_band_grad_filter_try(eg_ctx* ctx, bool f64, long N, long H, long W, long C, long F, long FH, long FW, const void* img, const void* gout, void* gflt,
+                               int accumulate, bool* launched);
 int conv2_direct_f64_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const double* img, const double* flt,
                          double* out, int accumulate, bool* launched);
 int conv2_direct_grad_filter_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,

@@ -266,7 +266,8 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
       case StepKind::ConvGradFilter: os << "conv2-grad-filter -> t" << L.c_tensor << (L.accumulate ? " accumulate" : ""); break;
       case StepKind::GenericA:
         os << "generated(map) kernel " << L.lowered << " -> t" << L.c_tensor;
-        if (L.conv_direct64) os << " | forward convolution: the float64 matrix-core kernel (eg_conv_mfma64_*) when the shape suits it";
+        if (L.conv_direct64) os << " | " << (L.conv_direct64 == 1 ? "convolution" : L.conv_direct64 == 2 ? "convolution's image gradient" : "convolution's filter gradient")
+                                 << ": the float64 matrix-core kernel (eg_conv_band_f64_* / eg_conv_mfma64_*) when the shape suits it";
         if (L.consumer >= 0) os << " (with its consumer, kernel " << L.consumer << ")";
         break;
       case StepKind::GenericB: os << "generated(split-reduce) kernel " << L.lowered << " -> t" << L.c_tensor; break;

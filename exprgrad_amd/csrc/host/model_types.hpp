@@ -114,10 +114,10 @@ struct Launch {
   // Slab fold (plan_groups.cpp fuse_slab_fold): the map group behind a sample group adds up the slab rows itself
   int fold_launch = -1;                     // SampleFused: index of the map group that folds its slab when a range holds both
   int fold_of = -1;                         // SmallFused: index of that sample group's launch
-  // float64 programs: a generated kernel that is a forward convolution (match_conv) first offers itself to the direct
-  // per-pixel kernel over double (kernels/conv2_direct.cpp; the conv fields above are filled in); what that kernel
-  // declines runs as the generated kernel.
-  bool conv_direct64 = false;
+  // float64 programs: a generated kernel that is a convolution or one of its two gradients (match_conv) first offers itself
+  // to the matrix-core kernels over double (kernels/conv2_band.cpp, kernels/conv2_direct.cpp; the conv fields above are
+  // filled in); what those decline runs as the generated kernel.
+  int conv_direct64 = 0;  // 1 forward, 2 image gradient, 3 filter gradient
 };
 
 // A run of per-sample kernels fused into one generated kernel (rowfuse.hpp), built per plan.

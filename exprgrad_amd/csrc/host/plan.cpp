@@ -558,27 +558,32 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
         int rc = fill_params(m, k, info, shapes, lo.mode_a.src, !overwrite, total, rtotal, 0, L.params);
         if (rc) return rc;
         note_vec4(L, total);
-        ConvMatch cm;
-        if (m->f64 && match_conv(k, cm) && cm.role == ConvMatch::Forward) {
-          // (operands of a matched forward convolution: image = reads[img_op], filters = reads[flt_op], the result is written)
-          const std::vector<long>& is = shapes.at(k.reads[cm.img_op].tensor);
-          const std::vector<long>& fs = shapes.at(k.reads[cm.flt_op].tensor);
-          const int o = cm.batched ? 1 : 0;
-          const bool valid = fs.size() == 4 && is.size() == (size_t)(3 + o) && wshape.size() == is.size() && fs[3] == is[o + 2] &&
-                             wshape[o] == is[o] - fs[1] + 1 && wshape[o + 1] == is[o + 1] - fs[2] + 1 && wshape[o + 2] == fs[0] &&
-                             (!cm.batched || wshape[0] == is[0]) && full_cover(k, info, wshape);
-          if (valid) {
-            L.conv_direct64 = true;
-            L.cN = cm.batched ? is[0] : 1;
-            L.cH = is[o];
-            L.cW = is[o + 1];
-            L.cC = is[o + 2];
-            L.cF = fs[0];
-            L.cFH = fs[1];
-            L.cFW = fs[2];
-            L.a_tensor = k.reads[cm.img_op].tensor;
-            L.b_tensor = k.reads[cm.flt_op].tensor;
-          }
+      }
+      ConvMatch cm;
+      if (m->f64 && match_conv(k, cm)) {
+        // operands of a matched convolution kernel: -1 = the written tensor, else a read (ConvMatch)
+        auto tensor_of = [&](int which) { return which < 0 ? k.write.tensor : k.reads[which].tensor; };
+        const int t_img = tensor_of(cm.img_op), t_flt = tensor_of(cm.flt_op), t_out = tensor_of(cm.out_op);
+        const std::vector<long>& is = shapes.at(t_img);
+        const std::vector<long>& fs = shapes.at(t_flt);
+        const std::vector<long>& os = shapes.at(t_out);
+        const int o = cm.batched ? 1 : 0;
+        const bool valid = fs.size() == 4 && is.size() == (size_t)(3 + o) && os.size() == is.size() && fs[3] == is[o + 2] &&
+                           os[o] == is[o] - fs[1] + 1 && os[o + 1] == is[o + 1] - fs[2] + 1 && os[o + 2] == fs[0] &&
+                           (!cm.batched || os[0] == is[0]) && (cm.role != ConvMatch::Forward || full_cover(k, info, wshape));
+        if (valid) {
+          L.conv_direct64 = cm.role == ConvMatch::Forward ? 1 : (cm.role == ConvMatch::GradImage ? 2 : 3);
+          L.cN = cm.batched ? is[0] : 1;
+          L.cH = is[o];
+          L.cW = is[o + 1];
+          L.cC = is[o + 2];
+          L.cF = fs[0];
+          L.cFH = fs[1];
+          L.cFW = fs[2];
+          // a / b as the float32 library launches take them: image + filters (forward), image + output gradient (filter
+          // gradient), filters + output gradient (image gradient)
+          L.a_tensor = cm.role == ConvMatch::GradImage ? t_flt : t_img;
+          L.b_tensor = cm.role == ConvMatch::Forward ? t_flt : t_out;
         }
       }
       for (size_t si = 0; si < L.generic->src.slots.size(); ++si) {

@@ -215,8 +215,16 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       if (L.conv_direct64) {
         bool launched = false;
         auto dp = [&](int t) { return reinterpret_cast<double*>(tensor_ptr(m, ts, plan, t)); };
-        int rc = eg::conv2_direct_f64_try(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, dp(L.a_tensor), dp(L.b_tensor), dp(L.c_tensor),
-                                          L.accumulate, &launched);
+        int rc = EG_OK;
+        if (L.conv_direct64 == 1) {
+          rc = eg::conv2_band_forward_try(ctx, true, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, dp(L.a_tensor), dp(L.b_tensor), dp(L.c_tensor), L.accumulate, &launched);
+          if (!rc && !launched)   // (images too wide for a band in LDS: column strips)
+            rc = eg::conv2_direct_f64_try(ctx, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, dp(L.a_tensor), dp(L.b_tensor), dp(L.c_tensor), L.accumulate, &launched);
+        } else if (L.conv_direct64 == 2) {
+          rc = eg::conv2_band_grad_image_try(ctx, true, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, dp(L.a_tensor), dp(L.b_tensor), dp(L.c_tensor), L.accumulate, &launched);
+        } else {
+          rc = eg::conv2_band_grad_filter_try(ctx, true, L.cN, L.cH, L.cW, L.cC, L.cF, L.cFH, L.cFW, dp(L.a_tensor), dp(L.b_tensor), dp(L.c_tensor), L.accumulate, &launched);
+        }
         if (rc || launched) return rc;
       }
       const GenericSource& src = L.generic->src;

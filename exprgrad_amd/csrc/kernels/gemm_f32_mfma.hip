@@ -994,6 +994,11 @@ extern "C" int eg_conv2_nhwc(eg_ctx* ctx, int64_t N, int64_t H, int64_t W, int64
     rc = eg::conv2_tiny_forward_try(ctx, N, H, W, C, F, FH, FW, img, flt, out, accumulate, &launched);
     if (rc || launched) return rc;
   }
+  if (C > 0 && C <= 16 && F <= 16) {  // few channels and few filters: the filter bank as fragments of 16 x 16 x 4 matrix instructions (conv2_band.cpp)
+    bool launched = false;
+    rc = eg::conv2_band_forward_try(ctx, false, N, H, W, C, F, FH, FW, img, flt, out, accumulate, &launched);
+    if (rc || launched) return rc;
+  }
   if (C > 0 && C <= 16) {  // few channels (an image network's first layers): per-pixel kernel specialised for the filter geometry
     bool launched = false;
     rc = eg::conv2_direct_try(ctx, N, H, W, C, F, FH, FW, img, flt, out, accumulate, &launched);
@@ -1109,6 +1114,11 @@ extern "C" int eg_conv2_nhwc_grad_filter(eg_ctx* ctx, int64_t N, int64_t H, int6
     rc = eg::conv2_tiny_grad_filter_try(ctx, N, H, W, C, F, FH, FW, img, gout, gflt, accumulate, &launched);
     if (rc || launched) return rc;
   }
+  if (C <= 16 && F <= 16) {  // few channels and few filters: 16 filter rows x 4 pixels x 16 taps per matrix instruction (conv2_band.cpp)
+    bool launched = false;
+    rc = eg::conv2_band_grad_filter_try(ctx, false, N, H, W, C, F, FH, FW, img, gout, gflt, accumulate, &launched);
+    if (rc || launched) return rc;
+  }
   if (C <= 4) {
     bool launched = false;
     rc = eg::conv2_direct_grad_filter_try(ctx, N, H, W, C, F, FH, FW, img, gout, gflt, accumulate, &launched);
@@ -1169,6 +1179,11 @@ extern "C" int eg_conv2_nhwc_grad_image(eg_ctx* ctx, int64_t N, int64_t H, int64
   {  // a few million multiply-adds in all: one thread per image element, no flipped bank, no padded gradient
     bool launched = false;
     rc = eg::conv2_tiny_grad_image_try(ctx, N, H, W, C, F, FH, FW, flt, gout, gimg, accumulate, &launched);
+    if (rc || launched) return rc;
+  }
+  if (C <= 16 && F <= 16) {  // few channels and few filters: the forward band kernel on the gradient with a virtual zero border and the bank read flipped
+    bool launched = false;
+    rc = eg::conv2_band_grad_image_try(ctx, false, N, H, W, C, F, FH, FW, flt, gout, gimg, accumulate, &launched);
     if (rc || launched) return rc;
   }
   const long Hp = Ho + 2 * (FH - 1), Wp = Wo + 2 * (FW - 1);

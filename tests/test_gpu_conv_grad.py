@@ -320,6 +320,76 @@ def test_tiny_convolutions_against_the_oracle_and_the_contraction_route(gpu_ctx,
         assert rel_err(tiny[key], other[key].astype(np.float64)) <= TOL, key
 
 
+BAND_SHAPES = [  # N, H, W, C, F, FH, FW: at most 16 channels and 16 filters, past the tiny limit -> kernels/conv2_band.cpp
+    (256, 28, 28, 1, 8, 5, 5),     # fashion_mnist, first layer (fashion_mnist.nim:39-57): whole images per block
+    (300, 12, 12, 8, 16, 3, 3),    # ... second layer; 300 images are not a whole number of seven-image bands
+    (3, 70, 90, 3, 5, 3, 3),       # bands of rows of one image; 5 outputs per pixel: the element-wise store path
+    (130, 16, 20, 16, 16, 3, 3),   # 16 -> 16
+    (2, 100, 64, 2, 3, 7, 5),      # 70 taps of a 7 x 5 filter
+]
+
+
+@pytest.mark.parametrize("shape", BAND_SHAPES)
+def test_band_convolutions_against_the_oracle_and_the_other_routes(gpu_ctx, refcpu, monkeypatch, shape):
+    """Round 5: conv2 and both gradients with at most 16 channels and 16 filters as 16 x 16 x 4 matrix instructions with the
+    small operand in registers (kernels/conv2_band.cpp).  Against the oracle's loop nests, against the routes they replace
+    (EG_CONV_NO_BAND=1: per-pixel kernels, implicit-GEMM tiles), onto existing values, and twice for run-to-run identity
+    (the filter gradient's per-block partial rows are folded in a fixed order)."""
+    N, H, W, C, F, FH, FW = shape
+    Ho, Wo = H - FH + 1, W - FW + 1
+    rng = np.random.default_rng(sum(shape))
+    img = rng.random((N, H, W, C), dtype=np.float32)
+    flt = (rng.random((F, FH, FW, C), dtype=np.float32) * 2 - 1).astype(np.float32)
+    gout = (rng.random((N, Ho, Wo, F), dtype=np.float32) - 0.5).astype(np.float32)
+    dimg, dflt, dg = dev(gpu_ctx, img), dev(gpu_ctx, flt), dev(gpu_ctx, gout)
+    base_out = rng.random((N, Ho, Wo, F), dtype=np.float32)
+    base_flt = rng.random(flt.shape, dtype=np.float32)
+    base_img = rng.random(img.shape, dtype=np.float32)
+    want = {
+        "out": refcpu.conv2_nhwc(img, flt), "out+": refcpu.conv2_nhwc(img, flt, out=base_out.copy()),
+        "gflt": refcpu.conv2_nhwc_grad_filter(img, gout, flt.shape),
+        "gflt+": refcpu.conv2_nhwc_grad_filter(img, gout, flt.shape, out=base_flt.copy()),
+        "gimg": refcpu.conv2_nhwc_grad_image(flt, gout, img.shape),
+        "gimg+": refcpu.conv2_nhwc_grad_image(flt, gout, img.shape, out=base_img.copy()),
+    }
+
+    def run():
+        got = {}
+        out = gpu_ctx.allocTensor(base_out.shape)
+        out.write(np.full(base_out.shape, np.nan, dtype=np.float32))        # must be overwritten
+        ops.conv2_nhwc(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dflt, out)
+        got["out"] = out.read()
+        out.write(base_out)
+        ops.conv2_nhwc(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dflt, out, accumulate=True)
+        got["out+"] = out.read()
+        gflt = gpu_ctx.allocTensor(flt.shape)
+        gflt.write(np.full(flt.shape, np.nan, dtype=np.float32))
+        ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dg, gflt)
+        got["gflt"] = gflt.read()
+        gflt.write(base_flt)
+        ops.conv2_nhwc_grad_filter(gpu_ctx, N, H, W, C, F, FH, FW, dimg, dg, gflt, accumulate=True)
+        got["gflt+"] = gflt.read()
+        gimg = gpu_ctx.allocTensor(img.shape)
+        gimg.write(np.full(img.shape, np.nan, dtype=np.float32))
+        ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dg, gimg)
+        got["gimg"] = gimg.read()
+        gimg.write(base_img)
+        ops.conv2_nhwc_grad_image(gpu_ctx, N, H, W, C, F, FH, FW, dflt, dg, gimg, accumulate=True)
+        got["gimg+"] = gimg.read()
+        return got
+
+    monkeypatch.delenv("EG_CONV_NO_BAND", raising=False)
+    band, again = run(), run()
+    monkeypatch.setenv("EG_CONV_NO_BAND", "1")
+    other = run()
+    for key, ref in want.items():
+        # (the filter gradient sums N * Ho * Wo terms per element: the bound is relative to the largest element as everywhere in this file)
+        assert rel_err(band[key], ref) <= TOL, key
+        assert rel_err(other[key], ref) <= TOL, key
+        assert np.array_equal(band[key], again[key]), key
+        assert rel_err(band[key], other[key].astype(np.float64)) <= TOL, key
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 def test_conv2_gradients_on_the_contraction_route(gpu_ctx, refcpu, monkeypatch, shape):
     """The shapes of test_conv2_gradients_against_the_oracle are small enough for kernels/conv2_tiny.hip now; the

@@ -397,3 +397,24 @@ def test_split_step_with_a_caller_owned_bucket_f64(gpu_ctx):
             assert np.array_equal(whole.params[tid], split.params[tid]), tid
         whole.close()
         split.close()
+
+
+@pytest.mark.parametrize("shape", [(48, 12, 12, 8, 16, 3, 3), (9, 28, 28, 1, 8, 5, 5), (3, 40, 50, 3, 5, 3, 3)])
+def test_band_convolution_training_step_f64(gpu_ctx, shape):
+    """conv2 and its two gradients of a float64 model on the matrix cores (kernels/conv2_band.cpp, the float64 instantiation):
+    conv2 -> mse -> gradientDescent at shapes past the kernels' pixel threshold, gradients and updated parameters against
+    the oracle; the launch list names the kernels."""
+    N, H, W, C, F, FH, FW = shape
+
+    def net():
+        out = layers.conv2(dsl.input("x"), C, FH, FW, F).target("predict")
+        return [layers.mse(out, dsl.input("y")).target("loss").backprop(layers.gradient_descent(0.05)).target("train")]
+    gpu, ref, rng = step_pair(gpu_ctx, net, sum(shape))
+    x, y = rng.random((N, H, W, C)), rng.random((N, H - FH + 1, W - FW + 1, F))
+    assert rel(gpu.call("predict", {"x": x}), ref.call("predict", {"x": x})) <= TOL64
+    for step in range(2):
+        gpu.apply("train", {"x": x, "y": y})
+        ref.apply("train", {"x": x, "y": y})
+        compare_state(gpu, ref, 1e-11, f"step {step}")
+    assert "filter gradient" in gpu.launch_plan("train")
+    gpu.close()
