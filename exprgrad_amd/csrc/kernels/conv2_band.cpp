@@ -61,7 +61,7 @@ struct Band {
 };
 
 // in: [N, HI, WI, CI] seen with a zero border of (PY, PX); out rows Ho = HI + 2 PY - FH + 1, columns Wo likewise
-Band plan_band(long HI, long WI, long CI, long FH, long FW, long PY, long PX, long elem_bytes) {
+Band plan_band(long HI, long WI, long CI, long FH, long FW, long PY, long PX, long elem_bytes, long per_pixel = 0) {  // per_pixel: further LDS elements per output pixel
   Band b;
   const long Ho = HI + 2 * PY - FH + 1, Wo = WI + 2 * PX - FW + 1;
   if (Ho < 1 || Wo < 1) return b;
@@ -73,9 +73,10 @@ Band plan_band(long HI, long WI, long CI, long FH, long FW, long PY, long PX, lo
   b.R = std::min(Ho, std::max(1L, target / Wo));
   b.NB = b.R == Ho ? std::max(1L, std::min(16L, target / (Ho * Wo))) : 1;
   auto elems = [&](long nb, long r) { return nb * (r + FH - 1) * b.WP * b.STR; };
-  while (b.NB > 1 && elems(b.NB, b.R) > budget) --b.NB;
-  while (b.R > 1 && elems(b.NB, b.R) > budget) --b.R;
-  if (elems(b.NB, b.R) > budget) return b;
+  auto all = [&](long nb, long r) { return elems(nb, r) + nb * r * Wo * per_pixel; };
+  while (b.NB > 1 && all(b.NB, b.R) > budget) --b.NB;
+  while (b.R > 1 && all(b.NB, b.R) > budget) --b.R;
+  if (all(b.NB, b.R) > budget) return b;
   b.RR = b.R + FH - 1;
   b.PT = b.NB * b.R * Wo;
   b.lds_elems = elems(b.NB, b.R);
@@ -103,14 +104,31 @@ std::string prelude() {
 // Stage the block's band: rows [y0 - PY, y0 - PY + RR) of images n0 .. n0 + NB - 1, columns [-PX, WI + PX), zeros outside.
 std::string stage_code(const Ty& ty, const Band& b, long HI, long WI, long CI, long PY, long PX, const char* src) {
   std::string s;
-  const long row_elems = b.WP * CI, total = b.NB * b.RR * row_elems;
-  s += "  for (int e = tid; e < " + S(total) + "; e += 256) {\n";
-  s += "    const int i = e / " + S(b.RR * row_elems) + ", r0 = e % " + S(b.RR * row_elems) + ", ry = r0 / " + S(row_elems) + ", r1 = r0 % " + S(row_elems) +
-       ", px = r1 / " + S(CI) + ", ci = r1 % " + S(CI) + ";\n";
-  s += "    const long gn = n0 + i, gy = y0 + ry - " + S(PY) + ", gx = px - " + S(PX) + ";\n";
-  s += "    " + std::string(ty.T) + " v = " + ty.zero + ";\n";
-  s += "    if (gn < N && gy >= 0 && gy < " + S(HI) + " && gx >= 0 && gx < " + S(WI) + ") v = " + src + "[((gn * " + S(HI) + " + gy) * " + S(WI) + " + gx) * " + S(CI) + " + ci];\n";
-  s += "    band[((i * " + S(b.RR) + " + ry) * " + S(b.WP) + " + px) * " + S(b.STR) + " + ci] = v;\n  }\n";
+  // A wave takes whole staged rows (image i, row ry: wave-uniform), its lanes walk the row's elements.  The loads of a CHUNK of
+  // rows are all issued before the first of them is stored: a loop that loads, waits and stores element by element keeps one
+  // load in flight per wave, and the waves then spend their life waiting for memory (measured: 14 500 cycles per wave of the
+  // image-gradient kernel for 2 300 cycles of matrix work, two thirds of the SIMDs empty).
+  const long row_elems = b.WP * CI, rows = b.NB * b.RR;
+  const long per_row = (row_elems + 63) / 64;                       // loads per lane and row
+  const long rows_per_wave = (rows + 3) / 4;
+  long chunk = std::max(1L, 32 / per_row);                          // rows per chunk: at most ~32 loads in flight per lane
+  if (chunk > rows_per_wave) chunk = rows_per_wave;
+  s += "  for (int rbase = 0; rbase < " + S(rows_per_wave) + "; rbase += " + S(chunk) + ") {\n";
+  s += "    " + std::string(ty.T) + " stg[" + S(chunk) + "][" + S(per_row) + "];\n";
+  s += "    _Pragma(\"unroll\") for (int rr = 0; rr < " + S(chunk) + "; ++rr) {\n";
+  s += "      const int row = (rbase + rr) * 4 + (tid >> 6), i = row / " + S(b.RR) + ", ry = row % " + S(b.RR) + ";\n";
+  s += "      const long gn = n0 + i, gy = y0 + ry - " + S(PY) + ";\n";
+  s += "      const bool row_ok = rbase + rr < " + S(rows_per_wave) + " && row < " + S(rows) + " && gn < N && gy >= 0 && gy < " + S(HI) + ";\n";
+  s += "      const " + std::string(ty.T) + "* src_row = " + src + " + (gn * " + S(HI) + " + gy) * " + S(WI * CI) + " - " + S(PX * CI) + ";\n";
+  s += "      _Pragma(\"unroll\") for (int u = 0; u < " + S(per_row) + "; ++u) {\n";
+  s += "        const int e = (tid & 63) + 64 * u, px = e / " + S(CI) + ";\n";
+  s += "        stg[rr][u] = (row_ok && e < " + S(row_elems) + " && px >= " + S(PX) + " && px < " + S(PX + WI) + ") ? src_row[e] : " + ty.zero + ";\n      }\n    }\n";
+  s += "    _Pragma(\"unroll\") for (int rr = 0; rr < " + S(chunk) + "; ++rr) {\n";
+  s += "      const int row = (rbase + rr) * 4 + (tid >> 6);\n";
+  s += "      if (rbase + rr < " + S(rows_per_wave) + " && row < " + S(rows) + ") {\n";
+  s += "        _Pragma(\"unroll\") for (int u = 0; u < " + S(per_row) + "; ++u) {\n";
+  s += "          const int e = (tid & 63) + 64 * u, px = e / " + S(CI) + ", ci = e % " + S(CI) + ";\n";
+  s += "          if (e < " + S(row_elems) + ") band[row * " + S(b.WP * b.STR) + " + px * " + S(b.STR) + " + ci] = stg[rr][u];\n        }\n      }\n    }\n  }\n";
   return s;
 }
 
@@ -159,10 +177,17 @@ int launch_forward(eg_ctx* ctx, const Ty& ty, bool flip, long N, long HI, long W
   s += "  for (int g = wave * 2; g < " + S(G) + "; g += 8) {\n";
   s += "    const int o0 = orig[g * 16 + fr], o1 = g + 1 < " + S(G) + " ? orig[g * 16 + 16 + fr] : 0;\n";
   s += "    " + std::string(ty.acc) + " acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};\n";
-  s += "    _Pragma(\"unroll\") for (int s = 0; s < " + S(KS) + "; ++s) {\n";
-  s += "      const " + std::string(ty.T) + " a0 = toff[s] < 0 ? " + ty.zero + " : band[o0 + toff[s]], a1 = toff[s] < 0 ? " + ty.zero + " : band[o1 + toff[s]];\n";
-  s += "      acc0 = " + std::string(ty.mfma) + "(a0, bf[s], acc0, 0, 0, 0);\n";
-  s += "      acc1 = " + std::string(ty.mfma) + "(a1, bf[s], acc1, 0, 0, 0);\n    }\n";
+  // fragments of eight steps are read before their sixteen matrix instructions are issued (read -> wait -> multiply step by
+  // step costs an LDS round trip per instruction: the image gradient of the 8 -> 16 layer ran 6x its matrix time)
+  s += "    _Pragma(\"unroll\") for (int s0 = 0; s0 < " + S(KS) + "; s0 += 8) {\n";
+  s += "      " + std::string(ty.T) + " a0[8], a1[8];\n";
+  s += "      _Pragma(\"unroll\") for (int u = 0; u < 8; ++u) {\n";
+  s += "        if (s0 + u < " + S(KS) + ") { const int to = toff[s0 + u] < 0 ? 0 : toff[s0 + u]; a0[u] = band[o0 + to]; a1[u] = band[o1 + to]; }\n      }\n";
+  s += "      _Pragma(\"unroll\") for (int u = 0; u < 8; ++u) {\n";
+  s += "        if (s0 + u < " + S(KS) + ") {\n";
+  s += "          const bool tap = toff[s0 + u] >= 0;\n";
+  s += "          acc0 = " + std::string(ty.mfma) + "(tap ? a0[u] : " + ty.zero + ", bf[s0 + u], acc0, 0, 0, 0);\n";
+  s += "          acc1 = " + std::string(ty.mfma) + "(tap ? a1[u] : " + ty.zero + ", bf[s0 + u], acc1, 0, 0, 0);\n        }\n      }\n    }\n";
   if (wide) {
     // D (column fr = output channel, row = pixel of the group) -> the wave's parking rows -> 16-byte pieces of the run
     s += "    if (fr < " + S(FO) + ") {\n";
@@ -207,15 +232,18 @@ int launch_grad_filter(eg_ctx* ctx, const Ty& ty, long N, long H, long W, long C
   *launched = false;
   const long taps = FH * FW * C, Ho = H - FH + 1, Wo = W - FW + 1;
   if (disabled() || C < 1 || F < 1 || F > 16 || C > 16 || taps > 144 || Ho < 1 || Wo < 1 || N * Ho * Wo < 4096) return EG_OK;
-  const Band b = plan_band(H, W, C, FH, FW, 0, 0, ty.f64 ? 8 : 4);
+  const Band b = plan_band(H, W, C, FH, FW, 0, 0, ty.f64 ? 8 : 4, F);   // (the band's piece of the output gradient is staged too)
   if (!b.ok) return EG_OK;
   const long TB = (taps + 15) / 16, Q = (b.PT + 3) / 4, E = F * taps;
+  const long GT = Q * 4 * F;                                            // elements of the staged output-gradient run
+  const long GL = (GT + 255) / 256;                                     // ... per thread
   const std::string name = std::string("eg_conv_band_") + ty.sfx + "_gf_c" + S(C) + "_f" + S(F) + "_" + S(FH) + "x" + S(FW) + "_" + S(H) + "x" + S(W) + "_b" + S(b.NB) + "r" + S(b.R);
   std::string s = prelude();
   s += "extern \"C\" __global__ void __launch_bounds__(256) " + name + "(const " + ty.T + "* __restrict__ img, const " + ty.T + "* __restrict__ gout, " + ty.T +
        "* __restrict__ partial, long N, long ybands, long nbands) {\n";
   s += "  __shared__ " + std::string(ty.T) + " band[" + S(std::max(b.lds_elems, 4 * 16 * TB * 16)) + "];\n";
   s += "  __shared__ int orig[" + S(Q * 4) + "];   // window origin of every output pixel of a band (the same for every band)\n";
+  s += "  __shared__ " + std::string(ty.T) + " grun[" + S(GT) + "];   // the band's run of the output gradient, zeros behind its end\n";
   s += "  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, fr = lane & 15, fk = lane >> 4;\n";
   s += "  for (int q = tid; q < " + S(Q * 4) + "; q += 256) {\n";
   s += "    const int qq = q < " + S(b.PT) + " ? q : 0, i = qq / " + S(b.R * Wo) + ", r0 = qq % " + S(b.R * Wo) + ", y = r0 / " + S(Wo) + ", x = r0 % " + S(Wo) + ";\n";
@@ -238,20 +266,24 @@ int launch_grad_filter(eg_ctx* ctx, const Ty& ty, long N, long H, long W, long C
     while ((pos = st.find("\n  ", pos)) != std::string::npos) { st.insert(pos + 1, "  "); pos += 3; }
     s += "  " + st;
   }
-  s += "    __syncthreads();\n";
   // the band's output pixels are one contiguous run of the output gradient (whole rows of one image, or whole images)
   s += "    const long pix0 = (n0 * " + S(Ho) + " + y0) * " + S(Wo) + ", lim = (n0 + " + S(b.NB) + " < N ? n0 + " + S(b.NB) + " : N) * " + S(Ho * Wo) + ";\n";
   s += "    const int live_px = lim - pix0 < " + S(b.PT) + " ? (int)(lim - pix0 > 0 ? lim - pix0 : 0) : " + S(b.PT) + ";   // pixels of the band that exist\n";
-  s += "    const " + std::string(ty.T) + "* gp = gout + pix0 * " + S(F) + " + fr;\n";
-  s += "    auto fetch = [&](int qq) -> " + std::string(ty.T) + " { const int q = 4 * qq + fk; return (q < live_px && fr < " + S(F) + ") ? gp[q * " + S(F) + "] : " + ty.zero + "; };\n";
-  s += "    " + std::string(ty.T) + " a_next = fetch(wave), a_next2 = fetch(wave + 4);\n";
+  // the run of the output gradient: every thread's loads are issued before the first is stored (one load in flight per wave
+  // and iteration made the loop wait for memory: 51 us with one image per block, 102 with seven)
+  s += "    {\n      const " + std::string(ty.T) + "* gp = gout + pix0 * " + S(F) + ";\n      const long glive = (long)live_px * " + S(F) + ";\n";
+  s += "      " + std::string(ty.T) + " gv[" + S(GL) + "];\n";
+  s += "      _Pragma(\"unroll\") for (int u = 0; u < " + S(GL) + "; ++u) { const int e = tid + 256 * u; gv[u] = e < glive ? gp[e] : " + ty.zero + "; }\n";
+  s += "      _Pragma(\"unroll\") for (int u = 0; u < " + S(GL) + "; ++u) { const int e = tid + 256 * u; if (e < " + S(GT) + ") grun[e] = gv[u]; }\n    }\n";
+  s += "    __syncthreads();\n";
+  s += "    int o_next = orig[4 * wave + fk];   // (the table holds pixel 0's origin behind the band's last pixel)\n";
   s += "    for (int qq = wave; qq < " + S(Q) + "; qq += 4) {\n";
-  s += "      const " + std::string(ty.T) + " a = a_next;\n      a_next = a_next2;\n      a_next2 = fetch(qq + 8);   // (two quads ahead: the loop does not wait for memory)\n";
-  s += "      const int q = 4 * qq + fk;\n";
-  s += "      const int o = q < live_px ? orig[q] : -1;\n";
-  s += "      _Pragma(\"unroll\") for (int t = 0; t < " + S(TB) + "; ++t) {\n";
-  s += "        const " + std::string(ty.T) + " bv = o < 0 ? " + ty.zero + " : band[o + toff[t]];\n";
-  s += "        acc[t] = " + std::string(ty.mfma) + "(a, bv, acc[t], 0, 0, 0);\n      }\n    }\n  }\n";
+  s += "      const int q = 4 * qq + fk, o = o_next;\n";
+  s += "      o_next = qq + 4 < " + S(Q) + " ? orig[q + 16] : 0;   // (one quad ahead: origin -> window value is two LDS round trips)\n";
+  s += "      const " + std::string(ty.T) + " a = fr < " + S(F) + " ? grun[q * " + S(F) + " + fr] : " + ty.zero + ";   // (zeros behind the band's last pixel: dead pixels add nothing)\n";
+  s += "      " + std::string(ty.T) + " bv[" + S(TB) + "];\n";
+  s += "      _Pragma(\"unroll\") for (int t = 0; t < " + S(TB) + "; ++t) bv[t] = band[o + toff[t]];\n";
+  s += "      _Pragma(\"unroll\") for (int t = 0; t < " + S(TB) + "; ++t) acc[t] = " + std::string(ty.mfma) + "(a, q < live_px ? bv[t] : " + ty.zero + ", acc[t], 0, 0, 0);\n    }\n  }\n";
   // fold the four waves in wave order: [wave][t][row 16][col 16]
   s += "  __syncthreads();\n";
   s += "  _Pragma(\"unroll\") for (int t = 0; t < " + S(TB) + "; ++t)\n";
