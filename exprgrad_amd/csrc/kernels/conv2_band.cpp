@@ -142,6 +142,8 @@ int launch_forward(eg_ctx* ctx, const Ty& ty, bool flip, long N, long HI, long W
   const Band b = plan_band(HI, WI, CI, FH, FW, PY, PX, ty.f64 ? 8 : 4);
   if (!b.ok) return EG_OK;
   const long KS = (taps + 3) / 4, G = (b.PT + 15) / 16;
+  // static LDS of the kernel: the band, the origin table, the waves' parking rows — 64 KB is the limit of a block's static allocation
+  if (b.lds_elems * (ty.f64 ? 8 : 4) + G * 64 + 4 * 32 * FO * (ty.f64 ? 8 : 4) > 60 * 1024) return EG_OK;
   const std::string name = std::string("eg_conv_band_") + ty.sfx + (flip ? "_gi" : "_fw") + "_c" + S(CI) + "_f" + S(FO) + "_" + S(FH) + "x" + S(FW) + "_" +
                            S(HI) + "x" + S(WI) + "_b" + S(b.NB) + "r" + S(b.R) + ((FO % (ty.f64 ? 2 : 4) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? "_w" : "");
   std::string s = prelude();
@@ -237,6 +239,8 @@ int launch_grad_filter(eg_ctx* ctx, const Ty& ty, long N, long H, long W, long C
   const long TB = (taps + 15) / 16, Q = (b.PT + 3) / 4, E = F * taps;
   const long GT = Q * 4 * F;                                            // elements of the staged output-gradient run
   const long GL = (GT + 255) / 256;                                     // ... per thread
+  // static LDS: max(band, the fold's 4 x TB accumulator blocks) + the run + the origin table; 64 KB is the limit
+  if ((std::max(b.lds_elems, 4 * 16 * TB * 16) + GT) * (ty.f64 ? 8 : 4) + Q * 16 > 60 * 1024 || GL > 64) return EG_OK;
   const std::string name = std::string("eg_conv_band_") + ty.sfx + "_gf_c" + S(C) + "_f" + S(F) + "_" + S(FH) + "x" + S(FW) + "_" + S(H) + "x" + S(W) + "_b" + S(b.NB) + "r" + S(b.R);
   std::string s = prelude();
   s += "extern \"C\" __global__ void __launch_bounds__(256) " + name + "(const " + ty.T + "* __restrict__ img, const " + ty.T + "* __restrict__ gout, " + ty.T +

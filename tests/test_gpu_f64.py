@@ -399,7 +399,7 @@ def test_split_step_with_a_caller_owned_bucket_f64(gpu_ctx):
         split.close()
 
 
-@pytest.mark.parametrize("shape", [(48, 12, 12, 8, 16, 3, 3), (9, 28, 28, 1, 8, 5, 5), (3, 40, 50, 3, 5, 3, 3)])
+@pytest.mark.parametrize("shape", [(48, 12, 12, 8, 16, 3, 3), (9, 28, 28, 1, 8, 5, 5), (3, 40, 50, 3, 5, 3, 3), (50, 12, 12, 16, 8, 3, 3)])
 def test_band_convolution_training_step_f64(gpu_ctx, shape):
     """conv2 and its two gradients of a float64 model on the matrix cores (kernels/conv2_band.cpp, the float64 instantiation):
     conv2 -> mse -> gradientDescent at shapes past the kernels' pixel threshold, gradients and updated parameters against
