@@ -148,7 +148,7 @@ int fuse_slab_fold(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
 //   * reads nothing that an earlier member sums over the batch (a block sees its own sample only), and
 //   * if it sums over the batch itself, writes a member of the gradient bucket without scatter (its per-sample
 //     contributions go to the slab; one slab_sum launch behind the kernel folds them, in a fixed order).
-// Switches: EG_NO_SAMPLE_FUSE=1, EG_SAMPLE_FUSE_MAX_BATCH (default 2048), EG_SAMPLE_THREADS (512), EG_SAMPLE_NO_LDS.
+// Switches: EG_NO_SAMPLE_FUSE=1, EG_SAMPLE_FUSE_MAX_BATCH (default 1280), EG_SAMPLE_THREADS (512), EG_SAMPLE_NO_LDS.
 int form_sample_group(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos, const std::map<int, int>& first_writer,
                       std::vector<int>& group_of, std::set<int>& needs_zero) {
   {
@@ -163,7 +163,10 @@ int form_sample_group(eg_model* m, TargetState& ts, Plan& plan, const std::vecto
       B = in.second.shape[0];
       break;
     }
-  long max_batch = 2048;  // (fashion_mnist step, one box: 43.7 vs 76.5 us at batch 32, 58 vs 180 at 256, 313 vs 381 at 2048; even at ~4096)
+  // (fashion_mnist step, one box, sample group vs launch chain: 43.7 vs 76.5 us at batch 32, 57 vs 119 at 256, 94 vs 136 at 512, 170 vs 183 at
+  //  1024, 299 vs 245 at 2048 — until the small-channel convolutions of round 5 made the chain's five convolution launches twice as fast, the
+  //  chain took 381 there and the limit was 2048)
+  long max_batch = 1280;
   if (const char* e = getenv("EG_SAMPLE_FUSE_MAX_BATCH")) max_batch = atol(e);
   if (B < 2 || B > max_batch) return EG_OK;
   const int n = (int)t.live.size();
