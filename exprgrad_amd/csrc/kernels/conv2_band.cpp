@@ -280,14 +280,19 @@ int launch_grad_filter(eg_ctx* ctx, const Ty& ty, long N, long H, long W, long C
   s += "      _Pragma(\"unroll\") for (int u = 0; u < " + S(GL) + "; ++u) { const int e = tid + 256 * u; gv[u] = e < glive ? gp[e] : " + ty.zero + "; }\n";
   s += "      _Pragma(\"unroll\") for (int u = 0; u < " + S(GL) + "; ++u) { const int e = tid + 256 * u; if (e < " + S(GT) + ") grun[e] = gv[u]; }\n    }\n";
   s += "    __syncthreads();\n";
-  s += "    int o_next = orig[4 * wave + fk];   // (the table holds pixel 0's origin behind the band's last pixel)\n";
-  s += "    for (int qq = wave; qq < " + S(Q) + "; qq += 4) {\n";
-  s += "      const int q = 4 * qq + fk, o = o_next;\n";
-  s += "      o_next = qq + 4 < " + S(Q) + " ? orig[q + 16] : 0;   // (one quad ahead: origin -> window value is two LDS round trips)\n";
-  s += "      const " + std::string(ty.T) + " a = fr < " + S(F) + " ? grun[q * " + S(F) + " + fr] : " + ty.zero + ";   // (zeros behind the band's last pixel: dead pixels add nothing)\n";
-  s += "      " + std::string(ty.T) + " bv[" + S(TB) + "];\n";
-  s += "      _Pragma(\"unroll\") for (int t = 0; t < " + S(TB) + "; ++t) bv[t] = band[o + toff[t]];\n";
-  s += "      _Pragma(\"unroll\") for (int t = 0; t < " + S(TB) + "; ++t) acc[t] = " + std::string(ty.mfma) + "(a, q < live_px ? bv[t] : " + ty.zero + ", acc[t], 0, 0, 0);\n    }\n  }\n";
+  // four quads per trip: their origins, then their window values and gradient values, then their matrix instructions — an LDS
+  // round trip per STEP of the chain origin -> window value -> multiply instead of per quad (one quad per trip left two waits
+  // of ~100 cycles in front of every pair of instructions: 50 us on the 28 x 28 x 1 -> 8 layer at batch 4096)
+  s += "    for (int qq = wave; qq < " + S(Q) + "; qq += 16) {\n";
+  s += "      int o[4];\n      " + std::string(ty.T) + " a[4], bv[4][" + S(TB) + "];\n";
+  s += "      _Pragma(\"unroll\") for (int u = 0; u < 4; ++u) o[u] = qq + 4 * u < " + S(Q) + " ? orig[4 * (qq + 4 * u) + fk] : 0;\n";
+  s += "      _Pragma(\"unroll\") for (int u = 0; u < 4; ++u) {\n";
+  s += "        const int q = 4 * (qq + 4 * u) + fk;\n";
+  s += "        a[u] = (qq + 4 * u < " + S(Q) + " && fr < " + S(F) + ") ? grun[q * " + S(F) + " + fr] : " + ty.zero + ";   // (zeros behind the band's last pixel)\n";
+  s += "        _Pragma(\"unroll\") for (int t = 0; t < " + S(TB) + "; ++t) bv[u][t] = band[o[u] + toff[t]];\n      }\n";
+  s += "      _Pragma(\"unroll\") for (int u = 0; u < 4; ++u) {\n";
+  s += "        const bool live = qq + 4 * u < " + S(Q) + " && 4 * (qq + 4 * u) + fk < live_px;\n";
+  s += "        _Pragma(\"unroll\") for (int t = 0; t < " + S(TB) + "; ++t) acc[t] = " + std::string(ty.mfma) + "(a[u], live ? bv[u][t] : " + ty.zero + ", acc[t], 0, 0, 0);\n      }\n    }\n  }\n";
   // fold the four waves in wave order: [wave][t][row 16][col 16]
   s += "  __syncthreads();\n";
   s += "  _Pragma(\"unroll\") for (int t = 0; t < " + S(TB) + "; ++t)\n";
