@@ -390,6 +390,51 @@ def test_band_convolutions_against_the_oracle_and_the_other_routes(gpu_ctx, refc
         assert rel_err(band[key], other[key].astype(np.float64)) <= TOL, key
 
 
+def test_band_convolutions_on_random_shapes(gpu_ctx, monkeypatch):
+    """Forty random shapes with at most 16 channels and 16 filters (image sizes, filter sizes, batches that do not divide
+    into bands, outputs per pixel that do and do not make 16-byte pieces): the band kernels against the routes they replace
+    (EG_CONV_NO_BAND=1), forward and both gradients, overwrite and accumulate."""
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        C, F = int(rng.integers(1, 17)), int(rng.integers(1, 17))
+        FH, FW = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        if FH == 1 and FW == 1:
+            FW = 2          # (1 x 1 filters are plain contractions)
+        H, W = int(rng.integers(FH + 3, 48)), int(rng.integers(FW + 3, 48))
+        Ho, Wo = H - FH + 1, W - FW + 1
+        N = int(max(1, (4096 + 2000 * rng.random()) // (Ho * Wo)) + 1)
+        while N * Ho * Wo * F * FH * FW * C < 6.5e6:     # past the tiny kernels' limit
+            N += 1
+        shape = (N, H, W, C, F, FH, FW)
+        img = rng.random((N, H, W, C), dtype=np.float32)
+        flt = (rng.random((F, FH, FW, C), dtype=np.float32) * 2 - 1).astype(np.float32)
+        gout = (rng.random((N, Ho, Wo, F), dtype=np.float32) - 0.5).astype(np.float32)
+        base = {"out": rng.random((N, Ho, Wo, F), dtype=np.float32), "gflt": rng.random(flt.shape, dtype=np.float32),
+                "gimg": rng.random(img.shape, dtype=np.float32)}
+        dimg, dflt, dg = dev(gpu_ctx, img), dev(gpu_ctx, flt), dev(gpu_ctx, gout)
+
+        def run(acc):
+            got = {}
+            for key, fn, a, b in (("out", ops.conv2_nhwc, dimg, dflt), ("gflt", ops.conv2_nhwc_grad_filter, dimg, dg),
+                                  ("gimg", ops.conv2_nhwc_grad_image, dflt, dg)):
+                t = gpu_ctx.allocTensor(base[key].shape)
+                t.write(base[key] if acc else np.full(base[key].shape, np.nan, dtype=np.float32))
+                fn(gpu_ctx, N, H, W, C, F, FH, FW, a, b, t, accumulate=acc)
+                got[key] = t.read()
+                t.buffer.dealloc()
+            return got
+        for acc in (False, True):
+            monkeypatch.delenv("EG_CONV_NO_BAND", raising=False)
+            band = run(acc)
+            monkeypatch.setenv("EG_CONV_NO_BAND", "1")
+            other = run(acc)
+            for key in band:
+                assert rel_err(band[key], other[key].astype(np.float64)) <= TOL, (shape, key, acc)
+        for t in (dimg, dflt, dg):
+            t.buffer.dealloc()
+    monkeypatch.delenv("EG_CONV_NO_BAND", raising=False)
+
+
 @pytest.mark.parametrize("shape", SHAPES)
 def test_conv2_gradients_on_the_contraction_route(gpu_ctx, refcpu, monkeypatch, shape):
     """The shapes of test_conv2_gradients_against_the_oracle are small enough for kernels/conv2_tiny.hip now; the
