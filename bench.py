@@ -306,6 +306,19 @@ class Timer:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
+    def run_cold(self, step, steps, warmup):
+        """The literal contract, nothing in front of it: W warmup steps, then K timed steps between two
+        barrier + synchronize brackets, from whatever clock state the device is in after start-up (idle).  Reported as
+        `value_cold` next to the sustained-clock `value` (run() below puts ~0.2 s of the same step in front)."""
+        for _ in range(warmup):
+            step()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.sync()
+        return time.perf_counter() - t0
+
     def run(self, step, steps, warmup):
         torch = self.torch
         # Untimed preparation, like the kernel builds that happen on the first call: keep the device
@@ -564,8 +577,12 @@ def run_matmul(args, env):
     a = torch.rand((n, n), device="cuda", dtype=torch.float32, generator=gen)  # U[0,1): matmul_gpu.nim:69-70
     b = torch.rand((n, n), device="cuda", dtype=torch.float32, generator=gen)
     c = torch.empty((n, n), device="cuda", dtype=torch.float32)
-    elapsed, ev_avg, ev_min = timer.run(lambda: ops.sgemm(ctx, n, n, n, a, n, b, n, c, n), args.steps, args.warmup)
     flops = 2.0 * n * n * n
+    ops.sgemm(ctx, n, n, n, a, n, b, n, c, n)          # first call: module load, workspace
+    timer.sync()
+    time.sleep(0.25)                                    # idle: the clocks fall back, as they are when a process starts
+    cold_s = timer.run_cold(lambda: ops.sgemm(ctx, n, n, n, a, n, b, n, c, n), args.steps, args.warmup)
+    elapsed, ev_avg, ev_min = timer.run(lambda: ops.sgemm(ctx, n, n, n, a, n, b, n, c, n), args.steps, args.warmup)
     # ONE clock for `value` and the roofline fraction: the wall time of the K timed steps (barrier + synchronize on both
     # sides).  HIP events are reported next to it (kernel_ms_avg / kernel_ms_min, frac_by_events; EVENTS_NOTE).
     achieved = flops * args.steps / elapsed / 1e12
@@ -582,6 +599,11 @@ def run_matmul(args, env):
         "metric": "GFLOP/s matmul 4096^3 f32 (1 GPU)" if n == 4096 else f"GFLOP/s matmul {n}^3 f32",
         "value": round(flops * args.steps * env["world"] / elapsed / 1e9, 1), "unit": "GFLOP/s",
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "value_cold": {"value": round(flops * args.steps * env["world"] / cold_s / 1e9, 1), "unit": "GFLOP/s",
+                       "ms_per_step": round(cold_s / args.steps * 1e3, 4),
+                       "frac": round(flops * args.steps / cold_s / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                       "note": "the literal --warmup W / --steps K figure from an idle device (no spin-up in front): the "
+                               "first ~20 ms after idle run inside the clock ramp"},
         "config": {"workload": f"matmul M=N=K={n} float32 (BASELINE configs[1]): C = A*B through eg_sgemm "
                                "(MFMA + LDS tiled HIP kernel), A, B ~ U[0,1) resident in HBM",
                    "parallelism": "single" if env["world"] == 1 else f"{env['world']} independent replicas",
@@ -624,6 +646,93 @@ def run_matmul_sizes(args, env):
                                    "sub-tile); 512^3 likewise; 1536^3 - 3072^3: gemm_f32_mfma_kernel<64,64,...>, four waves, "
                                    "up to four blocks per CU",
                          "traffic": None}}
+
+
+def run_hbm_kernels(args, env):
+    """The bandwidth-bound library kernels of SURVEY.md 8(a)-K at cfg-5 sizes (65 536 x 512 floats = 134 MB per tensor; the
+    skinny 65 536 x 10 forms next to them): elementwise maps and their derived gradients (dnn.nim:26-40), bias add
+    (dnn.nim:19-24), column / row / full reductions (bias gradient, softmax sums, loss: base.nim:57-67), axpy
+    (gradientDescent, base.nim:37-38).  Since round 2 every model fuses these away, so they are timed here through the
+    library entry points themselves: algorithmic bytes (each operand once) / mean launch time by HIP events on the launch
+    stream, against the 8 TB/s HBM peak (the guide's float4-copy ceiling is 6.29 TB/s)."""
+    torch, ops, ctx = env["torch"], env["ops"], env["ctx"]
+    stream = env["timer"].stream
+    rows_n, cols_n = 65536, 512
+    n = rows_n * cols_n
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    # FOUR operand sets in rotation (1.6 GB): a 134 MB operand would otherwise be served by the 256 MB Infinity Cache on
+    # every launch after the first (MI355X_MICROARCH.md "Infinity Cache") and the figure would not be an HBM rate
+    SETS = 4
+    xs_, gs_, ys_ = [], [], []
+    for _ in range(SETS):
+        xs_.append(torch.rand((rows_n, cols_n), device="cuda", generator=gen) - 0.5)
+        gs_.append(torch.rand((rows_n, cols_n), device="cuda", generator=gen) - 0.5)
+        ys_.append(torch.empty((rows_n, cols_n), device="cuda"))
+    bias = torch.rand((cols_n,), device="cuda", generator=gen)
+    colv, rowv, tot = torch.empty((cols_n,), device="cuda"), torch.empty((rows_n,), device="cuda"), torch.empty((1,), device="cuda")
+    xs = torch.rand((rows_n, 10), device="cuda", generator=gen) - 0.5
+    ys = torch.empty_like(xs)
+    bias_s, col_s = torch.rand((10,), device="cuda", generator=gen), torch.empty((10,), device="cuda")
+    steps = max(args.steps, 48)
+    turn = [0]
+
+    def timed(step):
+        def go():
+            i = turn[0] = (turn[0] + 1) % SETS
+            step(xs_[i], gs_[i], ys_[i])
+        t0 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t0 < 0.05 or k < 8:   # sustained clocks, like every other figure of the line
+            go()
+            k += 1
+            if k % 32 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(steps):
+            go()
+        b.record(stream)
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / steps * 1e3   # us per launch
+
+    f = 4
+    cases = [
+        ("map_relu", lambda x, g, y: ops.map_(ctx, "relu", n, x, y), 2 * n * f),
+        ("map_sigmoid", lambda x, g, y: ops.map_(ctx, "sigmoid", n, x, y), 2 * n * f),
+        ("map_tanh", lambda x, g, y: ops.map_(ctx, "tanh", n, x, y), 2 * n * f),
+        ("map_grad_relu", lambda x, g, y: ops.map_grad(ctx, "relu", n, x, g, y), 3 * n * f),
+        ("map_grad_sigmoid", lambda x, g, y: ops.map_grad(ctx, "sigmoid", n, x, g, y), 3 * n * f),
+        ("map_grad_tanh", lambda x, g, y: ops.map_grad(ctx, "tanh", n, x, g, y), 3 * n * f),
+        ("bias_add", lambda x, g, y: ops.bias_add(ctx, rows_n, cols_n, bias, y, accumulate=True), 2 * n * f),
+        ("colsum", lambda x, g, y: ops.colsum(ctx, rows_n, cols_n, x, colv), n * f),
+        ("rowsum", lambda x, g, y: ops.rowsum(ctx, rows_n, cols_n, x, rowv), n * f + rows_n * f),
+        ("sum", lambda x, g, y: ops.total(ctx, n, x, tot), n * f),
+        ("axpy", lambda x, g, y: ops.axpy(ctx, n, -0.01, g, y), 3 * n * f),
+        ("fill", lambda x, g, y: ops.fill(ctx, n, 0.0, y), n * f),
+        ("bias_add_65536x10", lambda x, g, y: ops.bias_add(ctx, rows_n, 10, bias_s, ys, accumulate=True), 2 * rows_n * 10 * f),
+        ("colsum_65536x10", lambda x, g, y: ops.colsum(ctx, rows_n, 10, xs, col_s), rows_n * 10 * f),
+        ("rowsum_65536x10", lambda x, g, y: ops.rowsum(ctx, rows_n, 10, xs, rowv), rows_n * 11 * f),
+    ]
+    out = {}
+    for name, step, nbytes in cases:
+        for y in ys_:
+            y.zero_()
+        us = timed(step)
+        gbs = nbytes / (us * 1e-6) / 1e9
+        out[name] = {"us": round(us, 2), "mb": round(nbytes / 1e6, 2), "gbs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    big = [k for k in out if not k.endswith("x10")]
+    worst = min(big, key=lambda k: out[k]["frac"])
+    return {"metric": "GB/s of the bandwidth-bound library kernels (eg_map / eg_map_grad / eg_bias_add / eg_colsum / eg_rowsum / "
+                      "eg_sum / eg_axpy / eg_fill_f32), 65536 x 512 float32 operands (134 MB each) and the 65536 x 10 forms",
+            "unit": "GB/s", "kernels": out, "timed_steps": steps, "sustained_clock_spinup_s": 0.05,
+            "bytes": "algorithmic: every operand read once, every result written once (an accumulating result also read); four "
+                     "operand sets (1.6 GB) in rotation, so that no launch finds its operands in the 256 MB Infinity Cache",
+            "clock": "one HIP event pair around the timed launches on the launch stream / launches",
+            "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": out[worst]["gbs"],
+                         "frac": out[worst]["frac"], "kernel": worst + " (the slowest of the 134 MB forms)",
+                         "copy_ceiling_gbs": 6290, **traffic_fields("hbm_kernels")}}
 
 
 def run_float64(args, env):
@@ -1104,6 +1213,51 @@ def compile_latency():
             "note": "seconds per model: eg_model_compile, then the first and second run of the train target at the config's batch"}
 
 
+def per_config_block(line, extra):
+    """Compact per-config figures INSIDE `roofline` (the driver keeps that dict whole but only a 2 000-character tail of
+    the line, so extra.* does not survive it): one entry per BASELINE config and per widening, each with its time, the
+    fraction of its bound and which bound that is."""
+    def get(d, *path):
+        for k in path:
+            if not isinstance(d, dict) or k not in d:
+                return None
+            d = d[k]
+        return d
+    pc = {"cfg2_matmul4096": {"ms": line.get("ms_per_step"), "frac": get(line, "roofline", "frac"), "bound": "mfma",
+                              "effective_clock_mhz": get(line, "roofline", "effective_clock_mhz")}}
+    t = extra.get("train", {})
+    if "error" not in t and t:
+        pc["cfg5_step"] = {"ms": t.get("ms_per_step"), "frac": get(t, "roofline", "frac"), "bound": "mfma",
+                           "effective_clock_mhz": get(t, "roofline", "effective_clock_mhz"),
+                           "frac_at_clock": get(t, "roofline", "frac_of_rate_at_effective_clock")}
+    x = extra.get("xor", {})
+    if "error" not in x and x:
+        pc["cfg3_xor"] = {"us": round(x["ms_per_step"] * 1e3, 2), "frac": get(x, "roofline", "frac"), "bound": "hbm (18.87 MB/step)"}
+    c = extra.get("conv2", {})
+    if "error" not in c and c:
+        flops = get(c, "roofline", "flops_per_launch") or 0.0
+        def fr(ms):
+            return round(flops / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4) if ms else None
+        pc["cfg4_conv2"] = {"bound": "mfma", "fwd_us": round(c["ms_per_step"] * 1e3, 2), "fwd": get(c, "roofline", "frac"),
+                            "gradf_us": round(get(c, "backward", "grad_filter_ms") * 1e3, 2), "gradf": fr(get(c, "backward", "grad_filter_ms")),
+                            "gradi_us": round(get(c, "backward", "grad_image_ms") * 1e3, 2), "gradi": fr(get(c, "backward", "grad_image_ms"))}
+    f = extra.get("fashion_mnist_fit", {})
+    if "error" not in f and f:
+        pc["fit_b32"] = {"us_per_batch": get(f, "batch_32", "us_per_batch"), "frac": get(f, "roofline", "frac"), "bound": "launch"}
+        pc["fit_b4096"] = {"us_per_batch": get(f, "batch_4096", "us_per_batch"),
+                           "hbm_floor_us": get(f, "batch_4096", "bound", "hbm_floor_us")}
+    m = extra.get("matmul_sizes", {})
+    if "error" not in m and m:
+        pc["matmul_sizes_frac"] = {k: v["frac_of_mfma_peak"] for k, v in m.get("sizes", {}).items()}
+    h = extra.get("hbm_kernels", {})
+    if "error" not in h and h:
+        pc["hbm_kernels_frac_of_8TBs"] = {k: v["frac"] for k, v in h.get("kernels", {}).items()}
+    d = extra.get("float64", {})
+    if "error" not in d and d:
+        pc["float64"] = {"dgemm4096_frac": get(d, "roofline", "frac")}
+    return pc
+
+
 def _free_port():
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
@@ -1224,9 +1378,14 @@ def main():
             guarded("conv2", lambda: run_conv2(small, env))
             guarded("fashion_mnist_fit", lambda: run_fashion_fit(small, env))
             guarded("matmul_sizes", lambda: run_matmul_sizes(small, env))
+            guarded("hbm_kernels", lambda: run_hbm_kernels(small, env))
             guarded("float64", lambda: run_float64(small, env))
             guarded("compile_latency", compile_latency)
             line["extra"] = extra
+            try:
+                line["roofline"]["per_config"] = per_config_block(line, extra)
+            except Exception as exc:  # noqa: BLE001 - a summary of figures that are all in extra.*
+                line["roofline"]["per_config"] = {"error": repr(exc)}
             if not args.no_cpu_baseline:
                 # every config gets its CPU figure, bounded to a few seconds each
                 def baseline(name, fn):
@@ -1263,6 +1422,13 @@ def main():
             line["runtime_compiler"] = buf.value.decode()
         except Exception as exc:  # noqa: BLE001
             line["runtime_compiler"] = repr(exc)
+        # ONE JSON line; the long secondary blocks come first so that the last 2 KB of the line (what a log tail keeps) hold
+        # the headline: value, roofline with per_config, cpu_baseline
+        head = ("metric", "value", "unit")
+        tail_keys = ("n_gpus", "steps", "warmup", "ms_per_step", "value_cold", "higher_is_better", "scaling", "vs_baseline",
+                     "dtype", "data", "config", "scaling_series_n1", "cpu_baseline", "roofline")
+        line = {**{k: line[k] for k in head}, **{k: v for k, v in line.items() if k not in head and k not in tail_keys},
+                **{k: line[k] for k in tail_keys if k in line}}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -17,6 +17,7 @@
 #include <thread>
 
 #include "eg_internal.hpp"
+#include "host/dp_schedule.hpp"
 
 namespace {
 
@@ -85,6 +86,7 @@ struct eg_dp {
   bool split = true;    // early / late split of the bucket allowed (eg_dp_set_split; EG_DP_NO_SPLIT=1 starts with false)
   int reserve_cus = 8;  // compute units the last long contraction leaves to the early collective (EG_DP_RESERVE_CUS)
   int64_t* agree_buf = nullptr;  // device scratch of the cross-rank comparison: 2 x 32 int64
+  uint64_t identity = 0;         // hash of the communicator's unique id: the same on every rank, new for every group
 };
 
 namespace {
@@ -161,6 +163,7 @@ int eg_dp_init(eg_ctx* ctx, const void* id128, int rank, int world, eg_dp** out)
   dp->comm = comm;
   dp->rank = rank;
   dp->world = world;
+  dp->identity = eg::dp::group_identity(id128, sizeof(UniqueId));
   dp->split = !env_on("EG_DP_NO_SPLIT");
   if (const char* e = getenv("EG_DP_RESERVE_CUS")) dp->reserve_cus = atoi(e);
   *out = dp;
@@ -240,6 +243,7 @@ int eg_model_step_dp(eg_model* model, const char* target, eg_dp* dp, int mean) {
   if (rc) return rc;
   eg::GradExchange gx;
   gx.user = dp;
+  gx.group = dp->identity;
   gx.split = dp->split;
   // (EG_DP_TEST_AS_MULTI=1: a one-rank group takes the multi-rank code paths — comparison collective, reserved compute
   // units — so that a one-GPU box exercises them)

@@ -201,6 +201,9 @@ struct GradExchange {
   // NULL: not checked (a one-rank group).
   int (*agree)(void* user, const int64_t* values, int n, int* same) = nullptr;
   void* user = nullptr;
+  // identity of the group, the same number on every rank (dp::group_identity of the communicator's unique id): the key
+  // of the target's exchange schedule.  0 = none (the schedule is keyed by `user`; only sound for a one-rank group)
+  uint64_t group = 0;
   bool split = true;    // allow the early / late split of the bucket (EG_DP_NO_SPLIT, eg_dp_set_split)
   int reserve_cus = 0;  // compute units the last long contraction leaves free for the collective's kernel
 };

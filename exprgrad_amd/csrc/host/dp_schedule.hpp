@@ -24,6 +24,7 @@
 // flags any step in which two ranks issue different collectives.
 #pragma once
 #include <cstdint>
+#include <map>
 #include <string>
 #include <utility>
 #include <vector>
@@ -143,6 +144,24 @@ inline int step_decision(Schedule& s, const Proposal& mine, bool split_allowed, 
     *how = (propose_split && mine.early == s.early && mine.late == s.late) ? How::Overlapped : How::Sequential;
   }
   return 0;
+}
+
+// The schedules of one target, one per data-parallel GROUP.  The key is an identity every rank of the group derives
+// identically — a hash of the communicator's 128-byte unique id (group_identity) — never the address of the rank's
+// group object: an allocator may hand the address of a destroyed group to its successor on SOME ranks only, and those
+// ranks would find the old group's Schedule (state != 0: no negotiation due, float SUM calls) while the others start from
+// state 0 with the int64 comparison collective — mismatched collectives on one communicator (ADVICE r5;
+// tests/dp_schedule_sim.cpp "regroup" / "regroup_by_address_is_caught").
+struct ScheduleTable {
+  std::map<uint64_t, Schedule> by_group;
+  Schedule& of(uint64_t group) { return by_group[group]; }
+  void forget(uint64_t group) { by_group.erase(group); }
+};
+
+inline uint64_t group_identity(const void* unique_id, size_t bytes) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < bytes; ++i) h = (h ^ static_cast<const unsigned char*>(unique_id)[i]) * 1099511628211ull;
+  return h ? h : 1;  // 0 is "no identity"
 }
 
 }  // namespace dp

@@ -59,7 +59,9 @@ int model_backward_with_exchange(eg_model* m, const char* target, const GradExch
     const char* e = getenv("EG_DP_REAGREE_STEPS");
     return e ? atol(e) : 256L;
   }();
-  eg::dp::Schedule& sched = ts->dp_schedules[gx.user];
+  // keyed by what every rank derives identically from the communicator, not by this rank's group address (a one-rank
+  // caller without an identity — gx.group 0 — has no peer to disagree with: its address serves)
+  eg::dp::Schedule& sched = ts->dp_schedules.of(gx.group ? gx.group : (uint64_t)reinterpret_cast<uintptr_t>(gx.user));
   eg::dp::How how = eg::dp::How::Whole;
   std::string why;
   rc = eg::dp::step_decision(sched, mine, gx.split, gx.agree, gx.user, reagree_every, &how, &why);
@@ -641,6 +643,13 @@ int eg_model_tensor_ptr(eg_model* m, const char* target, int tensor_id, float** 
   EG_REQUIRE(ts && ts->last, EG_ERR_RUNTIME, "target has not been run");
   auto s = ts->last->shapes.find(tensor_id);
   EG_REQUIRE(s != ts->last->shapes.end(), EG_ERR_INVALID, "tensor %d has no shape in the last run", tensor_id);
+  // the same refusals as eg_model_read_tensor: an address that was allocated but never written would read as garbage
+  EG_REQUIRE(!ts->last->predicated.count(tensor_id), EG_ERR_INVALID,
+             "tensor %d exists only as predicate bits in the last run's plan (eg_model_keep_values(model, 1) makes the plans keep values)",
+             tensor_id);
+  EG_REQUIRE(!(ts->last->sample_group && ts->last->sample_group->g.lds.count(tensor_id)), EG_ERR_INVALID,
+             "tensor %d lived in the LDS of a sample group's blocks in the last run's plan: its values were never stored "
+             "(eg_model_keep_values(model, 1) makes the plans keep values)", tensor_id);
   if (device_ptr) *device_ptr = tensor_ptr(m, *ts, *ts->last, tensor_id);
   if (count) *count = prod(s->second);
   return EG_OK;

@@ -244,8 +244,9 @@ struct TargetState {
   float* bucket = nullptr;
   bool bucket_owned = false;
   uint64_t last_stamp = ~0ull;  // eg_model::inputs_gen for which `last` was looked up
-  // exchange schedule of the data-parallel step per group (GradExchange::user): host/dp_schedule.hpp
-  std::map<void*, eg::dp::Schedule> dp_schedules;
+  // exchange schedule of the data-parallel step per group, keyed by the group's rank-independent identity
+  // (GradExchange::group): host/dp_schedule.hpp ScheduleTable
+  eg::dp::ScheduleTable dp_schedules;
   long last_epoch = -1;         // ... and Model.epoch (compared when the program computes host values from epoch())
 };
 

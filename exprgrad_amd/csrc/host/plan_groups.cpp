@@ -73,7 +73,15 @@ int fuse_row_tails(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
     // ticket counter instead of 256 (a fan-in of 255 costs ~3.3 us, MI355X_MICROARCH.md price list) and 64 partial rows
     // for the last block; 786 KB of input do not need 256 CUs.  Per-thread totals then span several samples: the sums
     // change their order (not their terms) against the one-sample-per-thread launch.
-    long cap = 64;
+    // The figure belongs to THAT size: 64 blocks for 786 KB of rows are 12 KB per block.  A larger batch keeps that
+    // share per block instead of the count (a 1 M-row group on 64 of 256 CUs with 64-sample serial loops per
+    // thread was a multi-x slowdown against ceil(B / 256) blocks); the fan-in it adds is microseconds.
+    long row_floats = 0;
+    for (auto& tt : pg.g.tensors)
+      if (tt.second.role == RowGroupTensor::RowExternal || (tt.second.role == RowGroupTensor::RowLocal && (tt.second.store || tt.second.load_first)))
+        row_floats += tt.second.inner;
+    const long bytes_touched = pg.g.B * std::max(1L, row_floats) * 4;
+    long cap = std::max(64L, (bytes_touched + 12287) / 12288);
     if (const char* e = getenv("EG_ROW_TAIL_BLOCKS")) cap = std::max(1L, atol(e));
     if (pg.nblocks > cap) pg.nblocks = (int)cap;
   }

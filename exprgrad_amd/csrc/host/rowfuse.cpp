@@ -269,9 +269,17 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
   const bool slim = g.B >= 4096 && state <= 64;
   std::string sig = std::string("extern \"C\" __global__ void __launch_bounds__(256") + (slim ? ", 5" : "") + ") " + g.name +
                     "(float* __restrict__ partial";
+  // a tensor the tail kernels touch is also reachable through u<t> (and written there): its t<t> must not promise
+  // that nobody else modifies it
+  std::set<int> tail_touched;
+  if (g.in_kernel_finalize && g.red_total > 0)
+    for (int ki : g.tail_kernels) {
+      tail_touched.insert(all[ki].write.tensor);
+      for (auto& rd : all[ki].reads) tail_touched.insert(rd.tensor);
+    }
   for (int t : g.ptr_args) {
     const RowGroupTensor& gt = g.tensors.at(t);
-    sig += gt.role == RowGroupTensor::RowLocal ? ", float* t" : ", const float* __restrict__ t";
+    sig += gt.role == RowGroupTensor::RowLocal ? ", float* t" : tail_touched.count(t) ? ", const float* t" : ", const float* __restrict__ t";
     sig += std::to_string(t);
   }
   sig += ", long B, float GS, long EP";
@@ -294,7 +302,9 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
       for (auto& rd : all[ki].reads) touched.insert(rd.tensor);
     }
     g.tail_ptr_args.assign(touched.begin(), touched.end());
-    for (int t : g.tail_ptr_args) sig += ", float* __restrict__ u" + std::to_string(t);  // (one name per tensor: no aliases)
+    // NOT __restrict__: the same tensors are reachable through d<t> (the totals just written) and t<t> (parameters the
+    // tail overwrites) in this kernel; the barriers between those accesses order them, the qualifier would deny them
+    for (int t : g.tail_ptr_args) sig += ", float* u" + std::to_string(t);
   }
   sig += ")";
 
@@ -373,6 +383,10 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
         // sides are a valid hand-off; the stores are drained — vmcnt(0) — before the block takes its ticket).
         // Sums in the order of row_finalize_kernel (reduce.hip): thread t of 256 adds rows t, t + 256, ...; xor-shuffle
         // tree per wave; ((w0 + w1) + w2) + w3 — the same value to the bit for the same number of blocks.
+        // This hand-off is OUTSIDE the HIP / LLVM memory model (relaxed atomics + an explicit vmcnt drain instead of a
+        // release / acquire pair on the ticket): it holds on gfx9-family ISAs, where stores count in vmcnt and sc0 sc1
+        // accesses go to memory.  The library is built for gfx950 only; the generated text refuses anything else.
+        c += "#if !defined(__gfx950__)\n#error \"row-tail hand-off relies on gfx950 cache-bypass stores and vmcnt store counting\"\n#endif\n";
         c += "  if (MODE != 0) {\n";
         c += "    __shared__ int s_last;\n";
         c += "    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n";

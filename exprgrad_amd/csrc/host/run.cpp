@@ -161,7 +161,13 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       if (rc || sg.g.slab_floats <= 0) return rc;
       if (slab_fold_active(plan, L)) return EG_OK;  // the optimizer's map group behind this launch adds the rows up itself
       // every sample's contribution to the parameter gradients -> the gradient bucket, in a fixed order
-      return eg::slab_sum(ctx, sg.g.B, sg.g.slab_floats, sg.slab, ts.bucket + sg.bucket_base, 0);
+      float* dst = ts.bucket + sg.bucket_base;
+      if (eg::slab_sum_supported(sg.g.slab_floats, sg.slab, dst)) return eg::slab_sum(ctx, sg.g.B, sg.g.slab_floats, sg.slab, dst, 0);
+      // a bucket bound to caller memory that is not 16-byte aligned (a sliced view), a row that is no multiple of four
+      // floats, or EG_NO_SLAB_SUM: the scalar two-pass column sum, as kernels/conv2_band.cpp falls back
+      rc = eg::ensure_workspace(ctx, (size_t)eg::colsum_scratch_floats(ctx, sg.g.B, sg.g.slab_floats) * sizeof(float));
+      if (rc) return rc;
+      return eg::colsum_with_scratch(ctx, sg.g.B, sg.g.slab_floats, sg.slab, dst, 0, static_cast<float*>(ctx->workspace));
     }
     case StepKind::RowFused: {
       PlanRowGroup& pg = *plan.row_groups[L.row_group];

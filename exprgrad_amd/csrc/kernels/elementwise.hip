@@ -3,8 +3,11 @@
 //
 // Reference lowering being replaced: tests/cache/relu_basic.ir — one work-item per element in
 // work-groups of 16 (ir.nim:283), i.e. a quarter of a wavefront per group.  Here: 256-thread
-// blocks, 16-byte accesses per lane (1 KiB per wave instruction), grid-stride over at most
-// 8 blocks per CU.
+// blocks, 16-byte accesses per lane (1 KiB per wave instruction).  Round 6 (tools/hbm_probe.hip, operands past the
+// 256 MB Infinity Cache): a block owns ONE CONTIGUOUS chunk and a thread has U = 4 sixteen-byte loads per stream in
+// flight before the first dependent store, every access nontemporal (nothing is read twice), at most 32 blocks per
+// CU — a two-stream map moves 268 MB at 6.27 TB/s and a three-stream gradient 403 MB at 6.29 (the guide's float4-copy
+// ceiling is 6.29); the grid-stride form with one load in flight it replaces: 5.40 / 5.46 TB/s.
 //
 // Arithmetic follows llvmgen.nim:212-301 operation by operation (fadd/fsub/fmul/fdiv, ordered
 // compares, select, libm-class exp/sin/cos); this file is built with -ffp-contract=off so no
@@ -16,6 +19,23 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NT = 256;
+constexpr int UV = 4;   // 16-byte pieces per thread and stream in flight (vector path)
+
+// vector path: blocks of a chunked launch over n4 sixteen-byte groups, and the chunk a block owns (a multiple of NT * UV)
+inline unsigned chunk_grid(const eg_ctx* ctx, long n4) {
+  long blocks = (n4 + (long)NT * UV - 1) / ((long)NT * UV);
+  const long cap = 32L * ctx->compute_units;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+__device__ __forceinline__ void chunk_range(long n4, long& lo, long& hi) {
+  const long per = ((n4 + gridDim.x - 1) / gridDim.x + (long)NT * UV - 1) / ((long)NT * UV) * ((long)NT * UV);
+  lo = (long)blockIdx.x * per;
+  hi = lo + per < n4 ? lo + per : n4;
+}
+__device__ __forceinline__ f32x4 ldnt(const f32x4* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void stnt(f32x4 v, f32x4* p) { __builtin_nontemporal_store(v, p); }
 
 inline unsigned grid_for(const eg_ctx* ctx, long work_items) {
   long blocks = (work_items + NT - 1) / NT;
@@ -101,27 +121,37 @@ __device__ __forceinline__ float map_bwd(float x, float g, float p) {
 template <int OP, bool ACC>
 __global__ __launch_bounds__(NT) void map_kernel(const float* __restrict__ in, float* __restrict__ out, long n,
                                                  float p, int vec) {
-  const long tid = (long)blockIdx.x * NT + threadIdx.x;
-  const long nthreads = (long)gridDim.x * NT;
   if (vec) {
     const long n4 = n >> 2;
-    for (long i = tid; i < n4; i += nthreads) {
-      f32x4 x = reinterpret_cast<const f32x4*>(in)[i];
-      f32x4 y;
+    long lo, hi;
+    chunk_range(n4, lo, hi);
+    const f32x4* in4 = reinterpret_cast<const f32x4*>(in);
+    f32x4* out4 = reinterpret_cast<f32x4*>(out);
+    for (long i = lo + threadIdx.x; i < hi; i += NT * UV) {
+      f32x4 x[UV], o[UV];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) y[j] = map_fwd<OP>(x[j], p);
-      if (ACC) {
-        f32x4 o = reinterpret_cast<f32x4*>(out)[i];
+      for (int u = 0; u < UV; ++u)
+        if (i + u * NT < hi) {
+          x[u] = ldnt(in4 + i + u * NT);
+          if (ACC) o[u] = ldnt(out4 + i + u * NT);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = o[j] + y[j];
+      for (int u = 0; u < UV; ++u)
+        if (i + u * NT < hi) {
+          f32x4 y;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] = ACC ? o[u][j] + map_fwd<OP>(x[u][j], p) : map_fwd<OP>(x[u][j], p);
+          stnt(y, out4 + i + u * NT);
+        }
+    }
+    if (blockIdx.x == 0)
+      for (long i = (n4 << 2) + threadIdx.x; i < n; i += NT) {
+        float y = map_fwd<OP>(in[i], p);
+        out[i] = ACC ? out[i] + y : y;
       }
-      reinterpret_cast<f32x4*>(out)[i] = y;
-    }
-    for (long i = (n4 << 2) + tid; i < n; i += nthreads) {
-      float y = map_fwd<OP>(in[i], p);
-      out[i] = ACC ? out[i] + y : y;
-    }
   } else {
+    const long tid = (long)blockIdx.x * NT + threadIdx.x;
+    const long nthreads = (long)gridDim.x * NT;
     for (long i = tid; i < n; i += nthreads) {
       float y = map_fwd<OP>(in[i], p);
       out[i] = ACC ? out[i] + y : y;
@@ -132,28 +162,39 @@ __global__ __launch_bounds__(NT) void map_kernel(const float* __restrict__ in, f
 template <int OP, bool ACC>
 __global__ __launch_bounds__(NT) void map_grad_kernel(const float* __restrict__ in, const float* __restrict__ gout,
                                                       float* __restrict__ gin, long n, float p, int vec) {
-  const long tid = (long)blockIdx.x * NT + threadIdx.x;
-  const long nthreads = (long)gridDim.x * NT;
   if (vec) {
     const long n4 = n >> 2;
-    for (long i = tid; i < n4; i += nthreads) {
-      f32x4 x = reinterpret_cast<const f32x4*>(in)[i];
-      f32x4 g = reinterpret_cast<const f32x4*>(gout)[i];
-      f32x4 y;
+    long lo, hi;
+    chunk_range(n4, lo, hi);
+    const f32x4* in4 = reinterpret_cast<const f32x4*>(in);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(gout);
+    f32x4* out4 = reinterpret_cast<f32x4*>(gin);
+    for (long i = lo + threadIdx.x; i < hi; i += NT * UV) {
+      f32x4 x[UV], g[UV], o[UV];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) y[j] = map_bwd<OP>(x[j], g[j], p);
-      if (ACC) {
-        f32x4 o = reinterpret_cast<f32x4*>(gin)[i];
+      for (int u = 0; u < UV; ++u)
+        if (i + u * NT < hi) {
+          x[u] = ldnt(in4 + i + u * NT);
+          g[u] = ldnt(g4 + i + u * NT);
+          if (ACC) o[u] = ldnt(out4 + i + u * NT);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = o[j] + y[j];
+      for (int u = 0; u < UV; ++u)
+        if (i + u * NT < hi) {
+          f32x4 y;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) y[j] = ACC ? o[u][j] + map_bwd<OP>(x[u][j], g[u][j], p) : map_bwd<OP>(x[u][j], g[u][j], p);
+          stnt(y, out4 + i + u * NT);
+        }
+    }
+    if (blockIdx.x == 0)
+      for (long i = (n4 << 2) + threadIdx.x; i < n; i += NT) {
+        float y = map_bwd<OP>(in[i], gout[i], p);
+        gin[i] = ACC ? gin[i] + y : y;
       }
-      reinterpret_cast<f32x4*>(gin)[i] = y;
-    }
-    for (long i = (n4 << 2) + tid; i < n; i += nthreads) {
-      float y = map_bwd<OP>(in[i], gout[i], p);
-      gin[i] = ACC ? gin[i] + y : y;
-    }
   } else {
+    const long tid = (long)blockIdx.x * NT + threadIdx.x;
+    const long nthreads = (long)gridDim.x * NT;
     for (long i = tid; i < n; i += nthreads) {
       float y = map_bwd<OP>(in[i], gout[i], p);
       gin[i] = ACC ? gin[i] + y : y;
@@ -165,23 +206,35 @@ __global__ __launch_bounds__(NT) void map_grad_kernel(const float* __restrict__ 
 template <bool ACC>
 __global__ __launch_bounds__(NT) void bias_add_kernel(const float* __restrict__ bias, float* __restrict__ out,
                                                       long rows, long cols, int vec) {
-  const long tid = (long)blockIdx.x * NT + threadIdx.x;
-  const long nthreads = (long)gridDim.x * NT;
   const long n = rows * cols;
   if (vec) {  // cols % 4 == 0: a 16-byte chunk never straddles a row
     const long n4 = n >> 2;
     const long c4 = cols >> 2;
-    for (long i = tid; i < n4; i += nthreads) {
-      const long c = (i % c4) << 2;
-      f32x4 b = *reinterpret_cast<const f32x4*>(bias + c);
-      if (ACC) {
-        f32x4 o = reinterpret_cast<f32x4*>(out)[i];
+    long lo, hi;
+    chunk_range(n4, lo, hi);
+    f32x4* out4 = reinterpret_cast<f32x4*>(out);
+    for (long i = lo + threadIdx.x; i < hi; i += NT * UV) {
+      f32x4 b[UV], o[UV];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = o[j] + b[j];
-      }
-      reinterpret_cast<f32x4*>(out)[i] = b;
+      for (int u = 0; u < UV; ++u)
+        if (i + u * NT < hi) {
+          b[u] = *reinterpret_cast<const f32x4*>(bias + (((i + u * NT) % c4) << 2));   // (the bias row is re-read: cached)
+          if (ACC) o[u] = ldnt(out4 + i + u * NT);
+        }
+#pragma unroll
+      for (int u = 0; u < UV; ++u)
+        if (i + u * NT < hi) {
+          f32x4 y = b[u];
+          if (ACC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[j] = o[u][j] + b[u][j];
+          }
+          stnt(y, out4 + i + u * NT);
+        }
     }
   } else {
+    const long tid = (long)blockIdx.x * NT + threadIdx.x;
+    const long nthreads = (long)gridDim.x * NT;
     for (long i = tid; i < n; i += nthreads) {
       const float b = bias[i % cols];
       out[i] = ACC ? out[i] + b : b;
@@ -191,32 +244,50 @@ __global__ __launch_bounds__(NT) void bias_add_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(NT) void axpy_kernel(float alpha, const float* __restrict__ x, float* __restrict__ y,
                                                   long n, int vec) {
-  const long tid = (long)blockIdx.x * NT + threadIdx.x;
-  const long nthreads = (long)gridDim.x * NT;
   if (vec) {
     const long n4 = n >> 2;
-    for (long i = tid; i < n4; i += nthreads) {
-      f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
-      f32x4 yv = reinterpret_cast<f32x4*>(y)[i];
+    long lo, hi;
+    chunk_range(n4, lo, hi);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    f32x4* y4 = reinterpret_cast<f32x4*>(y);
+    for (long i = lo + threadIdx.x; i < hi; i += NT * UV) {
+      f32x4 xv[UV], yv[UV];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) yv[j] = yv[j] + alpha * xv[j];
-      reinterpret_cast<f32x4*>(y)[i] = yv;
+      for (int u = 0; u < UV; ++u)
+        if (i + u * NT < hi) {
+          xv[u] = ldnt(x4 + i + u * NT);
+          yv[u] = ldnt(y4 + i + u * NT);
+        }
+#pragma unroll
+      for (int u = 0; u < UV; ++u)
+        if (i + u * NT < hi) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) yv[u][j] = yv[u][j] + alpha * xv[u][j];
+          stnt(yv[u], y4 + i + u * NT);
+        }
     }
-    for (long i = (n4 << 2) + tid; i < n; i += nthreads) y[i] = y[i] + alpha * x[i];
+    if (blockIdx.x == 0)
+      for (long i = (n4 << 2) + threadIdx.x; i < n; i += NT) y[i] = y[i] + alpha * x[i];
   } else {
+    const long tid = (long)blockIdx.x * NT + threadIdx.x;
+    const long nthreads = (long)gridDim.x * NT;
     for (long i = tid; i < n; i += nthreads) y[i] = y[i] + alpha * x[i];
   }
 }
 
 __global__ __launch_bounds__(NT) void fill_kernel(float value, float* __restrict__ out, long n, int vec) {
-  const long tid = (long)blockIdx.x * NT + threadIdx.x;
-  const long nthreads = (long)gridDim.x * NT;
   if (vec) {
     const long n4 = n >> 2;
+    long lo, hi;
+    chunk_range(n4, lo, hi);
     const f32x4 v = {value, value, value, value};
-    for (long i = tid; i < n4; i += nthreads) reinterpret_cast<f32x4*>(out)[i] = v;
-    for (long i = (n4 << 2) + tid; i < n; i += nthreads) out[i] = value;
+    f32x4* out4 = reinterpret_cast<f32x4*>(out);
+    for (long i = lo + threadIdx.x; i < hi; i += NT) stnt(v, out4 + i);
+    if (blockIdx.x == 0)
+      for (long i = (n4 << 2) + threadIdx.x; i < n; i += NT) out[i] = value;
   } else {
+    const long tid = (long)blockIdx.x * NT + threadIdx.x;
+    const long nthreads = (long)gridDim.x * NT;
     for (long i = tid; i < n; i += nthreads) out[i] = value;
   }
 }
@@ -362,8 +433,8 @@ int eg_map(eg_ctx* ctx, int op, int64_t n, const float* in, float* out, float pa
   EG_REQUIRE(in && out, EG_ERR_INVALID, "eg_map: NULL tensor");
   int rc = eg::set_device(ctx);
   if (rc) return rc;
-  const int vec = aligned16(in) && aligned16(out);
-  const unsigned grid = grid_for(ctx, vec ? (n + 3) / 4 : n);
+  const int vec = aligned16(in) && aligned16(out) && n >= 4;
+  const unsigned grid = vec ? chunk_grid(ctx, n >> 2) : grid_for(ctx, n);
 #define LAUNCH(OP)                                                                                          \
   do {                                                                                                      \
     if (accumulate)                                                                                         \
@@ -385,8 +456,8 @@ int eg_map_grad(eg_ctx* ctx, int op, int64_t n, const float* in, const float* go
   EG_REQUIRE(in && gout && gin, EG_ERR_INVALID, "eg_map_grad: NULL tensor");
   int rc = eg::set_device(ctx);
   if (rc) return rc;
-  const int vec = aligned16(in) && aligned16(gout) && aligned16(gin);
-  const unsigned grid = grid_for(ctx, vec ? (n + 3) / 4 : n);
+  const int vec = aligned16(in) && aligned16(gout) && aligned16(gin) && n >= 4;
+  const unsigned grid = vec ? chunk_grid(ctx, n >> 2) : grid_for(ctx, n);
 #define LAUNCH(OP)                                                                                           \
   do {                                                                                                       \
     if (accumulate)                                                                                          \
@@ -411,7 +482,7 @@ int eg_bias_add(eg_ctx* ctx, int64_t rows, int64_t cols, const float* bias, floa
   if (rc) return rc;
   const int vec = (cols % 4 == 0) && aligned16(bias) && aligned16(out);
   const long n = rows * cols;
-  const unsigned grid = grid_for(ctx, vec ? n / 4 : n);
+  const unsigned grid = vec ? chunk_grid(ctx, n / 4) : grid_for(ctx, n);
   if (accumulate)
     hipLaunchKernelGGL((bias_add_kernel<true>), dim3(grid), dim3(NT), 0, ctx->stream, bias, out, (long)rows,
                        (long)cols, vec);
@@ -429,8 +500,8 @@ int eg_axpy(eg_ctx* ctx, int64_t n, float alpha, const float* x, float* y) {
   EG_REQUIRE(x && y, EG_ERR_INVALID, "eg_axpy: NULL tensor");
   int rc = eg::set_device(ctx);
   if (rc) return rc;
-  const int vec = aligned16(x) && aligned16(y);
-  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(ctx, vec ? (n + 3) / 4 : n)), dim3(NT), 0, ctx->stream, alpha, x, y,
+  const int vec = aligned16(x) && aligned16(y) && n >= 4;
+  hipLaunchKernelGGL(axpy_kernel, dim3(vec ? chunk_grid(ctx, n >> 2) : grid_for(ctx, n)), dim3(NT), 0, ctx->stream, alpha, x, y,
                      (long)n, vec);
   EG_HIP_CHECK(hipGetLastError());
   return EG_OK;
@@ -443,8 +514,8 @@ int eg_fill_f32(eg_ctx* ctx, int64_t n, float value, float* out) {
   EG_REQUIRE(out, EG_ERR_INVALID, "eg_fill_f32: NULL tensor");
   int rc = eg::set_device(ctx);
   if (rc) return rc;
-  const int vec = aligned16(out);
-  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(ctx, vec ? (n + 3) / 4 : n)), dim3(NT), 0, ctx->stream, value, out,
+  const int vec = aligned16(out) && n >= 4;
+  hipLaunchKernelGGL(fill_kernel, dim3(vec ? chunk_grid(ctx, n >> 2) : grid_for(ctx, n)), dim3(NT), 0, ctx->stream, value, out,
                      (long)n, vec);
   EG_HIP_CHECK(hipGetLastError());
   return EG_OK;

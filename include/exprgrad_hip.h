@@ -277,7 +277,10 @@ int eg_model_run_update(eg_model* model, const char* target);
  * dropped).  data[i] is a host array (on_device[i] == 0: uploaded once, piecewise, overlapped
  * with the batches already queued) or a device array used in place; shapes8 holds 8 extents per
  * input.  Asynchronous with respect to the kernels; the host arrays are free on return.
- * EG_ERR_RUNTIME with the reference's message when n_inputs == 0. */
+ * EG_ERR_RUNTIME with the reference's message when n_inputs == 0.
+ * After fit the model's bound inputs are UNSPECIFIED (the reference leaves the last batch's views bound,
+ * model.nim:441-446): when the step's kernels read the batches where they lie in the data set, nothing is copied into
+ * the inputs' staging buffers.  Bind inputs again before the next eg_model_run. */
 int eg_model_fit(eg_model* model, const char* target, int n_inputs, const char* const* names, const float* const* data,
                  const int* on_device, const int* ranks, const int64_t* shapes8, int64_t batch_size);
 /* Scale applied to the seed gradient gradLoss (passes.nim:594-596) — B_local/B_global for
@@ -292,6 +295,8 @@ int eg_model_tensor_shape(eg_model* model, const char* target, int tensor_id, in
                           int64_t* shape8);
 int eg_model_read_tensor(eg_model* model, const char* target, int tensor_id, float* host,
                          int64_t count);
+/* (eg_model_read_tensor and eg_model_tensor_ptr refuse — EG_ERR_INVALID — a tensor whose values the last run's plan
+ * never stored: predicate bits, tensors that lived in the LDS of a sample group; see eg_model_keep_values.) */
 int eg_model_tensor_ptr(eg_model* model, const char* target, int tensor_id, float** device_ptr,
                         int64_t* count);
 /* Intermediates are an implementation matter of a plan: a tensor every reader of which is fused away may never exist,

@@ -993,6 +993,24 @@ class Model:
     def apply(self, target, inputs):
         self.call(target, inputs)
 
+    def fit(self, target, inputs, batch_size=32):
+        """Model.fit, model.nim:413-454: epoch += 1 ONCE (436), then the target once per mini-batch of `batch_size`
+        leading rows of every input (batchCount = rows of the FIRST input div batchSize, 425: the tail is dropped;
+        viewFirst slices, 441-443); result tensors start from zero for every batch (447-449: here every call does)."""
+        inputs = list(inputs.items()) if isinstance(inputs, dict) else list(inputs)
+        if not inputs:      # model.nim:418-419
+            raise RuntimeError("Model.fit requires at least one input tensor. Use Model.apply instead if the target has zero inputs.")
+        if target not in self.prog.targets:     # model.nim:420-421
+            raise RuntimeError(target + " is not a target of the model")
+        for name, _ in inputs:                  # model.nim:429-430
+            if name not in self.prog.inputs:
+                raise RuntimeError(name + " is not an input to the model")
+        batches = int(np.asarray(inputs[0][1]).shape[0]) // batch_size
+        self.epoch += 1
+        for b in range(batches):
+            lo = b * batch_size
+            self.apply(target, {name: np.asarray(arr)[lo:lo + batch_size] for name, arr in inputs})
+
     # ---- split step for the data-parallel tests: [forward + backward] | all-reduce | [update] ----
     def param_grads(self, target):
         """[(param tensor id, gradient tensor id)] of the target's optimizer (GenGradient markers)."""

@@ -51,6 +51,44 @@ def gpu_ctx():
     ctx.sync()
 
 
+# ---- the comparison in BASELINE.json's own words, as a gate (round 6) -------------------------------
+# "outputs match the reference LLVM CPU path on identical inputs within 1e-5 relative": the backend against the ORACLE
+# directly.  A comparison may exceed 1e-5 only if (a) the oracle itself is more than DIRECT_EXCUSE from the exact value
+# of the same quantity AND at least half as far as the backend is from it (a 65 536-term sequential float32 sum cannot
+# be matched to 1e-5 by any other order: DESIGN.md section 5), and (b) it is one of the comparisons committed in
+# tests/golden/parity_direct_allow.json by test id and label — a new one is a red test, not a line in a report.
+DIRECT_EXCUSE = 5e-6
+_ALLOW = None
+
+
+def _short_test_id():
+    t = os.environ.get("PYTEST_CURRENT_TEST", "")
+    return t.split("::")[-1].split(" ")[0].split("[")[0]
+
+
+def direct_allowed(what):
+    global _ALLOW
+    if _ALLOW is None:
+        import json
+        with open(os.path.join(ROOT, "tests", "golden", "parity_direct_allow.json")) as f:
+            _ALLOW = {(e["test"], e["what"]) for e in json.load(f)["allow"]}
+    return (_short_test_id(), what) in _ALLOW
+
+
+def direct_gate(e_go, e_ref, what):
+    """e_go: max|backend - oracle| / max|oracle|; e_ref: the oracle's distance from the exact value (None: unknown)."""
+    if e_go <= TOL:
+        return
+    excused = e_ref is not None and e_ref > DIRECT_EXCUSE and e_ref >= 0.5 * e_go
+    assert excused, (what, "backend vs oracle", e_go, "exceeds 1e-5 and the oracle's own distance from the exact value does not "
+                     "excuse it", e_ref)
+    # switches that change the summation order on purpose (tools/stress_suite.sh) may push a borderline comparison
+    # over the line: the allow-list is held in the default configuration, the excuse always
+    if not direct_allowed(what) and not debug_toggles_active():
+        raise AssertionError((_short_test_id(), what, "backend vs oracle", e_go, "oracle vs exact", e_ref,
+                              "exceeds 1e-5 and is not in tests/golden/parity_direct_allow.json"))
+
+
 def rel_err(got, want, what="direct comparison (rel_err)"):
     """max|got - want| / max|want| — the comparison SURVEY.md §7 budgets at 1e-5 for float32.
     `what` labels the line the parity survey logs for it (tools/parity_survey.py)."""

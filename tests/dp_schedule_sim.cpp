@@ -122,8 +122,12 @@ struct Result {
 };
 
 // proposal(rank, step), split_allowed(step)
-template <class P, class A>
-static Result run(int world, int steps, long reagree, P proposal, A allowed, bool legacy = false) {
+static uint64_t one_group(int, int) { return 1; }
+
+// proposal(rank, step), split_allowed(step), key(rank, step) = the key under which this rank looks up the group's schedule in
+// its ScheduleTable (a new key = the host destroyed the group and created another)
+template <class P, class A, class K = uint64_t (*)(int, int)>
+static Result run(int world, int steps, long reagree, P proposal, A allowed, bool legacy = false, K key = one_group) {
   Fabric fabric(world);
   Result res;
   res.how.assign(world, "");
@@ -132,12 +136,12 @@ static Result run(int world, int steps, long reagree, P proposal, A allowed, boo
   for (int r = 0; r < world; ++r)
     threads.emplace_back([&, r] {
       RankCtx ctx{&fabric, r};
-      Schedule sched;
+      ScheduleTable table;
       // legacy: one agreement per PLAN (a plan = a distinct proposal), as rounds 2-4 did
       std::vector<std::pair<Proposal, Schedule>> per_plan;
       for (int step = 0; step < steps; ++step) {
         const Proposal mine = proposal(r, step);
-        Schedule* s = &sched;
+        Schedule* s = &table.of(key(r, step));
         if (legacy) {
           s = nullptr;
           for (auto& pp : per_plan)
@@ -220,6 +224,19 @@ int main() {
   {  // the round-4 policy under early_replan: must be caught by the transport
     Result r = run(2, 20, 0, [&](int rank, int step) { return step >= (rank == 1 ? 5 : 6) ? cut(B, 0) : cut(B, 5130); }, [](int) { return true; }, true);
     report("legacy_policy_is_caught", r, false, true);
+  }
+  {  // regroup: at step 6 every rank destroys the group and creates a new one (another unique id); keyed by the
+     // identity derived from the id, every rank starts the new group's schedule from state 0 in the same step
+    Result r = run(2, 12, 0, [&](int, int) { return cut(B, 5130); }, [](int) { return true; }, false,
+                   [](int, int step) { return group_identity(step < 6 ? "first unique id" : "second unique id", 15); });
+    const bool shape = r.how[0] == std::string(12, 'O') && r.how[1] == r.how[0];
+    report("regroup", r, true, shape);
+  }
+  {  // the round-5 key (the group object's ADDRESS): rank 0's allocator hands the freed address to the new group, rank
+     // 1's does not — rank 0 replays the old schedule's float SUM calls while rank 1 negotiates: must be caught
+    Result r = run(2, 12, 0, [&](int, int) { return cut(B, 5130); }, [](int) { return true; }, false,
+                   [](int rank, int step) { return (uint64_t)(rank == 0 ? 0x7f00aa00 : (step < 6 ? 0x7f00aa00 : 0x7f00bb40)); });
+    report("regroup_by_address_is_caught", r, false, true);
   }
   printf("%s\n", all ? "ALL PASS" : "SOME FAILED");
   return all ? 0 : 1;

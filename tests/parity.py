@@ -30,7 +30,7 @@ import os
 import numpy as np
 
 import refcases
-from conftest import TOL, rel_err
+from conftest import TOL, direct_gate, rel_err
 from exprgrad_amd import model as egm
 
 U = 2.0 ** -24      # float32 unit roundoff
@@ -103,6 +103,10 @@ class Trio:
         # The rule (module docstring): 1e-5 of the exact value; where the reference's own float32
         # arithmetic is farther than that from it, at most twice the reference's distance, capped.
         assert e_ref <= ILL_CAP, (what, "oracle vs exact", e_ref)
+        # north_star's own comparison, asserted (conftest.direct_gate): backend against the oracle directly
+        ref64 = np.asarray(ref32, np.float64)
+        oscale = max(float(np.max(np.abs(ref64))) if ref64.size else 0.0, 1e-30)
+        direct_gate(float(np.max(np.abs(np.asarray(got, np.float64) - ref64))) / oscale if ref64.size else 0.0, e_ref, what)
         if not e_gpu <= max(TOL, min(2.0 * e_ref, ILL_CAP)) + floor:
             # where: worst element, how many elements are off, their bounding box (a tile? a row? everything?)
             err = np.abs(np.asarray(got, np.float64) - exact) / scale
@@ -139,6 +143,8 @@ class Trio:
             # gradient: every term is a 40-instruction expression with square roots and quotients — the rule of check():
             # at most twice the reference's distance, on this scale)
             assert e_ref <= ILL_CAP, (what, "oracle vs exact", e_ref)
+            direct_gate(float(np.max(np.abs(got64 - np.asarray(ref32, np.float64)) / scale)) if exact.size else 0.0, e_ref,
+                        what + " (vs sum of |terms|)")
             assert e_gpu <= max(TOL, min(2.0 * e_ref, ILL_CAP)) + floor, (
                 what, "backend vs exact, relative to the summed magnitudes", e_gpu, "oracle", e_ref)
 

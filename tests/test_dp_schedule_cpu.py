@@ -16,5 +16,6 @@ def test_exchange_schedule_scenarios(tmp_path):
     lines = out.stdout.strip().splitlines()
     assert out.returncode == 0 and lines[-1] == "ALL PASS", out.stdout + out.stderr
     names = [l.split()[1].rstrip(":") for l in lines[:-1]]
-    assert names == ["steady", "early_replan", "early_replan_new_cut", "lone_replan", "toggle", "buckets", "legacy_policy_is_caught"]
+    assert names == ["steady", "early_replan", "early_replan_new_cut", "lone_replan", "toggle", "buckets", "legacy_policy_is_caught",
+                     "regroup", "regroup_by_address_is_caught"]
     assert all(l.startswith("PASS") for l in lines[:-1])

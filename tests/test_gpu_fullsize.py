@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import refcases
-from conftest import TOL, debug_toggles_active, rel_err
+from conftest import TOL, debug_toggles_active, direct_gate, rel_err
 from exprgrad_amd import model as egm
 from exprgrad_amd import ops
 
@@ -120,7 +120,9 @@ def test_cfg3_xor_train_step_batch_65536(gpu_ctx):
         assert rel_err(du_gpu, exact[tid], what=f"update of parameter {tid}: backend vs exact") <= TOL, tid
         assert rel_err(du_ref, exact[tid], what=f"update of parameter {tid}: ORACLE vs exact (its own 65 536-term drift)") <= batch * 6e-8 / 2, tid
         # the comparison in BASELINE.json's words (backend against the reference CPU path): bounded by the oracle's own drift
-        assert rel_err(du_gpu, du_ref, what=f"update of parameter {tid}: backend vs oracle") <= batch * 6e-8 / 2 + TOL, tid
+        e_go = rel_err(du_gpu, du_ref, what=f"update of parameter {tid}: backend vs oracle")
+        assert e_go <= batch * 6e-8 / 2 + TOL, tid
+        direct_gate(e_go, rel_err(du_ref, exact[tid], what="(oracle vs exact, for the gate)"), f"update of parameter {tid}: backend vs oracle")
     for tid in sorted(ref.params):
         assert np.all(np.isfinite(ref.params[tid])) and np.all(np.isfinite(gpu.params[tid]))
     gpu.close()

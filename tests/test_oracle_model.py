@@ -107,6 +107,42 @@ def test_xor_layers_mse_scaling(refcpu):
     assert abs(loss / y.size - internal) < 1e-4
 
 
+def test_xor_layers_fit_mse_scaling(refcpu):
+    """tests/test_dnn.nim:51-78 ("xor/fit"): 2000 x Model.fit(batchSize = 4) on the four XOR samples, then the reference's
+    own three checks — internal mse < 0.1, sum of squares < 0.1, |sum of squares / len - mse| < 1e-4 — through the
+    oracle's fit (model.nim:413-454 restated: one epoch bump per call, rows div batchSize batches).  A 2000-step
+    chain of float32 updates: the longest reduction any reference-held check runs through this path."""
+    model = kd.Model(refcases.program_text(refcases.xor_layers()), fast_contractions=False)
+    xor_params(model, seed=1)
+    x = np.array([[0, 0], [0, 1], [1, 0], [1, 1]], dtype=np.float32)
+    y = np.array([[0], [1], [1], [0]], dtype=np.float32)
+    other = kd.Model(refcases.program_text(refcases.xor_layers()), fast_contractions=False)
+    xor_params(other, seed=1)
+    for _ in range(2000):
+        model.fit("train", {"x": x, "y": y}, batch_size=4)
+        other.apply("train", {"x": x, "y": y})
+    assert model.epoch == 2000                        # model.nim:436
+    for tid in model.params:                          # one batch per fit call: fit is apply (+ the epoch)
+        assert np.array_equal(model.params[tid], other.params[tid])
+    internal = float(model.call("loss", {"x": x, "y": y}).sum())
+    loss = float(np.sum((model.call("predict", {"x": x}) - y) ** 2))
+    assert internal < 0.1 and loss < 0.1
+    assert abs(loss / y.size - internal) < 1e-4
+    # rows div batchSize: a fifth row is dropped (model.nim:425), zero inputs and unknown names raise (418-421, 429-430)
+    before = {t: p.copy() for t, p in model.params.items()}
+    x5, y5 = np.concatenate([x, x[:1]]), np.concatenate([y, y[:1]])
+    model.fit("train", {"x": x5, "y": y5}, batch_size=4)
+    other.apply("train", {"x": x, "y": y})
+    for tid in before:
+        assert np.array_equal(model.params[tid], other.params[tid])
+    with pytest.raises(RuntimeError):
+        model.fit("train", {}, batch_size=4)
+    with pytest.raises(RuntimeError):
+        model.fit("nope", {"x": x, "y": y}, batch_size=4)
+    with pytest.raises(RuntimeError):
+        model.fit("train", {"z": x}, batch_size=4)
+
+
 def test_conv2_forms(refcpu):
     rng = np.random.default_rng(4)
     img = rng.random((2, 7, 6, 3), dtype=np.float32)
