@@ -44,6 +44,8 @@ _SIGS = {
     "eg_device_props": (c_int, [c_int, P(c_int), P(c_int), P(c_i64), c_char_p, c_size_t]),
     "eg_compiler_info": (c_int, [c_char_p, c_size_t]),
     "eg_kernel_cache_stats": (c_int, [P(c_i64), P(c_i64), P(ctypes.c_double)]),
+    "eg_switches_reload": (c_int, []),
+    "eg_switch_table": (c_i64, [c_char_p, c_size_t]),
     "eg_ctx_create": (c_int, [c_int, P(c_void_p)]),
     "eg_ctx_create_on_stream": (c_int, [c_int, c_void_p, P(c_void_p)]),
     "eg_ctx_destroy": (c_int, [c_void_p]),
@@ -188,3 +190,18 @@ def call(name, *args):
     if name not in _NOT_STATUS and fn.restype is c_int:
         check(rc)
     return rc
+
+
+def reload_switches():
+    """Re-read the environment switches (csrc/switches.cpp caches them at first use): call after changing an EG_*
+    variable in a live process.  A no-op before the library is loaded (the first use reads the environment anyway)."""
+    if _lib is not None:
+        _lib.eg_switches_reload()
+
+
+def switch_table():
+    """[(name, class, purpose)] of every environment switch the library honours."""
+    n = lib().eg_switch_table(None, 0)
+    buf = ctypes.create_string_buffer(int(n) + 1)
+    lib().eg_switch_table(buf, int(n) + 1)
+    return [tuple(line.split("\t")) for line in buf.value.decode().splitlines()]

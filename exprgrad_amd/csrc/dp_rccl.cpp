@@ -104,7 +104,7 @@ struct InitState {
 
 int init_with_watchdog(int device, int world, const UniqueId& id, int rank, Comm* out) {
   double timeout_s = 180;
-  if (const char* e = getenv("EG_DP_INIT_TIMEOUT_S")) timeout_s = atof(e);
+  if (const char* e = eg::sw::raw("EG_DP_INIT_TIMEOUT_S")) timeout_s = atof(e);
   auto st = std::make_shared<InitState>();
   std::thread([st, device, world, id, rank] {
     hipSetDevice(device);
@@ -131,7 +131,7 @@ int init_with_watchdog(int device, int world, const UniqueId& id, int rank, Comm
 }
 
 bool env_on(const char* name) {
-  const char* e = getenv(name);
+  const char* e = eg::sw::raw(name);
   return e && e[0] && e[0] != '0';
 }
 }  // namespace
@@ -165,7 +165,7 @@ int eg_dp_init(eg_ctx* ctx, const void* id128, int rank, int world, eg_dp** out)
   dp->world = world;
   dp->identity = eg::dp::group_identity(id128, sizeof(UniqueId));
   dp->split = !env_on("EG_DP_NO_SPLIT");
-  if (const char* e = getenv("EG_DP_RESERVE_CUS")) dp->reserve_cus = atoi(e);
+  if (const char* e = eg::sw::raw("EG_DP_RESERVE_CUS")) dp->reserve_cus = atoi(e);
   *out = dp;
   return EG_OK;
 }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "exprgrad_hip.h"
+#include "switches.hpp"
 
 namespace eg {
 

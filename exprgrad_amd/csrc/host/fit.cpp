@@ -15,7 +15,7 @@ namespace {
 // step of 550 us does not: groups only for small batches.
 long fit_group_size(long batch_size) {
   if (!graphs_enabled()) return 1;
-  if (const char* e = getenv("EG_FIT_GROUP")) {
+  if (const char* e = eg::sw::raw("EG_FIT_GROUP")) {
     const long g = atol(e);
     return g >= 1 && g <= 64 ? g : 1;
   }
@@ -25,7 +25,7 @@ long fit_group_size(long batch_size) {
 // Is the sample group's kernel the only launch of the plan that reads an input tensor?  (Then a batch's rows can be read
 // where they lie.)  Conservative: any launch kind whose operands are not enumerated here counts as a reader.
 bool inputs_read_by_sample_kernel_only(eg_model* m, TargetState& ts, Plan& plan) {
-  if (!plan.sample_group || getenv("EG_FIT_NO_DIRECT")) return false;
+  if (!plan.sample_group || eg::sw::raw("EG_FIT_NO_DIRECT")) return false;
   const Target& t = *ts.target;
   auto is_input = [&](int tid) { return tid > 0 && m->prog.tensors[tid].kind == TK::Input; };
   bool sample_reads = false;
@@ -147,7 +147,7 @@ int launch_group(eg_model* m, TargetState& ts, Plan& plan, long group, long b, R
     }
     for (hipGraphNode_t n : copies) ok = ok && n != nullptr;
     fg.direct = want_direct;
-    static const bool debug = getenv("EG_DEBUG_GRAPH") != nullptr;
+    static const bool debug = eg::sw::raw("EG_DEBUG_GRAPH") != nullptr;
     if (debug) fprintf(stderr, "[eg] fit group of %ld batches: %zu nodes captured, copy nodes %s\n", group, count, ok ? "found" : "NOT found");
     if (ok) ok = hipGraphInstantiate(&fg.exec, graph, nullptr, nullptr, 0) == hipSuccess;
     if (!ok) {
@@ -196,7 +196,7 @@ int launch_group(eg_model* m, TargetState& ts, Plan& plan, long group, long b, R
         set = eg::copy_segments_node_params(ctx, cs, &p, arg) && hipGraphExecKernelNodeSetParams(exec, fg.copies[(size_t)j], &p) == hipSuccess;
       }
       if (!set) {
-        if (getenv("EG_DEBUG_GRAPH")) fprintf(stderr, "[eg] fit group: hipGraphExecKernelNodeSetParams refused: %s\n", hipGetErrorString(hipGetLastError()));
+        if (eg::sw::raw("EG_DEBUG_GRAPH")) fprintf(stderr, "[eg] fit group: hipGraphExecKernelNodeSetParams refused: %s\n", hipGetErrorString(hipGetLastError()));
         (void)hipGetLastError();
         EG_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         hipGraphExecDestroy(fg.exec);
@@ -306,8 +306,8 @@ static int model_fit(eg_model* m, const char* target, int n_inputs, const char* 
     size_t have = 0;
     for (size_t v : m->fit_bytes) have += v;
     size_t budget = (free_b + have) / 2, piece_bytes = 8u << 20;  // ~8 MiB per upload
-    if (const char* e = getenv("EG_FIT_SEGMENT_BYTES")) budget = std::min<size_t>(budget, strtoull(e, nullptr, 10));
-    if (const char* e = getenv("EG_FIT_PIECE_BYTES")) piece_bytes = strtoull(e, nullptr, 10);
+    if (const char* e = eg::sw::raw("EG_FIT_SEGMENT_BYTES")) budget = std::min<size_t>(budget, strtoull(e, nullptr, 10));
+    if (const char* e = eg::sw::raw("EG_FIT_PIECE_BYTES")) piece_bytes = strtoull(e, nullptr, 10);
     const size_t batch_bytes = host_row_bytes * (size_t)batch_size;
     EG_REQUIRE(batch_bytes <= budget, EG_ERR_SIZE, "one batch (%zu bytes) does not fit the device", batch_bytes);
     seg_batches = std::min<long>(batch_count, (long)(budget / batch_bytes));

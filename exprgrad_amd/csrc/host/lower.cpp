@@ -26,7 +26,7 @@ int build_generic(eg_model* m, Generic& g) {
 // (passes.nim:1929-2004); its GPU target launches every kernel.
 void inline_producers(eg_model* m, TargetState& ts) {
   static const bool off = [] {
-    const char* e = getenv("EG_NO_INLINE");
+    const char* e = eg::sw::raw("EG_NO_INLINE");
     return e && e[0] && e[0] != '0';
   }();
   if (off) return;
@@ -127,7 +127,7 @@ void inline_producers(eg_model* m, TargetState& ts) {
 // the V have one shape (make_plan), otherwise both kernels run as they are.
 void inline_consumers(eg_model* m, TargetState& ts) {
   static const bool off = [] {
-    const char* e = getenv("EG_NO_INLINE");
+    const char* e = eg::sw::raw("EG_NO_INLINE");
     return e && e[0] && e[0] != '0';
   }();
   if (off) return;

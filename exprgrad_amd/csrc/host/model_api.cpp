@@ -56,7 +56,7 @@ int model_backward_with_exchange(eg_model* m, const char* target, const GradExch
   mine.early = ex.early;
   mine.late = ex.late;
   static const long reagree_every = [] {
-    const char* e = getenv("EG_DP_REAGREE_STEPS");
+    const char* e = eg::sw::raw("EG_DP_REAGREE_STEPS");
     return e ? atol(e) : 256L;
   }();
   // keyed by what every rank derives identically from the communicator, not by this rank's group address (a one-rank

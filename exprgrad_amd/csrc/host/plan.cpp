@@ -113,7 +113,7 @@ int fill_params(eg_model* m, const Kernel& k, const KernelInfo& info, const Shap
       }
       case Slot::SetupVal: v = info.vals.at(k.setup[s.a].res); break;
       case Slot::Vec4: {
-        static const bool off = getenv("EG_NO_VEC4") != nullptr;
+        constexpr bool off = false;
         const int l = src.indep.empty() ? -1 : src.indep.back();
         v = !off && l >= 0 && info.bounds[l].first == 0 && info.bounds[l].second % 4 == 0 && total % 4 == 0 && total > 0;
         auto rows_of_four = [&](int tensor) {
@@ -125,7 +125,7 @@ int fill_params(eg_model* m, const Kernel& k, const KernelInfo& info, const Shap
         break;
       }
       case Slot::Narrow: {
-        static const bool off = getenv("EG_NO_NARROW_INDEX") != nullptr;
+        static const bool off = eg::sw::raw("EG_NO_NARROW_INDEX") != nullptr;
         const long lim = 1L << 31;
         v = !off && total < lim && rtotal < lim;
         auto small = [&](int tensor) {
@@ -219,7 +219,7 @@ std::string shape_key(eg_model* m) {
 // src is complete by then (no later writer), same element count, dst not in the gradient bucket.
 bool copy_can_alias(eg_model* m, TargetState& ts, const Kernel& k, const KernelInfo& info, const Shapes& shapes, int p) {
   static const bool off = [] {
-    const char* e = getenv("EG_NO_ALIAS");
+    const char* e = eg::sw::raw("EG_NO_ALIAS");
     return e && e[0] && e[0] != '0';
   }();
   if (off || !info.ok) return false;
@@ -638,8 +638,12 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
       const bool z = needs_zero.count(tid) != 0 || (plan.predicated.count(tid) != 0 && plan.pred_unzeroed.count(tid) == 0) ||
                      plan.zero_extra.count(tid) != 0;
       if ((pass == 0) != z) continue;
+      // large tensors start on a 256-byte boundary: a streaming kernel's 1 KiB wave stores then cover whole 64-byte
+      // sectors (65 536 x 512 floats written from a base 16 bytes past a boundary: 34 us instead of 27, tools/bin/nk_harness4)
+      const long floats = storage_floats(plan, tid);
+      if (floats >= 16384) off = (off + 63) & ~63L;
       plan.arena_offset[tid] = off;
-      off += align4(storage_floats(plan, tid));
+      off += align4(floats);
     }
     if (pass == 0) plan.zero_floats = off;
   }

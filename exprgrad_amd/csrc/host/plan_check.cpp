@@ -161,7 +161,7 @@ void launch_io(eg_model* m, TargetState& ts, const Plan& plan, const Launch& L, 
 
 int check_plan(eg_model* m, TargetState& ts, Plan& plan) {
   static const bool off = [] {
-    const char* e = getenv("EG_NO_PLAN_CHECK");
+    const char* e = eg::sw::raw("EG_NO_PLAN_CHECK");
     return e && e[0] && e[0] != '0';
   }();
   if (off) return EG_OK;

@@ -21,11 +21,11 @@ static int predicate_tensors(eg_model* m, TargetState& ts, Plan& plan, const std
   plan.pred_unzeroed.clear();
   if (m->keep_values) return EG_OK;  // eg_model_keep_values
   {
-    const char* e = getenv("EG_NO_PREDICATE");
+    const char* e = eg::sw::raw("EG_NO_PREDICATE");
     if (e && e[0] && e[0] != '0') return EG_OK;
     // the batch pipeline (an experiment, off unless EG_PIPELINE=1) addresses half batches of [batch, N] tensors by rows;
     // bit-packed tensors are not addressed that way: the experiment keeps the values
-    const char* p = getenv("EG_PIPELINE");
+    const char* p = eg::sw::raw("EG_PIPELINE");
     if (p && p[0] && p[0] != '0') return EG_OK;
   }
   Target& t = *ts.target;
@@ -111,12 +111,12 @@ static int predicate_tensors(eg_model* m, TargetState& ts, Plan& plan, const std
 // row fusion / graphs.  EG_EPILOGUE_MIN_ELEMS overrides the threshold, EG_NO_EPILOGUE=1 disables.
 int fuse_epilogues(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos) {
   static const bool off = [] {
-    const char* e = getenv("EG_NO_EPILOGUE");
+    const char* e = eg::sw::raw("EG_NO_EPILOGUE");
     return e && e[0] && e[0] != '0';
   }();
   if (off) return EG_OK;
   long min_elems = 1L << 20;
-  if (const char* e = getenv("EG_EPILOGUE_MIN_ELEMS")) min_elems = atol(e);
+  if (const char* e = eg::sw::raw("EG_EPILOGUE_MIN_ELEMS")) min_elems = atol(e);
   Target& t = *ts.target;
   plan.epilogues.clear();
   for (size_t i = 0; i + 1 < plan.launches.size(); ++i) {
@@ -202,7 +202,7 @@ int fuse_epilogues(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
 int fold_row_products(eg_model* m, TargetState& ts, Plan& plan) {
   plan.zero_extra.clear();
   for (const char* name : {"EG_NO_ROW_PRODUCT", "EG_PIPELINE"}) {  // read per plan: a test compares folded and unfolded plans
-    const char* e = getenv(name);
+    const char* e = eg::sw::raw(name);
     if (e && e[0] && e[0] != '0') return EG_OK;
   }
   const Target& t = *ts.target;
@@ -225,6 +225,7 @@ int fold_row_products(eg_model* m, TargetState& ts, Plan& plan) {
       eg::clear_error();
       continue;
     }
+    eg::gemm::fused_withdraw_narrow(probe);   // (a row product rides on the matrix tile whatever K is: run.cpp withdraws it too)
     if (probe.bm != 256 || probe.bn != 256 || probe.splits > 1 || !eg::gemm::fused_wide_store(probe)) continue;
     const int R = t.all[ts.lowered[pe.consumer.lowered].all_index].write.tensor;  // the rows the product is taken of
     // the narrow contraction: the next launches up to it may not touch what moves
@@ -282,7 +283,7 @@ int fold_row_products(eg_model* m, TargetState& ts, Plan& plan) {
 // (a second pass over g: 134 MB at cfg 5) disappears.
 int fold_bias_gradients(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos) {
   {  // read per plan (not once per process): a test switches it to compare folded and unfolded plans
-    const char* e = getenv("EG_NO_ONES_ROW");
+    const char* e = eg::sw::raw("EG_NO_ONES_ROW");
     if (e && e[0] && e[0] != '0') return EG_OK;
   }
   const Target& t = *ts.target;

@@ -7,14 +7,14 @@ namespace model {
 
 bool row_fusion_enabled() {
   static const bool on = [] {
-    const char* e = getenv("EG_NO_ROWFUSE");
+    const char* e = eg::sw::raw("EG_NO_ROWFUSE");
     return !(e && e[0] && e[0] != '0');
   }();
   return on;
 }
 
 bool row_tails_enabled() {  // (read when a plan is made: a test builds one model each way)
-  const char* e = getenv("EG_NO_ROW_TAIL");
+  const char* e = eg::sw::raw("EG_NO_ROW_TAIL");
   return !(e && e[0] && e[0] != '0');
 }
 
@@ -82,7 +82,6 @@ int fuse_row_tails(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
         row_floats += tt.second.inner;
     const long bytes_touched = pg.g.B * std::max(1L, row_floats) * 4;
     long cap = std::max(64L, (bytes_touched + 12287) / 12288);
-    if (const char* e = getenv("EG_ROW_TAIL_BLOCKS")) cap = std::max(1L, atol(e));
     if (pg.nblocks > cap) pg.nblocks = (int)cap;
   }
   return EG_OK;
@@ -99,7 +98,7 @@ bool slab_fold_active(const Plan& plan, const Launch& L) {
 // Every summed tensor must be read by the group as a raw map of its own size; EG_NO_SLAB_FOLD=1 off.
 int fuse_slab_fold(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos) {
   {
-    const char* e = getenv("EG_NO_SLAB_FOLD");
+    const char* e = eg::sw::raw("EG_NO_SLAB_FOLD");
     if (e && e[0] && e[0] != '0') return EG_OK;
   }
   if (!plan.sample_group || plan.sample_group->g.slab_floats <= 0 || plan.pipe.active) return EG_OK;
@@ -160,7 +159,7 @@ int fuse_slab_fold(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
 int form_sample_group(eg_model* m, TargetState& ts, Plan& plan, const std::vector<KernelInfo>& infos, const std::map<int, int>& first_writer,
                       std::vector<int>& group_of, std::set<int>& needs_zero) {
   {
-    const char* e = getenv("EG_NO_SAMPLE_FUSE");
+    const char* e = eg::sw::raw("EG_NO_SAMPLE_FUSE");
     if ((e && e[0] && e[0] != '0') || !row_fusion_enabled()) return EG_OK;
   }
   Target& t = *ts.target;
@@ -175,7 +174,7 @@ int form_sample_group(eg_model* m, TargetState& ts, Plan& plan, const std::vecto
   //  1024, 299 vs 245 at 2048 — until the small-channel convolutions of round 5 made the chain's five convolution launches twice as fast, the
   //  chain took 381 there and the limit was 2048)
   long max_batch = 1280;
-  if (const char* e = getenv("EG_SAMPLE_FUSE_MAX_BATCH")) max_batch = atol(e);
+  if (const char* e = eg::sw::raw("EG_SAMPLE_FUSE_MAX_BATCH")) max_batch = atol(e);
   if (B < 2 || B > max_batch) return EG_OK;
   const int n = (int)t.live.size();
   const int limit = t.first_update >= 0 ? t.first_update : n;
@@ -220,7 +219,7 @@ int form_sample_group(eg_model* m, TargetState& ts, Plan& plan, const std::vecto
       }
     }
   }
-  static const bool debug = getenv("EG_DEBUG_SAMPLE") != nullptr;
+  static const bool debug = eg::sw::raw("EG_DEBUG_SAMPLE") != nullptr;
   if (debug)
     for (int p = 0; p < limit; ++p)
       fprintf(stderr, "[eg] sample: live %d ok %d loop %d raw %d reduced %d seed %d gather %d work %ld absorbed %d inlined %d | %s\n", p, (int)ski[p].ok,
@@ -341,7 +340,6 @@ int form_sample_group(eg_model* m, TargetState& ts, Plan& plan, const std::vecto
   // by sample, nobody outside the run touches them, not the target's output, and the model does not keep values.
   {
     long thr = 512;  // (measured on the fashion_mnist step at batch 32: 256 / 512 / 1024 threads -> 51.9 / 43.9 / 49.8 us per batch)
-    if (const char* e = getenv("EG_SAMPLE_THREADS")) thr = atol(e);
     g.threads = (int)std::min(1024L, std::max(64L, thr / 64 * 64));
     std::map<int, bool> first_plain;  // candidate -> its first member write is a plain store
     std::set<int> candidates;
@@ -360,7 +358,7 @@ int form_sample_group(eg_model* m, TargetState& ts, Plan& plan, const std::vecto
       candidates.erase(k.write.tensor);
       for (auto& rd : k.reads) candidates.erase(rd.tensor);
     }
-    static const bool no_lds = getenv("EG_SAMPLE_NO_LDS") != nullptr;
+    constexpr bool no_lds = false;
     long budget = 34L * 1024;  // floats (136 KB of the 160 KB a block may own; up to 16 KB more for the split reductions)
     if (!m->keep_values && !no_lds)
       for (int tid : candidates) {

@@ -70,7 +70,7 @@ bool launch_tensors(const Plan& plan, const Launch& L, std::set<int>& reads, std
 void plan_overlap(eg_model* m, TargetState& ts, Plan& plan) {
   (void)ts;
   static const bool off = [] {
-    const char* e = getenv("EG_NO_OVERLAP");
+    const char* e = eg::sw::raw("EG_NO_OVERLAP");
     return e && e[0] && e[0] != '0';
   }();
   plan.overlaps.clear();
@@ -99,7 +99,7 @@ void plan_overlap(eg_model* m, TargetState& ts, Plan& plan) {
       if (clash) break;
       first = i;
     }
-    static const bool debug = getenv("EG_DEBUG_OVERLAP") != nullptr;
+    static const bool debug = eg::sw::raw("EG_DEBUG_OVERLAP") != nullptr;
     if (debug) fprintf(stderr, "[eg] overlap: contraction %d (%.1f GFLOP) takes launches [%d, %d)\n", j, flops / 1e9, first, j);
     if (first < j && ensure_side_lane(m->ctx) == EG_OK) plan.overlaps.push_back({first, j});
   }

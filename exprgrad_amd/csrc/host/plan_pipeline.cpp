@@ -36,12 +36,12 @@ void plan_pipeline(eg_model* m, TargetState& ts, Plan& plan) {
     // slower (a 7 us row group: 51 us, an 18 us skinny product: 120 us, even at raised wave priority),
     // so each half's streaming chain (296 us) outlasts the contraction it should hide under (248 us) and
     // slows it by 35 us: 1.144 ms per step against 1.122 ms without the pipeline.
-    const char* e = getenv("EG_PIPELINE");
+    const char* e = eg::sw::raw("EG_PIPELINE");
     if (!(e && e[0] && e[0] != '0')) return;
   }
   if (!plan.predicated.empty()) return;  // (half-batch slices of predicate-bit tensors are not addressed by run_launch_sliced)
   double min_flops = 2e10;  // only steps with long contractions have something to hide work under
-  if (const char* e = getenv("EG_PIPELINE_MIN_FLOPS")) min_flops = atof(e);
+  if (const char* e = eg::sw::raw("EG_PIPELINE_MIN_FLOPS")) min_flops = atof(e);
   const Target& t = *ts.target;
   const int nb = plan.n_backward;
   if (nb < 3) return;

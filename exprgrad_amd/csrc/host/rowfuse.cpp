@@ -286,7 +286,7 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
   // One block (a batch of at most 256 rows): the totals go straight to their destinations.  In a captured graph a
   // dependent launch costs ~4.5 us whatever it does, and row_finalize of one partial row does nothing but copy
   // (p + 0 + 0 + 0 in its tree: the same value).
-  g.single_block = g.B <= 256 && g.red_total > 0 && getenv("EG_NO_ROW_DIRECT") == nullptr;
+  g.single_block = g.B <= 256 && g.red_total > 0 && eg::sw::raw("EG_NO_ROW_DIRECT") == nullptr;
   if (g.single_block) g.in_kernel_finalize = false;
   if (g.red_total <= 0) g.in_kernel_finalize = false;
   if (!g.in_kernel_finalize) g.tail_kernels.clear();
@@ -825,14 +825,7 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
   if (g.slab_floats > 0) c += "  float* const row = slab + n * " + std::to_string(g.slab_floats) + "L;\n";
   std::set<int> slab_seen;
   long scratch_floats = 0;
-  // EG_SAMPLE_STOP=<k> (measurement aid): the kernel ends behind member k — the time of the first k + 1 members
-  const char* stop_env = getenv("EG_SAMPLE_STOP");
-  const long stop = stop_env ? atol(stop_env) : -1;
-  const char* skip_env = getenv("EG_SAMPLE_SKIP");  // (measurement aid: member <k> left out — wrong numbers, the time it costs)
-  const long skip = skip_env ? atol(skip_env) : -1;
   for (size_t gi = 0; gi < g.kernel_index.size(); ++gi) {
-    if (stop >= 0 && (long)gi > stop) break;
-    if (skip >= 0 && (long)gi == skip) continue;
     const Kernel& k = all[g.kernel_index[gi]];
     const KernelInfo& info = infos[g.kernel_index[gi]];
     const SampleKernelInfo& si = g.infos[gi];
@@ -899,13 +892,13 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
     // them: the unrolled copies share every load that does not depend on that iterator (the compiler merges them).
     int blk = -1;
     long R = 1;
-    static const bool no_block = getenv("EG_SAMPLE_NO_BLOCK") != nullptr;
+    constexpr bool no_block = false;
     if (!no_block && !scatter && !si.raw && !si.seed && !red.empty() && rtotal >= 4) {
       // NOT the fastest iterator: consecutive lanes walk that one, so that a wave's LDS reads fall into consecutive banks
       // (blocking it measured 47 us against 32 for the whole kernel: eight-way bank conflicts); the next one up —
       // `x` of out[n, y, x, f], `dx` of gflt[f, dy, dx, c] — is where the window operand and the other operand repeat.
       // EG_SAMPLE_BLOCK_POS (tuning aid): which iterator, counted from the fastest one that has an extent (0), is blocked
-      static const long block_pos = getenv("EG_SAMPLE_BLOCK_POS") ? atol(getenv("EG_SAMPLE_BLOCK_POS")) : 1;
+      constexpr long block_pos = 1;
       long seen = 0;
       for (size_t i = indep.size(); i-- > 0 && blk < 0;) {
         const long ext = info.bounds[indep[i]].second - info.bounds[indep[i]].first;
@@ -1015,7 +1008,7 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
         const std::string r = "r" + std::to_string(k.loops[l].reg);
         // loads of several iterations in flight; EG_SAMPLE_UNROLL_MACS (tuning aid): outer reduction loops are unrolled too
         // while the unrolled body stays below that many multiply-adds (copies that read the same element merge)
-        static const long unroll_macs = getenv("EG_SAMPLE_UNROLL_MACS") ? atol(getenv("EG_SAMPLE_UNROLL_MACS")) : 0;
+        constexpr long unroll_macs = 0;
         long inner = R;
         for (size_t j = i; j < red.size(); ++j) inner *= std::max(1L, info.bounds[red[j]].second - info.bounds[red[j]].first);
         if (i + 1 == red.size()) d += ind + (ext * R <= 64 ? "_Pragma(\"unroll\")\n" : "_Pragma(\"unroll 4\")\n");
@@ -1074,7 +1067,7 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
   // computes with Index VALUES (`toScalar(i * 100000)`: only addressing is known to fit — the rule of Slot::Narrow,
   // codegen.hpp).  64-bit divisions and multiply-adds per element were most of a convolution member's time.
   if (scratch_floats > 0) c = "  __shared__ float scratch[" + std::to_string(scratch_floats) + "];\n" + c;
-  bool narrow = getenv("EG_NO_NARROW_INDEX") == nullptr && g.B * std::max(1L, g.slab_floats) < (1L << 31);
+  bool narrow = eg::sw::raw("EG_NO_NARROW_INDEX") == nullptr && g.B * std::max(1L, g.slab_floats) < (1L << 31);
   for (int t : touched) narrow = narrow && prodv(shapes.at(t)) < (1L << 31);
   for (int ki : g.kernel_index) {
     const Kernel& k = all[ki];

@@ -61,6 +61,7 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       // only valid when C holds plain values and the consumer reads plain values: a predicate tensor has M*N/32 words of
       // storage (eg_sgemm would overrun it), predicate operands hold bits, and a row product's destination would stay
       // zero.  Those launches run fused on one slice — the args of plan_fused always describe the whole K.
+      if (pe.row_product) eg::gemm::fused_withdraw_narrow(f);   // (a row product rides on the 256 x 256 matrix tile)
       const bool must_fuse = pe.pred_write || !pe.pred_reads.empty() || pe.row_product || !pe.store_c;
       if (f.splits > 1 && must_fuse) f.splits = 1;
       if (f.splits > 1) {
@@ -86,7 +87,7 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       if (!handle) {
         const std::string name = "eg_gemm_epi" + std::to_string(m->kernel_serial++);
         const std::string src = eg::gemm::fused_source(f, struct_code, pe.spec.struct_name, name);
-        if (const char* dump = getenv("EG_DUMP_FUSED")) {  // debugging aid: the generated translation unit
+        if (const char* dump = eg::sw::raw("EG_DUMP_FUSED")) {  // debugging aid: the generated translation unit
           if (FILE* fp = fopen((std::string(dump) + "/" + name + "_" + variant + ".hip").c_str(), "w")) {
             fputs(src.c_str(), fp);
             fclose(fp);
@@ -102,7 +103,8 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
         m->kernels.push_back(handle);
       }
       void* args[] = {f.args};
-      rc = eg::kernel_launch_raw(handle, f.grid, 1, 1, (unsigned)f.nt, args);
+      rc = f.narrow ? eg::kernel_launch_raw(handle, f.narrow_grid, 1, 1, 256, args)
+                    : eg::kernel_launch_raw(handle, f.grid, 1, 1, (unsigned)f.nt, args);
       if (rc || !pe.row_product || with_product) return rc;
       return run_launch(m, ts, plan, pe.product);
     }
@@ -370,7 +372,7 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
     }
     // Two independent tiny contractions next to each other (a dense layer's two gradients at a small batch): one launch
     // (EG_NO_SMALL_PAIR=1: two).  Independence is checked on the storage: neither writes what the other touches.
-    const bool pair_off = getenv("EG_NO_SMALL_PAIR") != nullptr;   // (read per launch sequence: a test builds one model each way)
+    const bool pair_off = eg::sw::raw("EG_NO_SMALL_PAIR") != nullptr;   // (read per launch sequence: a test builds one model each way)
     if (!pair_off && !m->f64 && i + 1 < end && i + 1 != plan.n_backward &&
         !(next_overlap < plan.overlaps.size() && plan.overlaps[next_overlap].first == i + 1)) {
       const Launch &A = plan.launches[i], &B = plan.launches[i + 1];
@@ -404,7 +406,7 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
 
 bool graphs_enabled() {
   static const bool on = [] {
-    const char* e = getenv("EG_NO_GRAPH");
+    const char* e = eg::sw::raw("EG_NO_GRAPH");
     return !(e && e[0] && e[0] != '0');
   }();
   return on;
@@ -465,7 +467,7 @@ int run_range(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool
   }
   hipGraph_t graph = nullptr;
   hipError_t e = hipStreamBeginCapture(m->ctx->stream, hipStreamCaptureModeThreadLocal);
-  static const bool debug = getenv("EG_DEBUG_GRAPH") != nullptr;
+  static const bool debug = eg::sw::raw("EG_DEBUG_GRAPH") != nullptr;
   if (e != hipSuccess) {  // capture unavailable on this stream: stay eager
     if (debug) fprintf(stderr, "[eg] begin capture failed: %s\n", hipGetErrorString(e));
     (void)hipGetLastError();
@@ -536,6 +538,7 @@ int run_launch_sliced(eg_model* m, TargetState& ts, Plan& plan, Launch& L, const
       int rc = eg::gemm::plan_fused(ctx, L.trans_a, L.trans_b, sl.rows, L.N, L.K, A, L.lda, tensor_ptr(m, ts, plan, L.b_tensor),
                                     L.ldb, C, L.ldc, bias, f);
       if (rc) return rc;
+      eg::gemm::fused_withdraw_narrow(f);   // (the batch pipeline, an experiment, keeps the matrix tile)
       if (f.splits > 1) {
         set_error("batch pipeline: a half of a fused contraction needs split-K");
         return EG_ERR_RUNTIME;

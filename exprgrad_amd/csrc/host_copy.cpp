@@ -129,7 +129,6 @@ static int stager(eg_ctx* ctx, HostStager** out) {
       EG_HIP_CHECK(hipEventCreateWithFlags(&s->ev[i], hipEventDisableTiming));
     }
     int threads = 6;
-    if (const char* e = getenv("EG_COPY_THREADS")) threads = atoi(e);
     const int hw = (int)std::thread::hardware_concurrency();
     if (hw > 0 && threads > hw) threads = hw;
     if (threads < 1) threads = 1;
@@ -151,7 +150,7 @@ static void parallel_copy(Pool& pool, void* dst, const void* src, size_t bytes) 
 
 static bool staging_enabled() {
   static const bool on = [] {
-    const char* e = getenv("EG_NO_STAGED_COPY");
+    const char* e = eg::sw::raw("EG_NO_STAGED_COPY");
     return !(e && e[0] && e[0] != '0');
   }();
   return on;

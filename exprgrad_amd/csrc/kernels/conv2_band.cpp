@@ -32,7 +32,7 @@ namespace {
 eg_kernel* get_or_build(eg_ctx* ctx, const std::string& name, const std::string& source) {
   auto it = ctx->jit.find(name);
   if (it != ctx->jit.end()) return it->second;
-  if (const char* dump = getenv("EG_DUMP_BAND")) {  // debugging aid: the generated translation unit
+  if (const char* dump = eg::sw::raw("EG_DUMP_BAND")) {  // debugging aid: the generated translation unit
     if (FILE* fp = fopen((std::string(dump) + "/" + name + ".hip").c_str(), "w")) {
       fputs(source.c_str(), fp);
       fclose(fp);
@@ -45,7 +45,7 @@ eg_kernel* get_or_build(eg_ctx* ctx, const std::string& name, const std::string&
 }
 
 bool disabled() {
-  const char* e = getenv("EG_CONV_NO_BAND");  // read per call: a test compares the routes
+  const char* e = eg::sw::raw("EG_CONV_NO_BAND");  // read per call: a test compares the routes
   return e && e[0] && e[0] != '0';
 }
 
@@ -69,7 +69,7 @@ Band plan_band(long HI, long WI, long CI, long FH, long FW, long PY, long PX, lo
   b.STR = CI | 1;
   const long budget = 40 * 1024 / elem_bytes;
   long target = 1024;
-  if (const char* e = getenv("EG_CONV_BAND_PIXELS")) target = atol(e) > 0 ? atol(e) : target;  // tuning aid
+  if (const char* e = eg::sw::raw("EG_CONV_BAND_PIXELS")) target = atol(e) > 0 ? atol(e) : target;  // tuning aid
   b.R = std::min(Ho, std::max(1L, target / Wo));
   b.NB = b.R == Ho ? std::max(1L, std::min(16L, target / (Ho * Wo))) : 1;
   auto elems = [&](long nb, long r) { return nb * (r + FH - 1) * b.WP * b.STR; };
@@ -307,7 +307,6 @@ int launch_grad_filter(eg_ctx* ctx, const Ty& ty, long N, long H, long W, long C
   long ybands = (Ho + b.R - 1) / b.R;
   long nbands = ((N + b.NB - 1) / b.NB) * ybands;
   long blocks = 8L * ctx->compute_units;   // eight blocks (32 waves) per CU, each walking nbands / blocks bands: the loop is latency-bound, 1024 / 2048 / 4096 blocks = 81 / 51 / 52 us on the 28 x 28 x 1 -> 8 layer at batch 4096
-  if (const char* e = getenv("EG_CONV_BAND_GF_BLOCKS")) blocks = atol(e) > 0 ? atol(e) : blocks;  // tuning aid
   if (blocks > nbands) blocks = nbands;
   const size_t esz = ty.f64 ? 8 : 4;
   const size_t pelems = ((size_t)blocks * E + 3) & ~(size_t)3;

@@ -34,7 +34,7 @@ eg_kernel* get_or_build(eg_ctx* ctx, const std::string& name, const std::string&
 
 bool disabled() {
   static const bool off = [] {
-    const char* e = getenv("EG_CONV_NO_DIRECT");
+    const char* e = eg::sw::raw("EG_CONV_NO_DIRECT");
     return e && e[0] && e[0] != '0';
   }();
   return off;
@@ -51,7 +51,6 @@ int conv2_direct_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long F
   // F * taps multiply-adds per pixel on the vector pipe: only while that stays small (beyond it the
   // matrix cores win even with their padding), and only when there are enough pixels to fill the chip
   long max_c = 4, max_work = 512;
-  if (const char* e = getenv("EG_CONV_DIRECT_LIMITS")) sscanf(e, "%ld,%ld", &max_c, &max_work);  // tuning aid
   if (disabled() || C > max_c || F < 1 || F * taps > max_work) return EG_OK;
   const long Ho = H - FH + 1, Wo = W - FW + 1, P = N * Ho * Wo;
   if (P < 8192) return EG_OK;
@@ -191,7 +190,6 @@ int conv2_direct_f64_try(eg_ctx* ctx, long N, long H, long W, long C, long F, lo
   if (!k) return EG_ERR_COMPILE;
   long segs = (Wo + SEG - 1) / SEG;
   long rpb = (N * Ho * segs + 5L * ctx->compute_units - 1) / (5L * ctx->compute_units);  // ~5 blocks per CU
-  if (const char* e = getenv("EG_CONV64_ROWS")) rpb = atol(e);  // tuning aid
   if (rpb < 4) rpb = 4;
   if (rpb > 64) rpb = 64;
   if (rpb > Ho) rpb = Ho;
@@ -244,7 +242,7 @@ int conv2_direct_grad_filter_try(eg_ctx* ctx, long N, long H, long W, long C, lo
   if (!k) return EG_ERR_COMPILE;
   long blocks = (P + 256 * 8 - 1) / (256 * 8);  // at least 8 pixels per thread where the problem allows
   long cap = ctx->compute_units;  // few blocks: the shuffle reduction of E values per block is the fixed cost
-  if (const char* e = getenv("EG_CONV_DIRECT_BLOCKS")) cap = atol(e);
+  if (const char* e = eg::sw::raw("EG_CONV_DIRECT_BLOCKS")) cap = atol(e);
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   const size_t pfloats = ((size_t)blocks * E + 3) & ~(size_t)3;

@@ -272,7 +272,7 @@ namespace eg {
 int conv2_gradf_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img, const float* gout,
                          float* gflt, int accumulate, bool* launched) {
   *launched = false;
-  const char* e = getenv("EG_CONV_NO_GRADF_HALO");   // (read per call: a test compares the two routes)
+  const char* e = eg::sw::raw("EG_CONV_NO_GRADF_HALO");   // (read per call: a test compares the two routes)
   const bool off = e && e[0] && e[0] != '0';
   if (off || FH != 3 || FW != 3 || C % QB != 0 || F % QB != 0 || C < QB || F < QB) return EG_OK;
   const long Ho = H - 2, Wo = W - 2;
@@ -310,7 +310,7 @@ int conv2_gradf_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, lo
   a.segs = segs;
   a.qc = (int)(C / QB);
   a.ranges = (int)ranges;
-  static const bool trace_on = getenv("EG_GRADF_TRACE") != nullptr;
+  static const bool trace_on = eg::sw::raw("EG_GRADF_TRACE") != nullptr;
   const long nwaves = quadrants * ranges * WAVES;
   if (trace_on) EG_HIP_CHECK(hipMalloc((void**)&a.trace, (size_t)nwaves * 64 * sizeof(long long)));
   void* params[] = {&a};

@@ -312,7 +312,7 @@ int conv2_halo_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH,
 bool conv2_halo_suits(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, long py, long px, const float* img,
                       bool flt_aligned) {
   static const bool off = [] {
-    const char* e = getenv("EG_CONV_NO_HALO");
+    const char* e = eg::sw::raw("EG_CONV_NO_HALO");
     return e && e[0] && e[0] != '0';
   }();
   if (off) return false;
@@ -387,7 +387,7 @@ int conv2_halo_try_padded(eg_ctx* ctx, long N, long H, long W, long C, long F, l
     return EG_OK;
   }
   a.items = blocks;
-  static const bool wide_off = getenv("EG_CONV_NO_WIDE_STORE") != nullptr;
+  static const bool wide_off = eg::sw::raw("EG_CONV_NO_WIDE_STORE") != nullptr;
   a.wide_store = !wide_off && F % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
   // one block per CU (LDS); several rounds of work run as persistent blocks
   const long grid = blocks < (long)ctx->compute_units ? blocks : (long)ctx->compute_units;

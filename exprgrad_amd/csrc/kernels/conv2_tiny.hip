@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void conv2_tiny_grad_filter_kernel(TinyArgs a,
     if (threadIdx.x + u * 256 < total) slab[threadIdx.x + u * 256] = acc[u];
 }
 
-bool tiny_on() { return getenv("EG_CONV_NO_TINY") == nullptr; }   // (read per call: tests compare the two routes)
+bool tiny_on() { return eg::sw::raw("EG_CONV_NO_TINY") == nullptr; }   // (read per call: tests compare the two routes)
 
 bool fits_int(long v) { return v >= 0 && v < (1L << 31); }
 

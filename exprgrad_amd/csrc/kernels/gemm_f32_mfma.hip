@@ -85,7 +85,7 @@ int launch_conv(eg_ctx* ctx, const GemmArgs& args, bool vec) {
   constexpr int NT = Geometry<BM, BN, WM, WN>::NT;
   dim3 grid((unsigned)(args.tiles_m * args.tiles_n), 1, 1);
   // channels a multiple of the k-tile: interior tiles gather with LDS-DMA (a k-tile lies inside one tap)
-  if (vec && args.cC % CBK == 0 && getenv("EG_CONV_NO_DMA") == nullptr)
+  if (vec && args.cC % CBK == 0)
     hipLaunchKernelGGL((gemm_f32_mfma_kernel<BM, BN, CBK, WM, WN, MINB, true, true, 4, true, true, 0, true>), grid,
                        dim3(NT), 0, ctx->stream, args);
   else if (vec)
@@ -101,7 +101,6 @@ int launch_conv(eg_ctx* ctx, const GemmArgs& args, bool vec) {
 int run_conv(eg_ctx* ctx, GemmArgs args, bool vec) {
   args.a_rows = args.M;
   int v = 0;
-  if (const char* f = getenv("EG_CONV_VARIANT")) v = atoi(f);  // tuning aid
   args.partial = nullptr;
   auto tiles = [&](int bm, int bn, int bk) {
     args.tiles_m = (int)((args.M + bm - 1) / bm);
@@ -132,11 +131,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // against 3.8 us; 0.40 / 0.36 / 0.33: dense step 1.111 / 1.101 / 1.103 ms).
 double ragged_tile_share(int bm, long m_rest) {
   const double live = (double)((m_rest + 31) / 32 * 32) / bm;
-  static const double tuned = [] {  // tuning aid: EG_EDGE_SHARE=0.36
-    const char* e = getenv("EG_EDGE_SHARE");
-    return e ? atof(e) : 0.0;
-  }();
-  const double floor = bm >= 256 ? (tuned > 0 ? tuned : 0.36) : 0.55;
+  const double floor = bm >= 256 ? 0.36 : 0.55;
   return live > floor ? live : floor;
 }
 
@@ -308,11 +303,11 @@ double wide_tile_time(const WideTile& t, long M, long N, long k_tiles, int cus, 
 // Tile shape and split count for an M x N x K contraction on this device.
 void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& splits, bool vec = true, bool plain = true) {
   const long k_tiles = (K + BK - 1) / BK;
-  static const bool old_model = getenv("EG_GEMM_OLD_TILE_MODEL") != nullptr;
+  static const bool old_model = eg::sw::raw("EG_GEMM_OLD_TILE_MODEL") != nullptr;
   // (convolutions keep their measured choices; with fewer than 8 k-tiles a launch is bound by writing its output, which
   // the time model does not describe: 65536 x 512 x 10 with a generated epilogue, 67 us on the tile the older rule picks, 79 us)
-  if (plain && M > 64 && N > 64 && k_tiles >= 8 && !old_model && getenv("EG_GEMM_FORCE_TILE") == nullptr) {
-    static const bool debug_tile = getenv("EG_DEBUG_TILE") != nullptr;
+  if (plain && M > 64 && N > 64 && k_tiles >= 8 && !old_model && eg::sw::raw("EG_GEMM_FORCE_TILE") == nullptr) {
+    static const bool debug_tile = eg::sw::raw("EG_DEBUG_TILE") != nullptr;
     double best = 0;
     for (const WideTile& t : kWideTiles) {
       int sp;
@@ -325,7 +320,7 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
         splits = sp;
       }
     }
-    if (const char* f = getenv("EG_GEMM_FORCE_SPLITS")) {  // tuning aid
+    if (const char* f = eg::sw::raw("EG_GEMM_FORCE_SPLITS")) {  // tuning aid
       const int want = atoi(f);
       if (want >= 1 && want <= k_tiles) {
         const long per = (k_tiles + want - 1) / want;
@@ -340,7 +335,7 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
   static const TileCfg cfgs[] = {{256, 256, 1}, {128, 128, 4}, {128, 64, 4}, {128, 32, 4}, {256, 64, 2}, {64, 64, 4}};
   constexpr int NCFG = 6;
   int forced_bm = 0, forced_bn = 0;
-  if (const char* f = getenv("EG_GEMM_FORCE_TILE")) sscanf(f, "%d,%d", &forced_bm, &forced_bn);  // tuning aid
+  if (const char* f = eg::sw::raw("EG_GEMM_FORCE_TILE")) sscanf(f, "%d,%d", &forced_bm, &forced_bn);  // tuning aid
   int best = 1, best_splits = 1;
   double best_cost = 0;
   for (int c = 0; c < NCFG; ++c) {
@@ -363,7 +358,7 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
   bm = cfgs[best].bm;
   bn = cfgs[best].bn;
   splits = best_splits;
-  if (const char* f = getenv("EG_GEMM_FORCE_SPLITS")) {  // tuning aid
+  if (const char* f = eg::sw::raw("EG_GEMM_FORCE_SPLITS")) {  // tuning aid
     const int want = atoi(f);
     if (want >= 1 && want <= k_tiles) {
       const long per = (k_tiles + want - 1) / want;
@@ -375,12 +370,12 @@ void choose_tile(eg_ctx* ctx, long M, long N, long K, int& bm, int& bn, int& spl
 // Wide stores of whole tiles as nontemporal stores: the output of a contraction is not read again by the
 // same launch (4096^3: 137.1 -> 139.0 TFLOP/s, 65536x512x784: 447 -> 438 us; EG_GEMM_NO_NT_STORE=1 switches it off).
 int nt_store_enabled() {
-  static const bool off = getenv("EG_GEMM_NO_NT_STORE") != nullptr;
+  constexpr bool off = false;
   return off ? 0 : 1;
 }
 
 int side_priority(const eg_ctx* ctx) {
-  static const bool off = getenv("EG_NO_SIDE_PRIORITY") != nullptr;
+  constexpr bool off = false;
   return ctx->on_side_lane && !off ? 1 : 0;
 }
 
@@ -388,7 +383,7 @@ int side_priority(const eg_ctx* ctx) {
 // epilogue touches is 16-byte aligned: the output (or the split-K slabs, which come from the
 // workspace), the bias, and whole rows of four.
 bool wide_store_ok(const GemmArgs& a, bool to_partial, bool fused = false) {
-  static const bool off = getenv("EG_GEMM_NO_WIDE_STORE") != nullptr;
+  static const bool off = eg::sw::raw("EG_GEMM_NO_WIDE_STORE") != nullptr;
   if (off || a.N % 4 != 0) return false;
   // measured: +2.5 % at 4096^3, -10 % on a 65536 x 512 x 10 product (two barriers per block row against
   // almost no k loop): plain contractions with fewer than 8 k-tiles keep the direct stores
@@ -410,14 +405,14 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   // for sliced 64 x 64 tiles).  EG_GEMM_NO_PAIR=1 (or a forced tile / slice count) keeps the choice below.
   {
     const long t32 = ((M + 31) / 32) * ((N + 31) / 32);
-    const bool kw8_on = getenv("EG_GEMM_NO_PAIR") == nullptr && getenv("EG_GEMM_FORCE_TILE") == nullptr &&
-                        getenv("EG_GEMM_FORCE_SPLITS") == nullptr;
+    const bool kw8_on = eg::sw::raw("EG_GEMM_NO_PAIR") == nullptr && eg::sw::raw("EG_GEMM_FORCE_TILE") == nullptr &&
+                        eg::sw::raw("EG_GEMM_FORCE_SPLITS") == nullptr;
     // (whole tiles: 64 KB of LDS, two blocks share a CU — up to three blocks per CU pay: 640^3 14.4 -> 9.4 us, 768^3 16.7 -> 14.9,
     // 768 x 768 x 2048 35.9 -> 31.6; 896^3 and 1024^3 do not.  Ragged: 96 KB, one block per CU: up to two per CU, 576^3 13.5 -> 12.8)
     // (fewer tiles than half a chip: still better than slices with their second launch while K is short — 256 x 256 x 512
     // 12.0 -> 6.7 us, 256 x 256 x 1024 14.9 -> 8.1, 320 x 320 x 1024 14.7 -> 7.8, 256^3 7.9 -> 6.4; at K = 2048 the slices win, 10.6
-    // against 12.6.  EG_KW8_SMALL_K: tuning aid)
-    static const long kw8_small_k = getenv("EG_KW8_SMALL_K") ? atol(getenv("EG_KW8_SMALL_K")) : 1024;
+    // against 12.6.)
+    constexpr long kw8_small_k = 1024;
     const bool kw8_ragged = M % 32 != 0 || N % 32 != 0 || K % 128 != 0;
     if (kw8_on && !conv && vec_ok && !a_vec_only && !args.ones_row && t32 <= (kw8_ragged ? 2L : 3L) * ctx->compute_units && (2 * t32 >= ctx->compute_units || (K <= kw8_small_k && t32 >= 4)) &&
         K >= 256 && K <= 4096 && N % 4 == 0 && args.ldc % 4 == 0 && aligned16(args.C) && (args.bias == nullptr || aligned16(args.bias))) {
@@ -428,7 +423,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
       args.k_per_split = K;
       args.prio = side_priority(ctx);
       args.nt_store = nt_store_enabled();
-      args.no_skew = getenv("EG_GEMM_NO_SKEW") != nullptr;
+      args.no_skew = eg::sw::raw("EG_GEMM_NO_SKEW") != nullptr;
       const bool ragged = kw8_ragged;
       // (four stages — three 128-deep k-tiles in flight, 128 KB of LDS — measured equal: 512^3 5.7 / 5.7 us back to back, 512 x 512 x 2048 13.3 / 12.9)
       dim3 grid((unsigned)t32), block(512);
@@ -452,8 +447,8 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   // 64-deep k-tile (12 waves = three per SIMD, 24 matrix instructions per wave and k-tile).  EG_GEMM_NO_PAIR=1 keeps 64 x 64.
   {
     const long t96 = (M / 96) * (N / 96);
-    const bool on = getenv("EG_GEMM_NO_PAIR") == nullptr && getenv("EG_GEMM_NO_T96") == nullptr && getenv("EG_GEMM_FORCE_TILE") == nullptr &&
-                    getenv("EG_GEMM_FORCE_SPLITS") == nullptr;
+    const bool on = eg::sw::raw("EG_GEMM_NO_PAIR") == nullptr && eg::sw::raw("EG_GEMM_NO_T96") == nullptr && eg::sw::raw("EG_GEMM_FORCE_TILE") == nullptr &&
+                    eg::sw::raw("EG_GEMM_FORCE_SPLITS") == nullptr;
     if (on && !conv && vec_ok && !a_vec_only && !args.ones_row && M % 96 == 0 && N % 96 == 0 && K % 64 == 0 && K >= 512 &&
         t96 <= ctx->compute_units && 4 * t96 > 3L * ctx->compute_units && args.ldc % 4 == 0 && aligned16(args.C) &&
         (args.bias == nullptr || aligned16(args.bias))) {
@@ -464,7 +459,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
       args.k_per_split = K;
       args.prio = side_priority(ctx);
       args.nt_store = nt_store_enabled();
-      args.no_skew = getenv("EG_GEMM_NO_SKEW") != nullptr;
+      args.no_skew = eg::sw::raw("EG_GEMM_NO_SKEW") != nullptr;
       dim3 grid((unsigned)t96), block(768);
 #define EG_T96(AKC, BKC) hipLaunchKernelGGL((gemm_pair_kernel<96, 96, 96, 32, AKC, BKC, 0, 2, 64, false, 4>), grid, block, 0, ctx->stream, args)
       if (a_kc && !b_kc) EG_T96(true, false);
@@ -485,7 +480,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   // whole tiles + remainder rows + remainder columns when the ragged tiles would cost a round
   // (EG_GEMM_NO_REMAINDER=1: one launch).  Split-K launches keep their ragged tiles: those get fewer,
   // longer k-slices next to the whole tiles at about the same cost.
-  static const bool rem_split = getenv("EG_GEMM_NO_REMAINDER") == nullptr;
+  constexpr bool rem_split = true;
   if (rem_split && !conv && vec_ok && !a_vec_only && splits == 1 && !args.ones_row) {
     const long m_rem = M % 256, n_rem = N % 256;
     const long m0 = M - (m_rem <= 32 ? m_rem : 0), n0 = N - (n_rem <= 32 ? n_rem : 0);
@@ -526,17 +521,15 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   // beyond whole 256-row tiles and whose tiles cannot fill the chip by themselves.  The last tile row's blocks carry the
   // extra rows as a ninth accumulator block (+ 1/8 matrix work) and get proportionally more, shorter k-slices, so every
   // block finishes together; no ragged tile row exists.  EG_GEMM_NO_XROW=1: the ragged tile row of round 2.
-  static const bool xrow_on = getenv("EG_GEMM_NO_XROW") == nullptr;
+  static const bool xrow_on = eg::sw::raw("EG_GEMM_NO_XROW") == nullptr;
   if (xrow_on && !conv && vec_ok && !a_vec_only && !a_kc && !b_kc && M > 256 && M % 256 > 0 && M % 256 <= 32 && N % 256 == 0 &&
-      K % BK == 0 && args.ldc % 4 == 0 && getenv("EG_GEMM_FORCE_TILE") == nullptr) {
+      K % BK == 0 && args.ldc % 4 == 0 && eg::sw::raw("EG_GEMM_FORCE_TILE") == nullptr) {
     const long tm = M / 256, tn = N / 256, k_tiles = K / BK, slots = ctx->compute_units;
     const long full = (tm - 1) * tn;
     long best_s1 = 0, best_s2 = 0;
     double best_t = 0;
-    static const double xw = [] {  // k-tile of a strip-carrying block relative to a plain one (tuning aid: EG_XROW_WEIGHT)
-      const char* e = getenv("EG_XROW_WEIGHT");
-      return e ? atof(e) : 1.2;  // measured on 784 x 512 x 65536: 1.0 449 us, 1.125 441, 1.2 428, 1.3 446, 1.4 452 (the strip adds 2 DMA pieces and 16 LDS reads per k-tile to its 4 MFMAs)
-    }();
+    // k-tile of a strip-carrying block relative to a plain one
+    constexpr double xw = 1.2;  // measured on 784 x 512 x 65536: 1.0 449 us, 1.125 441, 1.2 428, 1.3 446, 1.4 452 (the strip adds 2 DMA pieces and 16 LDS reads per k-tile to its 4 MFMAs)
     for (long s1 = 2; full * s1 + tn * 2 <= slots && s1 <= k_tiles / 8; ++s1) {
       long s2 = (slots - full * s1) / tn;
       if (s2 > k_tiles / 8) s2 = k_tiles / 8;
@@ -567,7 +560,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
       args.wide_store = wide_store_ok(args, true);
       args.prio = side_priority(ctx);
       args.nt_store = nt_store_enabled();
-  args.no_skew = getenv("EG_GEMM_NO_SKEW") != nullptr;
+  args.no_skew = eg::sw::raw("EG_GEMM_NO_SKEW") != nullptr;
       const long total = M * N, slabs = std::max(s1, s2);
       int rc = eg::ensure_workspace(ctx, (((size_t)slabs * total + 3) & ~(size_t)3) * sizeof(float));
       if (rc) return rc;
@@ -588,17 +581,17 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   // (32-deep k-tiles for the 256x256 tile were measured in round 2: +1 % at 4096^3, -7 % at K = 784, 0 elsewhere)
   // the convolution's filter gradient (M = F = 64 rows, 64 x 64 tiles, K = every output pixel): a block has
   // little matrix work per barrier, so its k-tiles are 32 deep like the forward gather's (EG_CONVGF_BK16=1: 16)
-  static const bool gf16 = getenv("EG_CONVGF_BK16") != nullptr;
+  constexpr bool gf16 = false;
   int KB = (conv == 2 && BM == 64 && BN == 64 && vec_ok && !gf16) ? 32 : BK;
   // 64 x 64 tiles with at most two blocks per CU are bound by the LDS-DMA round trip of the next k-tile, not
   // by matrix work: 32-deep k-tiles halve the round trips (1024^3: 28.1 -> 23.9 us; four blocks per CU hide
   // it by themselves: 2048^3 142.5 vs 146.5 us).  EG_GEMM_SMALL_BK16=1: 16.
   // Round 4, sustained clocks: 32 also wins with up to four blocks per CU (1536^3 81.4 -> 77.0 us, 1792^3 120.8 -> 114.4,
   // 2048^3 137.9 -> 131.6); beyond that the two are equal within 1 % (2304^3 202 / 206, 3072^3 432 / 439): 16 stays there.
-  if (!conv && BM == 64 && BN == 64 && vec_ok && K >= 256 && getenv("EG_GEMM_SMALL_BK16") == nullptr &&
+  if (!conv && BM == 64 && BN == 64 && vec_ok && K >= 256 &&
       (M + 63) / 64 * ((N + 63) / 64) * splits <= 4L * ctx->compute_units)
     KB = 32;
-  if (getenv("EG_GEMM_SMALL_BK32") != nullptr && !conv && BM == 64 && BN == 64 && vec_ok && K >= 256) KB = 32;  // tuning aid
+  if (eg::sw::raw("EG_GEMM_SMALL_BK32") != nullptr && !conv && BM == 64 && BN == 64 && vec_ok && K >= 256) KB = 32;  // tuning aid
   const long k_tiles = (K + KB - 1) / KB;
   args.tiles_m = (int)((M + BM - 1) / BM);
   args.tiles_n = (int)((N + BN - 1) / BN);
@@ -623,7 +616,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   int edge_splits = 0;
   const long m_rest = M % BM;
   if (splits > 1 && !tree_reduce && !conv && vec_ok && m_rest != 0 && m_rest * 2 <= BM && args.tiles_m >= 2 &&
-      getenv("EG_GEMM_EVEN_SPLITS") == nullptr) {
+      true) {
     const double frac = ragged_tile_share(BM, m_rest);
     const long full_tiles = (long)(args.tiles_m - 1) * args.tiles_n;
     const long slots = (long)ctx->compute_units * (BM * BN >= 256 * 256 ? 1 : (BM == 256 ? 2 : 4));
@@ -645,7 +638,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   }
   // Tail tiles: more tiles than block slots and a short last round -> cut the last round's tiles along K.
   long tail_slab_floats = 0;
-  if (splits == 1 && !conv && getenv("EG_GEMM_NO_TAIL") == nullptr) {
+  if (splits == 1 && !conv) {
     const long tiles = (long)args.tiles_m * args.tiles_n;
     const long slots = (long)ctx->compute_units * (BM * BN >= 256 * 256 ? 1 : (BM == 256 ? 2 : 4));
     const long tail = tiles % slots;
@@ -667,7 +660,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   args.wide_store = wide_store_ok(args, splits > 1);
   args.prio = side_priority(ctx);
   args.nt_store = nt_store_enabled();
-  args.no_skew = getenv("EG_GEMM_NO_SKEW") != nullptr;
+  args.no_skew = eg::sw::raw("EG_GEMM_NO_SKEW") != nullptr;
   float* scratch = nullptr;
   if (args.tail_tiles > 0) {
     int rc = eg::ensure_workspace(ctx, (size_t)tail_slab_floats * sizeof(float));
@@ -690,7 +683,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   // Whole 256 x 256 tiles of a long, unsliced product: 32-deep k-tiles (half the barriers and half the load issues per
   // MFMA; 128 KB of LDS, still one block per CU).  With the skewed waves of round 4 on top: 4096^3 949 -> 941 us in the
   // harness (+0.8 %); short products keep 16 (K = 784: round 2 measured -7 % with 32).  EG_GEMM_NO_BK32=1: 16 everywhere.
-  const bool bk32_on = getenv("EG_GEMM_NO_BK32") == nullptr;   // (read per call: a test compares the two loops)
+  const bool bk32_on = eg::sw::raw("EG_GEMM_NO_BK32") == nullptr;   // (read per call: a test compares the two loops)
   if (bk32_on && BM == 256 && BN == 256 && !edge && !conv && splits <= 1 && args.tail_tiles == 0 && args.edge_splits == 0 &&
       K % 32 == 0 && K >= 2048 && args.k_per_split == K) {
     dim3 grid((unsigned)((long)args.tiles_m * args.tiles_n)), block(512);
@@ -713,7 +706,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
   // Ragged tiles and a K that ends inside a k-tile take the EDGE form of the same kernel (clamped row / column offsets,
   // masked stores, the k-tile K ends in loaded in the prologue and multiplied behind the loop): 1000^3 28.1 -> 23.1 us (NN),
   // 27.5 -> 22.0 (TN), 1000 x 1024 x 4096 90.8 -> 74.6.
-  const bool pair_on = getenv("EG_GEMM_NO_PAIR") == nullptr;
+  const bool pair_on = eg::sw::raw("EG_GEMM_NO_PAIR") == nullptr;
   if (pair_on && BM == 64 && BN == 64 && vec && !conv && splits <= 1 && args.tail_tiles == 0 && args.edge_splits == 0 &&
       args.wide_store && !args.ones_row && (long)args.tiles_m * args.tiles_n <= ctx->compute_units) {
     const bool ragged = edge || K % 64 != 0;
@@ -825,7 +818,7 @@ __global__ __launch_bounds__(256) void gemm_small_pair_kernel(eg::SmallGemm g0, 
 
 bool small_gemm_enabled() {
   static const bool on = [] {
-    const char* e = getenv("EG_NO_SMALL_GEMM");
+    const char* e = eg::sw::raw("EG_NO_SMALL_GEMM");
     return !(e && e[0] && e[0] != '0');
   }();
   return on;
@@ -834,7 +827,7 @@ bool small_gemm_enabled() {
 
 bool skinny_enabled() {
   static const bool on = [] {
-    const char* e = getenv("EG_NO_SKINNY_GEMM");
+    const char* e = eg::sw::raw("EG_NO_SKINNY_GEMM");
     return !(e && e[0] && e[0] != '0');
   }();
   return on;
@@ -919,7 +912,7 @@ extern "C" int eg_sgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_
   // (the LDS-DMA loaders address a tile with 32-bit byte offsets from its origin: 256 rows x ld x 4 bytes < 2^31)
   const bool vec_a = (lda % 4 == 0) && (a_contig % 4 == 0) && (A == nullptr || aligned16(A)) && lda < (1L << 21);
   const bool vec_b = (ldb % 4 == 0) && (b_contig % 4 == 0) && (B == nullptr || aligned16(B)) && ldb < (1L << 21);
-  static const bool no_mixed = getenv("EG_GEMM_NO_MIXED_VEC") != nullptr;
+  constexpr bool no_mixed = false;
   return run_gemm(ctx, a_kc, b_kc, args, /*conv=*/0, vec_a && vec_b, vec_a && !vec_b && !no_mixed);
 }
 
@@ -936,7 +929,7 @@ bool ones_row_supported(int trans_a, int trans_b, long M, long N, long K, const 
   const bool vec_a = (lda % 4 == 0) && (a_contig % 4 == 0) && aligned16(A) && lda < (1L << 21);
   const bool vec_b = (ldb % 4 == 0) && (b_contig % 4 == 0) && aligned16(B) && ldb < (1L << 21);
   // large enough for the matrix-core path (not the one-wave-per-output kernel) and at least one k-tile
-  const char* off = getenv("EG_NO_ONES_ROW");
+  const char* off = eg::sw::raw("EG_NO_ONES_ROW");
   return vec_a && vec_b && K >= 16 && !((M + 1) * N <= 16384 && K <= 2048) && !(off && off[0] && off[0] != '0');
 }
 
@@ -1192,7 +1185,7 @@ extern "C" int eg_conv2_nhwc_grad_image(eg_ctx* ctx, int64_t N, int64_t H, int64
   // The halo kernel pads by itself (pixels outside the gradient come from a block of zeros): only the flipped bank is
   // prepared — no padded copy of the gradient is written and read back (cfg 4: 2 x 17 MB, 8 -> 3 us of preparation).
   // EG_CONV_NO_VIRTUAL_PAD=1: the padded copy of rounds 1 and 2.
-  const bool virtual_pad = getenv("EG_CONV_NO_VIRTUAL_PAD") == nullptr;  // (read per call: a test compares the two routes)
+  const bool virtual_pad = eg::sw::raw("EG_CONV_NO_VIRTUAL_PAD") == nullptr;  // (read per call: a test compares the two routes)
   if (virtual_pad && FH <= 3 && FW <= 3 && F % 16 == 0 && aligned16(gout) &&
       eg::conv2_halo_suits(ctx, N, Ho, Wo, F, C, FH, FW, FH - 1, FW - 1, gout, true)) {   // (the bank goes to ctx->aux: aligned)
     rc = eg::ensure_aux(ctx, flt_floats * sizeof(float));
@@ -1294,9 +1287,31 @@ int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, co
   args.wide_store = wide_store_ok(args, false, true);   // set_epilogue_operands withdraws it for unaligned operands
   args.prio = side_priority(ctx);
   args.nt_store = nt_store_enabled();
-  args.no_skew = getenv("EG_GEMM_NO_SKEW") != nullptr;
+  args.no_skew = eg::sw::raw("EG_GEMM_NO_SKEW") != nullptr;
   memcpy(out.args, &args, sizeof(args));
   out.args_size = sizeof(args);
+  {  // tiny K: a store stream, not matrix work (gemm_narrow_k_block)
+    const bool off = eg::sw::raw("EG_NO_NARROW_K") != nullptr;   // (read per call: a test compares the two routes)
+    const long tpr = N / 4;
+    if (!off && K >= 1 && K <= 16 && N % 4 == 0 && tpr >= 1 && tpr <= 256 && 256 % tpr == 0 && ldc % 4 == 0 && aligned16(C) &&
+        (!bias || aligned16(bias)) && M * N >= (1L << 16)) {
+      out.narrow = true;
+      out.narrow_k = (int)K;
+      const long rows_per_trip = 4 * (256 / tpr), blocks = (M + rows_per_trip - 1) / rows_per_trip;
+      // eight blocks per CU (all resident at once): every block first loads its threads' 4 x K values of B — 40 KB per block
+      // at K = 10 — so more, shorter blocks cost more than they gain here (65 536 x 512 x 10, 1 024 / 2 048 / 4 096 / 8 192
+      // blocks: 28.8 / 24.3 / 28.4 / 37.2 us standalone)
+      const long cap = 8L * ctx->compute_units;
+      long grid = blocks < cap ? blocks : cap;
+      // a block's run of rows: a multiple of what it takes per trip; the kernel reads it from k_per_split (no use for it there)
+      const long per = ((M + grid - 1) / grid + rows_per_trip - 1) / rows_per_trip * rows_per_trip;
+      grid = (M + per - 1) / per;
+      out.narrow_grid = (unsigned)grid;
+      out.matrix_k_per_split = args.k_per_split;
+      args.k_per_split = per;
+      memcpy(out.args, &args, sizeof(args));
+    }
+  }
   return EG_OK;
 }
 
@@ -1304,17 +1319,33 @@ void set_epilogue_operands(FusedLaunch& f, void* const* ptrs, int count, float g
   GemmArgs* a = reinterpret_cast<GemmArgs*>(f.args);
   for (int i = 0; i < MAX_EPILOGUE_OPERANDS; ++i) a->epi[i] = i < count ? ptrs[i] : nullptr;
   for (int i = 0; i < count; ++i)
-    if (!aligned16(ptrs[i])) a->wide_store = 0;
+    if (!aligned16(ptrs[i])) {
+      a->wide_store = 0;
+      fused_withdraw_narrow(f);
+    }
   a->epi_gs = grad_scale;
   a->epi_ep = epoch;
 }
 
+void fused_withdraw_narrow(FusedLaunch& f) {
+  if (!f.narrow) return;
+  f.narrow = false;
+  reinterpret_cast<GemmArgs*>(f.args)->k_per_split = f.matrix_k_per_split;
+}
+
 bool fused_wide_store(const FusedLaunch& f) {
+  // (the streaming kernel covers every column of a row: predicate words are stored whole when a word is eight threads)
+  if (f.narrow) return reinterpret_cast<const GemmArgs*>(f.args)->ldc % 32 == 0 && (reinterpret_cast<const GemmArgs*>(f.args)->N / 4) % 8 == 0;
   return reinterpret_cast<const GemmArgs*>(f.args)->wide_store != 0 && !f.edge;
 }
 
 std::string fused_variant(const FusedLaunch& f) {
   char buf[96];
+  if (f.narrow) {
+    snprintf(buf, sizeof(buf), "narrow_k%d_n%ld_%c%c", f.narrow_k, (long)reinterpret_cast<const GemmArgs*>(f.args)->N, f.a_kc ? 'k' : 'm',
+             f.b_kc ? 'k' : 'n');
+    return buf;
+  }
   snprintf(buf, sizeof(buf), "%dx%dx%d_%dx%d_%d_%c%c_v%d%s%s", f.bm, f.bn, f.bk, f.wm, f.wn, f.minb, f.a_kc ? 'k' : 'm',
            f.b_kc ? 'k' : 'n', f.vec, f.edge ? "_edge" : "", f.dma ? "_dma" : "");
   return buf;
@@ -1325,6 +1356,15 @@ std::string fused_source(const FusedLaunch& f, const std::string& epi_struct, co
   std::string s = kGemmHeaderText;
   s += "\n" + epi_struct + "\n";
   char buf[512];
+  if (f.narrow) {
+    snprintf(buf, sizeof(buf),
+             "extern \"C\" __global__ __launch_bounds__(256) void %s(eg::gemm::GemmArgs a) {\n"
+             "  eg::gemm::gemm_narrow_k_block<%d, %d, %s, %s, %s>(a);\n}\n",
+             kernel_name.c_str(), f.narrow_k, (int)(reinterpret_cast<const GemmArgs*>(f.args)->N / 4), f.a_kc ? "true" : "false",
+             f.b_kc ? "true" : "false", epi_name.c_str());
+    s += buf;
+    return s;
+  }
   const int waves = f.nt / 64;
   // a ragged tile with a generated epilogue needs a few registers more than four waves per SIMD leave
   // (48 bytes of scratch at 128 VGPRs): three there

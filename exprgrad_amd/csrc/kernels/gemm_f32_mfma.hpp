@@ -1491,6 +1491,114 @@ gemm_f32_mfma_kernel(GemmArgs a) {
   gemm_block<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, EDGE, CONV, ABL, DMA, EpiNone, XR>(a);
 }
 
+// ---- contraction with a TINY K and a generated epilogue as a streaming kernel on the vector ALUs ----------------------
+// The activation-gradient product of a classifier's last layer, ga[y, j] = sum_c gz[y, c] * W2[j, c] with 10 classes
+// (dense, dnn.nim:19-24, differentiated: passes.nim:519-549), followed by relu's gradient in the epilogue: 65 536 x 512 x 10
+// is 0.67 GFLOP and 134 MB of output — a store stream.  On the matrix tile (128 x 128, whole tiles through LDS) it writes
+// at 3.1 TB/s (43 us).  Here a thread owns FOUR consecutive columns of a row: the K values of its columns of B sit in
+// registers for the whole launch, a row's K values of A are the same for every thread of the row (scalar loads when a
+// wave works on one row), the 4 x K multiply-adds run in k order (an fmaf chain, as the matrix core evaluates it), and
+// the row leaves as nontemporal 16-byte stores, the epilogue's operands read the same way.  A first version (round 4:
+// rows of a step a whole grid apart, eight blocks per CU) wrote at 3.1 TB/s like the tile and was dropped; what the
+// round-6 stream probe (tools/hbm_probe.hip, PROBE_GH) showed to matter is the shape of the stream: a block owns ONE
+// CONTIGUOUS run of rows, two rows' loads (U = 2 steps) are in flight before the first dependent store, up to 32 blocks
+// per CU — 23.5 us = 6.0 TB/s for the same 134 MB.  Requirements (host, plan_fused): K <= 16, N % 4 = 0, 256 % (N / 4) = 0
+// (a thread keeps its columns from row to row), 16-byte aligned C / epilogue operands, ldc % 4 = 0; no row product.
+// Predicate bits of the result: eight neighbouring threads hold one word (N % 32 = 0: whole words), else atomic OR.
+// TPR = N / 4 (threads per row) is a template argument and the block's run of rows arrives in a.k_per_split (the host
+// divides): with both computed in the kernel — two 64-bit and three 32-bit divisions per block in front of its first
+// load — the launch got SLOWER with more, shorter blocks (2 048 / 8 192 / 16 384 blocks: 27.7 / 41.6 / 57.2 us) where the
+// probe with literal extents got faster (27.6 / 23.7 us).
+template <int V>
+struct NarrowTrip {
+  static constexpr int value = V;
+};
+template <int K, int TPR, bool A_KC, bool B_KC, class Epi>
+__device__ __forceinline__ void gemm_narrow_k_block(const GemmArgs& a) {
+  const int tid = threadIdx.x;
+  constexpr int tpr = TPR;                          // threads per row (divides 256)
+  constexpr int rpb = 256 / tpr;                    // rows per block and step
+  const int c4 = tid % tpr;
+  const long n = (long)c4 * 4;
+  float w[4][K];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < K; ++k) w[e][k] = B_KC ? a.B[(n + e) * a.ldb + k] : a.B[(long)k * a.ldb + n + e];
+  f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+  if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+  const bool packed = (tpr & 7) == 0 && (a.ldc & 31) == 0;
+  // A through the CONSTANT address space: a row's K values are one address for the whole wave, and only loads the compiler
+  // knows to be invariant go through the scalar cache into SGPRs (a pointer out of the argument struct carries no such
+  // promise; as vector loads the rows cost U x K VGPRs, the kernel needed 161 registers and three blocks shared a CU
+  // instead of eight).  A is written by an earlier launch, never by this one.
+  typedef const __attribute__((address_space(4))) float* ConstF;
+  const ConstF Ap = (ConstF)(unsigned long)a.A;
+  float* __restrict__ const Cp = a.C;
+  float* __restrict__ const Op = static_cast<float*>(a.epi[Epi::OUT]);
+  constexpr int U = 4;
+  // the block's run of rows: a multiple of what it takes per trip (computed by the host, plan_fused)
+  const long per = a.k_per_split;
+  const long lo = (long)blockIdx.x * per;
+  const long hi = a.M < lo + per ? a.M : lo + per;
+  // UU rows per trip, every one of them inside [lo, hi): NO condition between the loads of a trip and its stores (with a
+  // bounds test per row the compiler sank the later rows' loads behind the earlier rows' stores: one load in flight)
+  auto trip = [&](long m0, auto uu_tag) {
+    constexpr int UU = decltype(uu_tag)::value;
+    float ar[UU][K];
+    f32x4 x4[UU][Epi::NX];
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+      const long m = m0 + (long)u * rpb;
+      if (tpr >= 64) {  // a wave works on ONE row: its K values of A arrive as scalar / uniform loads
+        const long mu = ((long)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+#pragma unroll
+        for (int k = 0; k < K; ++k) ar[u][k] = A_KC ? Ap[mu * a.lda + k] : Ap[(long)k * a.lda + mu];
+      } else {
+#pragma unroll
+        for (int k = 0; k < K; ++k) ar[u][k] = A_KC ? Ap[m * a.lda + k] : Ap[(long)k * a.lda + m];
+      }
+      Epi::prefetch4(a, m * a.ldc + n, x4[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UU; ++u) {
+      const long m = m0 + (long)u * rpb;
+      const long idx = m * a.ldc + n;
+      f32x4 v, res;
+      unsigned nibble = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc = __builtin_fmaf(ar[u][k], w[e][k], acc);
+        v[e] = acc + b4[e];
+        float x[Epi::NX];
+#pragma unroll
+        for (int o = 0; o < Epi::NX; ++o) x[o] = x4[u][o][e];
+        res[e] = Epi::compute(a, idx + e, v[e], x);
+        if constexpr (Epi::PRED >= 0) nibble |= (Epi::predicate(v[e]) ? 1u : 0u) << e;
+      }
+      if constexpr (Epi::PRED >= 0) {
+        unsigned* bits = static_cast<unsigned*>(a.epi[Epi::PRED >= 0 ? Epi::PRED : 0]);
+        if (packed) {
+          unsigned word = nibble << (4 * (tid & 7));
+          word |= __shfl_xor(word, 1, 64);
+          word |= __shfl_xor(word, 2, 64);
+          word |= __shfl_xor(word, 4, 64);
+          if ((tid & 7) == 0) bits[idx >> 5] = word;
+        } else if (nibble) {
+          atomicOr(bits + (idx >> 5), nibble << (idx & 31));
+        }
+      }
+      if (Epi::STORE_C) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Cp + idx));
+      __builtin_nontemporal_store(res, reinterpret_cast<f32x4*>(Op + idx));
+    }
+  };
+  long m0 = lo + tid / tpr;
+  for (; m0 + (long)(U - 1) * rpb < hi; m0 += (long)rpb * U) trip(m0, NarrowTrip<U>());
+  for (; m0 < hi; m0 += rpb) trip(m0, NarrowTrip<1>());   // (the ragged end of the last block)
+}
+
 // Second pass of split-K: C[m,n] = (accumulate ? C : 0) + sum_z partial[z][m][n] + bias[n],
 // slabs added in increasing z (fixed order => run-to-run deterministic).
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ partial, float* C,

@@ -390,7 +390,7 @@ extern "C" int eg_dgemm(eg_ctx* ctx, int trans_a, int trans_b, int64_t M, int64_
         best_splits = splits;
       }
     }
-  if (const char* e = getenv("EG_DGEMM_TILE")) {  // measurement aid: "<config>[,<splits>]"
+  if (const char* e = eg::sw::raw("EG_DGEMM_TILE")) {  // measurement aid: "<config>[,<splits>]"
     best = atoi(e) % 3;
     if (const char* comma = strchr(e, ',')) best_splits = atol(comma + 1) > 0 ? atol(comma + 1) : 1;
   }

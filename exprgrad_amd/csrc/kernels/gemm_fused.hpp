@@ -21,6 +21,13 @@ struct FusedLaunch {
   int vec = 1;
   int splits = 1;   // > 1: the problem needs split-K, run it unfused
   unsigned grid = 0;
+  // K <= 16 and a row-major output whose rows 256 threads cover evenly: a store stream, not matrix work — the streaming
+  // kernel on the vector ALUs (gemm_f32_mfma.hpp, gemm_narrow_k_block) instead of the matrix tile; narrow_grid blocks
+  // of 256 threads.  Withdrawn by set_epilogue_operands for unaligned operands and by the caller for a row product.
+  bool narrow = false;
+  int narrow_k = 0;
+  unsigned narrow_grid = 0;
+  long matrix_k_per_split = 0;   // GemmArgs::k_per_split of the matrix tile (the streaming kernel reads its rows per block there)
   alignas(8) unsigned char args[320];  // the kernel's GemmArgs (opaque to host-only translation units)
   unsigned args_size = 0;
 };
@@ -38,6 +45,9 @@ int sgemm_ones_row(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K
 
 // Tensors the generated epilogue reads / writes (a.epi[i]), the seed-gradient scale and the epoch.
 void set_epilogue_operands(FusedLaunch& f, void* const* ptrs, int count, float grad_scale, long epoch);
+
+// Back to the matrix tile (an operand turned out unaligned, a row product rides on the launch, the batch pipeline).
+void fused_withdraw_narrow(FusedLaunch& f);
 
 // Does every tile of the planned launch leave through the wide-store pass (after set_epilogue_operands)?
 bool fused_wide_store(const FusedLaunch& f);

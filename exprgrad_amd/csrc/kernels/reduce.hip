@@ -344,7 +344,7 @@ __global__ __launch_bounds__(NT) void slab_sum_kernel(const float* __restrict__ 
 
 bool slab_sum_supported(long total, const float* slab, const float* out) {
   static const bool off = [] {
-    const char* e = getenv("EG_NO_SLAB_SUM");
+    const char* e = eg::sw::raw("EG_NO_SLAB_SUM");
     return e && e[0] && e[0] != '0';
   }();
   return !off && total > 0 && total % 4 == 0 && (reinterpret_cast<uintptr_t>(slab) & 15) == 0 &&

@@ -98,7 +98,7 @@ bool try_open(const std::string& name) {
 
 void load() {
   std::vector<std::string> names;
-  if (const char* e = getenv("EG_HIPRTC_LIB"))
+  if (const char* e = eg::sw::raw("EG_HIPRTC_LIB"))
     if (e[0]) names.push_back(e);
   const std::string major = std::to_string(HIP_VERSION_MAJOR);
   names.push_back(std::string(EG_ROCM_LIBDIR) + "/libhiprtc.so." + major);
@@ -134,7 +134,7 @@ uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
 
 bool cache_enabled() {
   static const bool on = [] {
-    const char* e = getenv("EG_NO_KERNEL_CACHE");
+    const char* e = eg::sw::raw("EG_NO_KERNEL_CACHE");
     return !(e && e[0] && e[0] != '0');
   }();
   return on;
@@ -144,7 +144,7 @@ bool cache_enabled() {
 const std::string& cache_dir() {
   static const std::string dir = [] {
     std::string d;
-    if (const char* e = getenv("EG_KERNEL_CACHE")) d = e;
+    if (const char* e = eg::sw::raw("EG_KERNEL_CACHE")) d = e;
     else if (const char* x = getenv("XDG_CACHE_HOME")) d = std::string(x) + "/exprgrad_hip";
     else if (const char* h = getenv("HOME")) d = std::string(h) + "/.cache/exprgrad_hip";
     if (d.empty()) return d;

@@ -41,7 +41,7 @@ void clear_error() { g_error.clear(); }
 // in the result instead of as whatever an earlier launch left there.
 bool poison_enabled() {
   static const bool on = [] {
-    const char* e = getenv("EG_POISON");
+    const char* e = eg::sw::raw("EG_POISON");
     return e && e[0] && e[0] != '0';
   }();
   return on;
@@ -131,7 +131,7 @@ int kernels_compile_batch(eg_ctx* ctx, const char* label, const char* source, co
   std::vector<char> code;
   int rc = rtc::compile(label, source, ctx->arch, code);
   if (rc) return rc;
-  if (const char* dump = getenv("EG_DUMP_CODE")) {  // debugging aid: the code object, for llvm-objdump -d
+  if (const char* dump = eg::sw::raw("EG_DUMP_CODE")) {  // debugging aid: the code object, for llvm-objdump -d
     if (FILE* fp = fopen((std::string(dump) + "/" + label + ".co").c_str(), "wb")) {
       fwrite(code.data(), 1, code.size(), fp);
       fclose(fp);

@@ -75,6 +75,14 @@ int eg_device_props(int device, int* compute_units, int* clock_khz, int64_t* hbm
 int eg_compiler_info(char* text, size_t cap);
 /* Run-time compilations of this process: served from the on-disk cache / compiled, and the seconds spent compiling. */
 int eg_kernel_cache_stats(int64_t* hits, int64_t* misses, double* compile_seconds);
+/* Environment switches (csrc/switches.cpp): the library honours exactly the names of ONE table — every optimisation can
+ * be turned off (class "execution"), detectors and dumps ("detector"), the data-parallel and run-time-compiler settings,
+ * and measurement aids ("tuning") that are read only under EG_TUNING=1.  The environment is read once, at first use;
+ * eg_switches_reload re-reads it (a host that changes a variable between two calls).  eg_switch_table writes
+ * "<name>\t<class>\t<purpose>\n" per switch into text (at most cap - 1 bytes) and returns the length of the whole table.
+ * No reference counterpart (its only switches are compile-time defines: -d:opencl, -d:exprgrad_fast_math). */
+int eg_switches_reload(void);
+int64_t eg_switch_table(char* text, size_t cap);
 
 /* newGpuContext(device): gpu.nim:39, cl.nim:83-93. Creates one non-blocking in-order stream. */
 int eg_ctx_create(int device, eg_ctx** out);

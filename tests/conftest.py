@@ -9,6 +9,38 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# measurement aids (class "tuning" of csrc/switches.cpp: forced tiles, thresholds) are honoured only under EG_TUNING=1; the
+# suite uses a few of them (EG_EPILOGUE_MIN_ELEMS=0 so that small test shapes get generated epilogues, EG_FIT_GROUP, ...)
+os.environ.setdefault("EG_TUNING", "1")
+
+
+def _reload_switches():
+    try:
+        from exprgrad_amd import _lib
+        _lib.reload_switches()
+    except Exception:       # the library is not built / not loaded: its first use reads the environment
+        pass
+
+
+@pytest.fixture
+def monkeypatch(monkeypatch):
+    """pytest's monkeypatch whose setenv / delenv also make the library re-read its switches (it caches the environment at
+    first use, csrc/switches.cpp), and which re-reads them once more after the test's changes have been undone."""
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def setenv_and_reload(*a, **k):
+        setenv(*a, **k)
+        _reload_switches()
+
+    def delenv_and_reload(*a, **k):
+        delenv(*a, **k)
+        _reload_switches()
+    monkeypatch.setenv, monkeypatch.delenv = setenv_and_reload, delenv_and_reload
+    yield monkeypatch
+    monkeypatch.undo()
+    _reload_switches()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -90,3 +90,35 @@ def test_null_handles_are_errors_with_a_message():
         assert _lib.last_error(), i
     assert lib.eg_dp_free(null) == 0 and lib.eg_model_free(null) == 0      # freeing nothing is fine
     assert lib.eg_dp_world(null) == 0 and lib.eg_dp_rank(null) == -1
+
+
+def test_switches_are_one_closed_table():
+    """Every environment variable the library reads is a row of csrc/switches.cpp: no getenv() anywhere else (rtc.cpp's
+    HOME / XDG_CACHE_HOME for the cache directory excepted), every name passed to eg::sw::raw / on / present / integer /
+    real is in the table, every row of the table is read somewhere, and DESIGN.md documents every row."""
+    import glob
+    import re
+    from exprgrad_amd import _lib
+    table = _lib.switch_table()
+    names = [t[0] for t in table]
+    assert len(names) == len(set(names)) and all(len(t) == 3 and t[1] in ("execution", "data-parallel", "compiler", "detector", "tuning") for t in table)
+    used = set()
+    src = os.path.join(ROOT, "exprgrad_amd", "csrc")
+    for path in glob.glob(os.path.join(src, "**", "*"), recursive=True):
+        if not path.endswith((".cpp", ".hip", ".hpp")) or os.sep + "build" + os.sep in path:
+            continue
+        text = open(path).read()
+        base = os.path.basename(path)
+        raw_env = re.findall(r'(?<![A-Za-z_:])getenv\("([A-Z_0-9]+)"\)', text)
+        if base == "rtc.cpp":
+            assert sorted(raw_env) == ["HOME", "XDG_CACHE_HOME"], raw_env
+        elif base not in ("switches.cpp", "switches.hpp"):
+            assert not raw_env and "getenv(" not in text.replace("eg::sw::", ""), (base, raw_env)
+        used.update(re.findall(r'sw::(?:raw|on|present|integer|real)\("([A-Z_0-9]+)"', text))
+        used.update(re.findall(r'env_on\("([A-Z_0-9]+)"', text))
+        used.update(re.findall(r'\{"(EG_[A-Z_0-9]+)", "EG_', text))          # a loop over several names
+        used.update(re.findall(r', "(EG_[A-Z_0-9]+)"\}\)', text))
+    assert used <= set(names), sorted(used - set(names))
+    assert set(names) - used <= {"EG_TUNING"}, sorted(set(names) - used)
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert [n for n in names if n not in design] == []

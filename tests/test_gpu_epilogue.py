@@ -178,6 +178,7 @@ def test_generated_kernels_wait_for_their_lds_dma_before_the_barrier(gpu_ctx, mo
         pytest.skip("no llvm-objdump")
     monkeypatch.setenv("EG_EPILOGUE_MIN_ELEMS", "0")
     monkeypatch.setenv("EG_DUMP_CODE", str(tmp_path))
+    monkeypatch.setenv("EG_NO_NARROW_K", "1")      # (K = 16 would run on the vector ALUs: this test is about the LDS-DMA loops)
     checked = 0
     for k, n, batch in [(16, 128, 2048), (20, 96, 1500), (784, 512, 4096)]:   # whole tiles; ragged M, N, K; the 256 x 256 tile
         m = egm.compile(layers.tanh(layers.dense(dsl.input("x"), k, n)).target("predict"), gpu=gpu_ctx)
@@ -200,6 +201,8 @@ def test_generated_kernels_wait_for_their_lds_dma_before_the_barrier(gpu_ctx, mo
                     pending = False     # what follows in the layout is not reached by falling through
                 elif ins == "s_barrier":
                     assert not pending, (name, "s_barrier with an LDS-DMA load not waited for", line.strip())
+            if "v_mfma" not in text:       # (a narrow-K product runs on the vector ALUs: no LDS-DMA loop in it)
+                continue
             assert loads > 0, name      # the LDS-DMA loop is what this test is about
             checked += 1
     assert checked >= 3
@@ -288,6 +291,26 @@ def test_keep_values_is_a_per_model_switch(gpu_ctx, monkeypatch):
         gpu.close()
     for t in states[0]:
         assert np.array_equal(states[0][t], states[1][t]), t
+
+
+@pytest.mark.parametrize("batch", [1024, 1000])
+def test_narrow_k_streaming_kernel_agrees_with_the_matrix_tile(gpu_ctx, monkeypatch, batch):
+    """`ga = gz * W2^T` of a 16-class layer with relu's gradient in the epilogue: K = 16, 128 columns — the streaming
+    kernel on the vector ALUs (gemm_narrow_k_block: one fmaf chain in k order per output, the reference's own order)
+    against the same launch on the matrix tile (EG_NO_NARROW_K=1), whose 16-deep k-tile reaches the matrix core as
+    k = 0, 4, 1, 5, ...: the same 16 products in another order, so the parameters after three steps agree to rounding,
+    not to the bit — held to 1e-5 of the largest element, tensor by tensor — and the plan is the same launch list."""
+    dims = (64, 128, 16)
+    rng = np.random.default_rng(batch)
+    x = (rng.random((batch, dims[0]), dtype=np.float32) - 0.5).astype(np.float32)
+    y = rng.random((batch, dims[-1]), dtype=np.float32)
+    monkeypatch.delenv("EG_NO_NARROW_K", raising=False)
+    plan_a, params_a = _train_state(gpu_ctx, monkeypatch, "relu", dims, x, y, 3, no_predicate=False)
+    monkeypatch.setenv("EG_NO_NARROW_K", "1")
+    plan_b, params_b = _train_state(gpu_ctx, monkeypatch, "relu", dims, x, y, 3, no_predicate=False)
+    assert "gemm+epilogue NT" in plan_a and plan_a == plan_b, plan_a
+    for t in params_a:
+        assert rel_err(params_a[t], params_b[t], what=f"parameter {t}: streaming narrow-K kernel vs matrix tile") <= TOL, t
 
 
 @pytest.mark.parametrize("act", ["tanh", "sigmoid"])

@@ -146,3 +146,44 @@ def test_the_row_product_variant_builds_without_a_device(tmp_path):
                            capture_output=True, text=True).stdout
     lds = [int(line.split(":")[1]) for line in notes.splitlines() if ".group_segment_fixed_size" in line]
     assert lds and max(lds) <= 160 * 1024, lds
+
+
+NARROW_K = """
+struct EgEpi {
+  static constexpr bool ACTIVE = true;
+  static constexpr int NX = 1;
+  static constexpr bool STORE_C = false;
+  static constexpr int OUT = 0;
+  static constexpr int PRED = -1;
+  static constexpr int RD_N = 0, RD_W = 0, RD_OUT = 0, RD_BIAS = -1, RD_LDW = 0, RD_LDO = 0;
+  __device__ __forceinline__ static bool predicate(float) { return false; }
+  __device__ __forceinline__ static void prefetch(const eg::gemm::GemmArgs& a, long idx, float (&x)[1]) {
+    x[0] = (float)((((const unsigned*)a.epi[1])[idx >> 5] >> (idx & 31)) & 1u);
+  }
+  __device__ __forceinline__ static void prefetch4(const eg::gemm::GemmArgs& a, long idx, eg::gemm::f32x4 (&x)[1]) {
+    const unsigned w = ((const unsigned*)a.epi[1])[idx >> 5] >> (idx & 31);
+    for (int e = 0; e < 4; ++e) x[0][e] = (float)((w >> e) & 1u);
+  }
+  __device__ __forceinline__ static float compute(const eg::gemm::GemmArgs&, long, float v, const float (&x)[1]) {
+    return x[0] != 0.0f ? v : 0.0f;
+  }
+};
+extern "C" __global__ __launch_bounds__(256) void k(eg::gemm::GemmArgs a) {
+  eg::gemm::gemm_narrow_k_block<10, 128, true, true, EgEpi>(a);
+}
+"""
+
+
+def test_the_narrow_k_variant_builds_without_a_device(tmp_path):
+    """The activation-gradient product of a 10-class layer with relu's gradient in the epilogue runs as a streaming kernel
+    on the vector ALUs (gemm_f32_mfma.hpp, gemm_narrow_k_block), built by hiprtc at run time only: compile it here — no
+    scratch, no matrix instruction, 16-byte stores, and the K values of a row as scalar loads on the one-wave-per-row path."""
+    rtc = bundled_hiprtc()
+    if rtc is None or not os.path.exists(OBJDUMP):
+        pytest.skip("no bundled hiprtc / llvm-objdump")
+    with open(os.path.join(ROOT, "exprgrad_amd", "csrc", "kernels", "gemm_f32_mfma.hpp")) as f:
+        header = f.read()
+    isa = compile_to_isa(rtc, header + NARROW_K, str(tmp_path))
+    assert "scratch_" not in isa and "v_mfma" not in isa
+    assert "global_store_dwordx4" in isa and "s_load_dword" in isa
+    assert "v_fma_f32" in isa or "v_fmac_f32" in isa or "v_pk_fma_f32" in isa

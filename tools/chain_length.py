@@ -12,6 +12,7 @@ Run on the GPU box:  python tools/chain_length.py [out.json]
 """
 import json
 import os
+os.environ.setdefault("EG_TUNING", "1")   # measurement aids (class `tuning` of csrc/switches.cpp) are honoured only with it
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

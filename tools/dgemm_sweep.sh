@@ -1,4 +1,5 @@
 #!/bin/bash
+export EG_TUNING=1   # measurement aids (class `tuning` of csrc/switches.cpp) are honoured only with it
 # eg_dgemm: every tile config (EG_DGEMM_TILE=<config>[,<splits>]) and the library's own choice, per size
 export PYTHONPATH=.
 SIZES=${SIZES:-"512 1024 1536 2048 3072 4096"}

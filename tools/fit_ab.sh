@@ -1,4 +1,5 @@
 #!/bin/bash
+export EG_TUNING=1   # measurement aids (class `tuning` of csrc/switches.cpp) are honoured only with it
 # Model.fit on the fashion_mnist network: us per batch at several batch sizes, tiny convolution kernels on / off (one box)
 python - <<'PY'
 import os, time, subprocess, sys, json

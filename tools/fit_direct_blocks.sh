@@ -1,3 +1,4 @@
+export EG_TUNING=1   # measurement aids (class `tuning` of csrc/switches.cpp) are honoured only with it
 for b in 256 512 768 1024 2048; do
 EG_CONV_DIRECT_BLOCKS=$b python - <<'PY'
 import os, sys, time

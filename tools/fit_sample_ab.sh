@@ -1,4 +1,5 @@
 #!/bin/bash
+export EG_TUNING=1   # measurement aids (class `tuning` of csrc/switches.cpp) are honoured only with it
 # Model.fit on the fashion_mnist network: us per batch at several batch sizes with and without sample groups (one box).
 # tools/fit_sample_ab.sh [batch sizes...]
 python - "$@" <<'PY'

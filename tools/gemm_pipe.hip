@@ -46,6 +46,9 @@ std::vector<Variant> variants() {
       {"256x256x16 unskewed ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 256>},
       {"256x256x16 skewed   ", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 0>},
       {"256x256x16 skew half", 256, 256, 16, launch<256, 256, 16, 128, 64, 1, AKC, BKC, 512>},
+      {"256x128 4w 128x64 b2", 256, 128, 16, launch<256, 128, 16, 128, 64, 2, AKC, BKC, 0>},
+      {"128x256 4w 128x64 b2", 128, 256, 16, launch<128, 256, 16, 128, 64, 2, AKC, BKC, 0>},
+      {"256x128 4w 128x64 b1", 256, 128, 16, launch<256, 128, 16, 128, 64, 1, AKC, BKC, 0>},
       {"128x128 8w 64x32 b1 ", 128, 128, 16, launch<128, 128, 16, 64, 32, 1, AKC, BKC, 0>},
       {"128x128 8w 64x32 b2 ", 128, 128, 16, launch<128, 128, 16, 64, 32, 2, AKC, BKC, 0>},
       {"128x128 8w 64x32 uns", 128, 128, 16, launch<128, 128, 16, 64, 32, 2, AKC, BKC, 256>},

@@ -2,6 +2,7 @@
 """Time eg_sgemm on one problem shape: tools/gemm_shape.py M N K [nn|nt|tn|tt] [reps]
 (run on the GPU box; EG_GEMM_FORCE_TILE=bm,bn forces a tile)."""
 import os
+os.environ.setdefault("EG_TUNING", "1")   # measurement aids (class `tuning` of csrc/switches.cpp) are honoured only with it
 import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch

@@ -109,6 +109,56 @@ __global__ __launch_bounds__(256) void mapg_chunk_k(const f4* __restrict__ in, c
   }
 }
 
+// ---- the activation-gradient product of cfg 5: gh[y, j] = bit(y, j) ? sum_c gz[y, c] * W2[j, c] : 0  (65 536 x 512 x 10) ----
+// thread = 4 consecutive columns of a row, its 4 x 10 values of W2 in registers; 128 threads per row, 2 rows per block-step.
+// STRIDE: rows of a step gridDim * 2 apart (the round-4 experiment); else a block owns a contiguous run of rows.
+template <int U, bool CHUNK, bool NT_>
+__global__ __launch_bounds__(256) void gh_k(const float* __restrict__ gz, const float* __restrict__ w2, const unsigned* __restrict__ bits,
+                                            float* __restrict__ out, long M) {
+  constexpr int K = 10, N = 512, TPR = N / 4, RPB = 256 / TPR;
+  const int tid = threadIdx.x, c4 = tid % TPR;
+  const long n = (long)c4 * 4;
+  float w[4][K];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < K; ++k) w[e][k] = w2[(n + e) * K + k];
+  long lo, hi, step;
+  if (CHUNK) {
+    const long per = ((M + gridDim.x - 1) / gridDim.x + RPB * U - 1) / (RPB * U) * (RPB * U);
+    lo = (long)blockIdx.x * per; hi = min(M, lo + per); step = RPB;
+  } else {
+    lo = (long)blockIdx.x * RPB; hi = M; step = (long)gridDim.x * RPB;
+  }
+  for (long m0 = lo + tid / TPR; m0 < hi; m0 += step * U) {
+    float ar[U][K];
+    unsigned bw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long m = m0 + u * step;
+      if (m > hi - 1) m = hi - 1;
+      const long mu = ((long)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+#pragma unroll
+      for (int k = 0; k < K; ++k) ar[u][k] = gz[mu * K + k];
+      bw[u] = bits[(m * N + n) >> 5] >> ((m * N + n) & 31);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long m = m0 + u * step;
+      if (m >= hi) break;
+      f4 res;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc = __builtin_fmaf(ar[u][k], w[e][k], acc);
+        res[e] = ((bw[u] >> e) & 1u) ? acc : 0.f;
+      }
+      if (NT_) __builtin_nontemporal_store(res, reinterpret_cast<f4*>(out + m * N + n)); else *reinterpret_cast<f4*>(out + m * N + n) = res;
+    }
+  }
+}
+
 // ---- full sum ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -230,7 +280,15 @@ int main() {
   };
 #define MAPV(U, NTV, G) { char nm[64]; snprintf(nm, 64, "map relu stride U=%d nt=%d grid=%d/CU", U, NTV, G); \
     time(nm, 2.0 * n * 4, [&](int s) { hipLaunchKernelGGL((map_k<U, NTV>), dim3(256 * G), dim3(256), 0, st, (const f4*)x[s], (f4*)y[s], n4); }); }
-  if (getenv("PROBE_ROUND1")) {
+  if (getenv("PROBE_GH")) {
+    float *gz, *w2; unsigned* bits;
+    CK(hipMalloc(&gz, rows * 10 * 4)); CK(hipMalloc(&w2, 512 * 10 * 4)); CK(hipMalloc(&bits, n / 8));
+    CK(hipMemset(gz, 0, rows * 10 * 4)); CK(hipMemset(w2, 0, 512 * 10 * 4)); CK(hipMemset(bits, 0x5a, n / 8));
+#define GHV(U, CH, NTV, G) { char nm[64]; snprintf(nm, 64, "gh %s U=%d nt=%d grid=%d/CU", CH ? "chunk " : "stride", U, NTV, G); \
+    time(nm, 1.0 * n * 4 + rows * 40.0 + n / 8.0, [&](int s) { hipLaunchKernelGGL((gh_k<U, CH, NTV>), dim3(256 * G), dim3(256), 0, st, gz, w2, bits, y[s], rows); }); }
+    GHV(4, false, true, 8) GHV(4, false, false, 8) GHV(4, true, true, 8) GHV(4, true, true, 16) GHV(4, true, true, 32) GHV(8, true, true, 8) GHV(8, true, true, 16)
+    GHV(2, true, true, 16) GHV(2, true, true, 32) GHV(8, true, true, 4) GHV(4, true, false, 16)
+  } else if (getenv("PROBE_ROUND1")) {
   MAPV(1, false, 8) MAPV(1, true, 8) MAPV(2, false, 8) MAPV(4, false, 8) MAPV(4, true, 8) MAPV(2, false, 16) MAPV(4, false, 4) MAPV(8, false, 4)
   MAPV(1, false, 16) MAPV(1, false, 32) MAPV(2, true, 16)
 #define MAPC(U, NTV, G) { char nm[64]; snprintf(nm, 64, "map relu chunk  U=%d nt=%d grid=%d/CU", U, NTV, G); \

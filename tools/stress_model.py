@@ -20,6 +20,7 @@ involved and the per-step deltas; the summary line ends the log.
 import argparse
 import json
 import os
+os.environ.setdefault("EG_TUNING", "1")   # measurement aids (class `tuning` of csrc/switches.cpp) are honoured only with it
 import sys
 import time
 

@@ -2,6 +2,7 @@
 """The library's own tile choice over a list of shapes, old cost model beside the new one is a matter of
 running it twice (EG_GEMM_OLD_TILE_MODEL=1): [SPIN_MS=100] tools/sweep_auto.py [nn|tn|nt] MxNxK ..."""
 import os, sys
+os.environ.setdefault("EG_TUNING", "1")   # measurement aids (class `tuning` of csrc/switches.cpp) are honoured only with it
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import exprgrad_amd as eg

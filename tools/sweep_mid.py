@@ -2,6 +2,7 @@
 """Tile / split / k-depth sweep over square mid-size contractions in one process (tuning aid):
 tools/sweep_mid.py [nn|tn] size..."""
 import os, sys
+os.environ.setdefault("EG_TUNING", "1")   # measurement aids (class `tuning` of csrc/switches.cpp) are honoured only with it
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import exprgrad_amd as eg
