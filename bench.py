@@ -630,7 +630,7 @@ def run_matmul_sizes(args, env):
     gen = torch.Generator(device="cuda")
     gen.manual_seed(7)
     rows = {}
-    for n in (512, 1024, 1536, 2048, 3072):
+    for n in (512, 1024, 1280, 1536, 1792, 2048, 3072):
         a = torch.rand((n, n), device="cuda", dtype=torch.float32, generator=gen)
         b = torch.rand((n, n), device="cuda", dtype=torch.float32, generator=gen)
         c = torch.empty((n, n), device="cuda", dtype=torch.float32)

@@ -471,6 +471,58 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
       return EG_OK;
     }
   }
+  // Stream-K on 64 x 64 tiles (round 6; gemm_streamk_kernel): the planner's choice is unsliced 64 x 64 tiles, there are more
+  // tiles than CUs, and they do not divide evenly over the four block slots of a CU — the launch is as long as its busiest
+  // CU (1280^3: 400 tiles, 1.56 per CU; 1792^3: 784 tiles, 3.06 per CU).  Persistent blocks (four per CU) share the
+  // (tile, k-tile) space evenly instead; the tiles they cut are folded in k order by one more launch.  EG_GEMM_NO_STREAMK=1 off.
+  if (BM == 64 && BN == 64 && splits == 1 && !conv && vec_ok && !a_vec_only && !args.ones_row && M % 64 == 0 && N % 64 == 0 && K % 32 == 0 &&
+      K >= 256 && args.ldc % 4 == 0 && aligned16(args.C) && (args.bias == nullptr || aligned16(args.bias)) &&
+      !eg::sw::present("EG_GEMM_NO_STREAMK") && !eg::sw::present("EG_GEMM_FORCE_TILE") && !eg::sw::present("EG_GEMM_FORCE_SPLITS")) {
+    const long tiles = (M / 64) * (N / 64), cus = ctx->compute_units, slots = 4 * cus;
+    const long nk = K / 32;
+    const long busiest = (tiles + cus - 1) / cus;
+    const double even = (double)tiles / (double)cus;
+    // Every tile's units are shared (rounds = 0) by four blocks per CU (two when there are fewer than two tiles per CU).  The
+    // hybrid form — `rounds` whole tiles per block first, only the remaining tiles shared — is kept behind the tuning aid
+    // EG_STREAMK_BLOCKS_PER_CU: it wins at 2560^3 (278 -> 265 us) and loses at 1792^3 (three blocks per CU: 118 against 105).
+    long g = tiles > 2 * cus ? 4 : 2, rounds = 0;
+    if (const char* e = eg::sw::raw("EG_STREAMK_BLOCKS_PER_CU")) {   // tuning aid
+      g = atol(e);
+      rounds = tiles / (g * cus);
+    }
+    const long grid = g * cus;
+    const long rest = tiles - rounds * grid;          // tiles the blocks share unit by unit
+    // a block's share of the units: even, but at least four k-tiles (a piece pays a prologue and a slab)
+    long per = (rest * nk + grid - 1) / grid;
+    if (per < 4) per = 4;
+    // What it buys: (1 - even / busiest) of the one-block-per-tile launch, whose length is about busiest x nk x 0.51 us
+    // (2048^3: four blocks per CU, 64 k-tiles, 131 us); with more tiles than block slots the dispatcher refills slots as they
+    // free up and the busiest CU carries about even + 0.5.  What it costs: nearly every tile is cut, so the output travels
+    // through the slabs and a second launch — 14 us at 1792^3.  Measured (tools/streamk_ab.py): 1792^3 115 -> 105 us, 1280 x
+    // 1280 x 4096 139 -> 122, 1152^3 42.6 -> 39.3; equal at 1280^3; 3 - 5 % slower at 1664^3 / 1920^3 / 2304^3 — hence the bar.
+    const double busiest_eff = tiles >= slots ? even + 0.5 : (double)busiest;
+    const double saved_us = (1.0 - even / busiest_eff) * busiest_eff * (double)nk * 0.51;
+    const double min_saved = eg::sw::real("EG_STREAMK_MIN_RATIO", 24.0);   // tuning aid: microseconds the model must promise
+    if (tiles > cus && tiles < 6 * slots && rest > 0 && saved_us >= min_saved) {
+      int rc = eg::ensure_workspace(ctx, (size_t)grid * 2 * 64 * 64 * sizeof(float));
+      if (rc) return rc;
+      args.tiles_m = (int)(M / 64);
+      args.tiles_n = (int)(N / 64);
+      args.partial = static_cast<float*>(ctx->workspace);
+      args.splits = (int)rounds;
+      args.k_per_split = per;
+      args.a_rows = M;
+      dim3 gd((unsigned)grid), block(256);
+      if (a_kc && !b_kc) hipLaunchKernelGGL((gemm_streamk_kernel<32, true, false>), gd, block, 0, ctx->stream, args);
+      else if (a_kc && b_kc) hipLaunchKernelGGL((gemm_streamk_kernel<32, true, true>), gd, block, 0, ctx->stream, args);
+      else if (!a_kc && !b_kc) hipLaunchKernelGGL((gemm_streamk_kernel<32, false, false>), gd, block, 0, ctx->stream, args);
+      else hipLaunchKernelGGL((gemm_streamk_kernel<32, false, true>), gd, block, 0, ctx->stream, args);
+      hipLaunchKernelGGL(gemm_streamk_fixup_kernel, dim3((unsigned)rest), dim3(256), 0, ctx->stream, args.partial, args.C, args.bias,
+                         args.ldc, args.tiles_m, args.tiles_n, rounds * grid, (int)nk, per, args.accumulate);
+      EG_HIP_CHECK(hipGetLastError());
+      return EG_OK;
+    }
+  }
   // (the same design on one round of 128 x 128 tiles — four 64 x 64 sub-tiles x four waves — measured equal to what the model
   //  picks: 2048^3 129.1 against 130.7 us, 1792^3 113.1 / 113.9, 2048 x 2048 x 512 40.8 / 39.2: the gain above is the whole round, not the wave count)
   // A few rows / columns beyond whole 256 x 256 tiles of a large output (4100 = 16 x 256 + 4): the ragged

@@ -1491,6 +1491,109 @@ gemm_f32_mfma_kernel(GemmArgs a) {
   gemm_block<BM, BN, BK, WM, WN, A_KC, B_KC, VEC, EDGE, CONV, ABL, DMA, EpiNone, XR>(a);
 }
 
+// ---- stream-K for 64 x 64 tiles (round 6) -------------------------------------------------------------------------------
+// A mid-size product on 64 x 64 tiles leaves the CUs unevenly loaded: 1792^3 is 784 tiles on 256 CUs (3.06 blocks per CU: the
+// launch is as long as the CUs that got four), 1152^3 324 tiles (1.27: as long as two) — 0.64 / 0.45 of peak where 2048^3,
+// exactly four blocks per CU, runs at 0.83.  Here the launch is gridDim PERSISTENT blocks.  Block b first multiplies `rounds`
+// whole tiles (b, b + gridDim, ...: stored as usual), then its share of the REMAINING tiles' (tile, k-tile) space, which the
+// blocks divide evenly: units [b * per, (b + 1) * per) of it, walked tile by tile.  A piece of a tile goes to one of the
+// block's two slabs — slot 0: the block's first piece, slot 1: its last — and gemm_streamk_fixup_kernel adds the pieces of
+// every remaining tile in k order (block order), a fixed order: run-to-run identical.  (A first version shared ALL tiles'
+// units: with about as many tiles as blocks nearly every tile was cut and the whole output travelled through the slabs —
+// 1920^3 126.9 us against 121.8 for one block per tile.)  Whole 64 x 64 tiles, K a multiple of BK, 16-byte aligned operands,
+// no generated epilogue (host: run_gemm).  rounds = a.splits, per = a.k_per_split (units of BK).
+template <int BK, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 4) void gemm_streamk_kernel(GemmArgs a) {
+  constexpr int BM = 64, BN = 64, WM = 32, WN = 32;
+  constexpr int SA = LdsStride<BM, BK, A_KC>::value, SB = LdsStride<BN, BK, B_KC>::value;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (SA + SB)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int i = lane & 31, hi = lane >> 5;
+  const int nk = (int)(a.K / BK);
+  const int rounds = a.splits;
+  const long tiles = (long)a.tiles_m * a.tiles_n, tiles_dp = (long)rounds * gridDim.x;
+  // (blocks in XCD-contiguous order: neighbouring tiles / unit ranges share an L2)
+  const long b = xcd_remap(blockIdx.x, gridDim.x);
+  // register r of lane l: row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31 of the wave's 32 x 32 block
+  auto piece = [&](int tile, int k0, int cnt, float* slab) {
+    long m_blk, n_blk;
+    tile_origin<BM, BN>(tile, a.tiles_m, a.tiles_n, m_blk, n_blk);
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    gemm_mainloop_dma<BM, BN, BK, WM, WN, A_KC, B_KC, 0, false, true, false, 0>(a, lds, acc, m_blk, n_blk, (long)k0 * BK, cnt, tid, wm0, wn0);
+    if (slab == nullptr) {
+      float* col = a.C + (m_blk + wm0 + 4 * hi) * a.ldc + n_blk + wn0 + i;
+      const float bias = a.bias ? a.bias[n_blk + wn0 + i] : 0.f;
+      if (a.accumulate) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float* p = col + (long)((r & 3) + 8 * (r >> 2)) * a.ldc;
+          *p = (*p + acc[0][0][r]) + bias;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) col[(long)((r & 3) + 8 * (r >> 2)) * a.ldc] = acc[0][0][r] + bias;
+      }
+    } else {
+      float* dst = slab + (wm0 + 4 * hi) * BN + wn0 + i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[((r & 3) + 8 * (r >> 2)) * BN] = acc[0][0][r];
+    }
+  };
+  for (int r = 0; r < rounds; ++r) piece((int)((long)r * gridDim.x + b), 0, nk, nullptr);
+  const long total = (tiles - tiles_dp) * nk;
+  const long per = a.k_per_split;
+  long u = b * per;
+  const long u_end = total < u + per ? total : u + per;
+  bool first = true;
+  while (u < u_end) {
+    const int t = (int)(u / nk);
+    const int k0 = (int)(u - (long)t * nk);
+    const int cnt = (int)((long)(nk - k0) < u_end - u ? nk - k0 : u_end - u);
+    // (a remaining tile that one block owns completely is stored directly; the fix-up skips it)
+    piece((int)(tiles_dp + t), k0, cnt, (k0 == 0 && cnt == nk) ? nullptr : a.partial + ((long)b * 2 + (first ? 0 : 1)) * (BM * BN));
+    first = false;
+    u += cnt;
+  }
+}
+
+// One block per REMAINING tile: the sum of its pieces in block (= k) order.
+__global__ __launch_bounds__(256) void gemm_streamk_fixup_kernel(const float* __restrict__ partial, float* C, const float* __restrict__ bias,
+                                                                 long ldc, int tiles_m, int tiles_n, long tiles_dp, int nk, long per,
+                                                                 int accumulate) {
+  constexpr int BM = 64, BN = 64;
+  const int t = blockIdx.x;                    // remaining tile t = tile tiles_dp + t
+  const long u0 = (long)t * nk, u1 = u0 + nk;
+  const long b_first = u0 / per, b_last = (u1 - 1) / per;
+  if (b_first == b_last) return;   // one block owned the whole tile and stored it
+  const int tile = (int)(tiles_dp + t);
+  long m_blk, n_blk;
+  {
+    constexpr int GROUP = 8;
+    const int per_group = GROUP * tiles_n, group = tile / per_group, first_m = group * GROUP;
+    const int gsize = tiles_m - first_m < GROUP ? tiles_m - first_m : GROUP, in_group = tile % per_group;
+    m_blk = (long)(first_m + in_group % gsize) * BM;
+    n_blk = (long)(in_group / gsize) * BN;
+  }
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  for (int e = threadIdx.x; e < BM * BN / 4; e += 256) {
+    v4 s = {0.f, 0.f, 0.f, 0.f};
+    for (long bb = b_first; bb <= b_last; ++bb) {
+      const int slot = (bb * per) / nk == t ? 0 : 1;   // the block's first piece, or its last
+      s += *reinterpret_cast<const v4*>(partial + (bb * 2 + slot) * (BM * BN) + e * 4);
+    }
+    const int row = (e * 4) / BN, c = (e * 4) % BN;
+    float* dst = C + (m_blk + row) * ldc + n_blk + c;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float bv = bias ? bias[n_blk + c + j] : 0.f;
+      dst[j] = accumulate ? (dst[j] + s[j]) + bv : s[j] + bv;
+    }
+  }
+}
+
 // ---- contraction with a TINY K and a generated epilogue as a streaming kernel on the vector ALUs ----------------------
 // The activation-gradient product of a classifier's last layer, ga[y, j] = sum_c gz[y, c] * W2[j, c] with 10 classes
 // (dense, dnn.nim:19-24, differentiated: passes.nim:519-549), followed by relu's gradient in the epilogue: 65 536 x 512 x 10

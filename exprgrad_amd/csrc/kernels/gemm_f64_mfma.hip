@@ -44,6 +44,9 @@ struct DgemmArgs {
 // neighbours in memory AND in LDS: one global_load_dwordx4, one ds_write_b128) and consecutive lanes walk consecutive
 // memory.  Both row strides put the two half-waves of a fragment read (ds_read_b64) on disjoint bank sets.
 // VEC = false (an odd leading dimension or a base that is not 16-byte aligned): the same pieces as two 8-byte loads.
+// (round 6: row paddings of 4 / 6 / 10 doubles instead of 2 measured SLOWER — 4096^3 NT 0.836 -> 0.76 / 0.69 / 0.69 of peak, NN
+//  0.78 -> 0.74 / 0.78 / 0.70 — although the counters report bank conflicts for this layout and none for [k][mn + 16]: NT, both
+//  operands in this layout, is the fastest order; the conflicts counted are the 16-byte writes of two rows per pass, not the reads)
 constexpr int LDK = BK + 2;
 
 template <int BMN, int NT, bool KC, bool VEC>

@@ -46,6 +46,7 @@ const Row kSwitches[] = {
     {"EG_GEMM_NO_BK32", "execution", "16-deep k-tiles for long whole-tile products"},
     {"EG_GEMM_NO_PAIR", "execution", "no wave-pair / eight-wave small-tile kernels"},
     {"EG_GEMM_NO_T96", "execution", "no 96 x 96 whole-round tiles"},
+    {"EG_GEMM_NO_STREAMK", "execution", "64 x 64 tiles one block per tile, not persistent stream-K blocks"},
     {"EG_GEMM_NO_XROW", "execution", "1 .. 32 rows beyond whole tiles as a ragged tile row, not a ninth accumulator block"},
     {"EG_GEMM_NO_WIDE_STORE", "execution", "tiles leave as 128-byte pieces instead of through LDS as whole rows"},
     {"EG_CONV_NO_TINY", "execution", "small convolutions on the contraction route"},
@@ -78,6 +79,8 @@ const Row kSwitches[] = {
     {"EG_GEMM_FORCE_TILE", "tuning", "bm,bn: force the contraction tile"},
     {"EG_GEMM_FORCE_SPLITS", "tuning", "n: force the k-slice count"},
     {"EG_GEMM_OLD_TILE_MODEL", "tuning", "round-1 cost model for wide outputs"},
+    {"EG_STREAMK_BLOCKS_PER_CU", "tuning", "persistent blocks per CU of a stream-K launch"},
+    {"EG_STREAMK_MIN_RATIO", "tuning", "microseconds the balance model must promise before a 64 x 64 launch goes stream-K (default 24)"},
     {"EG_GEMM_SMALL_BK32", "tuning", "32-deep k-tiles for every 64 x 64 launch"},
     {"EG_DGEMM_TILE", "tuning", "config[,splits]: force the float64 tile"},
     {"EG_CONV_BAND_PIXELS", "tuning", "pixels per band of the band convolutions"},

@@ -526,3 +526,43 @@ def test_wave_pair_kernel_without_accumulation_and_bias(gpu_ctx):
     dc.write(np.full((M, N), np.nan, dtype=np.float32))
     ops.sgemm(gpu_ctx, M, N, K, dev(gpu_ctx, a), K, dev(gpu_ctx, b), N, dc, N)
     assert rel_err(dc.read(), a.astype(np.float64) @ b.astype(np.float64)) <= TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["nn", "nt", "tn", "tt"])
+@pytest.mark.parametrize("shape,per_cu", [((1792, 1792, 512), 0), ((1152, 1216, 384), 0), ((1280, 1280, 1056), 4), ((1344, 1280, 288), 2),
+                                          ((1664, 1728, 320), 3), ((2112, 2048, 256), 4)])
+def test_stream_k_blocks_against_the_exact_product_and_one_block_per_tile(gpu_ctx, monkeypatch, mode, shape, per_cu):
+    """Round 6 (gemm_f32_mfma.hpp gemm_streamk_kernel): persistent blocks share the (tile, k-tile) space of a 64 x 64 launch
+    evenly; cut tiles are folded in k order by gemm_streamk_fixup_kernel.  Forced on here whatever the balance model says
+    (EG_STREAMK_MIN_RATIO=0; per_cu > 0: the hybrid form with that many blocks per CU — whole tiles first, the rest shared):
+    four layouts, a bias, onto an existing C and into a NaN-filled one; against the float64 product, against one block per
+    tile (EG_GEMM_NO_STREAMK=1: the same k order inside a piece, pieces added in k order — rounding only), and twice in a row
+    (fixed order: not one bit may differ from run to run)."""
+    M, N, K = shape
+    ta, tb = mode[0] == "t", mode[1] == "t"
+    rng = np.random.default_rng(M + N + K)
+    a = (rng.random((K, M) if ta else (M, K), dtype=np.float32) - 0.5).astype(np.float32)
+    b = (rng.random((N, K) if tb else (K, N), dtype=np.float32) - 0.5).astype(np.float32)
+    bias = rng.random((N,), dtype=np.float32)
+    base = rng.random((M, N), dtype=np.float32)
+    da, db, dbias = dev(gpu_ctx, a), dev(gpu_ctx, b), dev(gpu_ctx, bias)
+    dc = gpu_ctx.allocTensor((M, N))
+    monkeypatch.setenv("EG_STREAMK_MIN_RATIO", "0")
+    if per_cu:
+        monkeypatch.setenv("EG_STREAMK_BLOCKS_PER_CU", str(per_cu))
+    outs = []
+    for off in (False, False, True):
+        if off:
+            monkeypatch.setenv("EG_GEMM_NO_STREAMK", "1")
+        dc.write(base)
+        ops.sgemm(gpu_ctx, M, N, K, da, a.shape[1], db, b.shape[1], dc, N, trans_a=ta, trans_b=tb, accumulate=True, bias=dbias)
+        outs.append(dc.read())
+    monkeypatch.delenv("EG_GEMM_NO_STREAMK")
+    exact = (a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)
+    assert np.array_equal(outs[0], outs[1])
+    assert rel_err(outs[0], base.astype(np.float64) + exact + bias) <= TOL
+    assert rel_err(outs[0], outs[2].astype(np.float64), what="stream-K vs one block per tile") <= 5e-6
+    dc.write(np.full((M, N), np.nan, dtype=np.float32))         # a chunk the blocks or the fix-up skipped would show
+    ops.sgemm(gpu_ctx, M, N, K, da, a.shape[1], db, b.shape[1], dc, N, trans_a=ta, trans_b=tb)
+    assert rel_err(dc.read(), exact) <= TOL
