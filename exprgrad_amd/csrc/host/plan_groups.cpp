@@ -197,6 +197,25 @@ int form_sample_group(eg_model* m, TargetState& ts, Plan& plan, const std::vecto
     } else if (ski[p].ok && scatter && ski[p].reduced) {
       ski[p].ok = false;  // (the slab row would have to start from zero)
     }
+    if (ski[p].ok && !eg::sw::present("EG_SAMPLE_NO_MFMA") && match_conv(k, cm) && cm.batched) {
+      // a convolution member on the matrix cores (rowfuse.hpp conv_role): small operand fragments must fit registers
+      auto tensor_of = [&](int op) { return op < 0 ? k.write.tensor : k.reads[op].tensor; };
+      const int ti = tensor_of(cm.img_op), to = tensor_of(cm.out_op), tf = tensor_of(cm.flt_op);
+      const std::vector<long>&is = shapes.at(ti), &os = shapes.at(to), &fs = shapes.at(tf);
+      if (is.size() == 4 && os.size() == 4 && fs.size() == 4) {
+        const long C = is[3], F = os[3], taps = fs[1] * fs[2];
+        long frag = 0;   // registers of the small operand's fragments per lane
+        if (cm.role == ConvMatch::Forward) frag = ((F + 15) / 16) * ((taps * C + 3) / 4);
+        else if (cm.role == ConvMatch::GradImage) frag = ((C + 15) / 16) * ((taps * F + 3) / 4);
+        else frag = ((F + 15) / 16) * ((taps * C + 15) / 16) * 4;   // accumulator blocks
+        if (frag <= 64 && (cm.role != ConvMatch::GradFilter || ski[p].reduced)) {
+          ski[p].conv_role = cm.role == ConvMatch::Forward ? 1 : cm.role == ConvMatch::GradFilter ? 2 : 3;
+          ski[p].conv_img = ti;
+          ski[p].conv_out = to;
+          ski[p].conv_flt = tf;
+        }
+      }
+    }
     if (ski[p].ok && ski[p].reduced && !ts.bucket_offset.count(k.write.tensor)) ski[p].ok = false;
     if (ski[p].ok && plan.alias.count(k.write.tensor)) ski[p].ok = false;
     // What belongs on the matrix cores stays there: a contraction whose two other extents are both >= 32 (a hidden layer of
@@ -368,6 +387,25 @@ int form_sample_group(eg_model* m, TargetState& ts, Plan& plan, const std::vecto
         g.lds[tid] = inner;
         if (!first_plain[tid]) g.lds_zero.insert(tid);
       }
+    // parameters the members only read, into what is left of the block's LDS (at most 48 KB of them): rowfuse.hpp `staged`
+    if (!eg::sw::present("EG_SAMPLE_NO_STAGE")) {
+      std::set<int> read_only, written_by;
+      for (size_t i = 0; i < g.kernel_index.size(); ++i) {
+        const Kernel& k = t.all[g.kernel_index[i]];
+        written_by.insert(k.write.tensor);
+        for (auto& rd : k.reads) read_only.insert(rd.tensor);
+      }
+      long room = std::min(budget, 12L * 1024);
+      std::vector<std::pair<long, int>> by_size;
+      for (int tid : read_only)
+        if (!written_by.count(tid) && m->prog.tensors[tid].kind == TK::Param) by_size.push_back({prod(shapes.at(tid)), tid});
+      std::sort(by_size.begin(), by_size.end());
+      for (auto& pr : by_size)
+        if (pr.first > 0 && pr.first <= room) {
+          g.staged[pr.second] = pr.first;
+          room -= pr.first;
+        }
+    }
     // (what starts from zero in LDS needs no zeroed global storage)
     zero_these.erase(std::remove_if(zero_these.begin(), zero_these.end(), [&](int tid) { return g.lds.count(tid) != 0; }), zero_these.end());
   }

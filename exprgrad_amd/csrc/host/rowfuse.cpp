@@ -811,9 +811,16 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
     if (!g.lds.count(t)) g.ptr_args.push_back(t);
   const std::string NT = std::to_string(g.threads);
   std::string sig = "extern \"C\" __global__ void __launch_bounds__(" + NT + ") " + g.name + "(float* __restrict__ slab";
-  for (int t : g.ptr_args) sig += std::string(written.count(t) ? ", float* t" : ", const float* t") + std::to_string(t);
+  // (a staged parameter's argument is g<id>; t<id> names its copy in LDS, so the members' text does not change)
+  for (int t : g.ptr_args) sig += std::string(written.count(t) ? ", float* t" : (g.staged.count(t) ? ", const float* __restrict__ g" : ", const float* t")) + std::to_string(t);
   sig += ", float GS, long EP)";
   std::string c = "  const long n = blockIdx.x;  // this block's sample\n";
+  for (auto& kv : g.staged) {
+    const std::string id = std::to_string(kv.first), sz = std::to_string(kv.second);
+    c += "  __shared__ float t" + id + "[" + sz + "];\n";
+    c += "  for (int i = threadIdx.x; i < " + sz + "; i += " + NT + ") t" + id + "[i] = g" + id + "[i];\n";
+  }
+  if (!g.staged.empty()) c += "  __syncthreads();\n";
   for (auto& kv : g.lds) c += "  __shared__ float t" + std::to_string(kv.first) + "[" + std::to_string(kv.second) + "];\n";
   for (int t : g.lds_zero)
     c += "  for (int i = threadIdx.x; i < " + std::to_string(g.lds.at(t)) + "; i += " + NT + ") t" + std::to_string(t) + "[i] = 0.0f;\n";
@@ -825,12 +832,103 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
   if (g.slab_floats > 0) c += "  float* const row = slab + n * " + std::to_string(g.slab_floats) + "L;\n";
   std::set<int> slab_seen;
   long scratch_floats = 0;
+  // EG_SAMPLE_STOP=<k> (tuning aid): the kernel ends behind member k — wrong numbers, the time of the first k + 1 members
+  const long stop = eg::sw::integer("EG_SAMPLE_STOP", -1);
   for (size_t gi = 0; gi < g.kernel_index.size(); ++gi) {
+    if (stop >= 0 && (long)gi > stop) break;
     const Kernel& k = all[g.kernel_index[gi]];
     const KernelInfo& info = infos[g.kernel_index[gi]];
     const SampleKernelInfo& si = g.infos[gi];
     const std::vector<Ty> ty = infer_types(k);
     c += "  {  // kernel " + std::to_string(gi) + ": " + to_text(k).substr(0, 100) + "\n";
+    if (si.conv_role != 0) {
+      // ---- matrix-core convolution members (round 6).  The scalar members spend their time in LDS reads (two per multiply-add:
+      // conv1 forward 7.5 us, its filter gradient 12.3, conv2's three 3.5 + 5.4 + 4.9 of the 31 us kernel at batch 32).  Here a
+      // member is a handful of v_mfma_f32_16x16x4_f32 per wave: the SMALL operand (filter bank / its transpose) sits in
+      // registers as B fragments for the whole member, the other fragment is ONE gathered element per lane and instruction
+      // (window element, output gradient), the eight waves share row blocks (forward, image gradient) or the pixel range
+      // (filter gradient: the waves' accumulator blocks meet in LDS in wave order — a fixed order).  Padding lanes multiply by
+      // an exact 0.0f from the small operand (or read an element that is part of the true sum), never uninitialised memory.
+      const std::vector<long>&is = shapes.at(si.conv_img), &os = shapes.at(si.conv_out), &fs = shapes.at(si.conv_flt);
+      const long H = is[1], W = is[2], C = is[3], Ho = os[1], Wo = os[2], F = os[3], FH = fs[1], FW = fs[2];
+      (void)H;
+      const long K = FH * FW * C, P = Ho * Wo, Q = is[1] * is[2];
+      const long NW = g.threads / 64;
+      auto S = [](long v) { return std::to_string(v); };
+      auto at = [&](int tensor, const std::string& idx) {   // element idx of this sample's slice (the filter bank: of the bank)
+        const std::string name = "t" + std::to_string(tensor);
+        if (tensor == si.conv_flt) return name + "[" + idx + "]";
+        const long inner = prodv(shapes.at(tensor)) / std::max(1L, shapes.at(tensor)[0]);
+        return local(tensor) ? name + "[" + idx + "]" : name + "[n * " + S(inner) + "L + " + idx + "]";
+      };
+      c += "    typedef float mf4 __attribute__((ext_vector_type(4)));\n";
+      c += "    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;\n";
+      if (si.conv_role == 1) {   // out[p, f] (+)= sum_t img[pix(p) + tap(t)] * flt[f, t]
+        const long KS = (K + 3) / 4, NB = (F + 15) / 16, PB = (P + 15) / 16;
+        c += "    float bf[" + S(NB) + "][" + S(KS) + "];\n    int toff[" + S(KS) + "];\n";
+        c += "    _Pragma(\"unroll\") for (int ks = 0; ks < " + S(KS) + "; ++ks) {\n";
+        c += "      const int t = 4 * ks + l4, tc = t < " + S(K) + " ? t : 0;\n";
+        c += "      toff[ks] = ((tc / " + S(FW * C) + ") * " + S(W) + " + (tc / " + S(C) + ") % " + S(FW) + ") * " + S(C) + " + tc % " + S(C) + ";\n";
+        c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) {\n        const int f = 16 * nb + l15;\n";
+        c += "        bf[nb][ks] = (t < " + S(K) + " && f < " + S(F) + ") ? " + at(si.conv_flt, "f * " + S(K) + " + t") + " : 0.0f;\n      }\n    }\n";
+        c += "    for (int pb = wave; pb < " + S(PB) + "; pb += " + S(NW) + ") {\n";
+        c += "      int p = 16 * pb + l15;\n      if (p > " + S(P - 1) + ") p = " + S(P - 1) + ";\n";
+        c += "      const int poff = ((p / " + S(Wo) + ") * " + S(W) + " + p % " + S(Wo) + ") * " + S(C) + ";\n";
+        c += "      mf4 acc[" + S(NB) + "];\n      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
+        c += "      _Pragma(\"unroll\") for (int ks = 0; ks < " + S(KS) + "; ++ks) {\n";
+        c += "        const float a = " + at(si.conv_img, "poff + toff[ks]") + ";\n";
+        c += "        _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nb][ks], acc[nb], 0, 0, 0);\n      }\n";
+        c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb)\n        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) {\n";
+        c += "          const int pr = 16 * pb + 4 * l4 + j, f = 16 * nb + l15;\n";
+        const std::string o = at(si.conv_out, "pr * " + S(F) + " + f");
+        c += "          if (pr < " + S(P) + " && f < " + S(F) + ") " + o + " = " + (g.overwrite[gi] ? std::string("0.0f") : o) + " + acc[nb][j];\n        }\n    }\n";
+      } else if (si.conv_role == 3) {   // gimg[q, ch] (+)= sum_{s, f} gout[pixel(q) - tap(s), f] * flt[f, s, ch]
+        const long KD = FH * FW * F, KS = (KD + 3) / 4, NB = (C + 15) / 16, QB = (Q + 15) / 16;
+        c += "    float bf[" + S(NB) + "][" + S(KS) + "];\n";
+        c += "    _Pragma(\"unroll\") for (int ks = 0; ks < " + S(KS) + "; ++ks) {\n      const int kk = 4 * ks + l4, s = kk / " + S(F) + ", f = kk % " + S(F) + ";\n";
+        c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) {\n        const int ch = 16 * nb + l15;\n";
+        c += "        bf[nb][ks] = (kk < " + S(KD) + " && ch < " + S(C) + ") ? " + at(si.conv_flt, "f * " + S(K) + " + s * " + S(C) + " + ch") + " : 0.0f;\n      }\n    }\n";
+        c += "    for (int qb = wave; qb < " + S(QB) + "; qb += " + S(NW) + ") {\n";
+        c += "      int q = 16 * qb + l15;\n      if (q > " + S(Q - 1) + ") q = " + S(Q - 1) + ";\n      const int qy = q / " + S(W) + ", qx = q % " + S(W) + ";\n";
+        c += "      mf4 acc[" + S(NB) + "];\n      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
+        c += "      _Pragma(\"unroll\") for (int ks = 0; ks < " + S(KS) + "; ++ks) {\n";
+        c += "        const int kk = 4 * ks + l4, s = kk / " + S(F) + ", f = kk % " + S(F) + ", y = qy - s / " + S(FW) + ", x = qx - s % " + S(FW) + ";\n";
+        c += "        const bool ok = kk < " + S(KD) + " && y >= 0 && y < " + S(Ho) + " && x >= 0 && x < " + S(Wo) + ";\n";
+        c += "        const int go = ok ? (y * " + S(Wo) + " + x) * " + S(F) + " + f : 0;\n";
+        c += "        const float av = " + at(si.conv_out, "go") + ";\n        const float a = ok ? av : 0.0f;\n";
+        c += "        _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nb][ks], acc[nb], 0, 0, 0);\n      }\n";
+        c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb)\n        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) {\n";
+        c += "          const int qr = 16 * qb + 4 * l4 + j, ch = 16 * nb + l15;\n";
+        const std::string o = at(si.conv_img, "qr * " + S(C) + " + ch");
+        c += "          if (qr < " + S(Q) + " && ch < " + S(C) + ") " + o + " = " + (g.overwrite[gi] ? std::string("0.0f") : o) + " + acc[nb][j];\n        }\n    }\n";
+      } else {   // gflt[f, t] (+)= sum_p gout[p, f] * img[pix(p) + tap(t)]
+        const long MB = (F + 15) / 16, NB = (K + 15) / 16, PS = (P + 3) / 4;
+        const bool first = slab_seen.count(k.write.tensor) == 0;   // the first contribution of this block to that slab range
+        const long off = g.slab_offset.at(k.write.tensor);
+        c += "    int toff[" + S(NB) + "];\n";
+        c += "    _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) {\n      int t = 16 * nb + l15;\n      if (t > " + S(K - 1) + ") t = " + S(K - 1) + ";\n";
+        c += "      toff[nb] = ((t / " + S(FW * C) + ") * " + S(W) + " + (t / " + S(C) + ") % " + S(FW) + ") * " + S(C) + " + t % " + S(C) + ";\n    }\n";
+        c += "    mf4 acc[" + S(MB) + "][" + S(NB) + "];\n";
+        c += "    _Pragma(\"unroll\") for (int mb = 0; mb < " + S(MB) + "; ++mb) _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[mb][nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
+        c += "    for (int ps = wave; ps < " + S(PS) + "; ps += " + S(NW) + ") {\n";
+        c += "      const int p = 4 * ps + l4, pc = p < " + S(P) + " ? p : " + S(P - 1) + ";\n";
+        c += "      const int poff = ((pc / " + S(Wo) + ") * " + S(W) + " + pc % " + S(Wo) + ") * " + S(C) + ";\n";
+        c += "      float a[" + S(MB) + "];\n      _Pragma(\"unroll\") for (int mb = 0; mb < " + S(MB) + "; ++mb) {\n        const int f = 16 * mb + l15, fc = f < " + S(F) + " ? f : 0;\n";
+        c += "        const float av = " + at(si.conv_out, "pc * " + S(F) + " + fc") + ";\n        a[mb] = (p < " + S(P) + " && f < " + S(F) + ") ? av : 0.0f;\n      }\n";
+        c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) {\n        const float b = " + at(si.conv_img, "poff + toff[nb]") + ";\n";
+        c += "        _Pragma(\"unroll\") for (int mb = 0; mb < " + S(MB) + "; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b, acc[mb][nb], 0, 0, 0);\n      }\n    }\n";
+        c += "    _Pragma(\"unroll\") for (int mb = 0; mb < " + S(MB) + "; ++mb) _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) {\n";
+        c += "      _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) scratch[wave * 256 + (4 * l4 + j) * 16 + l15] = acc[mb][nb][j];\n      __syncthreads();\n";
+        c += "      if (threadIdx.x < 256) {\n        float s = 0.0f;\n        for (int w = 0; w < " + S(NW) + "; ++w) s = s + scratch[w * 256 + threadIdx.x];\n";
+        c += "        const int f = 16 * mb + (threadIdx.x >> 4), t = 16 * nb + (threadIdx.x & 15);\n";
+        const std::string o = "row[" + S(off) + " + f * " + S(K) + " + t]";
+        c += "        if (f < " + S(F) + " && t < " + S(K) + ") " + o + " = " + (first ? std::string("0.0f") : o) + " + s;\n      }\n      __syncthreads();\n    }\n";
+        scratch_floats = std::max(scratch_floats, NW * 256);
+        slab_seen.insert(k.write.tensor);
+      }
+      c += "  }\n  __syncthreads();\n";
+      continue;
+    }
     if (si.gather) {
       // gimg[n, Y, X, c] = sum over (dy, dx, f) of gout[n, Y - dy, X - dx, f] * flt[f, dy, dx, c] where the output pixel exists
       const std::vector<long>&gi_s = shapes.at(si.g_img), &go_s = shapes.at(si.g_out), &fl_s = shapes.at(si.g_flt);

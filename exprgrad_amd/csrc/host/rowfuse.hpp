@@ -137,6 +137,12 @@ struct SampleKernelInfo {
   // the image gradient's own elements (tensor ids; filled in by the planner from match_conv)
   bool gather = false;
   int g_img = 0, g_out = 0, g_flt = 0;
+  // Round 6: a batched conv2 member (forward, filter gradient or image gradient; planner: match_conv) on the matrix cores —
+  // 16 x 16 x 4 instructions whose fragments are gathered from the block's LDS-resident tensors (generate_sample_group,
+  // "matrix-core convolution members").  0 = the generic loop nest (or `gather`), 1 = forward, 2 = filter gradient,
+  // 3 = image gradient; tensor ids of image, output (or its gradient) and filter bank.
+  int conv_role = 0;
+  int conv_img = 0, conv_out = 0, conv_flt = 0;
 };
 
 SampleKernelInfo analyse_sample_kernel(const Program& prog, const Kernel& k, const KernelInfo& info, const Shapes& shapes, long B);
@@ -156,6 +162,10 @@ struct SampleGroup {
   std::map<int, long> lds;
   std::set<int> lds_zero;           // of those: accumulated into before being written whole (start from zero)
   int threads = 256;                // block size (a multiple of 64)
+  // Round 6: small PARAMETER tensors the members read (filter banks, a dense layer's weights) are copied into LDS once, at the
+  // kernel's start: a member that walked them with dependent loads paid an L2 round trip per iteration (the 400-term dense
+  // layer of the fashion_mnist network: eight of them in a row).  tensor id -> floats.
+  std::map<int, long> staged;
 };
 
 // Arguments of the generated kernel: (float* slab, float* t<ids>..., float grad_scale, long epoch); grid = B blocks of `threads`.

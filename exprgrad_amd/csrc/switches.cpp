@@ -38,6 +38,8 @@ const Row kSwitches[] = {
     {"EG_NO_SKINNY_GEMM", "execution", "N <= 16 products on the matrix tiles instead of the streaming skinny kernel"},
     {"EG_NO_NARROW_K", "execution", "K <= 16 products with a generated epilogue on the matrix tile instead of the streaming kernel"},
     {"EG_NO_SAMPLE_FUSE", "execution", "no sample groups (one block per sample): the launch chain of a small-batch step"},
+    {"EG_SAMPLE_NO_STAGE", "execution", "a sample group's members read parameters from global memory, not from a copy in LDS"},
+    {"EG_SAMPLE_NO_MFMA", "execution", "convolution members of a sample group as scalar loop nests, not on the matrix cores"},
     {"EG_NO_SLAB_FOLD", "execution", "the optimizer's map group does not add up the sample kernel's slab rows itself"},
     {"EG_NO_SLAB_SUM", "execution", "k-slices folded by the two-launch column sum instead of slab_sum"},
     {"EG_NO_ROW_TAIL", "execution", "a row group's last block neither folds the partial rows nor runs the update"},
@@ -85,6 +87,7 @@ const Row kSwitches[] = {
     {"EG_DGEMM_TILE", "tuning", "config[,splits]: force the float64 tile"},
     {"EG_CONV_BAND_PIXELS", "tuning", "pixels per band of the band convolutions"},
     {"EG_CONV_DIRECT_BLOCKS", "tuning", "block cap of the direct filter gradient"},
+    {"EG_SAMPLE_STOP", "tuning", "k: a sample kernel ends behind member k (wrong numbers: the time of its first k + 1 members)"},
     {"EG_SAMPLE_FUSE_MAX_BATCH", "tuning", "largest batch that forms a sample group (default 1280)"},
     {"EG_EPILOGUE_MIN_ELEMS", "tuning", "smallest output that gets a generated epilogue (default 2^20; tests: 0)"},
     {"EG_PIPELINE_MIN_FLOPS", "tuning", "smallest contraction the batch pipeline cuts"},

@@ -23,7 +23,10 @@ print(f"batch {batch}: {dt / (n // batch) * 1e6:.1f} us per batch, {n / dt / 1e3
 '''
 sizes = [int(a) for a in sys.argv[1:]] or [8, 16, 32, 64, 128, 256]
 for batch in sizes:
-    for label, env in (("sample groups", {"EG_SAMPLE_FUSE_MAX_BATCH": "100000"}), ("launch chain ", {"EG_NO_SAMPLE_FUSE": "1"})):
+    for label, env in (("sample groups, matrix-core convolution members", {"EG_SAMPLE_FUSE_MAX_BATCH": "100000"}),
+                       ("sample groups, parameters not staged in LDS   ", {"EG_SAMPLE_FUSE_MAX_BATCH": "100000", "EG_SAMPLE_NO_STAGE": "1"}),
+                       ("sample groups, scalar convolution members     ", {"EG_SAMPLE_FUSE_MAX_BATCH": "100000", "EG_SAMPLE_NO_MFMA": "1", "EG_SAMPLE_NO_STAGE": "1"}),
+                       ("launch chain                                  ", {"EG_NO_SAMPLE_FUSE": "1"})):
         e = dict(os.environ, FIT_BATCH=str(batch), **env)
         out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True)
         print(label + ": " + (out.stdout.strip().splitlines() or [out.stderr[-300:]])[-1], flush=True)
