@@ -54,6 +54,15 @@ int fuse_row_tails(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
     }
     if (!ok || work > 16384) continue;
     pg.g.tail_kernels = sg.g.kernel_index;
+    {  // the grid this launch will use (below), known to the generator: rowfuse.hpp grid_blocks
+      long row_floats = 0;
+      for (auto& tt : pg.g.tensors)
+        if (tt.second.role == RowGroupTensor::RowExternal || (tt.second.role == RowGroupTensor::RowLocal && (tt.second.store || tt.second.load_first)))
+          row_floats += tt.second.inner;
+      long cap = std::max(64L, (pg.g.B * std::max(1L, row_floats) * 4 + 12287) / 12288);
+      cap = eg::sw::integer("EG_ROW_TAIL_BLOCKS", cap);   // tuning aid
+      pg.g.grid_blocks = std::min<long>(pg.nblocks, std::max(1L, cap));
+    }
     int rc = generate_row_group(m->prog, t.all, infos, plan.shapes, pg.g);
     if (rc) return rc;
     bool replaced = false;
@@ -82,6 +91,7 @@ int fuse_row_tails(eg_model* m, TargetState& ts, Plan& plan, const std::vector<K
         row_floats += tt.second.inner;
     const long bytes_touched = pg.g.B * std::max(1L, row_floats) * 4;
     long cap = std::max(64L, (bytes_touched + 12287) / 12288);
+    cap = std::max(1L, eg::sw::integer("EG_ROW_TAIL_BLOCKS", cap));   // tuning aid
     if (pg.nblocks > cap) pg.nblocks = (int)cap;
   }
   return EG_OK;

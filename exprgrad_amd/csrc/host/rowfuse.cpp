@@ -330,7 +330,7 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
       else init += z;
     }
   }
-  if (strided) c += "  for (long y = (long)blockIdx.x * 256 + threadIdx.x; y < B; y += (long)gridDim.x * 256) {\n  const bool active = true;\n";
+  if (strided) c += "  auto one_sample = [&](const long y) {\n  const bool active = true;\n";
   c += init;
   for (size_t i = 0; i < g.kernel_index.size(); ++i)
     em.emit_kernel(all[g.kernel_index[i]], infos[g.kernel_index[i]], g.infos[i], (int)i);
@@ -342,7 +342,20 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
     c += "  if (active) { _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) t" + id + "[y * " +
          std::to_string(t.inner) + "L + j] = L" + id + "[j]; }\n";
   }
-  if (strided) c += "  }\n";
+  if (strided) {
+    c += "  };\n";
+    const long per_trip = g.grid_blocks * 256;
+    const long trips = per_trip > 0 && g.B % per_trip == 0 ? g.B / per_trip : 0;
+    if (trips >= 2 && trips <= 8) {
+      // the launch this kernel was generated for: every thread has exactly `trips` samples, no bounds test between them
+      c += "  if (gridDim.x == " + std::to_string(g.grid_blocks) + " && B == " + std::to_string(g.B) + "L) {\n";
+      c += "    _Pragma(\"unroll\") for (int trip = 0; trip < " + std::to_string(trips) + "; ++trip) one_sample((long)blockIdx.x * 256 + threadIdx.x + (long)trip * " +
+           std::to_string(per_trip) + "L);\n  } else {\n";
+      c += "    for (long y = (long)blockIdx.x * 256 + threadIdx.x; y < B; y += (long)gridDim.x * 256) one_sample(y);\n  }\n";
+    } else {
+      c += "  for (long y = (long)blockIdx.x * 256 + threadIdx.x; y < B; y += (long)gridDim.x * 256) one_sample(y);\n";
+    }
+  }
   // batch reductions: wave shuffles, then the four wave totals through LDS, one partial row per block
   if (g.red_total > 0) {
     const std::string E = std::to_string(g.red_total);

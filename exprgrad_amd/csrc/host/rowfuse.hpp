@@ -68,6 +68,11 @@ struct RowGroup {
   // Arguments behind `epoch`: d<id> per reduction, unsigned* counter, long MODE (0: partial rows only, the caller
   // launches row_finalize; 1: fold in the kernel; 2: fold, then the tail), u<id> per tail tensor.
   bool in_kernel_finalize = false;
+  // Round 6: the grid the launch will use when it is known at generation time (fuse_row_tails: a row group with a tail runs on
+  // few, long blocks).  With B a multiple of grid_blocks * 256 the strided sample loop is emitted with a literal trip count and
+  // fully unrolled: the loads of all of a thread's samples are in flight together instead of one memory round trip per sample
+  // (four in a row at the XOR step).  The generic loop stays in the kernel for any other grid / B.
+  long grid_blocks = 0;
   std::vector<int> tail_kernels;   // indices into target.all, in execution order
   std::vector<int> tail_ptr_args;  // tensor ids of the tail kernels, in pointer-argument order
 };

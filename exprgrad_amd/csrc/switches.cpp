@@ -87,6 +87,7 @@ const Row kSwitches[] = {
     {"EG_DGEMM_TILE", "tuning", "config[,splits]: force the float64 tile"},
     {"EG_CONV_BAND_PIXELS", "tuning", "pixels per band of the band convolutions"},
     {"EG_CONV_DIRECT_BLOCKS", "tuning", "block cap of the direct filter gradient"},
+    {"EG_ROW_TAIL_BLOCKS", "tuning", "blocks of a row group that carries a tail (default: 12 KB of rows per block, at least 64)"},
     {"EG_SAMPLE_STOP", "tuning", "k: a sample kernel ends behind member k (wrong numbers: the time of its first k + 1 members)"},
     {"EG_SAMPLE_FUSE_MAX_BATCH", "tuning", "largest batch that forms a sample group (default 1280)"},
     {"EG_EPILOGUE_MIN_ELEMS", "tuning", "smallest output that gets a generated epilogue (default 2^20; tests: 0)"},
