@@ -95,7 +95,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="auto", choices=["auto", "matmul", "train", "xor", "conv2"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "matmul", "train", "xor", "conv2", "hbm"])
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch of the train/xor workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -115,7 +115,9 @@ def parse():
 
 
 DEPENDENT_LAUNCH_US = 1.5   # boundary between two dependent launches inside a captured graph (MI355X_MICROARCH.md)
-SPINUP_S = 0.2   # untimed seconds of the same step in front of the W warmup steps (Timer.run): a sustained-clock figure
+# untimed seconds of the same step in front of the W warmup steps (Timer.run): a sustained-clock figure.  tools/profile.sh shortens it
+# for its counter passes (EG_BENCH_SPINUP_S): under --pmc every dispatch is serialised and 0.2 s of a 12 us step is 16 000 of them
+SPINUP_S = float(os.environ.get("EG_BENCH_SPINUP_S", "0.2"))
 
 EVENTS_NOTE = ("kernel_ms_avg = one HIP event pair around the K timed steps / K, on the stream the kernels run on; "
                "kernel_ms_min = shortest step of a second, untimed pass of K steps with an event pair each")
@@ -1026,11 +1028,12 @@ def run_xor(args, env):
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(gbs / HBM_PEAK_GBS, 4),
                          **(traffic_fields("xor") if batch == 65536 else {"traffic": None}),
-                         "kernel": "whole step (19 kernels fused into 4 launches replayed as HIP graphs; launch-latency bound)",
+                         "kernel": "whole step = ONE launch (eg_rows: 15 forward / backward kernels per sample in registers; the last block to "
+                                   "arrive folds the partial rows and runs the four update kernels); launch- and hand-off-latency bound",
                          "bytes_per_launch": XOR_BYTES_PER_SAMPLE * batch, "clock": "wall time of the timed steps",
                          "kernel_ms_avg": round(ev_avg, 4)},
-            "scaling_note": "launch-bound: the step is 3 dependent launches (~25 us) around 1 MB of real traffic, so its "
-                            "time is launch latency, not bandwidth.  Under data parallelism a step adds one 17-float "
+            "scaling_note": "launch-bound: the step is one launch of ~12 us around 1 MB of real traffic, so its "
+                            "time is launch and hand-off latency, not bandwidth.  Under data parallelism a step adds one 17-float "
                             "all-reduce (tens of us) and cannot get shorter: steps/s does NOT scale with GPUs.  The only "
                             "claim this workload supports is weak scaling in samples/s (65536 samples per GPU: N GPUs "
                             "process N x 65536 samples in one step time + one all-reduce latency); the north-star's "
@@ -1138,11 +1141,11 @@ def run_fashion_fit(args, env):
             "kernels_per_batch": len(plan) + 1,
             "sample_group": any("sample-fused" in ln for ln in plan),
             "measured_us_per_dependent_kernel": 4.5,
-            "measured_note": "round 5: the forward + backward pass of a step is ONE kernel with one block per sample (DESIGN.md §3 "
-                             "'Round 5', profiles/r05_fit_timeline.txt: copy_segments 4.7 + eg_samples 31 + eg_maps 4.3 us at batch "
-                             "32; the launch chain it replaces, EG_NO_SAMPLE_FUSE=1: 16 kernels of 4.1 - 8.0 us each, 72 us).  A "
-                             "dependent kernel ends >= 4.5 us after its predecessor here whatever it does; the floor above uses the "
-                             "guide's 1.5 us per boundary.",
+            "measured_note": "the forward + backward pass of a step is ONE kernel with one block per sample (DESIGN.md section 3 'Round 5'); "
+                             "round 6: its five convolution members run on the matrix cores (16 x 16 x 4, gathered fragments) and the "
+                             "parameters are staged in LDS once: 36.7 -> 28.3 us per batch-32 step on one box (tools/fit_sample_ab.sh); the "
+                             "launch chain it replaces, EG_NO_SAMPLE_FUSE=1: 16 kernels of 4.1 - 8.0 us each, 71 us.  A dependent kernel "
+                             "ends >= 4.5 us after its predecessor here whatever it does; the floor above uses the guide's 1.5 us per boundary.",
             "note": "calls = launches of the plan + the segment copy of the batch's rows; some calls are two kernels (a "
                     "k-sliced contraction and its fixed-order sum).  Bytes: every activation / gradient of the network "
                     "written once and read once, float32.  At batch 32 the step is launch-bound, at 4096 "
@@ -1152,10 +1155,9 @@ def run_fashion_fit(args, env):
                        "peak": out["batch_32"]["bound"]["dependent_launch_floor_us"],
                        "frac": round(out["batch_32"]["bound"]["dependent_launch_floor_us"] / out["batch_32"]["us_per_batch"], 3),
                        "traffic": None,
-                       "note": "floor / achieved: the batch-32 step against its dependent-launch floor.  Since round 5 the step is "
-                               "three launches and its time is the sample kernel's (31 of 38 us), which is bound by LDS "
-                               "instructions (two reads per multiply-add), not by launches: the fraction says how far the step is "
-                               "from a chain of three empty kernels"}
+                       "note": "floor / achieved: the batch-32 step against its dependent-launch floor.  The step is three launches and "
+                               "its time is the sample kernel's (~22 of 28 us): 26 members separated by block barriers, each a pass over "
+                               "LDS-resident tensors; the fraction says how far the step is from a chain of three empty kernels"}
     model.close()
     return out
 
@@ -1337,6 +1339,9 @@ def main():
         line, model = run_train(args, env)
     elif workload == "xor":
         line = run_xor(args, env)
+    elif workload == "hbm":
+        line = run_hbm_kernels(args, env)
+        line["value"] = line["roofline"]["achieved"]
     else:
         line = run_conv2(args, env)
 

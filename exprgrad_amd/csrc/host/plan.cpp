@@ -639,7 +639,7 @@ int make_plan(eg_model* m, TargetState& ts, Plan& plan) {
                      plan.zero_extra.count(tid) != 0;
       if ((pass == 0) != z) continue;
       // large tensors start on a 256-byte boundary: a streaming kernel's 1 KiB wave stores then cover whole 64-byte
-      // sectors (65 536 x 512 floats written from a base 16 bytes past a boundary: 34 us instead of 27, tools/bin/nk_harness4)
+      // sectors (65 536 x 512 floats written from a base 16 bytes past a boundary: 34 us instead of 27, tools/narrow_k_harness.hip OUT_OFFSET=4)
       const long floats = storage_floats(plan, tid);
       if (floats >= 16384) off = (off + 63) & ~63L;
       plan.arena_offset[tid] = off;

@@ -40,11 +40,17 @@ proc eg_kernel_set_arg_i64(kernel: ptr EgKernel, index: cint, value: int64): cin
 proc eg_kernel_set_arg_f32(kernel: ptr EgKernel, index: cint, value: float32): cint
 proc eg_kernel_set_arg_f64(kernel: ptr EgKernel, index: cint, value: float64): cint
 proc eg_kernel_launch(kernel: ptr EgKernel, dims: cint, groups, local: ptr int64): cint
+proc eg_switches_reload(): cint
 {.pop.}
 
 proc check(status: cint) =                       # cl.nim:41-43
   if status != 0:
     raise GpuError(msg: $eg_last_error())
+
+proc reloadSwitches*() =
+  ## The library reads its environment switches (EG_NO_GRAPH, ...: DESIGN.md section 4) once, at first use; a program that
+  ## changes one with putEnv afterwards calls this.  No reference counterpart (its switches are compile-time defines).
+  check eg_switches_reload()
 
 proc listDevices*(): seq[GpuDevice] =            # cl.nim:64-66
   var n: cint

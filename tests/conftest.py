@@ -142,8 +142,7 @@ TOL = 1e-5
 
 
 def debug_toggles_active():
-    """EG_NO_GRAPH / EG_NO_OVERLAP / EG_NO_ROWFUSE (tools/stress_suite.sh cycles through them) change the launch
-    plan on purpose: assertions about the plan's STRUCTURE only hold without them; numbers must hold always."""
-    return any(os.environ.get(k, "") not in ("", "0") for k in ("EG_NO_GRAPH", "EG_NO_OVERLAP", "EG_NO_ROWFUSE", "EG_NO_EPILOGUE",
-                                                                  "EG_NO_INLINE", "EG_NO_ONES_ROW", "EG_NO_PREDICATE",
-                                                                  "EG_NO_ROW_PRODUCT", "EG_PIPELINE"))
+    """Switches of class `execution` (EG_NO_*, EG_*_NO_*, EG_PIPELINE; tools/stress_suite.sh cycles through them) change the
+    launch plan and the summation orders on purpose: assertions about the plan's STRUCTURE and the committed allow-list of
+    the direct parity gate only hold without them; numbers must hold always."""
+    return any(k.startswith("EG_") and ("_NO_" in k or k == "EG_PIPELINE") and v not in ("", "0") for k, v in os.environ.items())

@@ -35,7 +35,9 @@ def short(name):
 
 def ours(name):
     return (name.startswith("eg") or "eg::" in name or "eg_" in name or
-            any(k in name for k in ("colsum", "rowsum", "conv2_halo", "conv2_gradf", "grad_image_operands", "copy_segments", "dgemm_")))
+            any(k in name for k in ("colsum", "rowsum", "conv2_halo", "conv2_gradf", "grad_image_operands", "copy_segments", "dgemm_",
+                                    "map_kernel", "map_grad_kernel", "bias_add_kernel", "axpy_kernel", "fill_kernel", "sum_partial",
+                                    "sum_final", "slab_sum", "zero_ranges", "gemm_streamk")))
 
 
 def main():
