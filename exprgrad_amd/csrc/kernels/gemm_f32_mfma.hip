@@ -486,9 +486,23 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     // hybrid form — `rounds` whole tiles per block first, only the remaining tiles shared — is kept behind the tuning aid
     // EG_STREAMK_BLOCKS_PER_CU: it wins at 2560^3 (278 -> 265 us) and loses at 1792^3 (three blocks per CU: 118 against 105).
     long g = tiles > 2 * cus ? 4 : 2, rounds = 0;
+    // More tiles than block slots: whole rounds of tiles first (one per block and round, stored directly), only the tiles of
+    // the partial last round shared — worth it while that round is at most 0.6 full and K is long (2432^3 238 -> 233 us, 2560^3
+    // 280 -> 269, 2560 x 2560 x 4096 446 -> 425, 3584^3 733 -> 720; 2688^3 / 2816^3, last round 0.72 / 0.89 full: 3 % slower;
+    // K = 1024: slower).
+    bool hybrid = false;
+    if (tiles >= slots && nk >= 64) {
+      const long last = tiles % slots;
+      if (last > 0 && 10 * last <= 6 * slots) {
+        g = 4;
+        rounds = tiles / slots;
+        hybrid = true;
+      }
+    }
     if (const char* e = eg::sw::raw("EG_STREAMK_BLOCKS_PER_CU")) {   // tuning aid
       g = atol(e);
       rounds = tiles / (g * cus);
+      hybrid = false;
     }
     const long grid = g * cus;
     const long rest = tiles - rounds * grid;          // tiles the blocks share unit by unit
@@ -503,7 +517,7 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
     const double busiest_eff = tiles >= slots ? even + 0.5 : (double)busiest;
     const double saved_us = (1.0 - even / busiest_eff) * busiest_eff * (double)nk * 0.51;
     const double min_saved = eg::sw::real("EG_STREAMK_MIN_RATIO", 24.0);   // tuning aid: microseconds the model must promise
-    if (tiles > cus && tiles < 6 * slots && rest > 0 && saved_us >= min_saved) {
+    if (tiles > cus && tiles < 6 * slots && rest > 0 && (hybrid || saved_us >= min_saved)) {
       int rc = eg::ensure_workspace(ctx, (size_t)grid * 2 * 64 * 64 * sizeof(float));
       if (rc) return rc;
       args.tiles_m = (int)(M / 64);
