@@ -304,9 +304,12 @@ int colsum_with_scratch(eg_ctx* ctx, long rows, long cols, const float* in, floa
 // slabs over 256 / G lanes each: lane s of a group adds slabs s, s + L, s + 2 L, ... in that order, a fixed tree in LDS
 // folds the L partial sums — run-to-run identical.  G groups x 16 bytes are contiguous in every slab.
 template <bool ACC>
-__global__ __launch_bounds__(NT) void slab_sum_kernel(const float* __restrict__ slab, float* out, long total, int slabs, int G) {
+__global__ __launch_bounds__(NT) void slab_sum_kernel(const float* __restrict__ slab, float* out, long total, int slabs, int G, int prio) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   __shared__ f4 part[NT];
+  // on the side lane, next to a long contraction whose waves are always ready to issue: raise the issue priority like the
+  // side lane's contractions do (GemmArgs::prio) — without it this 6 us fold took 36 us there
+  if (prio) __builtin_amdgcn_s_setprio(3);
   const int L = NT / G;                       // slab lanes per group
   const int gi = threadIdx.x % G, sl = threadIdx.x / G;
   const long group = (long)blockIdx.x * G + gi;
@@ -359,10 +362,11 @@ int slab_sum(eg_ctx* ctx, long slabs, long total, const float* slab, float* out,
   int G = 16;
   while (G > 1 && (groups / G < 2L * ctx->compute_units || slabs / (NT / G) > 16)) G >>= 1;
   const long blocks = (groups + G - 1) / G;
+  const int prio = ctx->on_side_lane ? 1 : 0;
   if (accumulate)
-    hipLaunchKernelGGL((slab_sum_kernel<true>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, slab, out, total, (int)slabs, G);
+    hipLaunchKernelGGL((slab_sum_kernel<true>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, slab, out, total, (int)slabs, G, prio);
   else
-    hipLaunchKernelGGL((slab_sum_kernel<false>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, slab, out, total, (int)slabs, G);
+    hipLaunchKernelGGL((slab_sum_kernel<false>), dim3((unsigned)blocks), dim3(NT), 0, ctx->stream, slab, out, total, (int)slabs, G, prio);
   EG_HIP_CHECK(hipGetLastError());
   return EG_OK;
 }

@@ -19,3 +19,4 @@ bash tools/fit_sample_ab.sh 8 32 256 1024 2>&1 | grep -v amdgpu > gpurun_out/sum
 python tools/streamk_ab.py nn 1024x1024x1024 1152x1152x1152 1280x1280x1280 1536x1536x1536 1792x1792x1792 2048x2048x2048 2304x2304x2304 1280x1280x4096 2>&1 | grep -v amdgpu > gpurun_out/summ/${TAG}_streamk_ab.txt
 ls gpurun_out/summ
 tail -c 1500 gpurun_out/summ/${TAG}_bench_n1.json
+python -m pytest tests -m gpu -q -x -p no:cacheprovider > gpurun_out/summ/gputests_final.log 2>&1; tail -3 gpurun_out/summ/gputests_final.log
