@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Condense the log of a survey run of the GPU suite into profiles/parity_survey_<tag>.json:
     EG_PARITY_RECORD=$PWD/gpurun_out/parity_record.jsonl python -m pytest tests -m gpu -q      (on the GPU box)
-    python tools/parity_survey.py gpurun_out/parity_record.jsonl profiles/parity_survey_r05.json
+    python tools/parity_survey.py gpurun_out/parity_record.jsonl profiles/parity_survey_r06.json
 Every three-way comparison of tests/parity.py is one line: distance of the backend and of the oracle from the
 float64 shadow (e_gpu, e_ref; relative to max|exact|) and — round 5, the comparison in BASELINE.json's own words
 ("outputs match the reference LLVM CPU path on identical inputs within 1e-5 relative") — the distance of the backend

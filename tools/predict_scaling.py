@@ -16,7 +16,7 @@ quoted at 20 - 40 us for messages of this size) and BETA = 100 GB/s effective pe
 ~153 GB/s raw each, MI355X_MICROARCH / task brief).  Both constants are in the JSON; nothing here was measured on more
 than one GPU.
 
-    python tools/predict_scaling.py profiles/scaling_prediction_r05.json"""
+    python tools/predict_scaling.py profiles/scaling_prediction_r06.json"""
 import json
 import os
 import subprocess
