@@ -68,9 +68,6 @@ struct eg_ctx {
   std::vector<hipEvent_t> pipe_events;  // batch pipeline (host/plan_pipeline.cpp): per-stage, per-half dependencies between the lanes
   eg::HostStager* stager = nullptr;  // created by the first large host copy
   float* ones = nullptr;             // {1,1,1,1, 1,0,0,0}: source of a contraction's virtual row of ones (GemmArgs::ones)
-  float* zeros = nullptr;            // zeros_floats zeros: what a convolution's virtual padding reads (conv2_halo.hip)
-  size_t zeros_floats = 0;
-  std::vector<float*> zeros_retired;  // outgrown blocks: captured graphs may still hold their address; freed with the context
   int compute_units = 256;
   std::string arch;
   // kernels a library call specialises at run time (hiprtc) and keeps: by name

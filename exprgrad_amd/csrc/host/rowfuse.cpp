@@ -828,13 +828,26 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
   for (int t : g.ptr_args) sig += std::string(written.count(t) ? ", float* t" : (g.staged.count(t) ? ", const float* __restrict__ g" : ", const float* t")) + std::to_string(t);
   sig += ", float GS, long EP)";
   std::string c = "  const long n = blockIdx.x;  // this block's sample\n";
-  for (auto& kv : g.staged) {
-    const std::string id = std::to_string(kv.first), sz = std::to_string(kv.second);
-    c += "  __shared__ float t" + id + "[" + sz + "];\n";
-    c += "  for (int i = threadIdx.x; i < " + sz + "; i += " + NT + ") t" + id + "[i] = g" + id + "[i];\n";
+  // Staged parameters: ALL loads first (literal trip counts, one register each), then the stores.  As one copy loop per
+  // parameter the compiler emitted load - wait - store round trips one after the other (rolled loops for the longer ones):
+  // ten dependent trips to L2 in front of the first member, 5 - 6 us of a 23 us kernel (ISA of the batch-32 fit step).
+  if (!g.staged.empty()) {
+    std::string loads, stores;
+    long nv = 0;
+    for (auto& kv : g.staged) {
+      const std::string id = std::to_string(kv.first);
+      c += "  __shared__ __attribute__((aligned(16))) float t" + id + "[" + std::to_string(kv.second) + "];\n";
+      for (long base = 0; base < kv.second; base += g.threads, ++nv) {
+        const std::string v = "sv" + std::to_string(nv), i = "threadIdx.x + " + std::to_string(base);
+        const bool whole = base + g.threads <= kv.second;
+        const std::string guard = whole ? "" : "if (threadIdx.x < " + std::to_string(kv.second - base) + ") ";
+        loads += "    float " + v + " = 0.0f; " + guard + v + " = g" + id + "[" + i + "];\n";
+        stores += "    " + guard + "t" + id + "[" + i + "] = " + v + ";\n";
+      }
+    }
+    c += "  {\n" + loads + stores + "  }\n  __syncthreads();\n";
   }
-  if (!g.staged.empty()) c += "  __syncthreads();\n";
-  for (auto& kv : g.lds) c += "  __shared__ float t" + std::to_string(kv.first) + "[" + std::to_string(kv.second) + "];\n";
+  for (auto& kv : g.lds) c += "  __shared__ __attribute__((aligned(16))) float t" + std::to_string(kv.first) + "[" + std::to_string(kv.second) + "];\n";
   for (int t : g.lds_zero)
     c += "  for (int i = threadIdx.x; i < " + std::to_string(g.lds.at(t)) + "; i += " + NT + ") t" + std::to_string(t) + "[i] = 0.0f;\n";
   if (!g.lds_zero.empty()) c += "  __syncthreads();\n";
@@ -845,6 +858,7 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
   if (g.slab_floats > 0) c += "  float* const row = slab + n * " + std::to_string(g.slab_floats) + "L;\n";
   std::set<int> slab_seen;
   long scratch_floats = 0;
+  bool need_zeros4 = false;   // four zeros in LDS: what an image-gradient member's gather reads outside the output
   // EG_SAMPLE_STOP=<k> (tuning aid): the kernel ends behind member k — wrong numbers, the time of the first k + 1 members
   const long stop = eg::sw::integer("EG_SAMPLE_STOP", -1);
   for (size_t gi = 0; gi < g.kernel_index.size(); ++gi) {
@@ -876,44 +890,140 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
       };
       c += "    typedef float mf4 __attribute__((ext_vector_type(4)));\n";
       c += "    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;\n";
-      if (si.conv_role == 1) {   // out[p, f] (+)= sum_t img[pix(p) + tap(t)] * flt[f, t]
+      // Shapes of the loops below (round 6, after the cycle stamps of EG_SAMPLE_TRACE): a wave's row blocks are a lambda
+      // called with a LITERAL trip count (the whole trips; the ragged one under a wave-uniform guard) so that the gathers of
+      // block i + 1 are in flight under the MFMAs of block i — the rolled `for (pb = wave; ...)` exposed the LDS latency and
+      // the whole dependent MFMA chain of every block; k-steps alternate between two accumulators (one chain of KS
+      // dependent MFMAs becomes two of KS / 2).
+      // A row block's store without a branch when the destination lives in LDS: lanes outside the tensor write their value to
+      // a slot of `scratch` of their own instead (a guarded store is a basic-block boundary, and the compiler does not move
+      // the next block's gathers across it — the blocks of a wave ran one after the other, latencies and all).
+      auto guarded_store = [&](int tensor, const std::string& cond, const std::string& idx, const std::string& value) {
+        const std::string o = at(tensor, idx);
+        if (!local(tensor))
+          return "          if (" + cond + ") " + o + " = " + (g.overwrite[gi] ? std::string("0.0f") : o) + " + " + value + ";\n";
+        scratch_floats = std::max(scratch_floats, (long)g.threads);
+        std::string d = "          float* const dst_ = (" + cond + ") ? &" + o + " : &scratch[threadIdx.x];\n";
+        d += "          *dst_ = " + (g.overwrite[gi] ? std::string("0.0f") : std::string("*dst_")) + " + " + value + ";\n";
+        return d;
+      };
+      auto trips = [&](const std::string& fn, long units) {   // calls fn(unit) for unit = wave, wave + NW, ...
+        std::string d;
+        const long whole = units / NW, ragged = units % NW;
+        if (whole > 0) d += "    _Pragma(\"unroll\") for (int it_ = 0; it_ < " + S(whole) + "; ++it_) " + fn + "(wave + it_ * " + S(NW) + ");\n";
+        if (ragged > 0) d += "    if (wave < " + S(ragged) + ") " + fn + "(wave + " + S(whole * NW) + ");\n";
+        return d;
+      };
+      // Gathers of FOUR k-values per lane and instruction (round 6; these members are bound by the number of instructions a
+      // wave issues, ~10 per MFMA with one 4-byte gather, its address and its mask each): with the channels (forward) / the
+      // filters (image gradient) a multiple of 4 and the gathered tensor in LDS, the k index is permuted so that the lane
+      // group l4 holds k = 16 g + 4 l4 + j in the j-th MFMA of group g — four consecutive channels of ONE tap, one
+      // ds_read_b128, one address, one bounds test.  Any bijection of k is the same sum; B fragments use the same one.
+      if (si.conv_role == 1 && C % 4 == 0 && local(si.conv_img)) {
+        const long G = (K + 15) / 16, NB = (F + 15) / 16, PB = (P + 15) / 16;
+        c += "    float bf[" + S(NB) + "][" + S(4 * G) + "];\n    int toff[" + S(G) + "];\n";
+        c += "    _Pragma(\"unroll\") for (int g4 = 0; g4 < " + S(G) + "; ++g4) {\n";
+        c += "      const int t0 = 16 * g4 + 4 * l4, tc = t0 < " + S(K) + " ? t0 : 0;\n";
+        c += "      toff[g4] = ((tc / " + S(FW * C) + ") * " + S(W) + " + (tc / " + S(C) + ") % " + S(FW) + ") * " + S(C) + " + tc % " + S(C) + ";\n";
+        c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) {\n        const int f = 16 * nb + l15;\n";
+        // (columns f >= F of B are never stored: they read filter F - 1 instead of a masked zero; only k past the end is masked)
+        c += "        const int fc = f < " + S(F) + " ? f : " + S(F - 1) + ";\n";
+        if (K % 16 == 0) {
+          c += "        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) bf[nb][4 * g4 + j] = " + at(si.conv_flt, "fc * " + S(K) + " + t0 + j") + ";\n      }\n    }\n";
+        } else {
+          c += "        const bool in_ = t0 < " + S(K) + ";\n";
+          c += "        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) {\n          const float bv = " + at(si.conv_flt, "fc * " + S(K) + " + (in_ ? t0 : 0) + j") +
+               ";\n          bf[nb][4 * g4 + j] = in_ ? bv : 0.0f;\n        }\n      }\n    }\n";
+        }
+        c += "    auto block = [&](const int pb) {\n";
+        c += "      int p = 16 * pb + l15;\n      if (p > " + S(P - 1) + ") p = " + S(P - 1) + ";\n";
+        c += "      const int poff = ((p / " + S(Wo) + ") * " + S(W) + " + p % " + S(Wo) + ") * " + S(C) + ";\n";
+        c += "      mf4 acc[2][" + S(NB) + "];\n      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[0][nb] = acc[1][nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
+        c += "      _Pragma(\"unroll\") for (int g4 = 0; g4 < " + S(G) + "; ++g4) {\n";
+        c += "        const mf4 a4 = *reinterpret_cast<const mf4*>(&" + at(si.conv_img, "poff + toff[g4]") + ");\n";
+        c += "        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j)\n          _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) +
+             "; ++nb) acc[j & 1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bf[nb][4 * g4 + j], acc[j & 1][nb], 0, 0, 0);\n      }\n";
+        c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb)\n        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) {\n";
+        c += "          const int pr = 16 * pb + 4 * l4 + j, f = 16 * nb + l15;\n";
+        c += guarded_store(si.conv_out, "pr < " + S(P) + " && f < " + S(F), "pr * " + S(F) + " + f", "(acc[0][nb][j] + acc[1][nb][j])") + "        }\n    };\n";
+        c += trips("block", PB);
+      } else if (si.conv_role == 3 && F % 4 == 0 && local(si.conv_out)) {
+        const long KD = FH * FW * F, G = (KD + 15) / 16, NB = (C + 15) / 16, QB = (Q + 15) / 16;
+        // (F a multiple of 16: the tap of group g4 is a literal)
+        const std::string tap_s = F % 16 == 0 ? "g4 / " + S(F / 16) : "k0 / " + S(F);
+        const std::string tap_f = F % 16 == 0 ? "16 * (g4 % " + S(F / 16) + ") + 4 * l4" : "k0 % " + S(F);
+        c += "    float bf[" + S(NB) + "][" + S(4 * G) + "];\n";
+        c += "    _Pragma(\"unroll\") for (int g4 = 0; g4 < " + S(G) + "; ++g4) {\n      const int k0 = 16 * g4 + 4 * l4, s = " + tap_s + ", f0 = " + tap_f + ";\n";
+        c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) {\n        const int ch = 16 * nb + l15;\n";
+        c += "        const int cc = ch < " + S(C) + " ? ch : " + S(C - 1) + ";   // (columns ch >= C are never stored)\n";
+        if (KD % 16 == 0) {
+          c += "        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) bf[nb][4 * g4 + j] = " + at(si.conv_flt, "(f0 + j) * " + S(K) + " + s * " + S(C) + " + cc") + ";\n      }\n    }\n";
+        } else {
+          c += "        const bool in_ = k0 < " + S(KD) + ";\n";
+          c += "        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) {\n          const float bv = " +
+               at(si.conv_flt, "(in_ ? (f0 + j) * " + S(K) + " + s * " + S(C) + " + cc : 0)") + ";\n          bf[nb][4 * g4 + j] = in_ ? bv : 0.0f;\n        }\n      }\n    }\n";
+        }
+        c += "    auto block = [&](const int qb) {\n";
+        c += "      int q = 16 * qb + l15;\n      if (q > " + S(Q - 1) + ") q = " + S(Q - 1) + ";\n      const int qy = q / " + S(W) + ", qx = q % " + S(W) + ";\n";
+        c += "      mf4 acc[2][" + S(NB) + "];\n      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[0][nb] = acc[1][nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
+        c += "      _Pragma(\"unroll\") for (int g4 = 0; g4 < " + S(G) + "; ++g4) {\n";
+        c += "        const int k0 = 16 * g4 + 4 * l4, s = " + tap_s + ", f0 = " + tap_f + ", y = qy - s / " + S(FW) + ", x = qx - s % " + S(FW) + ";\n";
+        c += "        const bool ok = k0 < " + S(KD) + " && y >= 0 && y < " + S(Ho) + " && x >= 0 && x < " + S(Wo) + ";\n";
+        // (outside the output: the lane reads four zeros kept in LDS — one select of the address instead of four of the values)
+        need_zeros4 = true;
+        c += "        const float* const ap = ok ? &" + at(si.conv_out, "(y * " + S(Wo) + " + x) * " + S(F) + " + f0") + " : zeros4_;\n";
+        c += "        const mf4 a4 = *reinterpret_cast<const mf4*>(ap);\n";
+        c += "        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) {\n          const float a = a4[j];\n";
+        c += "          _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) +
+             "; ++nb) acc[j & 1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nb][4 * g4 + j], acc[j & 1][nb], 0, 0, 0);\n        }\n      }\n";
+        c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb)\n        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) {\n";
+        c += "          const int qr = 16 * qb + 4 * l4 + j, ch = 16 * nb + l15;\n";
+        c += guarded_store(si.conv_img, "qr < " + S(Q) + " && ch < " + S(C), "qr * " + S(C) + " + ch", "(acc[0][nb][j] + acc[1][nb][j])") + "        }\n    };\n";
+        c += trips("block", QB);
+      } else if (si.conv_role == 1) {   // out[p, f] (+)= sum_t img[pix(p) + tap(t)] * flt[f, t]
         const long KS = (K + 3) / 4, NB = (F + 15) / 16, PB = (P + 15) / 16;
         c += "    float bf[" + S(NB) + "][" + S(KS) + "];\n    int toff[" + S(KS) + "];\n";
         c += "    _Pragma(\"unroll\") for (int ks = 0; ks < " + S(KS) + "; ++ks) {\n";
         c += "      const int t = 4 * ks + l4, tc = t < " + S(K) + " ? t : 0;\n";
         c += "      toff[ks] = ((tc / " + S(FW * C) + ") * " + S(W) + " + (tc / " + S(C) + ") % " + S(FW) + ") * " + S(C) + " + tc % " + S(C) + ";\n";
         c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) {\n        const int f = 16 * nb + l15;\n";
-        c += "        bf[nb][ks] = (t < " + S(K) + " && f < " + S(F) + ") ? " + at(si.conv_flt, "f * " + S(K) + " + t") + " : 0.0f;\n      }\n    }\n";
-        c += "    for (int pb = wave; pb < " + S(PB) + "; pb += " + S(NW) + ") {\n";
+        c += "        const bool in_ = t < " + S(K) + ";\n        const float bv = " + at(si.conv_flt, "(f < " + S(F) + " ? f : " + S(F - 1) + ") * " + S(K) + " + tc") + ";\n";
+        c += "        bf[nb][ks] = in_ ? bv : 0.0f;   // (columns f >= F are never stored: they repeat filter F - 1)\n      }\n    }\n";
+        c += "    auto block = [&](const int pb) {\n";
         c += "      int p = 16 * pb + l15;\n      if (p > " + S(P - 1) + ") p = " + S(P - 1) + ";\n";
         c += "      const int poff = ((p / " + S(Wo) + ") * " + S(W) + " + p % " + S(Wo) + ") * " + S(C) + ";\n";
-        c += "      mf4 acc[" + S(NB) + "];\n      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
+        c += "      mf4 acc[2][" + S(NB) + "];\n      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[0][nb] = acc[1][nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
         c += "      _Pragma(\"unroll\") for (int ks = 0; ks < " + S(KS) + "; ++ks) {\n";
         c += "        const float a = " + at(si.conv_img, "poff + toff[ks]") + ";\n";
-        c += "        _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nb][ks], acc[nb], 0, 0, 0);\n      }\n";
+        c += "        _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[ks & 1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nb][ks], acc[ks & 1][nb], 0, 0, 0);\n      }\n";
         c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb)\n        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) {\n";
         c += "          const int pr = 16 * pb + 4 * l4 + j, f = 16 * nb + l15;\n";
-        const std::string o = at(si.conv_out, "pr * " + S(F) + " + f");
-        c += "          if (pr < " + S(P) + " && f < " + S(F) + ") " + o + " = " + (g.overwrite[gi] ? std::string("0.0f") : o) + " + acc[nb][j];\n        }\n    }\n";
+        c += guarded_store(si.conv_out, "pr < " + S(P) + " && f < " + S(F), "pr * " + S(F) + " + f", "(acc[0][nb][j] + acc[1][nb][j])") + "        }\n    };\n";
+        c += trips("block", PB);
       } else if (si.conv_role == 3) {   // gimg[q, ch] (+)= sum_{s, f} gout[pixel(q) - tap(s), f] * flt[f, s, ch]
         const long KD = FH * FW * F, KS = (KD + 3) / 4, NB = (C + 15) / 16, QB = (Q + 15) / 16;
+        // With F a multiple of 4 the four lanes groups of a k-step share their tap: tap and window offset of k-step ks are
+        // literals (the bounds test is per tap, not per k-step, and the gather's address is the pixel's base + a literal).
+        const bool f4 = F % 4 == 0;
+        const std::string tap_s = f4 ? "ks / " + S(F / 4) : "kk / " + S(F), tap_f = f4 ? "4 * (ks % " + S(F / 4) + ") + l4" : "kk % " + S(F);
         c += "    float bf[" + S(NB) + "][" + S(KS) + "];\n";
-        c += "    _Pragma(\"unroll\") for (int ks = 0; ks < " + S(KS) + "; ++ks) {\n      const int kk = 4 * ks + l4, s = kk / " + S(F) + ", f = kk % " + S(F) + ";\n";
+        c += "    _Pragma(\"unroll\") for (int ks = 0; ks < " + S(KS) + "; ++ks) {\n      const int kk = 4 * ks + l4, s = " + tap_s + ", f = " + tap_f + ";\n";
         c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) {\n        const int ch = 16 * nb + l15;\n";
-        c += "        bf[nb][ks] = (kk < " + S(KD) + " && ch < " + S(C) + ") ? " + at(si.conv_flt, "f * " + S(K) + " + s * " + S(C) + " + ch") + " : 0.0f;\n      }\n    }\n";
-        c += "    for (int qb = wave; qb < " + S(QB) + "; qb += " + S(NW) + ") {\n";
+        c += "        const bool in_ = kk < " + S(KD) + ";\n        const float bv = " + at(si.conv_flt, "(in_ ? f * " + S(K) + " + s * " + S(C) + " + (ch < " + S(C) + " ? ch : " + S(C - 1) + ") : 0)") + ";\n";
+        c += "        bf[nb][ks] = in_ ? bv : 0.0f;   // (columns ch >= C are never stored)\n      }\n    }\n";
+        c += "    auto block = [&](const int qb) {\n";
         c += "      int q = 16 * qb + l15;\n      if (q > " + S(Q - 1) + ") q = " + S(Q - 1) + ";\n      const int qy = q / " + S(W) + ", qx = q % " + S(W) + ";\n";
-        c += "      mf4 acc[" + S(NB) + "];\n      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
+        c += "      mf4 acc[2][" + S(NB) + "];\n      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[0][nb] = acc[1][nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
         c += "      _Pragma(\"unroll\") for (int ks = 0; ks < " + S(KS) + "; ++ks) {\n";
-        c += "        const int kk = 4 * ks + l4, s = kk / " + S(F) + ", f = kk % " + S(F) + ", y = qy - s / " + S(FW) + ", x = qx - s % " + S(FW) + ";\n";
+        c += "        const int kk = 4 * ks + l4, s = " + tap_s + ", f = " + tap_f + ", y = qy - s / " + S(FW) + ", x = qx - s % " + S(FW) + ";\n";
         c += "        const bool ok = kk < " + S(KD) + " && y >= 0 && y < " + S(Ho) + " && x >= 0 && x < " + S(Wo) + ";\n";
         c += "        const int go = ok ? (y * " + S(Wo) + " + x) * " + S(F) + " + f : 0;\n";
         c += "        const float av = " + at(si.conv_out, "go") + ";\n        const float a = ok ? av : 0.0f;\n";
-        c += "        _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nb][ks], acc[nb], 0, 0, 0);\n      }\n";
+        c += "        _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[ks & 1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nb][ks], acc[ks & 1][nb], 0, 0, 0);\n      }\n";
         c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb)\n        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) {\n";
         c += "          const int qr = 16 * qb + 4 * l4 + j, ch = 16 * nb + l15;\n";
-        const std::string o = at(si.conv_img, "qr * " + S(C) + " + ch");
-        c += "          if (qr < " + S(Q) + " && ch < " + S(C) + ") " + o + " = " + (g.overwrite[gi] ? std::string("0.0f") : o) + " + acc[nb][j];\n        }\n    }\n";
+        c += guarded_store(si.conv_img, "qr < " + S(Q) + " && ch < " + S(C), "qr * " + S(C) + " + ch", "(acc[0][nb][j] + acc[1][nb][j])") + "        }\n    };\n";
+        c += trips("block", QB);
       } else {   // gflt[f, t] (+)= sum_p gout[p, f] * img[pix(p) + tap(t)]
         const long MB = (F + 15) / 16, NB = (K + 15) / 16, PS = (P + 3) / 4;
         const bool first = slab_seen.count(k.write.tensor) == 0;   // the first contribution of this block to that slab range
@@ -923,20 +1033,63 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
         c += "      toff[nb] = ((t / " + S(FW * C) + ") * " + S(W) + " + (t / " + S(C) + ") % " + S(FW) + ") * " + S(C) + " + t % " + S(C) + ";\n    }\n";
         c += "    mf4 acc[" + S(MB) + "][" + S(NB) + "];\n";
         c += "    _Pragma(\"unroll\") for (int mb = 0; mb < " + S(MB) + "; ++mb) _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[mb][nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
-        c += "    for (int ps = wave; ps < " + S(PS) + "; ps += " + S(NW) + ") {\n";
+        // Output rows a multiple of 4 pixels wide: a wave takes WHOLE ROWS (row = wave + NW * ri) and walks them in literal
+        // steps of 4 pixels, so every gather is a per-lane base (computed once) plus a literal offset — the linear walk
+        // `p = 4 ps + l4` paid a division by Wo, two multiplies and three additions per step and lane (the members are bound
+        // by instruction issue: EG_SAMPLE_TRACE, 5 000 cycles for 18 steps of 2 MFMAs).
+        // (rows not a multiple of 4 wide but even, an even number of them: the four pixels of a step are a 2 x 2 tile)
+        const long th = Wo % 4 == 0 ? 1 : 2, tw = 4 / th, trows = Ho / th;
+        const bool by_rows = Wo % tw == 0 && Ho % th == 0 && (trows / NW + 1) * (Wo / tw) <= 40;
+        if (by_rows) {
+          c += "    const int wu = __builtin_amdgcn_readfirstlane(wave), lr = l4 / " + S(tw) + ", lc = l4 % " + S(tw) + ";\n";
+          c += "    const int pbase = ((wu * " + S(th) + " + lr) * " + S(W) + " + lc) * " + S(C) + ";\n";
+          c += "    int abase[" + S(MB) + "];\n    _Pragma(\"unroll\") for (int mb = 0; mb < " + S(MB) + "; ++mb) {\n      const int f = 16 * mb + l15;\n";
+          c += "      abase[mb] = ((wu * " + S(th) + " + lr) * " + S(Wo) + " + lc) * " + S(F) + " + (f < " + S(F) + " ? f : 0);\n    }\n";
+          c += "    auto rowstep = [&](const int ri) {\n      _Pragma(\"unroll\") for (int cg = 0; cg < " + S(Wo / tw) + "; ++cg) {\n";
+          c += "        float a[" + S(MB) + "];\n        _Pragma(\"unroll\") for (int mb = 0; mb < " + S(MB) + "; ++mb) a[mb] = " +
+               at(si.conv_out, "abase[mb] + (" + S(NW * th * Wo) + " * ri + " + S(tw) + " * cg) * " + S(F)) + ";\n";
+          c += "        _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) {\n          const float b = " +
+               at(si.conv_img, "pbase + toff[nb] + (" + S(NW * th * W) + " * ri + " + S(tw) + " * cg) * " + S(C)) + ";\n";
+          c += "          _Pragma(\"unroll\") for (int mb = 0; mb < " + S(MB) + "; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b, acc[mb][nb], 0, 0, 0);\n        }\n      }\n    };\n";
+          const long whole = trows / NW, ragged = trows % NW;
+          if (whole > 0) c += "    _Pragma(\"unroll\") for (int ri = 0; ri < " + S(whole) + "; ++ri) rowstep(ri);\n";
+          if (ragged > 0) c += "    if (wu < " + S(ragged) + ") rowstep(" + S(whole) + ");\n";
+        }
+        c += "    auto step = [&](const int ps) {\n";
         c += "      const int p = 4 * ps + l4, pc = p < " + S(P) + " ? p : " + S(P - 1) + ";\n";
         c += "      const int poff = ((pc / " + S(Wo) + ") * " + S(W) + " + pc % " + S(Wo) + ") * " + S(C) + ";\n";
+        // (rows f >= F of the result are never stored: they repeat filter 0; pixels past the end are masked, if there are any)
         c += "      float a[" + S(MB) + "];\n      _Pragma(\"unroll\") for (int mb = 0; mb < " + S(MB) + "; ++mb) {\n        const int f = 16 * mb + l15, fc = f < " + S(F) + " ? f : 0;\n";
-        c += "        const float av = " + at(si.conv_out, "pc * " + S(F) + " + fc") + ";\n        a[mb] = (p < " + S(P) + " && f < " + S(F) + ") ? av : 0.0f;\n      }\n";
+        c += "        const float av = " + at(si.conv_out, "pc * " + S(F) + " + fc") + ";\n        a[mb] = " + (P % 4 == 0 ? std::string("av") : "p < " + S(P) + " ? av : 0.0f") + ";\n      }\n";
         c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) {\n        const float b = " + at(si.conv_img, "poff + toff[nb]") + ";\n";
-        c += "        _Pragma(\"unroll\") for (int mb = 0; mb < " + S(MB) + "; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b, acc[mb][nb], 0, 0, 0);\n      }\n    }\n";
-        c += "    _Pragma(\"unroll\") for (int mb = 0; mb < " + S(MB) + "; ++mb) _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) {\n";
-        c += "      _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) scratch[wave * 256 + (4 * l4 + j) * 16 + l15] = acc[mb][nb][j];\n      __syncthreads();\n";
-        c += "      if (threadIdx.x < 256) {\n        float s = 0.0f;\n        for (int w = 0; w < " + S(NW) + "; ++w) s = s + scratch[w * 256 + threadIdx.x];\n";
-        c += "        const int f = 16 * mb + (threadIdx.x >> 4), t = 16 * nb + (threadIdx.x & 15);\n";
-        const std::string o = "row[" + S(off) + " + f * " + S(K) + " + t]";
-        c += "        if (f < " + S(F) + " && t < " + S(K) + ") " + o + " = " + (first ? std::string("0.0f") : o) + " + s;\n      }\n      __syncthreads();\n    }\n";
-        scratch_floats = std::max(scratch_floats, NW * 256);
+        c += "        _Pragma(\"unroll\") for (int mb = 0; mb < " + S(MB) + "; ++mb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mb], b, acc[mb][nb], 0, 0, 0);\n      }\n    };\n";
+        // (more than 24 whole trips: the unrolled body would not fit the instruction cache's reach; a rolled loop of 4)
+        if (by_rows) {
+          c += "    (void)step;\n";
+        } else if (PS / NW <= 24) {
+          c += trips("step", PS);
+        } else {
+          c += "    _Pragma(\"unroll 4\") for (int ps = wave; ps < " + S(PS) + "; ps += " + S(NW) + ") step(ps);\n";
+        }
+        // the waves' accumulator blocks meet in LDS — as many of the MB x NB at a time as 16 KB of scratch hold (the planner's
+        // LDS budget leaves that much: plan_groups.cpp) — and are added in wave order
+        const long BL = MB * NB, per_round = std::max(1L, 4096 / (NW * 256));
+        for (long b0 = 0; b0 < BL; b0 += per_round) {
+          const long nb_round = std::min(per_round, BL - b0);
+          if (b0 > 0) c += "    __syncthreads();\n";
+          for (long b = b0; b < b0 + nb_round; ++b)
+            c += "    _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) scratch[(" + S(b - b0) + " * " + S(NW) + " + wave) * 256 + (4 * l4 + j) * 16 + l15] = acc[" +
+                 S(b / NB) + "][" + S(b % NB) + "][j];\n";
+          c += "    __syncthreads();\n";
+          c += "    _Pragma(\"unroll\") for (int e0 = 0; e0 < " + S(nb_round * 256) + "; e0 += " + NT + ") {\n      const int e = e0 + threadIdx.x, bl = " + S(b0) +
+               " + (e >> 8), el = e & 255;\n";
+          c += "      if (e < " + S(nb_round * 256) + ") {\n        float s = 0.0f;\n        _Pragma(\"unroll\") for (int w = 0; w < " + S(NW) +
+               "; ++w) s = s + scratch[((e >> 8) * " + S(NW) + " + w) * 256 + el];\n";
+          c += "        const int f = 16 * (bl / " + S(NB) + ") + (el >> 4), t = 16 * (bl % " + S(NB) + ") + (el & 15);\n";
+          const std::string o = "row[" + S(off) + " + f * " + S(K) + " + t]";
+          c += "        if (f < " + S(F) + " && t < " + S(K) + ") " + o + " = " + (first ? std::string("0.0f") : o) + " + s;\n      }\n    }\n";
+        }
+        scratch_floats = std::max(scratch_floats, NW * 256 * std::min(per_round, BL));
         slab_seen.insert(k.write.tensor);
       }
       c += "  }\n  __syncthreads();\n";
@@ -1138,45 +1291,73 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
       {
         const int l = red[0];
         const std::string r = "r" + std::to_string(k.loops[l].reg);
-        c += "        for (long " + r + " = " + std::to_string(info.bounds[l].first) + "L + part; " + r + " < " + std::to_string(info.bounds[l].second) +
-             "L; " + r + " += " + TS + "L) {\n";
+        // literal trip count for the whole trips (their loads go out together), the ragged last one guarded
+        const long ext0 = info.bounds[l].second - info.bounds[l].first, whole = ext0 / T, ragged = ext0 % T;
+        std::string body = inner_loops(1, "          ") + accumulate("          ");
+        for (size_t i = 1; i < red.size(); ++i) body += "          }\n";
+        if (whole <= 16) {
+          if (whole > 0)
+            c += "        _Pragma(\"unroll\") for (int it_ = 0; it_ < " + std::to_string(whole) + "; ++it_) {\n          const long " + r + " = " +
+                 std::to_string(info.bounds[l].first) + "L + part + it_ * " + TS + "L;\n" + body + "        }\n";
+          if (ragged > 0)
+            c += "        if (part < " + std::to_string(ragged) + "L) {\n          const long " + r + " = " +
+                 std::to_string(info.bounds[l].first + whole * T) + "L + part;\n" + body + "        }\n";
+        } else {
+          c += "        for (long " + r + " = " + std::to_string(info.bounds[l].first) + "L + part; " + r + " < " +
+               std::to_string(info.bounds[l].second) + "L; " + r + " += " + TS + "L) {\n" + body + "        }\n";
+        }
       }
-      c += inner_loops(1, "          ");
-      c += accumulate("          ");
-      for (size_t i = 1; i < red.size(); ++i) c += "          }\n";
-      c += "        }\n      }\n";
+      c += "      }\n";
       c += "      _Pragma(\"unroll\") for (int u = 0; u < " + RS + "; ++u) scratch[u * " + NT + " + threadIdx.x] = acc[u];\n      __syncthreads();\n";
       c += "      if (out < " + std::to_string(items) + "L && part == 0) {\n";
       c += decode_indep("out", "        ");
       c += "        _Pragma(\"unroll\") for (int u = 0; u < " + RS + "; ++u) {\n          float sum = 0.0f;\n";
-      c += "          for (int q = 0; q < " + TS + "; ++q) sum = sum + scratch[u * " + NT + " + out * " + TS + "L + q];\n          acc[u] = sum;\n        }\n";
+      c += "          _Pragma(\"unroll\") for (int q = 0; q < " + TS + "; ++q) sum = sum + scratch[u * " + NT + " + out * " + TS + "L + q];\n          acc[u] = sum;\n        }\n";
       c += store("        ");
       c += "      }\n    }\n  }\n  __syncthreads();\n";
       scratch_floats = std::max(scratch_floats, (long)g.threads * R);
       if (si.reduced) slab_seen.insert(k.write.tensor);
       continue;
     }
-    c += "    for (long idx = threadIdx.x; idx < " + std::to_string(items) + "L; idx += " + NT + ") {\n";
-    c += decode_indep("idx", "      ");
+    std::string body = decode_indep("idx", "      "), body_store;
     if (scatter) {
       // the element depends on the reduction iterators: add term by term (the destination starts from zero)
-      c += inner_loops(0, "      ");
-      c += term("        ");
-      c += "        " + w + " = " + w + " + r" + std::to_string(k.result) + ";\n";
-      for (size_t i = 0; i < red.size(); ++i) c += "      }\n";
+      body += inner_loops(0, "      ");
+      body += term("        ");
+      body += "        " + w + " = " + w + " + r" + std::to_string(k.result) + ";\n";
+      for (size_t i = 0; i < red.size(); ++i) body += "      }\n";
     } else {
-      c += zero_acc;
-      c += inner_loops(0, "      ");
-      c += accumulate("        ");
-      for (size_t i = 0; i < red.size(); ++i) c += "      }\n";
-      c += store("      ");
+      body += zero_acc;
+      body += inner_loops(0, "      ");
+      body += accumulate("        ");
+      for (size_t i = 0; i < red.size(); ++i) body += "      }\n";
+      body_store = store("      ");
     }
-    c += "    }\n  }\n  __syncthreads();\n";
+    // The whole trips of the item loop with a literal trip count (a thread's start depends on threadIdx.x, so the
+    // compiler cannot count the trips of `for (idx = threadIdx.x; idx < items; idx += threads)` and leaves it rolled: every
+    // trip a read - compute - write round trip to LDS; unrolled, the reads of all trips go out together), the ragged last
+    // trip computes element 0 again in the threads past the end and guards only its STORE (a guarded trip is a branch the
+    // compiler does not move loads across: the 784-float copy of a sample's image was two dependent trips to memory).  A
+    // scatter adds onto elements other trips may touch: it keeps the rolled loop.
+    const long whole_trips = items / g.threads, ragged_items = items % g.threads;
+    if (!scatter && whole_trips <= 12 && rtotal * whole_trips <= 256) {
+      if (ragged_items > 0)
+        c += "    {\n      const bool ok_ = threadIdx.x < " + std::to_string(ragged_items) + ";\n      const long idx = ok_ ? threadIdx.x + " +
+             std::to_string(whole_trips * g.threads) + "L : 0L;\n" + body + "      if (ok_) {\n" + body_store + "      }\n    }\n";
+      if (whole_trips > 0)
+        c += "    _Pragma(\"unroll\") for (int it_ = 0; it_ < " + std::to_string(whole_trips) + "; ++it_) {\n      const long idx = threadIdx.x + it_ * " +
+             NT + "L;\n" + body + body_store + "    }\n";
+    } else {
+      c += "    for (long idx = threadIdx.x; idx < " + std::to_string(items) + "L; idx += " + NT + ") {\n" + body + body_store + "    }\n";
+    }
+    c += "  }\n  __syncthreads();\n";
     if (si.reduced) slab_seen.insert(k.write.tensor);
   }
   // 32-bit index arithmetic where it is exact: every tensor (and the slab) has fewer than 2^31 elements and no member
   // computes with Index VALUES (`toScalar(i * 100000)`: only addressing is known to fit — the rule of Slot::Narrow,
   // codegen.hpp).  64-bit divisions and multiply-adds per element were most of a convolution member's time.
+  if (need_zeros4)
+    c = "  __shared__ __attribute__((aligned(16))) float zeros4_[4];\n  if (threadIdx.x < 4) zeros4_[threadIdx.x] = 0.0f;\n  __syncthreads();\n" + c;
   if (scratch_floats > 0) c = "  __shared__ float scratch[" + std::to_string(scratch_floats) + "];\n" + c;
   bool narrow = eg::sw::raw("EG_NO_NARROW_INDEX") == nullptr && g.B * std::max(1L, g.slab_floats) < (1L << 31);
   for (int t : touched) narrow = narrow && prodv(shapes.at(t)) < (1L << 31);
@@ -1192,6 +1373,25 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
   if (narrow) {
     c = std::regex_replace(c, std::regex("\\blong\\b"), "int");
     c = std::regex_replace(c, std::regex("\\b([0-9]+)L\\b"), "$1");
+  }
+  // EG_SAMPLE_TRACE=1 (detector): block 0 stamps the cycle counter behind every member's barrier and prints the stamps
+  // (cycles since the first) at the end — where a sample kernel's time goes, without the dead-code elimination that makes
+  // EG_SAMPLE_STOP's differences hard to read (a member whose result never leaves LDS disappears with its producers).
+  if (eg::sw::raw("EG_SAMPLE_TRACE") != nullptr) {
+    const std::string stamp = "  if (threadIdx.x == 0 && blockIdx.x == 0 && trn_ < 48) tr_[trn_++] = __builtin_readcyclecounter();\n";
+    std::string traced = "  long long tr_[48]; int trn_ = 0;\n" + stamp;
+    size_t pos = 0;
+    const std::string barrier = "\n  __syncthreads();\n";
+    while (true) {
+      const size_t at = c.find(barrier, pos);
+      if (at == std::string::npos) break;
+      traced += c.substr(pos, at + barrier.size() - pos) + stamp;
+      pos = at + barrier.size();
+    }
+    traced += c.substr(pos);
+    traced += "  if (threadIdx.x == 0 && blockIdx.x == 0) {\n    printf(\"[eg] " + g.name + " cycles behind each member barrier:\");\n"
+              "    for (int k_ = 1; k_ < trn_; ++k_) printf(\" %d:%lld\", k_, tr_[k_] - tr_[0]);\n    printf(\"\\n\");\n  }\n";
+    c = traced;
   }
   g.source = sig + " {\n" + c + "}\n";
   return EG_OK;

@@ -266,8 +266,6 @@ int eg_ctx_destroy(eg_ctx* ctx) {
   if (ctx->side_stream) hipStreamDestroy(ctx->side_stream);
   eg::host_stager_free(ctx->stager);
   if (ctx->ones) hipFree(ctx->ones);
-  if (ctx->zeros) hipFree(ctx->zeros);
-  for (float* z : ctx->zeros_retired) hipFree(z);
   for (auto& kv : ctx->jit) delete kv.second;  // eg_kernel: the code object goes with it
   if (ctx->owns_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -25,7 +25,10 @@ cases = {
     "grad_filter": lambda: ops.conv2_nhwc_grad_filter(ctx, N, H, W, C, F, FH, FW, img, gout, gflt),
     "grad_image": lambda: ops.conv2_nhwc_grad_image(ctx, N, H, W, C, F, FH, FW, flt, gout, gimg),
 }
+only = os.environ.get("CASES")  # e.g. CASES=forward,grad_image
 for name, run in cases.items():
+    if only and name not in only.split(","):
+        continue
     for _ in range(3):
         run()
     torch.cuda.synchronize()
