@@ -845,12 +845,19 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
         stores += "    " + guard + "t" + id + "[" + i + "] = " + v + ";\n";
       }
     }
-    c += "  {\n" + loads + stores + "  }\n  __syncthreads();\n";
+    c += "  {\n" + loads + stores + "  }\n";
   }
   for (auto& kv : g.lds) c += "  __shared__ __attribute__((aligned(16))) float t" + std::to_string(kv.first) + "[" + std::to_string(kv.second) + "];\n";
   for (int t : g.lds_zero)
     c += "  for (int i = threadIdx.x; i < " + std::to_string(g.lds.at(t)) + "; i += " + NT + ") t" + std::to_string(t) + "[i] = 0.0f;\n";
-  if (!g.lds_zero.empty()) c += "  __syncthreads();\n";
+  // ONE barrier behind the prologue (staged copies, zeroed tensors, the four zeros of the image-gradient gathers); it goes
+  // too when the first member touches none of that (the copy of a sample's image: its loads then travel with the staged ones)
+  c += "/*zeros4*/";
+  size_t prologue_barrier = std::string::npos;
+  if (!g.staged.empty() || !g.lds_zero.empty()) {
+    prologue_barrier = c.size();
+    c += "  __syncthreads();\n";
+  }
   auto local = [&](int tensor) -> long {
     auto it = g.lds.find(tensor);
     return it == g.lds.end() ? 0 : it->second;
@@ -858,6 +865,8 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
   if (g.slab_floats > 0) c += "  float* const row = slab + n * " + std::to_string(g.slab_floats) + "L;\n";
   std::set<int> slab_seen;
   long scratch_floats = 0;
+  bool need_dummy = false;    // a slot per thread that row blocks store the lanes outside their tensor to
+  std::vector<size_t> member_start;   // offset of every emitted member's text in c
   bool need_zeros4 = false;   // four zeros in LDS: what an image-gradient member's gather reads outside the output
   // EG_SAMPLE_STOP=<k> (tuning aid): the kernel ends behind member k — wrong numbers, the time of the first k + 1 members
   const long stop = eg::sw::integer("EG_SAMPLE_STOP", -1);
@@ -867,6 +876,7 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
     const KernelInfo& info = infos[g.kernel_index[gi]];
     const SampleKernelInfo& si = g.infos[gi];
     const std::vector<Ty> ty = infer_types(k);
+    member_start.push_back(c.size());
     c += "  {  // kernel " + std::to_string(gi) + ": " + to_text(k).substr(0, 100) + "\n";
     if (si.conv_role != 0) {
       // ---- matrix-core convolution members (round 6).  The scalar members spend their time in LDS reads (two per multiply-add:
@@ -902,8 +912,8 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
         const std::string o = at(tensor, idx);
         if (!local(tensor))
           return "          if (" + cond + ") " + o + " = " + (g.overwrite[gi] ? std::string("0.0f") : o) + " + " + value + ";\n";
-        scratch_floats = std::max(scratch_floats, (long)g.threads);
-        std::string d = "          float* const dst_ = (" + cond + ") ? &" + o + " : &scratch[threadIdx.x];\n";
+        need_dummy = true;   // (not `scratch`: a member behind an elided barrier may be using that)
+        std::string d = "          float* const dst_ = (" + cond + ") ? &" + o + " : &dummy_[threadIdx.x];\n";
         d += "          *dst_ = " + (g.overwrite[gi] ? std::string("0.0f") : std::string("*dst_")) + " + " + value + ";\n";
         return d;
       };
@@ -1041,7 +1051,9 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
         const long th = Wo % 4 == 0 ? 1 : 2, tw = 4 / th, trows = Ho / th;
         const bool by_rows = Wo % tw == 0 && Ho % th == 0 && (trows / NW + 1) * (Wo / tw) <= 40;
         if (by_rows) {
-          c += "    const int wu = __builtin_amdgcn_readfirstlane(wave), lr = l4 / " + S(tw) + ", lc = l4 % " + S(tw) + ";\n";
+          // (rows go to the waves from the LAST one down: the row-block members in front of this one — no barrier in between
+          // when they are independent — give their ragged extra block to the first waves)
+          c += "    const int wu = " + S(NW - 1) + " - __builtin_amdgcn_readfirstlane(wave), lr = l4 / " + S(tw) + ", lc = l4 % " + S(tw) + ";\n";
           c += "    const int pbase = ((wu * " + S(th) + " + lr) * " + S(W) + " + lc) * " + S(C) + ";\n";
           c += "    int abase[" + S(MB) + "];\n    _Pragma(\"unroll\") for (int mb = 0; mb < " + S(MB) + "; ++mb) {\n      const int f = 16 * mb + l15;\n";
           c += "      abase[mb] = ((wu * " + S(th) + " + lr) * " + S(Wo) + " + lc) * " + S(F) + " + (f < " + S(F) + " ? f : 0);\n    }\n";
@@ -1263,6 +1275,14 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
     if (!scatter && !si.raw && items > 0 && items * 2 <= g.threads && rtotal >= 16 && outer_ext >= 2) {
       T = std::min<long>(g.threads / items, std::min<long>(outer_ext, 64));
       if (T < 2) T = 1;
+      // a power of two: the T threads of an item are consecutive lanes of ONE wave and their partial sums meet in a
+      // butterfly of shuffles (log2 T steps, every lane ends with the same sum) instead of LDS, a block barrier and one
+      // thread adding T values one after the other (the dense member of the fashion_mnist step: 51 dependent additions)
+      if (T >= 2) {
+        long p2 = 2;
+        while (p2 * 2 <= T) p2 *= 2;
+        T = p2;
+      }
     }
     auto inner_loops = [&](size_t from, const std::string& ind) {  // reduction loops red[from ...], innermost unrolled
       std::string d;
@@ -1308,14 +1328,12 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
         }
       }
       c += "      }\n";
-      c += "      _Pragma(\"unroll\") for (int u = 0; u < " + RS + "; ++u) scratch[u * " + NT + " + threadIdx.x] = acc[u];\n      __syncthreads();\n";
+      c += "      _Pragma(\"unroll\") for (int u = 0; u < " + RS + "; ++u)\n        _Pragma(\"unroll\") for (int m_ = " + std::to_string(T / 2) +
+           "; m_ >= 1; m_ >>= 1) acc[u] = acc[u] + __shfl_xor(acc[u], m_, " + TS + ");\n";
       c += "      if (out < " + std::to_string(items) + "L && part == 0) {\n";
       c += decode_indep("out", "        ");
-      c += "        _Pragma(\"unroll\") for (int u = 0; u < " + RS + "; ++u) {\n          float sum = 0.0f;\n";
-      c += "          _Pragma(\"unroll\") for (int q = 0; q < " + TS + "; ++q) sum = sum + scratch[u * " + NT + " + out * " + TS + "L + q];\n          acc[u] = sum;\n        }\n";
       c += store("        ");
       c += "      }\n    }\n  }\n  __syncthreads();\n";
-      scratch_floats = std::max(scratch_floats, (long)g.threads * R);
       if (si.reduced) slab_seen.insert(k.write.tensor);
       continue;
     }
@@ -1356,8 +1374,70 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
   // 32-bit index arithmetic where it is exact: every tensor (and the slab) has fewer than 2^31 elements and no member
   // computes with Index VALUES (`toScalar(i * 100000)`: only addressing is known to fit — the rule of Slot::Narrow,
   // codegen.hpp).  64-bit divisions and multiply-adds per element were most of a convolution member's time.
-  if (need_zeros4)
-    c = "  __shared__ __attribute__((aligned(16))) float zeros4_[4];\n  if (threadIdx.x < 4) zeros4_[threadIdx.x] = 0.0f;\n  __syncthreads();\n" + c;
+  // ---- barriers between INDEPENDENT members go.  Member b needs no barrier in front of it when, for every member a since the
+  // last barrier that stays, a's result is neither read nor written by b, b's result is not read by a, and at most one of
+  // them uses `scratch`.  Then the waves that are done with a (a row-block member with 9 blocks for 8 waves leaves seven
+  // waves waiting for the ninth block) start on b; the barrier behind b orders both against what follows.
+  if (eg::sw::raw("EG_SAMPLE_KEEP_BARRIERS") == nullptr) {
+    const std::string barrier = "  __syncthreads();\n";
+    struct Use {
+      std::set<int> reads, writes;
+      bool scratch = false;
+    };
+    std::vector<Use> use(member_start.size());
+    for (size_t gi = 0; gi < member_start.size(); ++gi) {
+      const Kernel& k = all[g.kernel_index[gi]];
+      for (auto& rd : k.reads) use[gi].reads.insert(rd.tensor);
+      use[gi].writes.insert(k.write.tensor);
+      if (!g.overwrite[gi]) use[gi].reads.insert(k.write.tensor);
+      const size_t end = gi + 1 < member_start.size() ? member_start[gi + 1] : c.size();
+      const std::string text = c.substr(member_start[gi], end - member_start[gi]);
+      use[gi].scratch = text.find("scratch[") != std::string::npos;
+      if (text.find("zeros4_") != std::string::npos) use[gi].reads.insert(-4);   // (the prologue writes them)
+    }
+    Use prologue;
+    for (auto& kv : g.staged) prologue.writes.insert(kv.first);
+    for (int t : g.lds_zero) prologue.writes.insert(t);
+    prologue.writes.insert(-4);
+    auto conflict = [](const Use& a, const Use& b) {   // b behind a without a barrier
+      for (int w : a.writes)
+        if (b.reads.count(w) || b.writes.count(w)) return true;
+      for (int w : b.writes)
+        if (a.reads.count(w)) return true;
+      return a.scratch && b.scratch;
+    };
+    std::vector<size_t> erase;   // offsets of the barriers that go
+    std::vector<const Use*> since;
+    if (!member_start.empty()) {
+      if (prologue_barrier != std::string::npos && !conflict(prologue, use[0])) {
+        erase.push_back(prologue_barrier);
+        since.push_back(&prologue);
+      }
+      since.push_back(&use[0]);
+    }
+    for (size_t b = 1; b < member_start.size(); ++b) {
+      bool independent = member_start[b] >= barrier.size() && c.compare(member_start[b] - barrier.size(), barrier.size(), barrier) == 0;
+      for (const Use* a : since)
+        if (independent && conflict(*a, use[b])) independent = false;
+      if (independent) {
+        erase.push_back(member_start[b] - barrier.size());
+      } else {
+        since.clear();
+      }
+      since.push_back(&use[b]);
+    }
+    for (size_t i = erase.size(); i-- > 0;) c.erase(erase[i], barrier.size());
+  }
+  if (need_dummy) c = "  __shared__ float dummy_[" + NT + "];\n" + c;
+  {
+    const size_t at = c.find("/*zeros4*/");
+    std::string init;
+    if (need_zeros4) {
+      init = "  __shared__ __attribute__((aligned(16))) float zeros4_[4];\n  if (threadIdx.x < 4) zeros4_[threadIdx.x] = 0.0f;\n";
+      if (g.staged.empty() && g.lds_zero.empty()) init += "  __syncthreads();\n";   // (no prologue barrier to ride on)
+    }
+    if (at != std::string::npos) c.replace(at, 10, init);
+  }
   if (scratch_floats > 0) c = "  __shared__ float scratch[" + std::to_string(scratch_floats) + "];\n" + c;
   bool narrow = eg::sw::raw("EG_NO_NARROW_INDEX") == nullptr && g.B * std::max(1L, g.slab_floats) < (1L << 31);
   for (int t : touched) narrow = narrow && prodv(shapes.at(t)) < (1L << 31);

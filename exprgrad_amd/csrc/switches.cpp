@@ -38,6 +38,7 @@ const Row kSwitches[] = {
     {"EG_NO_SKINNY_GEMM", "execution", "N <= 16 products on the matrix tiles instead of the streaming skinny kernel"},
     {"EG_NO_NARROW_K", "execution", "K <= 16 products with a generated epilogue on the matrix tile instead of the streaming kernel"},
     {"EG_NO_SAMPLE_FUSE", "execution", "no sample groups (one block per sample): the launch chain of a small-batch step"},
+    {"EG_SAMPLE_KEEP_BARRIERS", "execution", "sample kernels keep the barrier between independent members"},
     {"EG_SAMPLE_NO_STAGE", "execution", "a sample group's members read parameters from global memory, not from a copy in LDS"},
     {"EG_SAMPLE_NO_MFMA", "execution", "convolution members of a sample group as scalar loop nests, not on the matrix cores"},
     {"EG_NO_SLAB_FOLD", "execution", "the optimizer's map group does not add up the sample kernel's slab rows itself"},
