@@ -929,8 +929,44 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
       // filters (image gradient) a multiple of 4 and the gathered tensor in LDS, the k index is permuted so that the lane
       // group l4 holds k = 16 g + 4 l4 + j in the j-th MFMA of group g — four consecutive channels of ONE tap, one
       // ds_read_b128, one address, one bounds test.  Any bijection of k is the same sum; B fragments use the same one.
+      // A forward member's row block of 16 output pixels: 16 consecutive pixels of the row-major image, or — when the output
+      // tiles exactly into bw x (16 / bw) patches — such a patch: the block's part of every address is then wave-uniform
+      // (scalar arithmetic) and the lane's part a constant, instead of a division by the row width per lane and block, and
+      // no pixel of a block lies past the end (the store tests the filter only).
+      std::string fw_head, fw_store, fw_pre, fw_calls;
+      long fw_blocks = 1;   // row blocks per call of the member's lambda
+      if (si.conv_role == 1) {
+        long bw = 0;
+        for (long cand : {16L, 8L, 4L, 2L})
+          if (!bw && Wo % cand == 0 && Ho % (16 / cand) == 0) bw = cand;
+        const std::string value = "(acc[bi][0][nb][j] + acc[bi][1][nb][j])";
+        if (bw) {
+          // ... and a wave takes whole ROWS of patches (patch row = wave + NW * ri), so that ri and the patch's column are
+          // literals at every call: every gather and store is a per-lane base plus a literal offset.
+          const long bh = 16 / bw, nbc = Wo / bw, nbr = Ho / bh, whole = nbr / NW, ragged = nbr % NW;
+          fw_pre = "    const int wu = __builtin_amdgcn_readfirstlane(wave);\n";
+          fw_blocks = nbc <= 4 ? nbc : 1;
+          if (whole > 0)
+            fw_calls += "    _Pragma(\"unroll\") for (int ri = 0; ri < " + S(whole) + "; ++ri) _Pragma(\"unroll\") for (int bc = 0; bc < " + S(nbc) +
+                        "; bc += " + S(fw_blocks) + ") block(ri * " + S(nbc) + " + bc);\n";
+          if (ragged > 0)
+            fw_calls += "    if (wu < " + S(ragged) + ") { _Pragma(\"unroll\") for (int bc = 0; bc < " + S(nbc) + "; bc += " + S(fw_blocks) + ") block(" +
+                        S(whole * nbc) + " + bc); }\n";
+          fw_head = "      const int br = wu + " + S(NW) + " * (pb / " + S(nbc) + "), bc = pb % " + S(nbc) + ";\n";
+          fw_head += "      const int poff = ((br * " + S(bh) + " + l15 / " + S(bw) + ") * " + S(W) + " + bc * " + S(bw) + " + l15 % " + S(bw) + ") * " + S(C) + ";\n";
+          fw_store = "          const int m_ = 4 * l4 + j, f = 16 * nb + l15;\n";
+          fw_store += guarded_store(si.conv_out, "f < " + S(F),
+                                    "((br * " + S(bh) + " + m_ / " + S(bw) + ") * " + S(Wo) + " + bc * " + S(bw) + " + m_ % " + S(bw) + ") * " + S(F) + " + f", value);
+        } else {
+          fw_head = "      int p = 16 * pb + l15;\n      if (p > " + S(P - 1) + ") p = " + S(P - 1) + ";\n";
+          fw_head += "      const int poff = ((p / " + S(Wo) + ") * " + S(W) + " + p % " + S(Wo) + ") * " + S(C) + ";\n";
+          fw_store = "          const int pr = 16 * pb + 4 * l4 + j, f = 16 * nb + l15;\n";
+          fw_store += guarded_store(si.conv_out, "pr < " + S(P) + " && f < " + S(F), "pr * " + S(F) + " + f", value);
+          fw_calls = trips("block", (P + 15) / 16);
+        }
+      }
       if (si.conv_role == 1 && C % 4 == 0 && local(si.conv_img)) {
-        const long G = (K + 15) / 16, NB = (F + 15) / 16, PB = (P + 15) / 16;
+        const long G = (K + 15) / 16, NB = (F + 15) / 16;
         c += "    float bf[" + S(NB) + "][" + S(4 * G) + "];\n    int toff[" + S(G) + "];\n";
         c += "    _Pragma(\"unroll\") for (int g4 = 0; g4 < " + S(G) + "; ++g4) {\n";
         c += "      const int t0 = 16 * g4 + 4 * l4, tc = t0 < " + S(K) + " ? t0 : 0;\n";
@@ -945,18 +981,22 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
           c += "        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) {\n          const float bv = " + at(si.conv_flt, "fc * " + S(K) + " + (in_ ? t0 : 0) + j") +
                ";\n          bf[nb][4 * g4 + j] = in_ ? bv : 0.0f;\n        }\n      }\n    }\n";
         }
-        c += "    auto block = [&](const int pb) {\n";
-        c += "      int p = 16 * pb + l15;\n      if (p > " + S(P - 1) + ") p = " + S(P - 1) + ";\n";
-        c += "      const int poff = ((p / " + S(Wo) + ") * " + S(W) + " + p % " + S(Wo) + ") * " + S(C) + ";\n";
-        c += "      mf4 acc[2][" + S(NB) + "];\n      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[0][nb] = acc[1][nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
+        // A call covers fw_blocks row blocks (a whole row of patches, or one block): first the gathers and MFMAs of ALL of
+        // them — one straight-line run the scheduler can interleave: block by block, every block's LDS latency and dependent
+        // MFMA chain stood in line (conv1 forward: 4 300 cycles for 42 MFMAs per wave whatever was trimmed around them) —
+        // then all their stores.
+        c += fw_pre + "    auto block = [&](const int pb0) {\n";
+        c += "      mf4 acc[" + S(fw_blocks) + "][2][" + S(NB) + "];\n";
+        c += "      _Pragma(\"unroll\") for (int bi = 0; bi < " + S(fw_blocks) + "; ++bi) {\n      const int pb = pb0 + bi;\n" + fw_head;
+        c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[bi][0][nb] = acc[bi][1][nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
         c += "      _Pragma(\"unroll\") for (int g4 = 0; g4 < " + S(G) + "; ++g4) {\n";
         c += "        const mf4 a4 = *reinterpret_cast<const mf4*>(&" + at(si.conv_img, "poff + toff[g4]") + ");\n";
         c += "        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j)\n          _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) +
-             "; ++nb) acc[j & 1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bf[nb][4 * g4 + j], acc[j & 1][nb], 0, 0, 0);\n      }\n";
+             "; ++nb) acc[bi][j & 1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], bf[nb][4 * g4 + j], acc[bi][j & 1][nb], 0, 0, 0);\n      }\n";
+        c += "      }\n      _Pragma(\"unroll\") for (int bi = 0; bi < " + S(fw_blocks) + "; ++bi) {\n      const int pb = pb0 + bi;\n" + fw_head + "      (void)poff;\n";
         c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb)\n        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) {\n";
-        c += "          const int pr = 16 * pb + 4 * l4 + j, f = 16 * nb + l15;\n";
-        c += guarded_store(si.conv_out, "pr < " + S(P) + " && f < " + S(F), "pr * " + S(F) + " + f", "(acc[0][nb][j] + acc[1][nb][j])") + "        }\n    };\n";
-        c += trips("block", PB);
+        c += fw_store + "        }\n      }\n    };\n";
+        c += fw_calls;
       } else if (si.conv_role == 3 && F % 4 == 0 && local(si.conv_out)) {
         const long KD = FH * FW * F, G = (KD + 15) / 16, NB = (C + 15) / 16, QB = (Q + 15) / 16;
         // (F a multiple of 16: the tap of group g4 is a literal)
@@ -991,7 +1031,7 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
         c += guarded_store(si.conv_img, "qr < " + S(Q) + " && ch < " + S(C), "qr * " + S(C) + " + ch", "(acc[0][nb][j] + acc[1][nb][j])") + "        }\n    };\n";
         c += trips("block", QB);
       } else if (si.conv_role == 1) {   // out[p, f] (+)= sum_t img[pix(p) + tap(t)] * flt[f, t]
-        const long KS = (K + 3) / 4, NB = (F + 15) / 16, PB = (P + 15) / 16;
+        const long KS = (K + 3) / 4, NB = (F + 15) / 16;
         c += "    float bf[" + S(NB) + "][" + S(KS) + "];\n    int toff[" + S(KS) + "];\n";
         c += "    _Pragma(\"unroll\") for (int ks = 0; ks < " + S(KS) + "; ++ks) {\n";
         c += "      const int t = 4 * ks + l4, tc = t < " + S(K) + " ? t : 0;\n";
@@ -999,17 +1039,21 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
         c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) {\n        const int f = 16 * nb + l15;\n";
         c += "        const bool in_ = t < " + S(K) + ";\n        const float bv = " + at(si.conv_flt, "(f < " + S(F) + " ? f : " + S(F - 1) + ") * " + S(K) + " + tc") + ";\n";
         c += "        bf[nb][ks] = in_ ? bv : 0.0f;   // (columns f >= F are never stored: they repeat filter F - 1)\n      }\n    }\n";
-        c += "    auto block = [&](const int pb) {\n";
-        c += "      int p = 16 * pb + l15;\n      if (p > " + S(P - 1) + ") p = " + S(P - 1) + ";\n";
-        c += "      const int poff = ((p / " + S(Wo) + ") * " + S(W) + " + p % " + S(Wo) + ") * " + S(C) + ";\n";
-        c += "      mf4 acc[2][" + S(NB) + "];\n      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[0][nb] = acc[1][nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
+        // A call covers fw_blocks row blocks (a whole row of patches, or one block): first the gathers and MFMAs of ALL of
+        // them — one straight-line run the scheduler can interleave: block by block, every block's LDS latency and dependent
+        // MFMA chain stood in line (conv1 forward: 4 300 cycles for 42 MFMAs per wave whatever was trimmed around them) —
+        // then all their stores.
+        c += fw_pre + "    auto block = [&](const int pb0) {\n";
+        c += "      mf4 acc[" + S(fw_blocks) + "][2][" + S(NB) + "];\n";
+        c += "      _Pragma(\"unroll\") for (int bi = 0; bi < " + S(fw_blocks) + "; ++bi) {\n      const int pb = pb0 + bi;\n" + fw_head;
+        c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[bi][0][nb] = acc[bi][1][nb] = mf4{0.0f, 0.0f, 0.0f, 0.0f};\n";
         c += "      _Pragma(\"unroll\") for (int ks = 0; ks < " + S(KS) + "; ++ks) {\n";
         c += "        const float a = " + at(si.conv_img, "poff + toff[ks]") + ";\n";
-        c += "        _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[ks & 1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nb][ks], acc[ks & 1][nb], 0, 0, 0);\n      }\n";
+        c += "        _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb) acc[bi][ks & 1][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[nb][ks], acc[bi][ks & 1][nb], 0, 0, 0);\n      }\n";
+        c += "      }\n      _Pragma(\"unroll\") for (int bi = 0; bi < " + S(fw_blocks) + "; ++bi) {\n      const int pb = pb0 + bi;\n" + fw_head + "      (void)poff;\n";
         c += "      _Pragma(\"unroll\") for (int nb = 0; nb < " + S(NB) + "; ++nb)\n        _Pragma(\"unroll\") for (int j = 0; j < 4; ++j) {\n";
-        c += "          const int pr = 16 * pb + 4 * l4 + j, f = 16 * nb + l15;\n";
-        c += guarded_store(si.conv_out, "pr < " + S(P) + " && f < " + S(F), "pr * " + S(F) + " + f", "(acc[0][nb][j] + acc[1][nb][j])") + "        }\n    };\n";
-        c += trips("block", PB);
+        c += fw_store + "        }\n      }\n    };\n";
+        c += fw_calls;
       } else if (si.conv_role == 3) {   // gimg[q, ch] (+)= sum_{s, f} gout[pixel(q) - tap(s), f] * flt[f, s, ch]
         const long KD = FH * FW * F, KS = (KD + 3) / 4, NB = (C + 15) / 16, QB = (Q + 15) / 16;
         // With F a multiple of 4 the four lanes groups of a k-step share their tap: tap and window offset of k-step ks are
@@ -1458,6 +1502,18 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
   // (cycles since the first) at the end — where a sample kernel's time goes, without the dead-code elimination that makes
   // EG_SAMPLE_STOP's differences hard to read (a member whose result never leaves LDS disappears with its producers).
   if (eg::sw::raw("EG_SAMPLE_TRACE") != nullptr) {
+    // (EG_SAMPLE_TRACE=100 + k: member k runs twice — idempotent when it overwrites its result — so that the stamps show
+    // what its second, instruction-cache-warm execution costs)
+    const long repeat = eg::sw::integer("EG_SAMPLE_TRACE", 1) - 100;
+    if (repeat >= 0) {
+      const size_t from = c.find("  {  // kernel " + std::to_string(repeat) + ":");
+      const size_t to = from == std::string::npos ? from : c.find("  {  // kernel " + std::to_string(repeat + 1) + ":", from);
+      if (from != std::string::npos && to != std::string::npos) {
+        std::string again = c.substr(from, to - from);
+        if (again.find("\n  __syncthreads();\n") == std::string::npos) again += "  __syncthreads();\n";
+        c.replace(from, to - from, "  _Pragma(\"nounroll\") for (int rep_ = 0; rep_ < 2; ++rep_) {\n" + again + "  }\n");
+      }
+    }
     const std::string stamp = "  if (threadIdx.x == 0 && blockIdx.x == 0 && trn_ < 48) tr_[trn_++] = __builtin_readcyclecounter();\n";
     std::string traced = "  long long tr_[48]; int trn_ = 0;\n" + stamp;
     size_t pos = 0;
