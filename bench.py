@@ -1143,7 +1143,9 @@ def run_fashion_fit(args, env):
             "measured_us_per_dependent_kernel": 4.5,
             "measured_note": "the forward + backward pass of a step is ONE kernel with one block per sample (DESIGN.md section 3 'Round 5'); "
                              "round 6: its five convolution members run on the matrix cores (16 x 16 x 4, gathered fragments) and the "
-                             "parameters are staged in LDS once: 36.7 -> 28.3 us per batch-32 step on one box (tools/fit_sample_ab.sh); the "
+                             "parameters are staged in LDS once (36.7 -> 28.3 us per batch-32 step), then, under cycle stamps (EG_SAMPLE_TRACE), batched "
+                             "staging loads, literal trip counts, four-wide gathers, no barrier between independent members: 21.4 us on one box "
+                             "(tools/fit_sample_ab.sh); the "
                              "launch chain it replaces, EG_NO_SAMPLE_FUSE=1: 16 kernels of 4.1 - 8.0 us each, 71 us.  A dependent kernel "
                              "ends >= 4.5 us after its predecessor here whatever it does; the floor above uses the guide's 1.5 us per boundary.",
             "note": "calls = launches of the plan + the segment copy of the batch's rows; some calls are two kernels (a "
@@ -1156,7 +1158,7 @@ def run_fashion_fit(args, env):
                        "frac": round(out["batch_32"]["bound"]["dependent_launch_floor_us"] / out["batch_32"]["us_per_batch"], 3),
                        "traffic": None,
                        "note": "floor / achieved: the batch-32 step against its dependent-launch floor.  The step is three launches and "
-                               "its time is the sample kernel's (~22 of 28 us): 26 members separated by block barriers, each a pass over "
+                               "its time is the sample kernel's (~15 of 21 us): 26 members, 22 block barriers, each member a pass over "
                                "LDS-resident tensors; the fraction says how far the step is from a chain of three empty kernels"}
     model.close()
     return out

@@ -352,6 +352,18 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
       eg_ctx* ctx = m->ctx;
       EG_HIP_CHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
       EG_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+      // The contraction is issued FIRST (round 6): in a captured graph the branch whose node is created first stays on the
+      // queue of what precedes it and the other branch moves to a second queue, 10 - 12 us behind (r06_step_timeline.txt: the
+      // long weight gradient started 12 us after the kernel that makes its operand, and the update 10 us after the
+      // gradient's last kernel).  Measured on one box, six alternating runs: 0.9708 against 0.9737 ms per step — the gaps
+      // shrink by 11 us, the contraction shares its CUs from the start and takes 14 us longer.  A data-parallel step keeps
+      // the side lane first: its early gradient exchange rides that lane and must not queue behind 256 resident blocks.
+      // EG_OVERLAP_SIDE_FIRST=1: the order of rounds 2 - 5 everywhere.
+      const bool side_first = eg::sw::raw("EG_OVERLAP_SIDE_FIRST") != nullptr || (hook && hook->big == big);
+      if (!side_first) {
+        int rc = run_launch(m, ts, plan, plan.launches[big]);
+        if (rc) return rc;
+      }
       {
         LaneSwap lane(ctx);
         for (int s2 = i; s2 < big; ++s2) {
@@ -364,8 +376,10 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
         }
         EG_HIP_CHECK(hipEventRecord(ctx->ev_join, ctx->stream));  // (the side stream, while swapped)
       }
-      int rc = run_launch(m, ts, plan, plan.launches[big]);
-      if (rc) return rc;
+      if (side_first) {
+        int rc = run_launch(m, ts, plan, plan.launches[big]);
+        if (rc) return rc;
+      }
       EG_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
       i = big;
       continue;

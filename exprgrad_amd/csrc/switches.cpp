@@ -38,6 +38,7 @@ const Row kSwitches[] = {
     {"EG_NO_SKINNY_GEMM", "execution", "N <= 16 products on the matrix tiles instead of the streaming skinny kernel"},
     {"EG_NO_NARROW_K", "execution", "K <= 16 products with a generated epilogue on the matrix tile instead of the streaming kernel"},
     {"EG_NO_SAMPLE_FUSE", "execution", "no sample groups (one block per sample): the launch chain of a small-batch step"},
+    {"EG_OVERLAP_SIDE_FIRST", "execution", "the side lane's launches are issued in front of the long contraction they run beside (the order of rounds 2 - 5)"},
     {"EG_SAMPLE_KEEP_BARRIERS", "execution", "sample kernels keep the barrier between independent members"},
     {"EG_SAMPLE_NO_STAGE", "execution", "a sample group's members read parameters from global memory, not from a copy in LDS"},
     {"EG_SAMPLE_NO_MFMA", "execution", "convolution members of a sample group as scalar loop nests, not on the matrix cores"},
