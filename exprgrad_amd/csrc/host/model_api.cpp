@@ -293,8 +293,10 @@ const char* eg_model_launch_text(eg_model* m, const char* target) {
         break;
       }
     }
-    for (auto& ov : plan.overlaps)
+    for (auto& ov : plan.overlaps) {
       if ((int)i >= ov.first && (int)i < ov.big) os << "   || side lane, next to launch " << ov.big;
+      if ((int)i == ov.deferred_row) os << "   || its fold runs beside launch " << ov.big << " (when a range holds both)";
+    }
     if (plan.pipe.active && (int)i < plan.n_backward)
       os << (L.heavy ? "   || main lane" : "   || side lane") << (L.slice_mode == 2 ? ", halves accumulate" : ", by rows");
     os << "\n";

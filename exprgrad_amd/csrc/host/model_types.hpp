@@ -207,7 +207,11 @@ struct Plan {
   // long contraction `big` runs on the main stream; both are joined before launch big + 1.
   struct Overlap {
     int first = 0, big = 0;
+    // a row group in front of the overlap whose partial rows nothing up to and including the contraction needs: its fold
+    // (row_finalize) is the side lane's first launch instead of the row kernel's tail on the main lane (-1: none)
+    int deferred_row = -1;
   };
+  int defer_finalize_of = -1;   // set while a launch sequence is being issued: the row group whose fold the next fork runs
   std::vector<Overlap> overlaps;
   // Batch pipeline: the backward range [0, n_backward) runs as two half batches, the long contractions
   // of both halves back to back on the main lane, everything between them on the side lane — the

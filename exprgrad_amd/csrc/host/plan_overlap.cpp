@@ -101,7 +101,38 @@ void plan_overlap(eg_model* m, TargetState& ts, Plan& plan) {
     }
     static const bool debug = eg::sw::raw("EG_DEBUG_OVERLAP") != nullptr;
     if (debug) fprintf(stderr, "[eg] overlap: contraction %d (%.1f GFLOP) takes launches [%d, %d)\n", j, flops / 1e9, first, j);
-    if (first < j && ensure_side_lane(m->ctx) == EG_OK) plan.overlaps.push_back({first, j});
+    if (first < j && ensure_side_lane(m->ctx) == EG_OK) {
+      plan.overlaps.push_back({first, j});
+      // Round 6: a row group shortly in front of the group whose totals (a bias gradient's column sums) nobody reads before
+      // the contraction is over hands its fold to the side lane: in the dense step the row kernel's in-kernel fold was
+      // 5 of its 12.8 us, on the critical path between the forward product and the backward chain.
+      const bool keep_tail = eg::sw::raw("EG_NO_DEFERRED_FOLD") != nullptr;   // (read per plan: a test builds one model each way)
+      for (int r = first - 1; !keep_tail && r >= 0 && r >= first - 3; --r) {
+        const Launch& R = plan.launches[r];
+        if (r + 1 == plan.n_backward) break;
+        if (R.kind != StepKind::RowFused) continue;
+        const PlanRowGroup& pg = *plan.row_groups[R.row_group];
+        if (pg.g.single_block || pg.g.red_total <= 0 || pg.tail_group >= 0 || !pg.g.in_kernel_finalize) break;
+        std::set<int> totals;
+        for (int tid : pg.red_tensors) {
+          int t = tid;
+          for (int guard = 0; guard < 64; ++guard) {
+            auto al = plan.alias.find(t);
+            if (al == plan.alias.end()) break;
+            t = al->second;
+          }
+          totals.insert(t);
+        }
+        bool free_of_readers = true;
+        for (int k = r + 1; k <= j && free_of_readers; ++k) {
+          std::set<int> kr, kw;
+          if (!launch_tensors(plan, plan.launches[k], kr, kw)) free_of_readers = false;
+          for (int t : totals) free_of_readers = free_of_readers && !kr.count(t) && !kw.count(t);
+        }
+        if (free_of_readers) plan.overlaps.back().deferred_row = r;
+        break;
+      }
+    }
   }
 }
 

@@ -193,8 +193,9 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       // holds the small group behind this launch as well, runs it (MODE 2; run_range_eager skips that launch)
       long MODE = 0;
       unsigned* counter = pg.counter;
+      const bool deferred = plan.defer_finalize_of == (int)(&L - plan.launches.data());   // the next fork folds the rows
       if (pg.g.in_kernel_finalize) {
-        MODE = row_tail_active(plan, L) ? 2 : 1;
+        MODE = deferred ? 0 : row_tail_active(plan, L) ? 2 : 1;
         args.push_back(&counter);
         args.push_back(&MODE);
         const size_t first_tail = dsts.size();
@@ -203,6 +204,7 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
       }
       int rc = eg::kernel_launch_raw(pg.handle, (unsigned)pg.nblocks, 1, 1, 256, args.data());
       if (rc) return rc;
+      if (deferred) return EG_OK;
       if (pg.g.red_total > 0 && !pg.g.single_block && MODE == 0) {
         eg::RowFinalizeArgs fa = {};
         fa.nseg = (int)pg.red_tensors.size();
@@ -284,7 +286,24 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
   return EG_OK;
 }
 
+// the fold of a row group's partial rows as a launch of its own (what run_launch does behind the row kernel when the kernel
+// does not fold them itself)
+static int run_row_fold(eg_model* m, TargetState& ts, Plan& plan, const Launch& L) {
+  PlanRowGroup& pg = *plan.row_groups[L.row_group];
+  eg::RowFinalizeArgs fa = {};
+  fa.nseg = (int)pg.red_tensors.size();
+  for (int s = 0; s < fa.nseg; ++s) {
+    const RowGroupTensor& gt = pg.g.tensors.at(pg.red_tensors[s]);
+    fa.dst[s] = tensor_ptr(m, ts, plan, pg.red_tensors[s]);
+    fa.offset[s] = (int)gt.red_offset;
+    fa.accumulate[s] = gt.accumulate ? 1 : 0;
+  }
+  fa.offset[fa.nseg] = (int)pg.g.red_total;
+  return eg::row_finalize(m->ctx, pg.partial, pg.nblocks, (int)pg.g.red_total, fa);
+}
+
 int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero, const SideHook* hook) {
+  plan.defer_finalize_of = -1;
   if (zero) {
     // allocShapes / zeroResultTensor (model.nim:318, 383): results start from zero on every call
     {
@@ -340,7 +359,11 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
   plan.active_begin = begin;
   plan.active_end = end;
   size_t next_overlap = 0;
+  plan.defer_finalize_of = -1;
   for (int i = begin; i < end; ++i) {
+    // a row group whose fold the fork of an overlap group inside this range runs on the side lane (plan_overlap)
+    for (const Plan::Overlap& ov : plan.overlaps)
+      if (ov.deferred_row == i && ov.first >= begin && ov.big < end) plan.defer_finalize_of = i;
     // a small group that the last block of the row group in front of it has run already (fuse_row_tails)
     if (plan.launches[i].tail_of >= begin && row_tail_active(plan, plan.launches[plan.launches[i].tail_of])) continue;
     while (next_overlap < plan.overlaps.size() && plan.overlaps[next_overlap].first < i) ++next_overlap;
@@ -366,6 +389,11 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
       }
       {
         LaneSwap lane(ctx);
+        if (plan.overlaps[next_overlap].deferred_row >= 0 && plan.defer_finalize_of == plan.overlaps[next_overlap].deferred_row) {
+          int rc = run_row_fold(m, ts, plan, plan.launches[plan.defer_finalize_of]);
+          plan.defer_finalize_of = -1;
+          if (rc) return rc;
+        }
         for (int s2 = i; s2 < big; ++s2) {
           int rc = run_launch(m, ts, plan, plan.launches[s2]);
           if (rc) return rc;

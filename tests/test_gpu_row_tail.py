@@ -109,3 +109,31 @@ def test_dense_softmax_row_group_folds_its_partial_rows_itself(gpu_ctx, monkeypa
         b.apply("train", {"x": x, "y": y})
     a.close()
     b.close()
+
+
+def test_dense_step_hands_the_fold_to_the_side_lane(gpu_ctx, monkeypatch):
+    """Round 6 (plan_overlap.cpp, Overlap::deferred_row): with a long contraction behind it (the first layer's weight
+    gradient: 2 * 784 * 64 * 16384 = 1.6 GFLOP is not enough, 784 x 512 x 16384 is) the row group's fold runs as the side lane's
+    first launch instead of the row kernel's tail.  Same kernel order of additions (row_finalize_kernel): parameters to
+    the bit against EG_NO_DEFERRED_FOLD=1, eager and replayed."""
+    rng = np.random.default_rng(9)
+    batch = 16384
+    x = rng.random((batch, 784), dtype=np.float32)
+    y = np.eye(10, dtype=np.float32)[rng.integers(0, 10, size=batch)]
+    graphs = lambda: refcases.dense_softmax_net()
+    monkeypatch.delenv("EG_NO_DEFERRED_FOLD", raising=False)
+    a = build(gpu_ctx, graphs, monkeypatch, True)
+    a.apply("train", {"x": x, "y": y})
+    if not debug_toggles_active():
+        assert "its fold runs beside launch" in a.launch_plan("train"), a.launch_plan("train")
+    monkeypatch.setenv("EG_NO_DEFERRED_FOLD", "1")
+    b = build(gpu_ctx, graphs, monkeypatch, True)
+    b.apply("train", {"x": x, "y": y})
+    assert "its fold runs beside launch" not in b.launch_plan("train")
+    for step in range(6):
+        for tid in a.params.ids():
+            assert np.array_equal(a.params[tid], b.params[tid]), (step, tid)
+        a.apply("train", {"x": x, "y": y})
+        b.apply("train", {"x": x, "y": y})
+    a.close()
+    b.close()

@@ -4,7 +4,7 @@ export EG_TUNING=1   # measurement aids (class `tuning` of csrc/switches.cpp) ar
 # four execution toggles, one pytest process per run like the driver's, and log one line per run.
 #   tools/stress_suite.sh <runs> [prefix|full] [logfile]
 # Toggles cycle: none, EG_NO_GRAPH, EG_NO_OVERLAP, EG_NO_ROWFUSE, EG_NO_PREDICATE + EG_NO_ROW_PRODUCT, EG_POISON, and (round 4)
-# the round-3 kernels: EG_GEMM_NO_SKEW + EG_GEMM_NO_BK32 + EG_GEMM_NO_PAIR + EG_CONV_NO_TINY + EG_CONV_NO_GRADF_HALO + EG_CONV_NO_WIDE_STORE + EG_NO_ROW_DIRECT + EG_NO_SMALL_PAIR (+ round 5: EG_CONV_NO_BAND + EG_GEMM_NO_T96); (round 5) EG_NO_ROW_TAIL + EG_NO_SAMPLE_FUSE; (round 6) EG_OVERLAP_SIDE_FIRST rides with EG_NO_GRAPH, EG_SAMPLE_KEEP_BARRIERS with EG_NO_OVERLAP.  Exit status 1 if any run failed.
+# the round-3 kernels: EG_GEMM_NO_SKEW + EG_GEMM_NO_BK32 + EG_GEMM_NO_PAIR + EG_CONV_NO_TINY + EG_CONV_NO_GRADF_HALO + EG_CONV_NO_WIDE_STORE + EG_NO_ROW_DIRECT + EG_NO_SMALL_PAIR (+ round 5: EG_CONV_NO_BAND + EG_GEMM_NO_T96); (round 5) EG_NO_ROW_TAIL + EG_NO_SAMPLE_FUSE; (round 6) EG_OVERLAP_SIDE_FIRST + EG_NO_DEFERRED_FOLD ride with EG_NO_GRAPH, EG_SAMPLE_KEEP_BARRIERS with EG_NO_OVERLAP.  Exit status 1 if any run failed.
 runs=${1:-4}
 what=${2:-prefix}
 log=${3:-gpurun_out/stress_suite.log}
@@ -14,7 +14,7 @@ if [ "$what" = full ]; then
 else
   files="tests/test_adam.py tests/test_config_fixtures.py tests/test_dropout.py tests/test_gan.py tests/test_gpu_conv_grad.py tests/test_gpu_epilogue.py"
 fi
-toggles=("" "EG_NO_GRAPH=1 EG_OVERLAP_SIDE_FIRST=1" "EG_NO_OVERLAP=1 EG_SAMPLE_KEEP_BARRIERS=1" "EG_NO_ROWFUSE=1" "EG_NO_PREDICATE=1 EG_NO_ROW_PRODUCT=1" "EG_POISON=1" "EG_GEMM_NO_SKEW=1 EG_GEMM_NO_BK32=1 EG_GEMM_NO_PAIR=1 EG_CONV_NO_TINY=1 EG_CONV_NO_GRADF_HALO=1 EG_CONV_NO_WIDE_STORE=1 EG_NO_ROW_DIRECT=1 EG_NO_SMALL_PAIR=1 EG_CONV_NO_BAND=1 EG_GEMM_NO_T96=1 EG_NO_NARROW_K=1 EG_GEMM_NO_STREAMK=1 EG_SAMPLE_NO_MFMA=1 EG_SAMPLE_NO_STAGE=1" "EG_NO_ROW_TAIL=1 EG_NO_SAMPLE_FUSE=1")
+toggles=("" "EG_NO_GRAPH=1 EG_OVERLAP_SIDE_FIRST=1 EG_NO_DEFERRED_FOLD=1" "EG_NO_OVERLAP=1 EG_SAMPLE_KEEP_BARRIERS=1" "EG_NO_ROWFUSE=1" "EG_NO_PREDICATE=1 EG_NO_ROW_PRODUCT=1" "EG_POISON=1" "EG_GEMM_NO_SKEW=1 EG_GEMM_NO_BK32=1 EG_GEMM_NO_PAIR=1 EG_CONV_NO_TINY=1 EG_CONV_NO_GRADF_HALO=1 EG_CONV_NO_WIDE_STORE=1 EG_NO_ROW_DIRECT=1 EG_NO_SMALL_PAIR=1 EG_CONV_NO_BAND=1 EG_GEMM_NO_T96=1 EG_NO_NARROW_K=1 EG_GEMM_NO_STREAMK=1 EG_SAMPLE_NO_MFMA=1 EG_SAMPLE_NO_STAGE=1" "EG_NO_ROW_TAIL=1 EG_NO_SAMPLE_FUSE=1")
 bad=0
 for ((i = 0; i < runs; i++)); do
   t=${toggles[$((i % 8))]}
