@@ -900,14 +900,22 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
       };
       c += "    typedef float mf4 __attribute__((ext_vector_type(4)));\n";
       c += "    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, l4 = lane >> 4;\n";
-      // Shapes of the loops below (round 6, after the cycle stamps of EG_SAMPLE_TRACE): a wave's row blocks are a lambda
-      // called with a LITERAL trip count (the whole trips; the ragged one under a wave-uniform guard) so that the gathers of
-      // block i + 1 are in flight under the MFMAs of block i — the rolled `for (pb = wave; ...)` exposed the LDS latency and
-      // the whole dependent MFMA chain of every block; k-steps alternate between two accumulators (one chain of KS
-      // dependent MFMAs becomes two of KS / 2).
-      // A row block's store without a branch when the destination lives in LDS: lanes outside the tensor write their value to
-      // a slot of `scratch` of their own instead (a guarded store is a basic-block boundary, and the compiler does not move
-      // the next block's gathers across it — the blocks of a wave ran one after the other, latencies and all).
+      // Shapes of the loops below (round 6, after the cycle stamps of EG_SAMPLE_TRACE):
+      //  * a wave's row blocks are a lambda called with a LITERAL trip count (the whole trips; the ragged one under a
+      //    wave-uniform guard) so that the gathers of block i + 1 are in flight under the MFMAs of block i — the rolled
+      //    `for (pb = wave; ...)` exposed the LDS latency and the whole dependent MFMA chain of every block; k-steps
+      //    alternate between two accumulators (one chain of KS dependent MFMAs becomes two of KS / 2);
+      //  * gathers of FOUR k-values per lane and instruction: with the channels (forward) / the filters (image gradient) a
+      //    multiple of 4 and the gathered tensor in LDS, the k index is permuted so that lane group l4 holds
+      //    k = 16 g + 4 l4 + j in the j-th MFMA of group g — four consecutive channels of ONE tap, one ds_read_b128, one
+      //    address, one bounds test.  Any bijection of k is the same sum; the B fragments use the same one;
+      //  * a forward member's row block of 16 output pixels is 16 consecutive pixels of the row-major image or — when the
+      //    output tiles exactly into bw x (16 / bw) patches — such a patch, and a wave then takes whole ROWS of patches:
+      //    patch row and column are literals at every call, every gather and store a per-lane base plus a literal
+      //    offset, no pixel of a block lies past the end (the store tests the filter only).
+      // A row block's store without a branch when the destination lives in LDS: lanes outside the tensor write their value
+      // to a slot of `dummy_` of their own instead (a guarded store is a basic-block boundary the compiler moves no gather
+      // across).
       auto guarded_store = [&](int tensor, const std::string& cond, const std::string& idx, const std::string& value) {
         const std::string o = at(tensor, idx);
         if (!local(tensor))
@@ -924,15 +932,6 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
         if (ragged > 0) d += "    if (wave < " + S(ragged) + ") " + fn + "(wave + " + S(whole * NW) + ");\n";
         return d;
       };
-      // Gathers of FOUR k-values per lane and instruction (round 6; these members are bound by the number of instructions a
-      // wave issues, ~10 per MFMA with one 4-byte gather, its address and its mask each): with the channels (forward) / the
-      // filters (image gradient) a multiple of 4 and the gathered tensor in LDS, the k index is permuted so that the lane
-      // group l4 holds k = 16 g + 4 l4 + j in the j-th MFMA of group g — four consecutive channels of ONE tap, one
-      // ds_read_b128, one address, one bounds test.  Any bijection of k is the same sum; B fragments use the same one.
-      // A forward member's row block of 16 output pixels: 16 consecutive pixels of the row-major image, or — when the output
-      // tiles exactly into bw x (16 / bw) patches — such a patch: the block's part of every address is then wave-uniform
-      // (scalar arithmetic) and the lane's part a constant, instead of a division by the row width per lane and block, and
-      // no pixel of a block lies past the end (the store tests the filter only).
       std::string fw_head, fw_store, fw_pre, fw_calls;
       long fw_blocks = 1;   // row blocks per call of the member's lambda
       if (si.conv_role == 1) {
@@ -941,8 +940,7 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
           if (!bw && Wo % cand == 0 && Ho % (16 / cand) == 0) bw = cand;
         const std::string value = "(acc[bi][0][nb][j] + acc[bi][1][nb][j])";
         if (bw) {
-          // ... and a wave takes whole ROWS of patches (patch row = wave + NW * ri), so that ri and the patch's column are
-          // literals at every call: every gather and store is a per-lane base plus a literal offset.
+          // patch row = wave + NW * ri
           const long bh = 16 / bw, nbc = Wo / bw, nbr = Ho / bh, whole = nbr / NW, ragged = nbr % NW;
           fw_pre = "    const int wu = __builtin_amdgcn_readfirstlane(wave);\n";
           fw_blocks = nbc <= 4 ? nbc : 1;
