@@ -106,23 +106,28 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv2_gradf_halo_kernel(GradFAr
   };
   stamp();   // 0: start
 
-  const __amdgpu_buffer_rsrc_t img_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_pointer(a.img)), (short)0, -1, 0x00020000);
-  const __amdgpu_buffer_rsrc_t gout_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_pointer(a.gout)), (short)0, -1, 0x00020000);
-  // Per-lane parts of the 17 loads, fixed for the whole kernel: halo instruction t covers halo pixels 8 t .. 8 t + 7
+  // One descriptor per SEGMENT and tensor (scalar arithmetic: base + the segment's first byte, num_records = the bytes
+  // from there to the tensor's end), so that the per-lane offsets of the 9 loads are constants of the kernel: a ragged
+  // last segment reads past its row into the next one (finite values that meet a zeroed gradient row) and, in the last
+  // rows of the tensor, past the end — which the range check answers with zeros.  Before round 6 every load clamped its
+  // pixel first: a v_min and a 64-bit multiply-add per load and segment in front of the MFMAs.
+  const char* const img_u = reinterpret_cast<const char*>(uniform_pointer(a.img));
+  const char* const gout_u = reinterpret_cast<const char*>(uniform_pointer(a.gout));
+  const unsigned img_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.N * a.H * a.W * a.C * 4));
+  const unsigned gout_bytes = __builtin_amdgcn_readfirstlane((unsigned)(a.N * a.Ho * a.Wo * a.F * 4));
+  // Per-lane byte offsets of the 9 loads, fixed for the whole kernel: halo instruction t covers halo pixels 8 t .. 8 t + 7
   // (dy, hx), eight lanes x 16 bytes = the pixel's 32 channels; gout instruction t covers pixels 8 t .. 8 t + 7.  What
-  // changes from segment to segment is a block-uniform byte offset (scalar operand of the load) and, for the ragged last
-  // segment of a row, the clamp of the pixels past the end: a v_min and a multiply-add per load instead of the whole
-  // address arithmetic (a wave alone on its SIMD pays for every vector instruction in front of its MFMAs).
-  int halo_dy[HALO_INSTR], halo_hx[HALO_INSTR];
+  // changes from segment to segment is the descriptor (above).
+  const unsigned chunk_bytes = (unsigned)(lane & 7) * 16u;
+  const unsigned row_bytes = (unsigned)(a.W * a.C * 4), px_bytes = (unsigned)(a.C * 4), gpx_bytes = (unsigned)(a.F * 4);
+  unsigned halo_off[HALO_INSTR];
 #pragma unroll
   for (int t = 0; t < HALO_INSTR; ++t) {
     int q = t * 8 + (lane >> 3);
     if (q > HALO_PX - 1) q = HALO_PX - 1;
-    halo_dy[t] = q / HW;
-    halo_hx[t] = q - halo_dy[t] * HW;
+    const int dy = q / HW, hx = q - dy * HW;
+    halo_off[t] = (unsigned)dy * row_bytes + (unsigned)hx * px_bytes + chunk_bytes;
   }
-  const unsigned chunk_bytes = (unsigned)(lane & 7) * 16u;
-  const unsigned row_bytes = (unsigned)(a.W * a.C * 4), px_bytes = (unsigned)(a.C * 4), gpx_bytes = (unsigned)(a.F * 4);
   // the segment the next issue() loads, as (image, segment column, row): decoded once, then stepped (three 64-bit
   // divisions per segment are several hundred scalar instructions in front of the MFMAs of a wave that has its SIMD to itself)
   long next_n, next_col, next_y;
@@ -135,8 +140,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv2_gradf_halo_kernel(GradFAr
   // A segment's block-uniform part of the loads: byte offsets of its first pixel in the image and in gout, the last
   // valid halo column / pixel (for the clamps).  next_segment() describes (next_n, next_col, next_y) and steps on.
   struct Seg {
-    unsigned img_base, gout_base;
-    int xmax, pmax;
+    __amdgpu_buffer_rsrc_t img, gout;
+    int pmax;
   };
   auto next_segment = [&]() {
     const long n = next_n, y = next_y, x0 = next_col * SEG;
@@ -148,23 +153,21 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv2_gradf_halo_kernel(GradFAr
       }
     }
     Seg g;
-    g.xmax = __builtin_amdgcn_readfirstlane((int)(a.W - 1 - x0));
     g.pmax = __builtin_amdgcn_readfirstlane((int)(a.Wo - 1 - x0));
-    g.img_base = __builtin_amdgcn_readfirstlane((unsigned)((((n * a.H + y) * a.W + x0) * a.C + c0) * 4));
-    g.gout_base = __builtin_amdgcn_readfirstlane((unsigned)((((n * a.Ho + y) * a.Wo + x0) * a.F + f0) * 4));
+    const unsigned img_base = __builtin_amdgcn_readfirstlane((unsigned)((((n * a.H + y) * a.W + x0) * a.C + c0) * 4));
+    const unsigned gout_base = __builtin_amdgcn_readfirstlane((unsigned)((((n * a.Ho + y) * a.Wo + x0) * a.F + f0) * 4));
+    g.img = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img_u + img_base), (short)0, (int)(img_bytes - img_base), 0x00020000);
+    g.gout = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(gout_u + gout_base), (short)0, (int)(gout_bytes - gout_base), 0x00020000);
     return g;
   };
   // load piece t (0 .. 16) of segment g into `stage`: 13 halo pieces, then 4 gout pieces
   auto piece = [&](int t, const Seg& g, float* stage) {
     if (t < HALO_INSTR) {
-      const int hx = halo_hx[t] < g.xmax ? halo_hx[t] : g.xmax;   // right of the image: only pixels of a ragged segment read it (times zero)
-      const unsigned off = (unsigned)halo_dy[t] * row_bytes + (unsigned)hx * px_bytes + chunk_bytes;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(img_rsrc, (__attribute__((address_space(3))) void*)(stage + t * 256), 16, off, g.img_base, 0, 0);
-    } else {                                    // pixels past the end of the row re-read its last pixel: their A values are masked
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(g.img, (__attribute__((address_space(3))) void*)(stage + t * 256), 16, halo_off[t], 0, 0, 0);
+    } else {                                    // (pixels past the end of a row: their rows are zeroed in LDS before they are used)
       const int u = t - HALO_INSTR, p0 = u * 8 + (lane >> 3);
-      const int p = p0 < g.pmax ? p0 : g.pmax;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(gout_rsrc, (__attribute__((address_space(3))) void*)(stage + HALO_FLOATS + u * 256), 16,
-                                               (unsigned)p * gpx_bytes + chunk_bytes, g.gout_base, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(g.gout, (__attribute__((address_space(3))) void*)(stage + HALO_FLOATS + u * 256), 16,
+                                               (unsigned)p0 * gpx_bytes + chunk_bytes, 0, 0, 0);
     }
   };
   f32x16 acc[TAPS];
@@ -199,13 +202,22 @@ __global__ __launch_bounds__(WAVES * 64, 1) void conv2_gradf_halo_kernel(GradFAr
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) B[t] = hs[((t / 3) * HW + 2 * j + t % 3) * QB];
     };
+    // A ragged last segment of a row: the wave zeroes the gradient rows of the pixels past the end in its own stage (they
+    // were loaded from the row's last pixel) — once per row instead of a compare and a select in front of the MFMAs of
+    // every k-step (round 6: every instruction a wave issues between two MFMAs costs the matrix pipe about four cycles).
+    if (nvalid < SEG) {
+      float* gz = cur + HALO_FLOATS + i;
+      for (int p = nvalid + hi; p < SEG; p += 2) gz[p * QB] = 0.f;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     fragments(0, av[0], bv[0]);
 #pragma unroll
     for (int j = 0; j < SEG / 2; ++j) {
       if (j + 1 < SEG / 2) fragments(j + 1, av[(j + 1) & 1], bv[(j + 1) & 1]);
       __builtin_amdgcn_sched_barrier(0);
-      // (masked where it is used, not where it is loaded: the select would wait for the read just issued)
-      const float A = 2 * j + hi < nvalid ? av[j & 1] : 0.f;   // a ragged last segment of a row
+      // (one explicit `s_waitcnt lgkmcnt(5)` here instead of the three or four the compiler spreads between the MFMAs:
+      // measured slower, 41.3 against 40.7 us — the first MFMAs then wait for the step's last fragment)
+      const float A = av[j & 1];
       // The nine loads of the next stage ride behind the first two MFMAs of the first five k-steps (three k-steps of
       // MFMAs, twice that with the SIMD's other wave, separate the last one from the wait at the end of the segment).
 #pragma unroll
