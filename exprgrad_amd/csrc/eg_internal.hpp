@@ -132,7 +132,7 @@ struct RowFinalizeArgs {
   int accumulate[16];
   int nseg;
 };
-int row_finalize(eg_ctx* ctx, const float* partial, int nblocks, int E, const RowFinalizeArgs& args);
+int row_finalize(eg_ctx* ctx, const float* partial, int nblocks, int E, int stride, const RowFinalizeArgs& args);
 // Direct per-pixel kernels for few input channels (kernels/conv2_direct.cpp), same convention.
 int conv2_direct_try(eg_ctx* ctx, long N, long H, long W, long C, long F, long FH, long FW, const float* img,
                      const float* flt, float* out, int accumulate, bool* launched);

@@ -642,7 +642,7 @@ int form_row_groups(eg_model* m, TargetState& ts, Plan& plan, const std::vector<
     plan.pending.push_back({g.name, g.source, &pg->handle});
     if (g.red_total > 0) {
       EG_HIP_CHECK(hipSetDevice(m->ctx->device));
-      EG_HIP_CHECK(hipMalloc((void**)&pg->partial, (size_t)pg->nblocks * g.red_total * sizeof(float)));
+      EG_HIP_CHECK(hipMalloc((void**)&pg->partial, (size_t)pg->nblocks * g.red_stride() * sizeof(float)));
       if (g.in_kernel_finalize) {
         EG_HIP_CHECK(hipMalloc((void**)&pg->counter, 64));
         EG_HIP_CHECK(hipMemsetAsync(pg->counter, 0, 64, m->ctx->stream));  // (the context's stream: ordered against the launches)

@@ -365,10 +365,14 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
       const RowGroupTensor& t = kv.second;
       if (t.role != RowGroupTensor::Reduction) continue;
       const std::string id = std::to_string(kv.first);
-      c += "  _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) {\n";
-      c += "    float v = R" + id + "[j];\n";
-      c += "    _Pragma(\"unroll\") for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);\n";
-      c += "    if (lane == 0) red[wave * " + E + " + " + std::to_string(t.red_offset) + " + j] = v;\n  }\n";
+      // The butterfly runs over ALL the values of a step together (round 6, EG_ROW_TRACE: one value after the other — the
+      // guarded store behind each kept the compiler from interleaving them — every one of the 6 x 17 shuffles of the XOR
+      // step's totals waited out the LDS crossbar's latency by itself: 7 700 cycles, and again in the last block's fold;
+      // together 6.5 of the kernel's 11.8 us).  Same additions per value, same order.
+      c += "  _Pragma(\"unroll\") for (int off = 32; off >= 1; off >>= 1)\n";
+      c += "    _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) R" + id + "[j] += __shfl_xor(R" + id + "[j], off, 64);\n";
+      c += "  if (lane == 0) {\n    _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) red[wave * " + E + " + " +
+           std::to_string(t.red_offset) + " + j] = R" + id + "[j];\n  }\n";
     }
     c += "  __syncthreads();\n";
     if (g.single_block) {
@@ -382,12 +386,23 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
         c += std::string("    d") + id + "[j] = " + (t.accumulate ? "d" + id + "[j] + s" : std::string("s")) + ";\n  }\n";
       }
     } else {
-      c += "  for (int e = threadIdx.x; e < " + E + "; e += 256) {\n";
-      c += "    const float total = (red[e] + red[" + E + " + e]) + (red[2 * " + E + " + e] + red[3 * " + E + " + e]);\n";
-      if (g.in_kernel_finalize)
-        c += "    __hip_atomic_store(partial + (long)blockIdx.x * " + E + " + e, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);\n  }\n";
-      else
-        c += "    partial[(long)blockIdx.x * " + E + " + e] = total;\n  }\n";
+      // A block's partial row: whole 16-byte groups at a stride of ES floats.  With the in-kernel fold the groups go out as
+      // ONE `global_store_dwordx4 sc0 sc1` each and come back as `global_load_dwordx4 sc0 sc1` (round 6, EG_ROW_TRACE: as
+      // 4-byte accesses — every one a transaction of its own on the fabric — the last block of the XOR step waited 3.6 us for
+      // its 17 stores to drain and 3.8 us for 64 x 17 loads: 7.4 of the kernel's 11.8 us).
+      const std::string ES = std::to_string(g.red_stride()), G4 = std::to_string(g.red_stride() / 4);
+      if (g.in_kernel_finalize) {
+        c += "  typedef float f4_ __attribute__((ext_vector_type(4)));\n";
+        c += "  if (threadIdx.x < " + G4 + ") {\n    f4_ tv;\n";
+        c += "    _Pragma(\"unroll\") for (int k = 0; k < 4; ++k) {\n      const int e = 4 * threadIdx.x + k;\n";
+        c += "      tv[k] = e < " + E + " ? (red[e] + red[" + E + " + e]) + (red[2 * " + E + " + e] + red[3 * " + E + " + e]) : 0.0f;\n    }\n";
+        c += "    float* const dst = partial + (long)blockIdx.x * " + ES + " + 4 * threadIdx.x;\n";
+        c += "    asm volatile(\"global_store_dwordx4 %0, %1, off sc0 sc1\" : : \"v\"(dst), \"v\"(tv) : \"memory\");\n  }\n";
+      } else {
+        c += "  for (int e = threadIdx.x; e < " + E + "; e += 256) {\n";
+        c += "    const float total = (red[e] + red[" + E + " + e]) + (red[2 * " + E + " + e] + red[3 * " + E + " + e]);\n";
+        c += "    partial[(long)blockIdx.x * " + ES + " + e] = total;\n  }\n";
+      }
       if (g.in_kernel_finalize) {
         // The last block to arrive folds the partial rows.  No agent-scope fences (each costs ~1.7 us on MI355X, and
         // every block would pay one): the partial rows go out as write-through stores (system scope: sc0 sc1) and are
@@ -415,12 +430,21 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
         c += "      float acc[" + E + "];\n";
         c += "      _Pragma(\"unroll\") for (int e = 0; e < " + E + "; ++e) acc[e] = 0.0f;\n";
         c += "      for (int b = threadIdx.x; b < NB; b += 256) {\n";
-        c += "        _Pragma(\"unroll\") for (int e = 0; e < " + E + "; ++e)\n";
-        c += "          acc[e] += __hip_atomic_load(partial + (long)b * " + E + " + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);\n      }\n";
-        c += "      _Pragma(\"unroll\") for (int e = 0; e < " + E + "; ++e) {\n";
-        c += "        float v = acc[e];\n";
-        c += "        _Pragma(\"unroll\") for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);\n";
-        c += "        if (lane == 0) red[wave * " + E + " + e] = v;\n      }\n";
+        c += "        const float* const src = partial + (long)b * " + ES + ";\n        f4_ q_[" + G4 + "];\n";
+        {
+          std::string tie;
+          for (long q = 0; q < g.red_stride() / 4; ++q) {
+            c += "        asm volatile(\"global_load_dwordx4 %0, %1, off sc0 sc1\" : \"=v\"(q_[" + std::to_string(q) + "]) : \"v\"(src + " +
+                 std::to_string(4 * q) + ") : \"memory\");\n";
+            tie += std::string(q ? ", " : "") + "\"+v\"(q_[" + std::to_string(q) + "])";
+          }
+          // (the compiler does not count loads issued from inline assembly: the wait is explicit and tied to the registers)
+          c += "        asm volatile(\"s_waitcnt vmcnt(0)\" : " + tie + " : : \"memory\");\n";
+        }
+        c += "        _Pragma(\"unroll\") for (int e = 0; e < " + E + "; ++e) acc[e] += q_[e >> 2][e & 3];\n      }\n";
+        c += "      _Pragma(\"unroll\") for (int off = 32; off >= 1; off >>= 1)\n";
+        c += "        _Pragma(\"unroll\") for (int e = 0; e < " + E + "; ++e) acc[e] += __shfl_xor(acc[e], off, 64);\n";
+        c += "      if (lane == 0) {\n        _Pragma(\"unroll\") for (int e = 0; e < " + E + "; ++e) red[wave * " + E + " + e] = acc[e];\n      }\n";
         c += "      __syncthreads();\n";
         for (auto& kv : g.tensors) {
           const RowGroupTensor& t = kv.second;
@@ -451,6 +475,29 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
           c += "      }\n";
         }
         c += "    }\n  }\n";
+        // EG_ROW_TRACE=1 (detector): the last block to arrive prints where ITS time went — cycles since its own start at:
+        // samples done, partial row stored and drained, ticket taken, partial rows of all blocks read, totals and tail done
+        if (eg::sw::raw("EG_ROW_TRACE") != nullptr) {
+          auto insert_before = [&](const std::string& anchor, const std::string& text, size_t from) {
+            const size_t at = c.find(anchor, from);
+            if (at == std::string::npos) return std::string::npos;
+            c.insert(at, text);
+            return at + text.size() + anchor.size();
+          };
+          auto stamp = [](int k) { return "  tr_[" + std::to_string(k) + "] = __builtin_readcyclecounter();\n"; };
+          c = "  long long tr_[8];\n" + stamp(0) + c;
+          size_t pos = insert_before("  __shared__ float red[", stamp(1), 0);
+          if (pos != std::string::npos) pos = insert_before("  if (threadIdx.x < ", stamp(6), pos);                  // wave totals in LDS
+          if (pos != std::string::npos) pos = insert_before("    asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\");\n", stamp(7), pos);   // store issued
+          if (pos != std::string::npos) pos = insert_before("    if (threadIdx.x == 0) {\n      const unsigned ticket", stamp(2), pos);
+          if (pos != std::string::npos) pos = insert_before("    if (s_last) {\n", stamp(3), pos);
+          if (pos != std::string::npos) pos = insert_before("      __syncthreads();\n", stamp(4), pos);
+          const size_t end = c.rfind("    }\n  }\n");
+          if (pos != std::string::npos && end != std::string::npos)
+            c.insert(end, stamp(5) + "      if (threadIdx.x == 0) printf(\"[eg] " + g.name +
+                              " last block (%d of %d): samples %lld, wave totals %lld, store issued %lld, drained %lld, ticket %lld, partials in %lld, done %lld cycles\\n\", "
+                              "(int)blockIdx.x, (int)gridDim.x, tr_[1] - tr_[0], tr_[6] - tr_[0], tr_[7] - tr_[0], tr_[2] - tr_[0], tr_[3] - tr_[0], tr_[4] - tr_[0], tr_[5] - tr_[0]);\n");
+        }
       }
     }
   }
@@ -1370,8 +1417,8 @@ int generate_sample_group(const Program& prog, const std::vector<Kernel>& all, c
         }
       }
       c += "      }\n";
-      c += "      _Pragma(\"unroll\") for (int u = 0; u < " + RS + "; ++u)\n        _Pragma(\"unroll\") for (int m_ = " + std::to_string(T / 2) +
-           "; m_ >= 1; m_ >>= 1) acc[u] = acc[u] + __shfl_xor(acc[u], m_, " + TS + ");\n";
+      c += "      _Pragma(\"unroll\") for (int m_ = " + std::to_string(T / 2) + "; m_ >= 1; m_ >>= 1)\n        _Pragma(\"unroll\") for (int u = 0; u < " + RS +
+           "; ++u) acc[u] = acc[u] + __shfl_xor(acc[u], m_, " + TS + ");\n";
       c += "      if (out < " + std::to_string(items) + "L && part == 0) {\n";
       c += decode_indep("out", "        ");
       c += store("        ");

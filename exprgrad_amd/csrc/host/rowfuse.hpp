@@ -57,6 +57,8 @@ struct RowGroup {
   std::map<int, RowGroupTensor> tensors;
   long B = 0;
   long red_total = 0;  // partial row length
+  // floats between two blocks' partial rows: whole 16-byte groups (the hand-off stores and loads them as such)
+  long red_stride() const { return (red_total + 3) & ~3L; }
   std::string name, source;
   std::vector<int> ptr_args;  // tensor ids in pointer-argument order (after `partial`)
   // B <= 256: the one block adds its totals to their destinations itself (arguments d<id> behind `epoch`, one per

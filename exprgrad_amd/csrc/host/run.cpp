@@ -215,7 +215,7 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
           fa.accumulate[s] = gt.accumulate ? 1 : 0;
         }
         fa.offset[fa.nseg] = (int)pg.g.red_total;
-        return eg::row_finalize(ctx, pg.partial, pg.nblocks, (int)pg.g.red_total, fa);
+        return eg::row_finalize(ctx, pg.partial, pg.nblocks, (int)pg.g.red_total, (int)pg.g.red_stride(), fa);
       }
       return EG_OK;
     }
@@ -299,7 +299,7 @@ static int run_row_fold(eg_model* m, TargetState& ts, Plan& plan, const Launch& 
     fa.accumulate[s] = gt.accumulate ? 1 : 0;
   }
   fa.offset[fa.nseg] = (int)pg.g.red_total;
-  return eg::row_finalize(m->ctx, pg.partial, pg.nblocks, (int)pg.g.red_total, fa);
+  return eg::row_finalize(m->ctx, pg.partial, pg.nblocks, (int)pg.g.red_total, (int)pg.g.red_stride(), fa);
 }
 
 int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end, bool zero, const SideHook* hook) {
@@ -333,7 +333,7 @@ int run_range_eager(eg_model* m, TargetState& ts, Plan& plan, int begin, int end
                                       m->ctx->stream));
       for (auto& rg : plan.row_groups)
         if (rg->partial)
-          EG_HIP_CHECK(hipMemsetAsync(rg->partial, 0xFF, (size_t)rg->nblocks * rg->g.red_total * sizeof(float), m->ctx->stream));
+          EG_HIP_CHECK(hipMemsetAsync(rg->partial, 0xFF, (size_t)rg->nblocks * rg->g.red_stride() * sizeof(float), m->ctx->stream));
     }
     // fresh random tensors for this call (model.nim:310-314 does it on the host); the draw counter
     // is bumped on the device so a captured sequence advances on every replay
@@ -651,7 +651,7 @@ int run_launch_sliced(eg_model* m, TargetState& ts, Plan& plan, Launch& L, const
           fa.accumulate[s] = (gt.accumulate || sl.second) ? 1 : 0;
         }
         fa.offset[fa.nseg] = (int)pg.g.red_total;
-        return eg::row_finalize(ctx, pg.partial, nblocks, (int)pg.g.red_total, fa);
+        return eg::row_finalize(ctx, pg.partial, nblocks, (int)pg.g.red_total, (int)pg.g.red_stride(), fa);
       }
       return EG_OK;
     }

@@ -232,9 +232,10 @@ int conv2_direct_grad_filter_try(eg_ctx* ctx, long N, long H, long W, long C, lo
        " + t] = acc[f * " + std::to_string(taps) + " + t] + g[f] * win[t];\n  }\n";
   s += "  __shared__ float red[4 * " + std::to_string(E) + "];\n";
   s += "  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;\n";
-  s += "  _Pragma(\"unroll\") for (int e = 0; e < " + std::to_string(E) + "; ++e) {\n    float v = acc[e];\n";
-  s += "    _Pragma(\"unroll\") for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);\n";
-  s += "    if (lane == 0) red[wave * " + std::to_string(E) + " + e] = v;\n  }\n  __syncthreads();\n";
+  // (the butterfly over all values of a step together, not value by value: rowfuse.cpp, round 6)
+  s += "  _Pragma(\"unroll\") for (int off = 32; off >= 1; off >>= 1)\n";
+  s += "    _Pragma(\"unroll\") for (int e = 0; e < " + std::to_string(E) + "; ++e) acc[e] += __shfl_xor(acc[e], off, 64);\n";
+  s += "  if (lane == 0) {\n    _Pragma(\"unroll\") for (int e = 0; e < " + std::to_string(E) + "; ++e) red[wave * " + std::to_string(E) + " + e] = acc[e];\n  }\n  __syncthreads();\n";
   s += "  for (int e = threadIdx.x; e < " + std::to_string(E) + "; e += 256)\n";
   s += "    partial[(long)blockIdx.x * " + std::to_string(E) + " + e] = (red[e] + red[" + std::to_string(E) + " + e]) + (red[2 * " +
        std::to_string(E) + " + e] + red[3 * " + std::to_string(E) + " + e]);\n}\n";

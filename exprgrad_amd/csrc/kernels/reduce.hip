@@ -371,12 +371,12 @@ int slab_sum(eg_ctx* ctx, long slabs, long total, const float* slab, float* out,
   return EG_OK;
 }
 
-__global__ __launch_bounds__(NT) void row_finalize_kernel(const float* __restrict__ partial, int nblocks, int E,
+__global__ __launch_bounds__(NT) void row_finalize_kernel(const float* __restrict__ partial, int nblocks, int E, int stride,
                                                           RowFinalizeArgs a) {
   __shared__ float red[4];
   const int e = blockIdx.x;
   float acc = 0.f;
-  for (int b = threadIdx.x; b < nblocks; b += NT) acc += partial[(long)b * E + e];
+  for (int b = threadIdx.x; b < nblocks; b += NT) acc += partial[(long)b * stride + e];
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
@@ -389,11 +389,11 @@ __global__ __launch_bounds__(NT) void row_finalize_kernel(const float* __restric
   }
 }
 
-int row_finalize(eg_ctx* ctx, const float* partial, int nblocks, int E, const RowFinalizeArgs& args) {
+int row_finalize(eg_ctx* ctx, const float* partial, int nblocks, int E, int stride, const RowFinalizeArgs& args) {
   if (E <= 0) return EG_OK;
   int rc = set_device(ctx);
   if (rc) return rc;
-  hipLaunchKernelGGL(row_finalize_kernel, dim3((unsigned)E), dim3(NT), 0, ctx->stream, partial, nblocks, E, args);
+  hipLaunchKernelGGL(row_finalize_kernel, dim3((unsigned)E), dim3(NT), 0, ctx->stream, partial, nblocks, E, stride, args);
   EG_HIP_CHECK(hipGetLastError());
   return EG_OK;
 }
