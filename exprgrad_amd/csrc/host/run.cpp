@@ -102,9 +102,19 @@ int run_launch(eg_model* m, TargetState& ts, Plan& plan, Launch& L) {
         }
         m->kernels.push_back(handle);
       }
+      static const bool gemm_trace = eg::sw::raw("EG_GEMM_TRACE") != nullptr;
+      long long* trace = nullptr;
+      if (gemm_trace && !f.narrow) {
+        trace = eg::gemm::trace_begin(ctx, f.grid, (unsigned)f.nt / 64);
+        eg::gemm::fused_set_trace(f, trace);
+      }
       void* args[] = {f.args};
       rc = f.narrow ? eg::kernel_launch_raw(handle, f.narrow_grid, 1, 1, 256, args)
                     : eg::kernel_launch_raw(handle, f.grid, 1, 1, (unsigned)f.nt, args);
+      if (trace) {
+        eg::gemm::trace_end(ctx, trace, f.grid, (unsigned)f.nt / 64, "fused contraction");
+        eg::gemm::fused_set_trace(f, nullptr);
+      }
       if (rc || !pe.row_product || with_product) return rc;
       return run_launch(m, ts, plan, pe.product);
     }

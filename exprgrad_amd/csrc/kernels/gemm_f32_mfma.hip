@@ -18,6 +18,13 @@
 
 #include "../eg_internal.hpp"
 
+namespace eg {
+namespace gemm {
+long long* trace_begin(eg_ctx* ctx, unsigned blocks, unsigned waves);   // EG_GEMM_TRACE (defined below, declared in gemm_fused.hpp)
+void trace_end(eg_ctx* ctx, long long* buffer, unsigned blocks, unsigned waves, const char* what);
+}  // namespace gemm
+}  // namespace eg
+
 namespace {
 
 using namespace eg::gemm;
@@ -632,9 +639,12 @@ int run_gemm(eg_ctx* ctx, bool a_kc, bool b_kc, GemmArgs args, int conv, bool ve
       if (rc) return rc;
       args.partial = static_cast<float*>(ctx->workspace);
       const unsigned grid = (unsigned)(full * s1 + tn * s2);
+      static const bool trace_on = eg::sw::raw("EG_GEMM_TRACE") != nullptr;
+      if (trace_on) args.trace = trace_begin(ctx, grid, 8);
       hipLaunchKernelGGL((gemm_f32_mfma_kernel<256, 256, BK, 128, 64, 1, false, false, 4, true, 0, 0, true, true>), dim3(grid), dim3(512),
                          0, ctx->stream, args);
       EG_HIP_CHECK(hipGetLastError());
+      if (trace_on) trace_end(ctx, args.trace, grid, 8, "TN 256 x 256 with extra rows, k-sliced");
       long blocks = (total + 255) / 256;
       if (blocks > 2048) blocks = 2048;
       // rows of the last tile row and the extra rows were cut into s2 slices, the others into s1
@@ -1303,6 +1313,47 @@ namespace eg {
 namespace gemm {
 
 static_assert(sizeof(GemmArgs) <= sizeof(FusedLaunch::args), "FusedLaunch::args too small");
+
+long long* trace_begin(eg_ctx* ctx, unsigned blocks, unsigned waves) {
+  long long* buffer = nullptr;
+  const size_t bytes = (size_t)blocks * waves * 4 * sizeof(long long);
+  if (hipMalloc((void**)&buffer, bytes) != hipSuccess) return nullptr;
+  if (hipMemsetAsync(buffer, 0, bytes, ctx->stream) != hipSuccess) {
+    (void)hipFree(buffer);
+    return nullptr;
+  }
+  return buffer;
+}
+
+void fused_set_trace(FusedLaunch& f, long long* buffer) {
+  GemmArgs a;
+  memcpy(&a, f.args, sizeof(a));
+  a.trace = buffer;
+  memcpy(f.args, &a, sizeof(a));
+}
+
+void trace_end(eg_ctx* ctx, long long* buffer, unsigned blocks, unsigned waves, const char* what) {
+  if (!buffer) return;
+  std::vector<long long> h((size_t)blocks * waves * 4);
+  if (hipStreamSynchronize(ctx->stream) == hipSuccess &&
+      hipMemcpy(h.data(), buffer, h.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess) {
+    double sum[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
+    long cnt = 0;
+    for (size_t w = 0; w < (size_t)blocks * waves; ++w) {
+      if (h[w * 4] == 0 || h[w * 4 + 3] == 0) continue;
+      ++cnt;
+      for (int k = 1; k < 4; ++k) {
+        const double d = (double)(h[w * 4 + k] - h[w * 4]);
+        sum[k] += d;
+        mx[k] = d > mx[k] ? d : mx[k];
+      }
+    }
+    if (cnt)
+      fprintf(stderr, "[eg] gemm trace %s (%u blocks x %u waves; cycles since wave start, mean / max): k loop begins %.0f / %.0f, ends %.0f / %.0f, "
+                      "epilogue done %.0f / %.0f\n", what, blocks, waves, sum[1] / cnt, mx[1], sum[2] / cnt, mx[2], sum[3] / cnt, mx[3]);
+  }
+  (void)hipFree(buffer);
+}
 static_assert(MAX_EPILOGUE_OPERANDS == sizeof(GemmArgs::epi) / sizeof(void*), "epilogue operand count");
 
 int plan_fused(eg_ctx* ctx, int trans_a, int trans_b, long M, long N, long K, const float* A, long lda, const float* B,

@@ -91,6 +91,8 @@ struct GemmArgs {
   // would stage whole B tiles for 1/8 of the matrix work (784 x 512 x 65536: the 16 (+1 virtual) rows beyond 768 cost
   // 47 us as a tile row).  Those blocks get edge_splits (more, shorter) k-slices.
   int x_rows;
+  // EG_GEMM_TRACE=1 (detector): four cycle stamps per wave — entry, in front of the k loop, behind it, behind the epilogue
+  long long* trace;
 };
 
 // Epilogue functor of the library kernels: plain store.  A generated epilogue (ACTIVE = true)
@@ -1069,6 +1071,12 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   const int wm0 = (wave / WAVES_N) * WM;
   const int wn0 = (wave % WAVES_N) * WN;
   if (a.prio) __builtin_amdgcn_s_setprio(3);
+  // (nothing of the trace stays live across the k loop: the pointer is re-read from the kernel arguments at every stamp —
+  // kept in registers it cost the extra-row kernel, which has none to spare, 10 - 15 us)
+  auto stamp = [&](int k) {
+    if (a.trace && lane == 0) a.trace[((long)blockIdx.x * (BM / WM) * WAVES_N + wave) * 4 + k] = __builtin_readcyclecounter();
+  };
+  stamp(0);
 
   // ---- tile coordinates: XCD-contiguous ids, then 8-row groups so co-resident tiles share
   //      A row-panels and B column-panels inside one L2.
@@ -1136,9 +1144,21 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
     constexpr int RT_ = (BM / WM) * 32, NTHREADS = Geometry<BM, BN, WM, WN>::NT;
     float* w2s = lds + 2 * RT_ * (BN + 4);
     const float* w2 = static_cast<const float*>(a.epi[Epi::RD_W]);
-    for (int e = tid; e < BN * 16; e += NTHREADS) {
-      const int k = e >> 4, c = e & 15;
-      w2s[(((k >> 2) * 16 + c) << 2) + (k & 3)] = c < Epi::RD_N ? w2[(n_blk + k) * (long)Epi::RD_LDW + c] : 0.f;
+    // (all loads first, then the stores: as one `w2s[...] = cond ? w2[...] : 0` loop the eight trips of a thread were eight
+    // dependent round trips to L2 — EG_GEMM_TRACE, round 6: the k loop of the fused forward product began 7 800 cycles after
+    // the wave's start, 1 600 in the plain kernel)
+    constexpr int TRIPS = (BN * 16 + NTHREADS - 1) / NTHREADS;
+    float wv[TRIPS];
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+      const int e = tid + t * NTHREADS, k = (e >> 4) < BN ? (e >> 4) : BN - 1, c = e & 15;
+      const float v = w2[(n_blk + k) * (long)Epi::RD_LDW + (c < Epi::RD_N ? c : 0)];
+      wv[t] = c < Epi::RD_N ? v : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+      const int e = tid + t * NTHREADS, k = e >> 4, c = e & 15;
+      if (e < BN * 16) w2s[(((k >> 2) * 16 + c) << 2) + (k & 3)] = wv[t];
     }
   }
   static_assert(!DMA || VEC == 4, "LDS-DMA loop: 16-byte aligned operands");
@@ -1148,6 +1168,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
   // on the interior loop and only the last one on the clamped loop (4096 x 4096 x 4100 took 1060 us with
   // every k-tile clamped, against 973 us for K = 4112).
   const bool k_tail_only = EDGE && DMA && CONV == 0 && !whole_k && k_end > k_begin && m_blk + BM <= a.a_rows && n_blk + BN <= a.N;
+  stamp(1);
   bool done = false;
   if constexpr (XR) {
     // extra rows: the blocks of the last tile row multiply and store the strip [tiles_m * BM, M) as well (split-K only:
@@ -1222,6 +1243,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
     if (s == 1.2345678e-30f) a.C[0] = s;
     return;
   }
+  stamp(2);
   // ---- epilogue.  32x32 accumulator block: register r of lane l holds
   //      row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5), col = l & 31.
   const bool to_partial = a.tail_tiles > 0 ? tail_slab >= 0 : a.partial != nullptr;
@@ -1260,14 +1282,19 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
     // staged rows 16 w + 4 (l / 16) + v.  Float atomics without return — nothing waits for them (a compare-and-swap loop
     // costs a memory round trip behind the tile's own store burst: +14 us per tile).  gfx950's global_atomic_add_f32
     // honours the denormal mode (tests/test_gpu_epilogue.py holds a denormal result to the bit).
+    // (the second layer's bias: loaded ONCE per tile here, not in front of the atomics of every pass — waves 0 .. 3 waited
+    // a memory round trip per pass for it and the other four waited for them at the pass's barrier)
+    float bias2 = 0.f;
+    if constexpr (RD) {
+      if (Epi::RD_BIAS >= 0 && n_blk == 0 && wave < 4 && (lane & 15) < Epi::RD_N)
+        bias2 = static_cast<const float*>(a.epi[Epi::RD_BIAS >= 0 ? Epi::RD_BIAS : 0])[lane & 15];
+    }
     auto rd_send = [&](int pass) {
       if constexpr (RD) {
         const int r = lane & 15, g = lane >> 4;
         if (wave < 4 && r < Epi::RD_N) {
           typedef float rd4 __attribute__((ext_vector_type(4)));
           const rd4 other = *reinterpret_cast<const rd4*>(rdx + (wave * 64 + lane) * 4);
-          float bias2 = 0.f;
-          if (Epi::RD_BIAS >= 0 && n_blk == 0) bias2 = static_cast<const float*>(a.epi[Epi::RD_BIAS >= 0 ? Epi::RD_BIAS : 0])[r];
           float* out2 = static_cast<float*>(a.epi[Epi::RD_OUT]);
 #pragma unroll
           for (int v = 0; v < 4; ++v) {
@@ -1316,6 +1343,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
       for (int g0 = 0; g0 < NQ; g0 += GROUP) {
       f32x4 x4[GROUP][Epi::NX];
       f32x4 old[GROUP];
+      unsigned nibs[GROUP];   // predicate bits of the group's chunks (packed words: folded behind the loop, all chunks together)
+#pragma unroll
+      for (int c = 0; c < GROUP; ++c) nibs[c] = 0;
 #pragma unroll
       for (int c = g0; c < g0 + GROUP && c < NQ; ++c) {
         if ((RT * C4) % NT_ != 0 && c * NT_ + tid >= RT * C4) break;
@@ -1343,13 +1373,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
           if constexpr (Epi::PRED >= 0) {
             unsigned* bits = static_cast<unsigned*>(a.epi[Epi::PRED]);
             if (packed) {
-              // (whole tiles: n_blk and the rows' starts are multiples of 32) fold the eight nibbles with three butterfly
-              // steps; one lane stores the word
-              unsigned w = nibble << (4 * (tid & 7));
-              w |= __shfl_xor(w, 1, 64);
-              w |= __shfl_xor(w, 2, 64);
-              w |= __shfl_xor(w, 4, 64);
-              if ((tid & 7) == 0) bits[idx >> 5] = w;
+              nibs[c - g0] = nibble;   // (folded below)
             } else if (nibble) {
               atomicOr(bits + (idx >> 5), nibble << (idx & 31));  // (idx is a multiple of 4: a nibble never straddles words)
             }
@@ -1375,6 +1399,29 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
           else *p = v;
         }
       }
+      if constexpr (Epi::ACTIVE && Epi::PRED >= 0) {
+        if (packed) {
+          // (whole tiles: n_blk and the rows' starts are multiples of 32) eight neighbouring lanes hold the eight nibbles of a
+          // 32-bit word: three butterfly steps, one lane stores the word.  The steps run over ALL chunks of the group together
+          // (round 6: chunk by chunk, each behind its guarded store, every one of the 3 x 8 crossbar shuffles of a pass
+          // waited out its own latency — the pattern EG_ROW_TRACE found in the row groups).
+          unsigned* bits = static_cast<unsigned*>(a.epi[Epi::PRED >= 0 ? Epi::PRED : 0]);
+          unsigned w[GROUP];
+#pragma unroll
+          for (int c = 0; c < GROUP; ++c) w[c] = nibs[c] << (4 * (tid & 7));
+#pragma unroll
+          for (int step = 1; step <= 4; step <<= 1)
+#pragma unroll
+            for (int c = 0; c < GROUP; ++c) w[c] |= __shfl_xor(w[c], step, 64);
+          if ((tid & 7) == 0) {
+#pragma unroll
+            for (int c = g0; c < g0 + GROUP && c < NQ; ++c) {
+              if ((RT * C4) % NT_ != 0 && c * NT_ + tid >= RT * C4) break;
+              bits[index_of(c) >> 5] = w[c - g0];
+            }
+          }
+        }
+      }
       }
       __syncthreads();
       if constexpr (RD) {
@@ -1388,7 +1435,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
         const int r = lane & 15, g = lane >> 4, mb = wave & 3, kh = wave >> 2;
         const float* arow = park + (mb * 16 + r) * PS + 4 * g + kh * (BN / 2);
         const float* brow = w2s + ((g * 16 + r) << 2) + kh * (BN / 2) * 16;
-        rd4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+        // (four accumulators — two windows x even / odd k of a window: a chain of 8 dependent MFMAs each instead of 16; the
+        // instruction's result is not ready for the next one of its chain when that is the next but one in line)
+        rd4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f}, d2 = {0.f, 0.f, 0.f, 0.f}, d3 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s2 = 0; s2 < BN / 32; s2 += 2) {
           const rd4 a0 = *reinterpret_cast<const rd4*>(arow + 16 * s2);
@@ -1396,13 +1445,15 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
           const rd4 a1 = *reinterpret_cast<const rd4*>(arow + 16 * s2 + 16);
           const rd4 b1 = *reinterpret_cast<const rd4*>(brow + 256 * s2 + 256);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
+          for (int j = 0; j < 4; j += 2) {
             d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], d0, 0, 0, 0);
             d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], d1, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j + 1], b0[j + 1], d2, 0, 0, 0);
+            d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j + 1], b1[j + 1], d3, 0, 0, 0);
           }
         }
 #pragma unroll
-        for (int v = 0; v < 4; ++v) rd_half[v] = d0[v] + d1[v];
+        for (int v = 0; v < 4; ++v) rd_half[v] = (d0[v] + d2[v]) + (d1[v] + d3[v]);
         if (kh == 1) *reinterpret_cast<rd4*>(rdx + (mb * 64 + lane) * 4) = rd4{rd_half[0], rd_half[1], rd_half[2], rd_half[3]};
       }
     }
@@ -1410,6 +1461,8 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
       __syncthreads();
       rd_send(MI - 1);
     }
+    if (a.trace) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(3);
     return;
   }
   if constexpr (RD) __builtin_trap();  // the host launches a row product only where every tile takes the wide-store pass
@@ -1470,6 +1523,8 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& a) {
       }
     }
   }
+  if (a.trace) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(3);
 }
 
 // Waves per SIMD the register allocator must leave room for.  The ragged-tile variants of the

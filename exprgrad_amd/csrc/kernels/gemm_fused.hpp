@@ -30,6 +30,7 @@ struct FusedLaunch {
   long matrix_k_per_split = 0;   // GemmArgs::k_per_split of the matrix tile (the streaming kernel reads its rows per block there)
   alignas(8) unsigned char args[320];  // the kernel's GemmArgs (opaque to host-only translation units)
   unsigned args_size = 0;
+  unsigned waves = 0;   // per block (EG_GEMM_TRACE)
 };
 constexpr int MAX_EPILOGUE_OPERANDS = 6;
 
@@ -59,6 +60,12 @@ std::string fused_variant(const FusedLaunch& f);
 // `struct <epi_name>` with ACTIVE and apply) and an extern "C" kernel `kernel_name(GemmArgs)`.
 std::string fused_source(const FusedLaunch& f, const std::string& epi_struct, const std::string& epi_name,
                          const std::string& kernel_name);
+
+// EG_GEMM_TRACE=1: cycle stamps of every wave of a launch (entry, k loop begins, k loop ends, epilogue done) — trace_begin
+// allocates and zeroes the buffer (the pointer goes into the launch's GemmArgs), trace_end waits, prints mean / max and frees.
+long long* trace_begin(eg_ctx* ctx, unsigned blocks, unsigned waves);
+void fused_set_trace(FusedLaunch& f, long long* buffer);
+void trace_end(eg_ctx* ctx, long long* buffer, unsigned blocks, unsigned waves, const char* what);
 
 }  // namespace gemm
 }  // namespace eg

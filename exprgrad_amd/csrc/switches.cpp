@@ -82,6 +82,7 @@ const Row kSwitches[] = {
     {"EG_DUMP_BAND", "detector", "directory: generated band-convolution sources"},
     {"EG_GRADF_TRACE", "detector", "per-wave cycle stamps of the halo filter-gradient kernel"},
     {"EG_HALO_TRACE", "detector", "per-wave cycle stamps of the halo convolution kernel"},
+    {"EG_GEMM_TRACE", "detector", "per-wave cycle stamps of the fused and the extra-row contraction kernels (k loop begins / ends, epilogue done)"},
     {"EG_ROW_TRACE", "detector", "the last block of a row group with a tail prints cycle stamps of its hand-off"},
     {"EG_SAMPLE_TRACE", "detector", "block 0 of a sample kernel prints cycle stamps behind every member's barrier"},
     {"EG_GEMM_FORCE_TILE", "tuning", "bm,bn: force the contraction tile"},
