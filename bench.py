@@ -1032,7 +1032,7 @@ def run_xor(args, env):
                                    "arrive folds the partial rows and runs the four update kernels); launch- and hand-off-latency bound",
                          "bytes_per_launch": XOR_BYTES_PER_SAMPLE * batch, "clock": "wall time of the timed steps",
                          "kernel_ms_avg": round(ev_avg, 4)},
-            "scaling_note": "launch-bound: the step is one launch of ~12 us around 1 MB of real traffic, so its "
+            "scaling_note": "launch-bound: the step is one launch of ~8 us around 1 MB of real traffic, so its "
                             "time is launch and hand-off latency, not bandwidth.  Under data parallelism a step adds one 17-float "
                             "all-reduce (tens of us) and cannot get shorter: steps/s does NOT scale with GPUs.  The only "
                             "claim this workload supports is weak scaling in samples/s (65536 samples per GPU: N GPUs "
