@@ -369,8 +369,9 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
       // guarded store behind each kept the compiler from interleaving them — every one of the 6 x 17 shuffles of the XOR
       // step's totals waited out the LDS crossbar's latency by itself: 7 700 cycles, and again in the last block's fold;
       // together 6.5 of the kernel's 11.8 us).  Same additions per value, same order.
-      c += "  _Pragma(\"unroll\") for (int off = 32; off >= 1; off >>= 1)\n";
-      c += "    _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) R" + id + "[j] += __shfl_xor(R" + id + "[j], off, 64);\n";
+      for (int off = 32; off >= 1; off >>= 1)
+        c += "  _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) R" + id + "[j] += eg_xor_lane<" + std::to_string(off) +
+             ">(R" + id + "[j]);\n";
       c += "  if (lane == 0) {\n    _Pragma(\"unroll\") for (int j = 0; j < " + std::to_string(t.inner) + "; ++j) red[wave * " + E + " + " +
            std::to_string(t.red_offset) + " + j] = R" + id + "[j];\n  }\n";
     }
@@ -442,8 +443,8 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
           c += "        asm volatile(\"s_waitcnt vmcnt(0)\" : " + tie + " : : \"memory\");\n";
         }
         c += "        _Pragma(\"unroll\") for (int e = 0; e < " + E + "; ++e) acc[e] += q_[e >> 2][e & 3];\n      }\n";
-        c += "      _Pragma(\"unroll\") for (int off = 32; off >= 1; off >>= 1)\n";
-        c += "        _Pragma(\"unroll\") for (int e = 0; e < " + E + "; ++e) acc[e] += __shfl_xor(acc[e], off, 64);\n";
+        for (int off = 32; off >= 1; off >>= 1)
+          c += "      _Pragma(\"unroll\") for (int e = 0; e < " + E + "; ++e) acc[e] += eg_xor_lane<" + std::to_string(off) + ">(acc[e]);\n";
         c += "      if (lane == 0) {\n        _Pragma(\"unroll\") for (int e = 0; e < " + E + "; ++e) red[wave * " + E + " + e] = acc[e];\n      }\n";
         c += "      __syncthreads();\n";
         for (auto& kv : g.tensors) {
@@ -501,7 +502,31 @@ int generate_row_group(const Program& prog, const std::vector<Kernel>& all, cons
       }
     }
   }
-  g.source = sig + " {\n" + c + "}\n";
+  // eg_xor_lane<OFF>(v): the value of lane (l ^ OFF) — what __shfl_xor(v, OFF, 64) returns through the LDS crossbar, here as
+  // DPP moves for OFF < 16 (quad permutations for 1 and 2; for 4 and 8 two row shifts whose bank masks pick, per group of four
+  // lanes, the one that comes from the right side): four of a butterfly's six steps become vector instructions without a
+  // trip to LDS.  Same partner lanes, so the same sums to the bit (tests/test_gpu_row_tail.py holds the in-kernel fold
+  // against row_finalize_kernel, which shuffles).
+  static const char* kXorLane =
+      "#ifndef EG_XOR_LANE\n#define EG_XOR_LANE\n"
+      "template <int OFF> __device__ __forceinline__ float eg_xor_lane(float v) {\n"
+      "  const int b = __builtin_bit_cast(int, v);\n"
+      "  if constexpr (OFF == 1) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0xB1, 0xF, 0xF, false));\n"
+      "  else if constexpr (OFF == 2) return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(b, b, 0x4E, 0xF, 0xF, false));\n"
+      "  else if constexpr (OFF == 4) {\n"
+      "    int t = __builtin_amdgcn_update_dpp(b, b, 0x104, 0xF, 0x5, false);   // row_shl:4 into lanes 0-3, 8-11 of a row\n"
+      "    t = __builtin_amdgcn_update_dpp(t, b, 0x114, 0xF, 0xA, false);       // row_shr:4 into lanes 4-7, 12-15\n"
+      "    return __builtin_bit_cast(float, t);\n"
+      "  } else if constexpr (OFF == 8) {\n"
+      "    int t = __builtin_amdgcn_update_dpp(b, b, 0x108, 0xF, 0x3, false);   // row_shl:8 into lanes 0-7\n"
+      "    t = __builtin_amdgcn_update_dpp(t, b, 0x118, 0xF, 0xC, false);       // row_shr:8 into lanes 8-15\n"
+      "    return __builtin_bit_cast(float, t);\n"
+      "  } else return __shfl_xor(v, OFF, 64);\n"
+      "}\n#endif\n";
+  g.source = (eg::sw::raw("EG_NO_DPP_BUTTERFLY") ? std::string("#ifndef EG_XOR_LANE\n#define EG_XOR_LANE\ntemplate <int OFF> __device__ __forceinline__ float "
+                                                               "eg_xor_lane(float v) { return __shfl_xor(v, OFF, 64); }\n#endif\n")
+                                                 : std::string(kXorLane)) +
+             sig + " {\n" + c + "}\n";
   return EG_OK;
 }
 

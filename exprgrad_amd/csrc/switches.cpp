@@ -23,6 +23,7 @@ struct Row {
 const Row kSwitches[] = {
     {"EG_TUNING", "execution", "honour the rows of class `tuning` (measurement aids); unset: they are ignored"},
     {"EG_NO_GRAPH", "execution", "launch one by one instead of replaying captured HIP graphs"},
+    {"EG_NO_DPP_BUTTERFLY", "execution", "row groups exchange lanes through the LDS crossbar in every step of a wave reduction (no DPP moves)"},
     {"EG_NO_DEFERRED_FOLD", "execution", "a row group in front of a side-lane group folds its partial rows itself, not on the side lane"},
     {"EG_NO_OVERLAP", "execution", "no side lane: bandwidth-bound launches run in front of the long contraction, not next to it"},
     {"EG_NO_ROWFUSE", "execution", "no row / sample / map / small fusion groups: one launch per kernel"},

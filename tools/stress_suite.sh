@@ -14,7 +14,7 @@ if [ "$what" = full ]; then
 else
   files="tests/test_adam.py tests/test_config_fixtures.py tests/test_dropout.py tests/test_gan.py tests/test_gpu_conv_grad.py tests/test_gpu_epilogue.py"
 fi
-toggles=("" "EG_NO_GRAPH=1 EG_OVERLAP_SIDE_FIRST=1 EG_NO_DEFERRED_FOLD=1" "EG_NO_OVERLAP=1 EG_SAMPLE_KEEP_BARRIERS=1" "EG_NO_ROWFUSE=1" "EG_NO_PREDICATE=1 EG_NO_ROW_PRODUCT=1" "EG_POISON=1" "EG_GEMM_NO_SKEW=1 EG_GEMM_NO_BK32=1 EG_GEMM_NO_PAIR=1 EG_CONV_NO_TINY=1 EG_CONV_NO_GRADF_HALO=1 EG_CONV_NO_WIDE_STORE=1 EG_NO_ROW_DIRECT=1 EG_NO_SMALL_PAIR=1 EG_CONV_NO_BAND=1 EG_GEMM_NO_T96=1 EG_NO_NARROW_K=1 EG_GEMM_NO_STREAMK=1 EG_SAMPLE_NO_MFMA=1 EG_SAMPLE_NO_STAGE=1" "EG_NO_ROW_TAIL=1 EG_NO_SAMPLE_FUSE=1")
+toggles=("" "EG_NO_GRAPH=1 EG_OVERLAP_SIDE_FIRST=1 EG_NO_DEFERRED_FOLD=1" "EG_NO_OVERLAP=1 EG_SAMPLE_KEEP_BARRIERS=1" "EG_NO_ROWFUSE=1" "EG_NO_PREDICATE=1 EG_NO_ROW_PRODUCT=1" "EG_POISON=1" "EG_GEMM_NO_SKEW=1 EG_GEMM_NO_BK32=1 EG_GEMM_NO_PAIR=1 EG_CONV_NO_TINY=1 EG_CONV_NO_GRADF_HALO=1 EG_CONV_NO_WIDE_STORE=1 EG_NO_ROW_DIRECT=1 EG_NO_SMALL_PAIR=1 EG_CONV_NO_BAND=1 EG_GEMM_NO_T96=1 EG_NO_NARROW_K=1 EG_GEMM_NO_STREAMK=1 EG_SAMPLE_NO_MFMA=1 EG_SAMPLE_NO_STAGE=1" "EG_NO_ROW_TAIL=1 EG_NO_SAMPLE_FUSE=1 EG_NO_DPP_BUTTERFLY=1")
 bad=0
 for ((i = 0; i < runs; i++)); do
   t=${toggles[$((i % 8))]}
